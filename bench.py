@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — one "step" = one full pass of the DSK hot path (Stage A scan+bucket, Stage B expand+sort+count) over one
+batch of synthetic 150 bp reads that is already resident in HBM when the timed region starts.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run, one rank per GPU).
+Rank 0 prints ONE JSON line. metric = BASELINE.json's "distinct k-mers/s at k=31".
+
+N=1 workload = BASELINE configs[1] shape (k=31, synthetic 150 bp reads, 30x coverage, 1 % substitutions, single pass,
+no Bloom), --reads per GPU (default 2e7 so the default run finishes in minutes; --reads 100000000 is the full config).
+N>1: weak scaling — every rank scans its own --reads reads; super-k-mer buckets are routed to the partition's owner
+rank with one RCCL all-to-all (torch.distributed, backend nccl == RCCL), each rank counts the partitions it owns.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def repart_for_bench(m, parts):
+    """a balanced minimizer->partition table: splitmix hash of the minimizer value (any table is a valid Repartitor)"""
+    gkc = ge.load().gkc
+    x = gkc.mix64_np(np.arange(4 ** m, dtype=np.uint64))
+    return (x % np.uint64(parts)).astype(np.uint16)
+
+
+def algorithmic_bytes_per_kmer(k, L, nbar, d):
+    """SURVEY.md §8(d) fixed accounting model (LSD 8-bit passes), bytes per valid input k-mer"""
+    W = 8 if k <= 31 else 16
+    R = 16 if k <= 31 else 32
+    P = (2 * k + 7) // 8
+    b_in = L / (L - k + 1)
+    b_sk = (1 + -(-(k + nbar - 1) // 4)) / nbar
+    return b_in + 2 * b_sk + W + 2 * W * P + W + W + R * d
+
+
+def cpu_baseline(k, m, parts, rep, seconds_target=15.0):
+    """the oracle (a scalar C port of the reference algorithm) timed on rank 0's host core on a bounded sample"""
+    from oracle import gko
+    gkc = ge.load().gkc
+    n = 100_000
+    bases, offs = gkc.synth_reads_np(1, n, 150, n * 5, 10000)
+    t0 = time.time()
+    d = gko.Dsk(bases, offs, k, m, parts, rep)
+    dt = time.time() - t0
+    # scale the sample once so the leg takes ~seconds_target
+    n2 = int(min(2_000_000, max(n, n * seconds_target / max(dt, 1e-3))))
+    if n2 > 1.5 * n:
+        bases, offs = gkc.synth_reads_np(1, n2, 150, n2 * 5, 10000)
+        t0 = time.time()
+        d = gko.Dsk(bases, offs, k, m, parts, rep)
+        dt = time.time() - t0
+        n = n2
+    return {"value": d.stats["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic 150 bp reads (same generator, seed 1, 30x), oracle/gkc_oracle.c single thread, %.1f s; "
+                      "%.3g valid k-mers/s" % (n, dt, d.stats["kmers_nb_valid"] / dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU")
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--m", type=int, default=10)
+    ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    gkc = ge.load().gkc
+    if not os.path.exists(gkc.SO):
+        raise SystemExit("libgkc_hip.so missing: run __graft_entry__.build()")
+
+    k, m, L = args.k, args.m, 150
+    n_reads = args.reads
+    n_kmers = n_reads * (L - k + 1)
+    parts = args.partitions or int(min(65535, max(64 * world, 2 ** int(np.ceil(np.log2(max(1, n_kmers * world / 3.0e6)))))))
+    parts = (parts + world - 1) // world * world
+    rep = repart_for_bench(m, parts)
+
+    c = gkc.Counter(local)
+    c.configure(k, m, parts, rep)
+    genome = max(L, n_reads * world * L // 30)               # 30x coverage over the whole job
+    # rank r draws reads [r*n, (r+1)*n) of ONE global read stream over the SAME genome (seed 2)
+    d_bases, d_offs = c.synth_reads_device(2, n_reads, L, genome, 10000, first_read=rank * n_reads)
+    n_bases = n_reads * L
+
+    if world > 1:
+        from gatb_core_amd import dist as gdist          # noqa
+        runner = gdist.DistributedCounter(c, rank, world, parts)
+    else:
+        runner = None
+
+    def step():
+        c.begin_pass(0)
+        c.push_reads_device(d_bases, d_offs, n_reads, n_bases)
+        if runner is not None:
+            runner.exchange()
+        c.finish_pass()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    # per-kernel timers are HIP events on the context's own stream, accumulated inside the library
+    names = ["scan_count", "scan_emit", "expand_count", "expand_scatter", "bucket_sort", "compact", "oversize_sort",
+             "total_stage_a", "total_stage_b"]
+    base = {nme: c.timing(nme) for nme in names}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    st = c.stats()
+    distinct = st["kmers_nb_distinct"]; valid = st["kmers_nb_valid"]
+    if world > 1:
+        t = torch.tensor([distinct, valid], device="cuda", dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
+    ktime = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = distinct / (dt / args.steps)
+        nbar = (valid / world) / max(1, st["nb_superkmers"])
+        d = distinct / max(1, valid)
+        # dominant kernel = the one with the largest accumulated time; its algorithmic bytes per launch are stated in DESIGN.md §Kernels
+        keys_per_rank = valid / world
+        rec_bytes = 16 if k <= 31 else 32; key_bytes = 8 if k <= 31 else 16
+        alg = {
+            "scan_count": n_bases * 1.0,
+            "scan_emit": n_bases * 1.0 + st["nb_superkmers"] * rec_bytes,
+            "expand_count": st["nb_superkmers"] * rec_bytes,
+            "expand_scatter": st["nb_superkmers"] * rec_bytes + keys_per_rank * key_bytes,
+            "bucket_sort": keys_per_rank * key_bytes + (distinct / world) * (key_bytes + 4),
+            "compact": (distinct / world) * (key_bytes + 4 + 2 * key_bytes),
+        }
+        dom = max(alg, key=lambda n_: ktime[n_][0])
+        dom_ms = ktime[dom][0] / max(1, args.steps)            # per step (a step may launch the kernel once per Stage-B batch)
+        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "distinct k-mers/s at k=%d" % k, "value": value, "unit": "distinct k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if k <= 31 else "u128",
+            "data": "synthetic (device generator, seeded; 150 bp reads, 30x, 1% substitutions)",
+            "config": {"workload": "k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions"
+                                   % (k, n_reads, m, parts),
+                       "reads_per_gpu": n_reads, "partitions": parts, "valid_kmers": valid, "distinct_kmers": distinct,
+                       "valid_kmers_per_s": valid / (dt / args.steps), "gbases_per_s": n_bases * world / (dt / args.steps) / 1e9,
+                       "mean_kmers_per_superkmer": nbar, "distinct_ratio": d,
+                       "model_bytes_per_kmer": algorithmic_bytes_per_kmer(k, L, nbar, d),
+                       "model_GBps": valid / world * algorithmic_bytes_per_kmer(k, L, nbar, d) / (dt / args.steps) / 1e9,
+                       "kernel_ms_per_step": {n_: round(ktime[n_][0] / args.steps, 3) for n_ in names}},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": dom_ms, "algorithmic_bytes_per_step": alg[dom]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(k, m, min(parts, 256), repart_for_bench(m, min(parts, 256)))
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    c.device_free(d_bases); c.device_free(d_offs)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

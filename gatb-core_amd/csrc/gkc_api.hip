@@ -1,0 +1,406 @@
+// gkc_api.hip — the C-ABI of libgkc_hip.so (include/gkc.h): context, configuration, pass control, results,
+// plus the synthetic-read generator and the independent k-mer checksum kernel used for full-size parity properties.
+#include "gkc_common.hpp"
+#include "gkc_device.hpp"
+#include <algorithm>
+#include <numeric>
+
+int gkc_result_checksum_impl(gkc_ctx* c, uint64_t* checksum, uint64_t* sum_abundance);
+
+static thread_local std::string g_create_error;
+
+// ------------------------------------------------------------------------------------------------ synthetic reads
+// rnd(seed, stream, idx) — counter-based; twin: gatb-core_amd/gkc.py:synth_rnd / tests/util.py
+__device__ __host__ __forceinline__ uint64_t synth_rnd(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    return mix64(mix64(seed ^ (stream << 56)) + idx);
+}
+__global__ void k_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, uint32_t sub_ppm,
+                              uint8_t* __restrict__ bases, uint64_t* __restrict__ offsets)
+{
+    const uint64_t total = n_reads * read_len;
+    const uint64_t span = genome_len - read_len + 1;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = g / read_len; const uint32_t j = (uint32_t)(g - i * read_len);
+        const uint64_t u = synth_rnd(seed, 2, first_read + i);
+        const uint64_t start = (u >> 1) % span;
+        uint32_t code;
+        if (u & 1) code = (uint32_t)(synth_rnd(seed, 1, start + read_len - 1 - j) & 3) ^ 2u;   // reverse complement
+        else       code = (uint32_t)(synth_rnd(seed, 1, start + j) & 3);
+        const uint64_t v = synth_rnd(seed, 3, first_read * read_len + g);
+        if ((v % 1000000ULL) < sub_ppm) code = (code + 1 + (uint32_t)((v >> 32) % 3)) & 3;
+        bases[g] = (uint8_t)("ACTG"[code]);
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n_reads; i += (uint64_t)gridDim.x * blockDim.x)
+        offsets[i] = i * read_len;
+}
+
+// ------------------------------------------------------------------------------------------------ independent checksum
+// one thread per read, plain rolling canonical k-mer (no minimizers, no buckets, no sort)
+template <int KW>
+__global__ void k_kmer_checksum(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint64_t n_reads, uint32_t k,
+                                unsigned long long* __restrict__ out)
+{
+    typedef typename KeyT<KW>::type key_t;
+    uint64_t cs = 0, nv = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = offsets[r], e = offsets[r + 1];
+        const key_t mask = KeyT<KW>::mask(k);
+        key_t fw = 0, rv = 0; uint32_t good = 0;
+        for (uint64_t g = b; g < e; g++) {
+            const uint32_t c = bases[g];
+            if (nt_valid(c)) {
+                const uint32_t code = nt_code(c);
+                fw = ((fw << 2) | (key_t)code) & mask;
+                rv = (rv >> 2) | ((key_t)(code ^ 2u) << (2 * (k - 1)));
+                good++;
+            } else { good = 0; fw = 0; rv = 0; }
+            if (good >= k) { cs += KeyT<KW>::mixv(fw < rv ? fw : rv); nv++; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { cs += __shfl_down(cs, d, 64); nv += __shfl_down(nv, d, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], (unsigned long long)cs); atomicAdd(&out[1], (unsigned long long)nv); }
+}
+
+static void free_pass_outputs(gkc_ctx* c, uint32_t pass)
+{
+    auto it = c->pass_outputs.find(pass);
+    if (it == c->pass_outputs.end()) return;
+    for (void* p : it->second) (void)hipFree(p);
+    c->pass_outputs.erase(it);
+}
+static void clear_segments(gkc_ctx* c)
+{
+    for (void* p : c->owned_arenas) (void)hipFree(p);
+    c->owned_arenas.clear(); c->segments.clear();
+}
+
+extern "C" {
+
+const char* gkc_version(void) { return "gkc-hip 0.1 (gfx950)"; }
+
+int gkc_create(int device, gkc_ctx** out)
+{
+    if (!out) return GKC_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = std::string("no HIP device: ") + hipGetErrorString(e); return GKC_ERR_NODEVICE; }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return GKC_ERR_ARG; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return GKC_ERR_HIP; }
+    gkc_ctx* c = new gkc_ctx();
+    c->device = device;
+    if ((e = hipStreamCreate(&c->stream)) != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return GKC_ERR_HIP; }
+    *out = c;
+    return GKC_OK;
+}
+
+void gkc_destroy(gkc_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    clear_segments(c);
+    std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first);
+    for (uint32_t p : passes) free_pass_outputs(c, p);
+    c->d_mkey_lut.release(); c->d_key2val.release(); c->d_repart.release(); c->d_histo.release();
+    c->d_scan_counters.release(); c->d_rsbits.release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* gkc_last_error(const gkc_ctx* c) { return c ? c->err.msg.c_str() : g_create_error.c_str(); }
+
+int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, uint32_t nb_passes,
+                  int minimizer_type, const uint16_t* repart, const uint32_t* freq_order)
+{
+    if (!c) return GKC_ERR_ARG;
+    GKC_HIP(c, hipSetDevice(c->device));
+    if (k <= 2) GKC_FAIL(c, GKC_ERR_ARG, "kmer size %u too small (SortingCountAlgorithm.cpp:662-666 refuses k<=2)", k);
+    if (k > 63) GKC_FAIL(c, GKC_ERR_ARG, "kmer size %u not supported (this build covers spans 32 and 64: k<=63)", k);
+    if (m < 2 || m >= k || m > 14) GKC_FAIL(c, GKC_ERR_ARG, "minimizer size %u invalid for k=%u (need 2 <= m <= min(k-1,14))", m, k);
+    if (nb_partitions < 1 || nb_partitions > 65535) GKC_FAIL(c, GKC_ERR_ARG, "nb_partitions must be in [1,65535] (Repartitor::Value is u16, PartiInfo.hpp:297)");
+    if (nb_passes < 1) GKC_FAIL(c, GKC_ERR_ARG, "nb_passes must be >= 1");
+    if (!repart) GKC_FAIL(c, GKC_ERR_ARG, "repart table is required");
+    if (minimizer_type != GKC_MINIMIZER_LEXI && minimizer_type != GKC_MINIMIZER_FREQ) GKC_FAIL(c, GKC_ERR_ARG, "bad minimizer_type");
+    if (minimizer_type == GKC_MINIMIZER_FREQ && !freq_order) GKC_FAIL(c, GKC_ERR_ARG, "frequency order requires freq_order[4^m]");
+    const uint64_t nm = 1ULL << (2 * m);
+    for (uint64_t i = 0; i < nm; i++) if (repart[i] >= nb_partitions) GKC_FAIL(c, GKC_ERR_ARG, "repart[%llu]=%u >= nb_partitions", (unsigned long long)i, repart[i]);
+
+    (void)hipStreamSynchronize(c->stream);
+    clear_segments(c);
+    { std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first); for (uint32_t p : passes) free_pass_outputs(c, p); }
+    c->k = k; c->m = m; c->nb_partitions = nb_partitions; c->nb_passes = nb_passes; c->minimizer_type = minimizer_type;
+    c->key_words = k <= 31 ? 1 : 2; c->record_bytes = k <= 31 ? 16 : 32;
+    const uint32_t def = k <= 31 ? 28 : 60;                      // min((8*sizeof(Type)-8)/2, 255), Sequence2SuperKmer.hpp:147
+    if (c->maxs == 0 || c->maxs > def) c->maxs = def;
+    c->datasets.assign((size_t)nb_partitions * nb_passes, Dataset());
+    c->pass_stats.assign(nb_passes, gkc_stats{}); c->pass = 0; c->timing.clear(); c->in_pass = false;
+
+    GKC_TRY(c->ensure(c->d_repart, nm * 2));
+    GKC_HIP(c, hipMemcpy(c->d_repart.p, repart, nm * 2, hipMemcpyHostToDevice));
+    if (minimizer_type == GKC_MINIMIZER_FREQ) {
+        // order keys: dense rank of canonical m-mers (and of the default 4^m-1) under (freq_order[c], c)   (Model.hpp:957-973)
+        auto revm = [&](uint32_t x) { uint32_t r = 0; for (uint32_t i = 0; i < m; i++) { r = (r << 2) | ((x & 3) ^ 2); x >>= 2; } return r; };
+        std::vector<uint32_t> canon(nm), cand;
+        cand.reserve(nm / 2 + 2);
+        for (uint64_t x = 0; x < nm; x++) { uint32_t r = revm((uint32_t)x); canon[x] = r < x ? r : (uint32_t)x; if (canon[x] == x) cand.push_back((uint32_t)x); }
+        const uint32_t defv = (uint32_t)(nm - 1);
+        if (canon[defv] != defv) cand.push_back(defv);
+        std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return freq_order[a] != freq_order[b] ? freq_order[a] < freq_order[b] : a < b; });
+        std::vector<uint32_t> rank(nm, 0), key2val(nm, defv), lut(nm);
+        for (uint32_t i = 0; i < cand.size(); i++) { rank[cand[i]] = i; key2val[i] = cand[i]; }
+        for (uint64_t x = 0; x < nm; x++) lut[x] = rank[canon[x]];
+        c->default_key = rank[defv];
+        GKC_TRY(c->ensure(c->d_mkey_lut, nm * 4)); GKC_TRY(c->ensure(c->d_key2val, nm * 4));
+        GKC_HIP(c, hipMemcpy(c->d_mkey_lut.p, lut.data(), nm * 4, hipMemcpyHostToDevice));
+        GKC_HIP(c, hipMemcpy(c->d_key2val.p, key2val.data(), nm * 4, hipMemcpyHostToDevice));
+    } else {
+        c->default_key = (uint32_t)(nm - 1);
+    }
+    GKC_TRY(c->ensure(c->d_histo, ((size_t)c->histo_max + 1) * 8));
+    GKC_HIP(c, hipMemset(c->d_histo.p, 0, ((size_t)c->histo_max + 1) * 8));
+    c->configured = true;
+    return GKC_OK;
+}
+
+int gkc_set_solidity(gkc_ctx* c, int32_t amin, int32_t amax, uint32_t histo_max)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (amin > amax) GKC_FAIL(c, GKC_ERR_ARG, "abundance_min > abundance_max");
+    if (histo_max < 1 || histo_max > (1u << 24)) GKC_FAIL(c, GKC_ERR_ARG, "histo_max out of range");
+    c->amin = amin; c->amax = amax;
+    if (histo_max != c->histo_max || !c->d_histo.p) {
+        c->histo_max = histo_max;
+        c->d_histo.release();
+        GKC_TRY(c->ensure(c->d_histo, ((size_t)histo_max + 1) * 8));
+        GKC_HIP(c, hipMemset(c->d_histo.p, 0, ((size_t)histo_max + 1) * 8));
+    }
+    return GKC_OK;
+}
+
+int gkc_set_max_superkmer(gkc_ctx* c, uint32_t maxs)
+{
+    if (!c) return GKC_ERR_ARG;
+    c->maxs = maxs;
+    if (c->configured) { const uint32_t def = c->k <= 31 ? 28 : 60; if (c->maxs == 0 || c->maxs > def) c->maxs = def; }
+    return GKC_OK;
+}
+
+int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "gkc_configure must be called first");
+    if (pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "pass %u >= nb_passes %u", pass, c->nb_passes);
+    GKC_HIP(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    clear_segments(c);
+    free_pass_outputs(c, pass);
+    for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
+    c->pass_stats[pass] = gkc_stats{};
+    if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
+    c->pass = pass; c->in_pass = true;
+    return GKC_OK;
+}
+
+int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
+    if (((uintptr_t)d_bases & 15) != 0) GKC_FAIL(c, GKC_ERR_ARG, "d_bases must be 16-byte aligned");
+    GKC_HIP(c, hipSetDevice(c->device));
+    ScopedTimer tm(c, "total_stage_a");
+    return gkc_scan_push(c, d_bases, d_offsets, n_reads, n_bases);
+}
+
+int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
+    if (!offsets) GKC_FAIL(c, GKC_ERR_ARG, "offsets is required");
+    if (offsets[0] != 0) GKC_FAIL(c, GKC_ERR_ARG, "offsets[0] must be 0");
+    GKC_HIP(c, hipSetDevice(c->device));
+    const uint64_t n_bases = offsets[n_reads];
+    DevBuf db, dof;
+    GKC_TRY(c->ensure(db, (size_t)n_bases + 64));
+    int rc = c->ensure(dof, (size_t)(n_reads + 1) * 8);
+    if (rc != GKC_OK) { db.release(); return rc; }
+    hipError_t e = hipSuccess;
+    if (n_bases) e = hipMemcpyAsync(db.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dof.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { db.release(); dof.release(); GKC_FAIL(c, GKC_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e)); }
+    rc = gkc_push_reads_device(c, (const char*)db.p, (const uint64_t*)dof.p, n_reads, n_bases);
+    (void)hipStreamSynchronize(c->stream);
+    db.release(); dof.release();
+    return rc;
+}
+
+int gkc_finish_pass(gkc_ctx* c)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
+    GKC_HIP(c, hipSetDevice(c->device));
+    int rc;
+    {   ScopedTimer tm(c, "total_stage_b");
+        rc = gkc_count_pass(c);
+    }
+    if (rc != GKC_OK) return rc;
+    c->in_pass = false;
+    return GKC_OK;
+}
+
+static int dataset_of(gkc_ctx* c, uint32_t pass, uint32_t part, Dataset** D)
+{
+    if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "not configured");
+    if (pass >= c->nb_passes || part >= c->nb_partitions) GKC_FAIL(c, GKC_ERR_ARG, "dataset (%u,%u) out of range", pass, part);
+    *D = &c->datasets[(size_t)pass * c->nb_partitions + part];
+    if (!(*D)->done) GKC_FAIL(c, GKC_ERR_ARG, "dataset (%u,%u) not counted yet", pass, part);
+    return GKC_OK;
+}
+
+int gkc_partition_info(gkc_ctx* c, uint32_t pass, uint32_t part, uint64_t* n_solid, uint64_t* n_distinct, uint64_t* n_kmers)
+{
+    if (!c) return GKC_ERR_ARG;
+    Dataset* D; GKC_TRY(dataset_of(c, pass, part, &D));
+    if (n_solid) *n_solid = D->n_solid;  if (n_distinct) *n_distinct = D->n_distinct;  if (n_kmers) *n_kmers = D->n_kmers;
+    return GKC_OK;
+}
+int gkc_partition_counts(gkc_ctx* c, uint32_t pass, uint32_t part, void* out, uint64_t cap, uint64_t* n_solid)
+{
+    if (!c) return GKC_ERR_ARG;
+    Dataset* D; GKC_TRY(dataset_of(c, pass, part, &D));
+    if (n_solid) *n_solid = D->n_solid;
+    if (cap < D->n_solid) GKC_FAIL(c, GKC_ERR_CAPACITY, "dataset holds %llu records, buffer %llu", (unsigned long long)D->n_solid, (unsigned long long)cap);
+    if (D->n_solid) {
+        GKC_HIP(c, hipMemcpyAsync(out, D->d_counts, (size_t)D->n_solid * (c->key_words == 1 ? 16 : 32), hipMemcpyDeviceToHost, c->stream));
+        GKC_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return GKC_OK;
+}
+int gkc_partition_counts_device(gkc_ctx* c, uint32_t pass, uint32_t part, const void** d_counts, uint64_t* n_solid)
+{
+    if (!c) return GKC_ERR_ARG;
+    Dataset* D; GKC_TRY(dataset_of(c, pass, part, &D));
+    if (d_counts) *d_counts = D->d_counts;  if (n_solid) *n_solid = D->n_solid;
+    return GKC_OK;
+}
+int gkc_histogram(gkc_ctx* c, uint64_t* out, uint32_t n_bins)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (n_bins < c->histo_max + 1) GKC_FAIL(c, GKC_ERR_CAPACITY, "histogram has %u bins", c->histo_max + 1);
+    GKC_HIP(c, hipMemcpyAsync(out, c->d_histo.p, ((size_t)c->histo_max + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    return GKC_OK;
+}
+int gkc_get_stats(gkc_ctx* c, gkc_stats* out)
+{
+    if (!c || !out) return GKC_ERR_ARG;
+    gkc_stats t{};
+    for (size_t p = 0; p < c->pass_stats.size(); p++) {
+        const gkc_stats& S = c->pass_stats[p];
+        if (p == 0) { t.kmers_nb_valid = S.kmers_nb_valid; t.kmers_nb_invalid = S.kmers_nb_invalid; t.nb_sequences = S.nb_sequences; t.nb_bases = S.nb_bases; }
+        t.kmers_nb_distinct += S.kmers_nb_distinct; t.kmers_nb_solid += S.kmers_nb_solid; t.nb_superkmers += S.nb_superkmers;
+        t.superkmer_bytes += S.superkmer_bytes; t.oversize_buckets += S.oversize_buckets;
+    }
+    *out = t;
+    return GKC_OK;
+}
+int gkc_get_timing(gkc_ctx* c, const char* name, double* ms, uint64_t* launches)
+{
+    if (!c || !name) return GKC_ERR_ARG;
+    auto it = c->timing.find(name);
+    if (ms) *ms = it == c->timing.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->timing.end() ? 0 : it->second.launches;
+    return GKC_OK;
+}
+
+int gkc_partition_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* n_bytes, uint64_t* n_sk, uint64_t* n_k)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->configured || part >= c->nb_partitions) GKC_FAIL(c, GKC_ERR_ARG, "bad partition");
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    uint64_t a = 0, b = 0, d = 0;
+    GKC_TRY(gkc_export_superkmers(c, part, out, cap, &a, &b, &d));
+    if (n_bytes) *n_bytes = a;  if (n_sk) *n_sk = b;  if (n_k) *n_k = d;
+    return GKC_OK;
+}
+
+int gkc_segment_count(gkc_ctx* c, uint32_t* n) { if (!c || !n) return GKC_ERR_ARG; *n = (uint32_t)c->segments.size(); return GKC_OK; }
+int gkc_segment_export(gkc_ctx* c, uint32_t seg, const void** d_records, uint32_t* record_bytes, uint64_t* rec_offsets, uint64_t* kmers)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (seg >= c->segments.size()) GKC_FAIL(c, GKC_ERR_ARG, "segment %u out of range", seg);
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    const Segment& s = c->segments[seg];
+    if (d_records) *d_records = s.d_records;  if (record_bytes) *record_bytes = c->record_bytes;
+    if (rec_offsets) memcpy(rec_offsets, s.rec_off.data(), (size_t)(c->nb_partitions + 1) * 8);
+    if (kmers) memcpy(kmers, s.nkmers.data(), (size_t)c->nb_partitions * 8);
+    return GKC_OK;
+}
+int gkc_segment_import(gkc_ctx* c, const void* d_records, const uint64_t* rec_offsets, const uint64_t* kmers)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
+    if (!rec_offsets || !kmers) GKC_FAIL(c, GKC_ERR_ARG, "offset / k-mer tables are required");
+    Segment s; s.d_records = d_records; s.owned = false;
+    s.rec_off.assign(rec_offsets, rec_offsets + c->nb_partitions + 1);
+    s.nkmers.assign(kmers, kmers + c->nb_partitions);
+    c->segments.push_back(std::move(s));
+    return GKC_OK;
+}
+int gkc_segments_clear(gkc_ctx* c) { if (!c) return GKC_ERR_ARG; (void)hipStreamSynchronize(c->stream); clear_segments(c); return GKC_OK; }
+
+int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len,
+                           uint32_t sub_ppm, char** d_bases, uint64_t** d_offsets)
+{
+    if (!c || !d_bases || !d_offsets) return GKC_ERR_ARG;
+    if (read_len == 0 || genome_len < read_len) GKC_FAIL(c, GKC_ERR_ARG, "genome_len must be >= read_len > 0");
+    GKC_HIP(c, hipSetDevice(c->device));
+    void *b = nullptr, *o = nullptr;
+    const size_t nb = (size_t)n_reads * read_len;
+    if (hipMalloc(&b, nb + 64) != hipSuccess) GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of %zu bases failed", nb);
+    if (hipMalloc(&o, (size_t)(n_reads + 1) * 8) != hipSuccess) { (void)hipFree(b); GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of offsets failed"); }
+    const unsigned grid = (unsigned)std::min<uint64_t>((nb + 255) / 256 + 1, 256 * 32);
+    hipLaunchKernelGGL(k_synth_reads, dim3(grid), dim3(256), 0, c->stream, seed, first_read, n_reads, read_len, genome_len, sub_ppm, (uint8_t*)b, (uint64_t*)o);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(b); (void)hipFree(o); GKC_FAIL(c, GKC_ERR_HIP, "synth kernel failed: %s", hipGetErrorString(e)); }
+    *d_bases = (char*)b; *d_offsets = (uint64_t*)o;
+    return GKC_OK;
+}
+int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) GKC_HIP(c, hipFree(p)); return GKC_OK; }
+int gkc_device_to_host(gkc_ctx* c, void* dst, const void* src, uint64_t n)
+{
+    if (!c) return GKC_ERR_ARG;
+    GKC_HIP(c, hipMemcpy(dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    return GKC_OK;
+}
+
+int gkc_kmer_checksum_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
+                             uint64_t* checksum, uint64_t* n_valid)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "not configured");
+    (void)n_bases;
+    DevBuf d; GKC_TRY(c->ensure(d, 16));
+    GKC_HIP(c, hipMemsetAsync(d.p, 0, 16, c->stream));
+    const unsigned grid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256 + 1, 256 * 64);
+    if (c->key_words == 1) hipLaunchKernelGGL((k_kmer_checksum<1>), dim3(grid), dim3(256), 0, c->stream, (const uint8_t*)d_bases, d_offsets, n_reads, c->k, (unsigned long long*)d.p);
+    else                   hipLaunchKernelGGL((k_kmer_checksum<2>), dim3(grid), dim3(256), 0, c->stream, (const uint8_t*)d_bases, d_offsets, n_reads, c->k, (unsigned long long*)d.p);
+    uint64_t h[2] = {0, 0};
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "checksum kernel failed: %s", hipGetErrorString(e));
+    if (checksum) *checksum = h[0];  if (n_valid) *n_valid = h[1];
+    return GKC_OK;
+}
+int gkc_result_checksum(gkc_ctx* c, uint64_t* checksum, uint64_t* sum_abundance)
+{
+    if (!c || !checksum || !sum_abundance) return GKC_ERR_ARG;
+    return gkc_result_checksum_impl(c, checksum, sum_abundance);
+}
+
+}  // extern "C"

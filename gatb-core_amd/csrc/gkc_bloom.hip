@@ -1,0 +1,267 @@
+// gkc_bloom.hip — Bloom filter of solid k-mers on gfx950 (insert / contains / contains8), bit-identical arrays.
+//
+// Replaces (reference, /root/reference/gatb-core/src/gatb/tools/collections/impl/Bloom.hpp):
+//   C1 HashFunctors seeds + hash1                 :59-98   (+ tools/math/LargeInt1.pri:157-170, LargeInt2.pri:200-206)
+//      simplehash16 (3-term 64-bit / 2-term 128-bit)        tools/math/LargeInt1.pri:190-211, NativeInt64.hpp:210-221
+//   C2 BloomSynchronized::insert / BloomContainer::contains :394-412, 211-234   ("basic")
+//   C3 BloomCacheCoherent::insert/contains                   :437-490            ("cache")
+//   C4 BloomNeighborCoherent::insert/contains/contains4/8    :555-828            ("neighbor")
+// Bits are set with 32-bit atomic OR on the little-endian word holding the byte (same bytes as __sync_fetch_and_or on
+// the u8 array). One thread per k-mer, grid-stride; the bitset (~11 bits per solid k-mer) is the only HBM traffic.
+#include "gkc_common.hpp"
+#include "gkc_device.hpp"
+
+__constant__ uint64_t c_random_values[256] = {
+#include "../../include/gkc_random_values.inc"
+};
+
+struct gkc_bloom {
+    gkc_ctx* ctx;
+    int kind; uint32_t nb_hash, k; int wide;
+    uint64_t tai, nchar, reduced_tai; int pow2;
+    uint64_t seeds[10];
+    DevBuf bits;
+};
+
+struct BloomParams {
+    uint32_t* words; int kind; uint32_t nb_hash, k; int wide, pow2;
+    uint64_t tai, reduced_tai; uint64_t seeds[10];
+};
+
+__device__ __forceinline__ uint64_t simplehash16_dev(uint64_t key_lo, int shift, int wide)
+{
+    uint64_t in = key_lo >> shift;
+    uint64_t r = c_random_values[in & 255];
+    in >>= 8;
+    r ^= c_random_values[in & 255];
+    if (!wide) r ^= c_random_values[key_lo & 255];      // LargeInt<1> adds the low byte; NativeInt64/LargeInt<2> do not
+    return r;
+}
+__device__ __forceinline__ uint64_t hash1_dev(u128 x, uint64_t seed, int wide)
+{
+    return wide ? (hash64((uint64_t)(x >> 64), seed) ^ hash64((uint64_t)x, seed)) : hash64((uint64_t)x, seed);
+}
+__device__ __forceinline__ u128 load_key(const uint8_t* p, int wide)
+{
+    uint64_t lo = *reinterpret_cast<const uint64_t*>(p);
+    uint64_t hi = wide ? *reinterpret_cast<const uint64_t*>(p + 8) : 0;
+    return ((u128)hi << 64) | lo;
+}
+__device__ __forceinline__ u128 kmask128(uint32_t k) { return (((u128)1) << (2 * k)) - 1; }
+
+__device__ const uint32_t d_cano2[16] = { 0, 1, 2, 3, 4, 5, 3, 7, 8, 9, 0, 4, 9, 13, 1, 5 };
+
+// canonical (k-2)-mer core + base bit position of the neighbor-coherent layout
+__device__ __forceinline__ void neighbor_root(const BloomParams& B, u128 x, u128& core, uint64_t& racine)
+{
+    const uint32_t k = B.k;
+    core = (x >> 2) & kmask128(k - 2);
+    u128 rv = revcomp128(core, k - 2);
+    if (rv < core) core = rv;
+    racine = hash1_dev(core, B.seeds[0], B.wide) % B.reduced_tai;
+}
+
+// bit positions of item x -> pos[0..nb_hash)
+__device__ __forceinline__ void bloom_positions(const BloomParams& B, u128 x, uint64_t* pos)
+{
+    if (B.kind == 0) {
+        for (uint32_t i = 0; i < B.nb_hash; i++) {
+            uint64_t h = hash1_dev(x, B.seeds[i], B.wide);
+            pos[i] = B.pow2 ? (h & B.tai) : (h % B.tai);
+        }
+    } else if (B.kind == 1) {
+        uint64_t h0 = hash1_dev(x, B.seeds[0], B.wide) % B.reduced_tai;
+        pos[0] = h0;
+        for (uint32_t i = 1; i < B.nb_hash; i++) pos[i] = h0 + (simplehash16_dev((uint64_t)x, (int)i, B.wide) & 4095);
+    } else {
+        const uint32_t k = B.k;
+        const uint32_t suffix = (uint32_t)x & 3u, prefix = ((uint32_t)(x >> (2 * (k - 1))) & 3u) << 2;
+        u128 core; uint64_t racine;
+        neighbor_root(B, x, core, racine);
+        uint64_t h0 = racine + d_cano2[(prefix + suffix) & 15];
+        pos[0] = h0;
+        for (uint32_t i = 1; i < B.nb_hash; i++) pos[i] = h0 + (simplehash16_dev((uint64_t)core, (int)i, B.wide) & 4095);
+    }
+}
+__device__ __forceinline__ bool test_bit(const uint32_t* w, uint64_t h) { return (w[h >> 5] >> (h & 31)) & 1u; }
+
+__global__ void k_bloom_insert(BloomParams B, const uint8_t* __restrict__ keys, uint64_t n, uint32_t stride)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        u128 x = load_key(keys + i * stride, B.wide);
+        uint64_t pos[20];
+        bloom_positions(B, x, pos);
+        for (uint32_t j = 0; j < B.nb_hash; j++) atomicOr(&B.words[pos[j] >> 5], 1u << (pos[j] & 31));
+    }
+}
+__global__ void k_bloom_contains(BloomParams B, const uint8_t* __restrict__ keys, uint64_t n, uint32_t stride, uint8_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        u128 x = load_key(keys + i * stride, B.wide);
+        uint64_t pos[20];
+        bloom_positions(B, x, pos);
+        bool ok = true;
+        for (uint32_t j = 0; j < B.nb_hash; j++) ok = ok && test_bit(B.words, pos[j]);
+        out[i] = ok;
+    }
+}
+// contains8 (Bloom.hpp:645-811): bits 0-3 = right extensions ((x<<2)|j)&mask, bits 4-7 = left extensions (x>>2)|(j<<2(k-1)),
+// j = A,C,T,G. The four neighbours of one side share the canonical (k-2)-mer core, hence one hash1 and one block.
+__global__ void k_bloom_contains8(BloomParams B, const uint8_t* __restrict__ keys, uint64_t n, uint32_t stride, uint8_t* __restrict__ out)
+{
+    const uint32_t k = B.k;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        u128 x = load_key(keys + i * stride, B.wide);
+        uint32_t res = 0;
+        for (int side = 0; side < 2; side++) {
+            const u128 elem = side == 0 ? ((x << 2) & kmask128(k)) : (x >> 2);
+            u128 core; uint64_t racine;
+            neighbor_root(B, elem, core, racine);
+            uint64_t tab[20];
+            for (uint32_t h = 1; h < B.nb_hash; h++) tab[h] = simplehash16_dev((uint64_t)core, (int)h, B.wide) & 4095;
+            for (uint32_t j = 0; j < 4; j++) {
+                uint32_t pre, suf;
+                if (side == 0) { pre = ((uint32_t)(elem >> (2 * (k - 1))) & 3u) << 2; suf = j; }
+                else { pre = j << 2; suf = (uint32_t)elem & 3u; }
+                const uint64_t h0 = racine + d_cano2[(pre + suf) & 15];
+                bool ok = test_bit(B.words, h0);
+                for (uint32_t h = 1; ok && h < B.nb_hash; h++) ok = test_bit(B.words, h0 + tab[h]);
+                res |= (uint32_t)ok << (4 * side + j);
+            }
+        }
+        out[i] = (uint8_t)res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C-ABI
+static BloomParams params_of(const gkc_bloom* b)
+{
+    BloomParams P{};
+    P.words = (uint32_t*)b->bits.p; P.kind = b->kind; P.nb_hash = b->nb_hash; P.k = b->k; P.wide = b->wide; P.pow2 = b->pow2;
+    P.tai = b->tai; P.reduced_tai = b->reduced_tai; memcpy(P.seeds, b->seeds, sizeof(P.seeds));
+    return P;
+}
+
+extern "C" {
+
+int gkc_bloom_create(gkc_ctx* c, int kind, uint64_t tai_bits, uint32_t nb_hash, uint32_t k, gkc_bloom** out)
+{
+    if (!c || !out) return GKC_ERR_ARG;
+    if (kind < 0 || kind > 2) GKC_FAIL(c, GKC_ERR_ARG, "bloom kind must be 0 (basic), 1 (cache) or 2 (neighbor)");
+    if (nb_hash < 1 || nb_hash > 10) GKC_FAIL(c, GKC_ERR_ARG, "nb_hash must be in [1,10] (HashFunctors holds 10 seeds, Bloom.hpp:94)");
+    if (k < 3 || k > 63) GKC_FAIL(c, GKC_ERR_ARG, "k must be in [3,63]");
+    if (tai_bits == 0) GKC_FAIL(c, GKC_ERR_ARG, "bloom size must be > 0");
+    gkc_bloom* b = new gkc_bloom();
+    b->ctx = c; b->kind = kind; b->nb_hash = nb_hash; b->k = k; b->wide = k > 31;
+    uint64_t tai = tai_bits;
+    if (kind != 0) tai += 2 * 4096;                        // BloomCacheCoherent ctor (Bloom.hpp:437-441)
+    b->nchar = 1 + tai / 8;                                // BloomContainer ctor (Bloom.hpp:185-198)
+    b->pow2 = (tai && !(tai & (tai - 1)));
+    if (b->pow2) tai--;
+    b->tai = tai;
+    b->reduced_tai = kind != 0 ? tai - 2 * 4096 : tai;
+    static const uint64_t rbase[10] = {
+        0xAAAAAAAA55555555ULL, 0x33333333CCCCCCCCULL, 0x6666666699999999ULL, 0xB5B5B5B54B4B4B4BULL, 0xAA55AA5555335533ULL,
+        0x33CC33CCCC66CC66ULL, 0x6699669999B599B5ULL, 0xB54BB54B4BAA4BAAULL, 0xAA33AA3355CC55CCULL, 0x33663366CC99CC99ULL };
+    for (int i = 0; i < 10; i++) b->seeds[i] = rbase[i];
+    for (int i = 0; i < 10; i++) b->seeds[i] = b->seeds[i] * b->seeds[(i + 3) % 10] + 0;   // user_seed = 0, in place (Bloom.hpp:80-91)
+    const size_t bytes = (size_t)((b->nchar + 3) / 4 * 4 + 8);
+    int rc = c->ensure(b->bits, bytes);
+    if (rc != GKC_OK) { delete b; return rc; }
+    if (hipMemsetAsync(b->bits.p, 0, bytes, c->stream) != hipSuccess) { b->bits.release(); delete b; GKC_FAIL(c, GKC_ERR_HIP, "memset failed"); }
+    *out = b;
+    return GKC_OK;
+}
+void gkc_bloom_destroy(gkc_bloom* b) { if (b) { b->bits.release(); delete b; } }
+uint64_t gkc_bloom_nbytes(const gkc_bloom* b) { return b ? b->nchar : 0; }
+uint64_t gkc_bloom_bitsize(const gkc_bloom* b) { return b ? (b->kind == 0 ? b->tai : b->reduced_tai) : 0; }
+
+static int check_stride(gkc_bloom* b, uint32_t stride)
+{
+    const uint32_t need = b->wide ? 16 : 8;
+    if (stride < need || (stride % 8) != 0) { b->ctx->set_error(GKC_ERR_ARG, "stride %u invalid for k=%u (need a multiple of 8, >= %u)", stride, b->k, need); return GKC_ERR_ARG; }
+    return GKC_OK;
+}
+
+int gkc_bloom_insert_device(gkc_bloom* b, const void* d_keys, uint64_t n, uint32_t stride)
+{
+    if (!b) return GKC_ERR_ARG;
+    gkc_ctx* c = b->ctx;
+    GKC_TRY(check_stride(b, stride));
+    if (!n) return GKC_OK;
+    ScopedTimer tm(c, "bloom_insert");
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_bloom_insert, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d_keys, n, stride);
+    GKC_HIP(c, hipGetLastError());
+    return GKC_OK;
+}
+int gkc_bloom_insert(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride)
+{
+    if (!b) return GKC_ERR_ARG;
+    gkc_ctx* c = b->ctx;
+    GKC_TRY(check_stride(b, stride));
+    if (!n) return GKC_OK;
+    DevBuf d; GKC_TRY(c->ensure(d, (size_t)n * stride));
+    hipError_t e = hipMemcpyAsync(d.p, keys, (size_t)n * stride, hipMemcpyHostToDevice, c->stream);
+    int rc = (e == hipSuccess) ? gkc_bloom_insert_device(b, d.p, n, stride) : GKC_ERR_HIP;
+    (void)hipStreamSynchronize(c->stream);
+    d.release();
+    if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e));
+    return rc;
+}
+int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* c)
+{
+    if (!b || !c) return GKC_ERR_ARG;
+    if (c->k != b->k) GKC_FAIL(c, GKC_ERR_ARG, "bloom k (%u) differs from the context's k (%u)", b->k, c->k);
+    for (const Dataset& D : c->datasets)
+        if (D.done && D.n_solid) GKC_TRY(gkc_bloom_insert_device(b, D.d_counts, D.n_solid, c->key_words == 1 ? 16 : 32));
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    return GKC_OK;
+}
+static int bloom_query(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out, bool c8)
+{
+    if (!b) return GKC_ERR_ARG;
+    gkc_ctx* c = b->ctx;
+    GKC_TRY(check_stride(b, stride));
+    if (c8 && b->kind != 2) GKC_FAIL(c, GKC_ERR_ARG, "contains8 is implemented by the neighbor kind only (Bloom.hpp:245-250 throws ExceptionNotImplemented)");
+    if (!n) return GKC_OK;
+    DevBuf d, o; GKC_TRY(c->ensure(d, (size_t)n * stride));
+    int rc = c->ensure(o, (size_t)n);
+    if (rc != GKC_OK) { d.release(); return rc; }
+    hipError_t e = hipMemcpyAsync(d.p, keys, (size_t)n * stride, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        ScopedTimer tm(c, c8 ? "bloom_contains8" : "bloom_contains");
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+        if (c8) hipLaunchKernelGGL(k_bloom_contains8, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d.p, n, stride, (uint8_t*)o.p);
+        else    hipLaunchKernelGGL(k_bloom_contains, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d.p, n, stride, (uint8_t*)o.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, o.p, (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release(); o.release();
+    if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "bloom query failed: %s", hipGetErrorString(e));
+    return GKC_OK;
+}
+int gkc_bloom_contains(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out) { return bloom_query(b, keys, n, stride, out, false); }
+int gkc_bloom_contains8(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out) { return bloom_query(b, keys, n, stride, out, true); }
+
+int gkc_bloom_get_array(gkc_bloom* b, uint8_t* out, uint64_t cap)
+{
+    if (!b) return GKC_ERR_ARG;
+    gkc_ctx* c = b->ctx;
+    if (cap < b->nchar) GKC_FAIL(c, GKC_ERR_CAPACITY, "bloom array needs %llu bytes", (unsigned long long)b->nchar);
+    GKC_HIP(c, hipMemcpyAsync(out, b->bits.p, (size_t)b->nchar, hipMemcpyDeviceToHost, c->stream));
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    return GKC_OK;
+}
+int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes)
+{
+    if (!b) return GKC_ERR_ARG;
+    gkc_ctx* c = b->ctx;
+    if (n_bytes != b->nchar) GKC_FAIL(c, GKC_ERR_ARG, "bloom array must be %llu bytes", (unsigned long long)b->nchar);
+    GKC_HIP(c, hipMemcpyAsync(b->bits.p, in, (size_t)n_bytes, hipMemcpyHostToDevice, c->stream));
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    return GKC_OK;
+}
+
+}  // extern "C"

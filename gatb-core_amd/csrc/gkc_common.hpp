@@ -1,0 +1,124 @@
+// gkc_common.hpp — shared host-side state and device helpers of libgkc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/gkc.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+struct gkc_error { int code; std::string msg; };
+
+#define GKC_FAIL(ctx, code_, ...) do { (ctx)->set_error((code_), __VA_ARGS__); return (code_); } while (0)
+#define GKC_HIP(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    (ctx)->set_error(e_ == hipErrorOutOfMemory ? GKC_ERR_NOMEM : GKC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    return e_ == hipErrorOutOfMemory ? GKC_ERR_NOMEM : GKC_ERR_HIP; } } while (0)
+#define GKC_TRY(expr) do { int rc_ = (expr); if (rc_ != GKC_OK) return rc_; } while (0)
+
+// ------------------------------------------------------------------------------------------------ geometry
+// Stage A tile: one 256-thread workgroup scans TILE k-mer start positions (16 per thread) plus a halo.
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_PER_THREAD = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;      // 4096 positions
+constexpr int SCAN_HALO_WORDS = 4;                             // 64 bases of look-ahead (k<=63)
+constexpr int SCAN_WORDS = SCAN_TILE / 16 + SCAN_HALO_WORDS;   // 16-base words per tile
+
+// Stage B: a partition is split by key range into <= MAX_SUB sub-buckets, each sorted inside LDS.
+constexpr int MAX_SUB_BITS = 12;
+constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram / cursors: 16 KB
+constexpr int SORT_CAP_W1 = 4096;                              // keys per LDS sort, 8-byte keys (32 KB)
+constexpr int SORT_CAP_W2 = 2048;                              // keys per LDS sort, 16-byte keys (32 KB)
+constexpr int SUB_TARGET = 1024;                               // mean keys per sub-bucket the host aims at
+
+// ------------------------------------------------------------------------------------------------ device buffer
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+};
+
+// one bucketed batch of super-k-mer records (device analogue of SuperKmerBinFiles for one push)
+struct Segment {
+    const void* d_records = nullptr;     // arena, partition-major
+    bool owned = false;
+    std::vector<uint64_t> rec_off;       // [P+1] in records
+    std::vector<uint64_t> nkmers;        // [P]
+};
+
+struct Dataset {                          // result of (pass, part)
+    const void* d_counts = nullptr;       // Count records (points into a pass-level output buffer)
+    uint64_t n_solid = 0, n_distinct = 0, n_kmers = 0;
+    bool done = false;
+};
+
+struct Timing { double ms = 0; uint64_t launches = 0; };
+
+struct gkc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    gkc_error err{0, ""};
+    // model
+    bool configured = false;
+    uint32_t k = 0, m = 0, nb_partitions = 0, nb_passes = 1;
+    int minimizer_type = 0;
+    uint32_t maxs = 0;
+    uint32_t key_words = 1, record_bytes = 16;
+    int32_t amin = 1, amax = 2147483647; uint32_t histo_max = 10000;
+    // device tables
+    DevBuf d_mkey_lut;      // u32[4^m] : m-mer (forward strand) -> order key (freq mode only)
+    DevBuf d_key2val;       // u32[4^m] : order key -> minimizer value (freq mode only)
+    DevBuf d_repart;        // u16[4^m] : minimizer value -> partition
+    uint32_t default_key = 0;   // order key of the default minimizer 4^m-1
+    // pass state
+    bool in_pass = false; uint32_t pass = 0;
+    std::vector<Segment> segments;
+    std::vector<void*> owned_arenas;
+    // results
+    std::vector<Dataset> datasets;                   // nb_passes * nb_partitions
+    std::map<uint32_t, std::vector<void*>> pass_outputs;   // pass -> output buffers
+    DevBuf d_histo;                                  // u64[histo_max+1]
+    std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them
+    gkc_stats& stats_now() { return pass_stats[pass]; }
+    std::map<std::string, Timing> timing;
+    // scratch reused across calls
+    DevBuf d_scan_counters;    // u64[2P + 8]
+    DevBuf d_rsbits;           // read-start bitmask
+    size_t key_budget = 0;     // max keys per Stage-B batch (0 = auto)
+
+    void set_error(int code, const char* fmt, ...) {
+        char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+        err.code = code; err.msg = buf;
+    }
+    int ensure(DevBuf& b, size_t bytes) {
+        if (b.bytes >= bytes && b.p) return GKC_OK;
+        b.release();
+        hipError_t e = hipMalloc(&b.p, bytes ? bytes : 16);
+        if (e != hipSuccess) { b.p = nullptr; set_error(GKC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GKC_ERR_NOMEM; }
+        b.bytes = bytes;
+        return GKC_OK;
+    }
+};
+
+// RAII event timer accumulating into ctx->timing[name]
+struct ScopedTimer {
+    gkc_ctx* c; const char* name; hipEvent_t a, b; bool on;
+    ScopedTimer(gkc_ctx* c_, const char* n) : c(c_), name(n), on(true) {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(b, c->stream); (void)hipEventSynchronize(b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        Timing& t = c->timing[name]; t.ms += ms; t.launches += 1;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ launchers (defined in the .hip files)
+int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases);
+int gkc_count_pass(gkc_ctx* c);
+int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk);

@@ -1,0 +1,418 @@
+// gkc_scan.hip — Stage A on gfx950: reads -> super-k-mer records bucketed by minimizer partition.
+//
+// Replaces (reference, under /root/reference/gatb-core/src/gatb/):
+//   A1 Data::ConvertASCII                      tools/misc/api/Data.hpp:185
+//   A2 validity window of ModelAbstract::iterate kmer/impl/Model.hpp:749-759
+//   A3 ModelMinimizer LUT / next / rescan       kmer/impl/Model.hpp:1032-1064, 1107-1139, 1254-1287
+//   A4 Sequence2SuperKmer + KmerFunctor         kmer/impl/Sequence2SuperKmer.hpp:81-159
+//   A5 FillPartitions::processSuperkmer         kmer/impl/SortingCountAlgorithm.cpp:1081-1151
+//   A6 SuperKmer::save + SuperKmerBinFiles      kmer/impl/Model.hpp:1386-1471, tools/storage/impl/Storage.cpp:360-580
+//
+// MI355X design (not a translation of the per-thread rolling loop of the reference):
+//   * one 256-thread workgroup per tile of 4096 k-mer start positions; ASCII is read once with coalesced 16-byte loads
+//     and turned into three bit-planes in LDS (big-endian 2-bit, little-endian 2-bit, invalid mask);
+//   * the minimizer order key of every m-mer is computed position-parallel (lexicographic/KMC2 order: pure ALU, the
+//     reverse complement comes from the little-endian plane for free; frequency order: one 4-byte gather from an
+//     L2-resident table) and written to LDS; the window minimum of k-m+1 keys uses a shared-core + prefix/suffix-min
+//     scheme, ~3 LDS reads per k-mer instead of k-m+1;
+//   * super-k-mer boundaries come from one workgroup-wide max-scan (wave64 shuffles + 4 partials in LDS); records are
+//     emitted at run ENDS so a single forward scan suffices, including the length cap;
+//   * the k-mer integer itself is never formed here: a record is a 16/32-byte aligned copy of the 2-bit plane.
+//   The pass runs twice per batch (count, then emit at exact offsets): no bucket can overflow whatever the skew.
+#include "gkc_common.hpp"
+#include "gkc_device.hpp"
+
+struct ScanParams {
+    const uint8_t* bases; uint64_t n_bases;
+    const uint32_t* rsbits;
+    uint32_t k, m, nb_mm, maxs, mmask, mask_ma1;
+    int freq_mode;
+    const uint32_t* mkey_lut; const uint32_t* key2val; uint32_t default_key;
+    const uint16_t* repart; uint32_t nb_passes, pass;
+    unsigned long long* cnt_rec; unsigned long long* cnt_kmers; unsigned long long* cursor;
+    uint64_t* arena;
+    unsigned long long* gstats;   // [0] valid k-mers [1] invalid k-mers [2] records emitted/counted
+};
+
+// ------------------------------------------------------------------------------------------------
+// read-start bitmask: bit g set iff some read starts at base g, or g == n_bases (offsets[n_reads])
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_t n_entries, uint32_t* __restrict__ bits)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_entries) return;
+    uint64_t g = offsets[i];
+    atomicOr(&bits[g >> 5], 1u << (g & 31));
+}
+
+constexpr int BE_PAD = 12;   // zero words after the tile planes so record extraction may read past the halo
+
+template <bool EMIT, int RW>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
+{
+    __shared__ uint32_t s_be[SCAN_WORDS + BE_PAD];
+    __shared__ uint32_t s_le[SCAN_WORDS + BE_PAD];
+    __shared__ uint16_t s_bad[SCAN_WORDS + 8];
+    __shared__ uint32_t s_rs[SCAN_TILE / 32 + 8];
+    __shared__ uint32_t s_mk[SCAN_TILE + 16 * SCAN_HALO_WORDS + 16];
+    __shared__ uint32_t s_end[SCAN_TILE];
+    __shared__ uint32_t s_lastmz[SCAN_THREADS], s_firstmz[SCAN_THREADS + 1];
+    __shared__ uint8_t  s_lastvalid[SCAN_THREADS], s_firstvalid[SCAN_THREADS + 1];
+    __shared__ int      s_wavecarry[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_stat[3];
+
+    const int t = threadIdx.x;
+    const uint64_t t0 = (uint64_t)blockIdx.x * SCAN_TILE;
+    const uint32_t k = P.k, m = P.m;
+
+    if (t < 3) s_stat[t] = 0;
+    if (t < BE_PAD) { s_be[SCAN_WORDS + t] = 0; s_le[SCAN_WORDS + t] = 0; }
+    if (t < 8) s_bad[SCAN_WORDS + t] = 0;
+
+    // ---- step 0: ASCII -> bit planes (A1) ----
+    for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
+        uint64_t g0 = t0 + 16ull * w;
+        uint32_t dw[4];
+        if (g0 + 16 <= P.n_bases) {
+            uint4 v = *reinterpret_cast<const uint4*>(P.bases + g0);
+            dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    uint64_t g = g0 + 4 * q + b;
+                    uint32_t c = (g < P.n_bases) ? P.bases[g] : 0u;
+                    x |= c << (8 * b);
+                }
+                dw[q] = x;
+            }
+        }
+        uint32_t be = 0, le = 0, bad = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t c = (dw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            uint32_t code = nt_code(c);
+            be |= code << (30 - 2 * j);
+            le |= code << (2 * j);
+            bad |= (nt_valid(c) ^ 1u) << j;
+        }
+        s_be[w] = be; s_le[w] = le; s_bad[w] = (uint16_t)bad;
+    }
+    for (int i = t; i < SCAN_TILE / 32 + 8; i += SCAN_THREADS) s_rs[i] = P.rsbits[t0 / 32 + i];
+    __syncthreads();
+
+    // ---- step 1: order key of the m-mer starting at every position (A3: LUT semantics) ----
+    for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
+        uint64_t X = ((uint64_t)s_be[w] << 32) | s_be[w + 1];
+        uint64_t Y = (uint64_t)s_le[w] | ((uint64_t)s_le[w + 1] << 32);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t fw = (uint32_t)(X >> (64 - 2 * (j + m))) & P.mmask;
+            uint32_t key;
+            if (P.freq_mode) {
+                key = P.mkey_lut[fw];                         // order key of canonical(fw) under (freq_order[c], c)
+            } else {
+                uint32_t rc = ((uint32_t)(Y >> (2 * j)) & P.mmask) ^ (0xAAAAAAAAu & P.mmask);
+                uint32_t c = fw < rc ? fw : rc;               // canonical m-mer
+                uint32_t a = ~(c | (c >> 2));
+                a = (a >> 1) & a & P.mask_ma1;                // "AA" anywhere but as prefix (KMC2 rule)
+                key = a ? P.mmask : c;
+            }
+            s_mk[16 * w + j] = key;
+        }
+    }
+    __syncthreads();
+
+    // ---- step 2: minimizer = window minimum of nb_mm keys (always the true minimum: Model.hpp:1107-1139 keeps it by
+    //      rescanning whenever the tracked one leaves the window) ----
+    const int p0 = 16 * t;
+    const uint32_t Wn = P.nb_mm;
+    uint32_t mz[16];
+    if (Wn >= 16) {
+        uint32_t core = P.default_key;                        // the default minimizer 4^m-1 takes part (Model.hpp:1260)
+        for (uint32_t i = 15; i < Wn; i++) { uint32_t v = s_mk[p0 + i]; core = v < core ? v : core; }
+        uint32_t suf = 0xFFFFFFFFu;
+        uint32_t sufL[16];
+        sufL[15] = suf;
+#pragma unroll
+        for (int j = 14; j >= 0; j--) { uint32_t v = s_mk[p0 + j]; suf = v < suf ? v : suf; sufL[j] = suf; }
+        uint32_t pre = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t r = sufL[j] < core ? sufL[j] : core;
+            mz[j] = pre < r ? pre : r;
+            uint32_t v = s_mk[p0 + Wn + j]; pre = v < pre ? v : pre;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint32_t best = P.default_key;
+            for (uint32_t i = 0; i < Wn; i++) { uint32_t v = s_mk[p0 + j + i]; best = v < best ? v : best; }
+            mz[j] = best;
+        }
+    }
+
+    // ---- step 3: which positions hold a k-mer, and which of those are valid (A2) ----
+    uint32_t existsmask = 0, validmask = 0;
+    {
+        const int q = t >> 1, off = (t & 1) * 16;
+        uint64_t rlo = (uint64_t)s_rs[q] | ((uint64_t)s_rs[q + 1] << 32);
+        uint64_t rhi = (uint64_t)s_rs[q + 2] | ((uint64_t)s_rs[q + 3] << 32);
+        if (off) { rlo = (rlo >> 16) | (rhi << 48); rhi >>= 16; }
+        uint64_t blo = (uint64_t)s_bad[t] | ((uint64_t)s_bad[t + 1] << 16) | ((uint64_t)s_bad[t + 2] << 32) | ((uint64_t)s_bad[t + 3] << 48);
+        uint64_t bhi = (uint64_t)s_bad[t + 4] | ((uint64_t)s_bad[t + 5] << 16) | ((uint64_t)s_bad[t + 6] << 32) | ((uint64_t)s_bad[t + 7] << 48);
+        const uint64_t maskk = (1ULL << k) - 1;               // k <= 63
+        const uint64_t maskk1 = (1ULL << (k - 1)) - 1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            uint64_t g = t0 + p0 + j;
+            bool ex = (g + k <= P.n_bases) && (((rlo >> 1) & maskk1) == 0);   // no read start inside (g, g+k-1]
+            bool va = ex && ((blo & maskk) == 0);                             // no invalid character inside [g, g+k-1]
+            existsmask |= (uint32_t)ex << j; validmask |= (uint32_t)va << j;
+            rlo = (rlo >> 1) | (rhi << 63); rhi >>= 1;
+            blo = (blo >> 1) | (bhi << 63); bhi >>= 1;
+        }
+    }
+
+    // ---- step 4: natural super-k-mer starts and the workgroup-wide "last start" max-scan (A4) ----
+    s_lastmz[t] = mz[15]; s_lastvalid[t] = (validmask >> 15) & 1;
+    s_firstmz[t] = mz[0]; s_firstvalid[t] = validmask & 1;
+    if (t == 0) { s_firstvalid[SCAN_THREADS] = 0; s_firstmz[SCAN_THREADS] = 0; }
+    __syncthreads();
+    uint32_t nsmask = 0;
+    {
+        bool pv = t > 0 ? (s_lastvalid[t - 1] != 0) : false;  // tile start forces a new super-k-mer
+        uint32_t pm = t > 0 ? s_lastmz[t - 1] : 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            bool v = (validmask >> j) & 1;
+            bool ns = v && (!pv || mz[j] != pm);
+            nsmask |= (uint32_t)ns << j;
+            pv = v; pm = mz[j];
+        }
+    }
+    int carry;   // position (tile-local) of the last natural start before p0, or -1
+    {
+        int v = nsmask ? (p0 + 31 - __clz((int)nsmask)) : -1;
+        int lane = t & 63, wave = t >> 6;
+        int x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d) x = y > x ? y : x; }
+        if (lane == 63) s_wavecarry[wave] = x;
+        __syncthreads();
+        int wc = -1;
+        for (int w2 = 0; w2 < wave; w2++) { int y = s_wavecarry[w2]; wc = y > wc ? y : wc; }
+        int ex = __shfl_up(x, 1, 64);
+        if (lane == 0) ex = -1;
+        carry = ex > wc ? ex : wc;
+    }
+
+    // ---- step 5: emit one record per run end (A4 cap, A5 pass filter + partition, A6 bucket write) ----
+    // run ends are first compacted per thread into LDS (own 16 slots), so the divergent emission loop runs
+    // max-over-lanes(#ends) times instead of 16
+    uint32_t n_rec = 0;
+    {
+        int ls = carry, n_end = 0;
+        const bool nxt_valid = s_firstvalid[t + 1] != 0;       // t==255: sentinel (tile end)
+        const uint32_t nxt_mz = s_firstmz[t + 1];
+        const int maxs = (int)P.maxs;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const bool v = (validmask >> j) & 1;
+            const int p = p0 + j;
+            if ((nsmask >> j) & 1) ls = p;
+            bool boundary;
+            if (j < 15) boundary = !((validmask >> (j + 1)) & 1) || ((nsmask >> (j + 1)) & 1);
+            else boundary = !nxt_valid || (nxt_mz != mz[15]);
+            const int d1 = p + 1 - ls;
+            const bool is_end = v && (boundary || (d1 % maxs) == 0);
+            if (is_end) {
+                const int start = ls + ((p - ls) / maxs) * maxs;
+                s_mk[p0 + n_end] = mz[j];                                    // own slots; s_mk is dead after step 2
+                s_end[p0 + n_end] = (uint32_t)start | ((uint32_t)(p - start + 1) << 16);
+                n_end++;
+            }
+        }
+#pragma unroll 1
+        for (int e = 0; e < n_end; e++) {
+            const uint32_t info = s_end[p0 + e];
+            const int start = (int)(info & 0xFFFFu);
+            const uint32_t nbk = info >> 16;
+            const uint32_t key = s_mk[p0 + e];
+            const uint32_t value = P.freq_mode ? P.key2val[key] : key;
+            if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
+            const uint32_t part = P.repart[value];
+            n_rec++;
+            if (!EMIT) {
+                atomicAdd(&P.cnt_rec[part], 1ULL);
+                atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk);
+            } else {
+                const unsigned long long slot = atomicAdd(&P.cursor[part], 1ULL);
+                // 2-bit plane, left-aligned at `start`
+                const int w0 = start >> 4, sh = 2 * (start & 15);
+                uint64_t A[RW + 1];
+#pragma unroll
+                for (int i = 0; i <= RW; i++) A[i] = ((uint64_t)s_be[w0 + 2 * i] << 32) | s_be[w0 + 2 * i + 1];
+                uint64_t B[RW];
+#pragma unroll
+                for (int i = 0; i < RW; i++) B[i] = sh ? ((A[i] << sh) | (A[i + 1] >> (64 - sh))) : A[i];
+                uint64_t R[RW];
+                R[0] = ((uint64_t)nbk << 56) | (B[0] >> 8);
+#pragma unroll
+                for (int i = 1; i < RW; i++) R[i] = (B[i - 1] << 56) | (B[i] >> 8);
+                // zero everything after the k+nbK-1 nucleotides of this super-k-mer
+                const int n = (int)k + (int)nbk - 1;
+                if (n < 28) R[0] &= ~((1ULL << (56 - 2 * n)) - 1);
+#pragma unroll
+                for (int i = 1; i < RW; i++) {
+                    const int have = n - 28 - 32 * (i - 1);       // nucleotides of word i that belong to the record
+                    if (have <= 0) R[i] = 0;
+                    else if (have < 32) R[i] &= ~((1ULL << (64 - 2 * have)) - 1);
+                }
+                uint64_t* dst = P.arena + slot * RW;
+#pragma unroll
+                for (int i = 0; i < RW; i += 2) *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(R[i], R[i + 1]);
+            }
+        }
+    }
+
+    // ---- statistics (Sequence2SuperKmer.hpp:103,108) ----
+    {
+        uint32_t nv = __popc(validmask), ni = __popc(existsmask & ~validmask);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_down(nv, d, 64); ni += __shfl_down(ni, d, 64); n_rec += __shfl_down(n_rec, d, 64); }
+        if ((t & 63) == 0) { atomicAdd(&s_stat[0], (unsigned long long)nv); atomicAdd(&s_stat[1], (unsigned long long)ni); atomicAdd(&s_stat[2], (unsigned long long)n_rec); }
+        __syncthreads();
+        if (t < 3 && s_stat[t]) atomicAdd(&P.gstats[t], s_stat[t]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, uint64_t n_tiles)
+{
+    dim3 grid((unsigned)n_tiles), block(SCAN_THREADS);
+    if (c->record_bytes == 16) {
+        if (emit) hipLaunchKernelGGL((k_scan_tile<true, 2>), grid, block, 0, c->stream, P);
+        else      hipLaunchKernelGGL((k_scan_tile<false, 2>), grid, block, 0, c->stream, P);
+    } else {
+        if (emit) hipLaunchKernelGGL((k_scan_tile<true, 4>), grid, block, 0, c->stream, P);
+        else      hipLaunchKernelGGL((k_scan_tile<false, 4>), grid, block, 0, c->stream, P);
+    }
+    GKC_HIP(c, hipGetLastError());
+    return GKC_OK;
+}
+
+int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
+{
+    const uint32_t Pn = c->nb_partitions;
+    if (n_bases >= (1ULL << 40)) GKC_FAIL(c, GKC_ERR_ARG, "a single push is limited to 2^40 bases");
+    const uint64_t n_tiles = (n_bases + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_tiles >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "too many tiles in one push; split the batch");
+
+    Segment seg; seg.rec_off.assign(Pn + 1, 0); seg.nkmers.assign(Pn, 0); seg.owned = true;
+    if (n_tiles == 0) { c->segments.push_back(seg); c->stats_now().nb_sequences += n_reads; return GKC_OK; }
+
+    // read-start bitmask (+ slack so every tile can read its halo words)
+    const size_t rs_words = (size_t)(n_tiles * SCAN_TILE / 32 + 64);
+    GKC_TRY(c->ensure(c->d_rsbits, rs_words * 4));
+    GKC_HIP(c, hipMemsetAsync(c->d_rsbits.p, 0, rs_words * 4, c->stream));
+    {
+        uint64_t n_entries = n_reads + 1;
+        dim3 g((unsigned)((n_entries + 255) / 256)), b(256);
+        hipLaunchKernelGGL(k_mark_read_starts, g, b, 0, c->stream, d_offsets, n_entries, (uint32_t*)c->d_rsbits.p);
+        GKC_HIP(c, hipGetLastError());
+    }
+    // counters: [0..P) records, [P..2P) k-mers, [2P..3P) cursors, [3P..3P+4) stats
+    const size_t n_cnt = (size_t)3 * Pn + 4;
+    GKC_TRY(c->ensure(c->d_scan_counters, n_cnt * 8));
+    GKC_HIP(c, hipMemsetAsync(c->d_scan_counters.p, 0, n_cnt * 8, c->stream));
+    unsigned long long* cnt = (unsigned long long*)c->d_scan_counters.p;
+
+    ScanParams P{};
+    P.bases = (const uint8_t*)d_bases; P.n_bases = n_bases; P.rsbits = (const uint32_t*)c->d_rsbits.p;
+    P.k = c->k; P.m = c->m; P.nb_mm = c->k - c->m + 1; P.maxs = c->maxs;
+    P.mmask = (uint32_t)((1ULL << (2 * c->m)) - 1);
+    P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
+    P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
+    P.mkey_lut = (const uint32_t*)c->d_mkey_lut.p; P.key2val = (const uint32_t*)c->d_key2val.p; P.default_key = c->default_key;
+    P.repart = (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
+    P.cnt_rec = cnt; P.cnt_kmers = cnt + Pn; P.cursor = cnt + 2 * (size_t)Pn; P.gstats = cnt + 3 * (size_t)Pn;
+    P.arena = nullptr;
+
+    {   ScopedTimer tm(c, "scan_count");
+        GKC_TRY(launch_scan(c, P, false, n_tiles));
+    }
+    std::vector<unsigned long long> h(n_cnt);
+    GKC_HIP(c, hipMemcpyAsync(h.data(), cnt, n_cnt * 8, hipMemcpyDeviceToHost, c->stream));
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (uint32_t p = 0; p < Pn; p++) { seg.rec_off[p] = total; total += h[p]; seg.nkmers[p] = h[Pn + p]; }
+    seg.rec_off[Pn] = total;
+    {   gkc_stats& S = c->stats_now();
+        S.kmers_nb_valid += h[3 * (size_t)Pn + 0]; S.kmers_nb_invalid += h[3 * (size_t)Pn + 1];
+        S.nb_sequences += n_reads; S.nb_bases += n_bases;
+        S.nb_superkmers += total; S.superkmer_bytes += total * c->record_bytes;
+    }
+
+    void* arena = nullptr;
+    if (total) {
+        hipError_t e = hipMalloc(&arena, (size_t)total * c->record_bytes);
+        if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of %llu super-k-mer records failed: %s", (unsigned long long)total, hipGetErrorString(e));
+        c->owned_arenas.push_back(arena);
+        // cursors start at the exact partition offsets
+        GKC_HIP(c, hipMemcpyAsync(cnt + 2 * (size_t)Pn, seg.rec_off.data(), (size_t)Pn * 8, hipMemcpyHostToDevice, c->stream));
+        GKC_HIP(c, hipMemsetAsync(cnt + 3 * (size_t)Pn, 0, 4 * 8, c->stream));
+        P.arena = (uint64_t*)arena;
+        {   ScopedTimer tm(c, "scan_emit");
+            GKC_TRY(launch_scan(c, P, true, n_tiles));
+        }
+    }
+    seg.d_records = arena;
+    c->segments.push_back(std::move(seg));
+    return GKC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// parity surface: partition -> reference wire format [u8 nbK][payload] (Model.hpp:1386-1471)
+// (host-side re-encoding of the device records; not on the timed path)
+// ------------------------------------------------------------------------------------------------
+int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk)
+{
+    const uint32_t k = c->k; const int RW = c->record_bytes / 8;
+    uint64_t bytes = 0, n_sk = 0, n_k = 0;
+    for (const Segment& s : c->segments) {
+        const uint64_t n = s.rec_off[part + 1] - s.rec_off[part];
+        if (!n) continue;
+        std::vector<uint64_t> recs((size_t)n * RW);
+        GKC_HIP(c, hipMemcpy(recs.data(), (const uint8_t*)s.d_records + s.rec_off[part] * c->record_bytes, (size_t)n * c->record_bytes, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < n; r++) {
+            const uint64_t* R = &recs[(size_t)r * RW];
+            const uint32_t nbk = (uint32_t)(R[0] >> 56);
+            const uint32_t nn = k + nbk - 1;
+            auto nt = [&](uint32_t i) -> uint32_t {
+                if (i < 28) return (uint32_t)(R[0] >> (54 - 2 * i)) & 3u;
+                uint32_t j = i - 28; return (uint32_t)(R[1 + (j >> 5)] >> (62 - 2 * (j & 31))) & 3u;
+            };
+            const uint64_t need = 1 + (nn + 3) / 4;
+            if (bytes + need > cap) GKC_FAIL(c, GKC_ERR_CAPACITY, "super-k-mer export buffer too small");
+            uint8_t* o = out + bytes;
+            o[0] = (uint8_t)nbk;
+            // first k-mer little-endian by bytes: byte b holds nucleotides k-4b-4 .. k-4b-1, last one in the low bits
+            uint32_t ob = 1; int rem = (int)k; int pos = (int)k;
+            while (rem >= 4) { uint8_t v = 0; for (int q = 0; q < 4; q++) v |= (uint8_t)(nt((uint32_t)(pos - 1 - q)) << (2 * q)); o[ob++] = v; pos -= 4; rem -= 4; }
+            uint8_t v = 0; for (int q = 0; q < rem; q++) v |= (uint8_t)(nt((uint32_t)(rem - 1 - q)) << (2 * q));
+            int uid = rem; uint32_t idx = k;
+            for (;;) {
+                while (uid < 4 && idx < nn) { v |= (uint8_t)(nt(idx) << (2 * uid)); uid++; idx++; }
+                if (uid > 0) o[ob++] = v;
+                if (idx >= nn) break;
+                v = 0; uid = 0;
+            }
+            bytes += ob; n_sk++; n_k += nbk;
+        }
+    }
+    *nb = bytes; *nsk = n_sk; *nk = n_k;
+    return GKC_OK;
+}

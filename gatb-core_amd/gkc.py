@@ -1,0 +1,364 @@
+"""ctypes binding over the C-ABI of libgkc_hip.so (include/gkc.h). No torch types cross the boundary.
+
+The extension is REQUIRED: every entry point raises GkcError if the library is missing or a call fails;
+there is no CPU fallback anywhere in this module (the CPU oracle lives in oracle/ and is test-only).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO = os.path.join(CSRC, "libgkc_hip.so")
+_LIB = None
+
+SYMBOLS = [
+    "gkc_create", "gkc_destroy", "gkc_last_error", "gkc_version", "gkc_configure", "gkc_set_solidity",
+    "gkc_set_max_superkmer", "gkc_begin_pass", "gkc_push_reads", "gkc_push_reads_device", "gkc_finish_pass",
+    "gkc_partition_info", "gkc_partition_counts", "gkc_partition_counts_device", "gkc_histogram", "gkc_get_stats",
+    "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
+    "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
+    "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
+    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_synth_reads_device", "gkc_device_free",
+    "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum",
+]
+
+
+class GkcError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "kmers_nb_valid", "kmers_nb_invalid", "kmers_nb_distinct", "kmers_nb_solid", "nb_superkmers", "nb_sequences",
+        "nb_bases", "superkmer_bytes", "oversize_buckets")] + [("reserved", C.c_uint64 * 7)]
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "gkc.h"))
+    stale = force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return SO
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO):
+        raise GkcError("libgkc_hip.so is missing (%s): run __graft_entry__.build(); there is no CPU fallback" % SO)
+    L = C.CDLL(SO)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
+    P = C.POINTER
+    sig = {
+        "gkc_create": (C.c_int, [C.c_int, P(vp)]),
+        "gkc_destroy": (None, [vp]),
+        "gkc_last_error": (C.c_char_p, [vp]),
+        "gkc_version": (C.c_char_p, []),
+        "gkc_configure": (C.c_int, [vp, u32, u32, u32, u32, C.c_int, vp, vp]),
+        "gkc_set_solidity": (C.c_int, [vp, i32, i32, u32]),
+        "gkc_set_max_superkmer": (C.c_int, [vp, u32]),
+        "gkc_begin_pass": (C.c_int, [vp, u32]),
+        "gkc_push_reads": (C.c_int, [vp, vp, vp, u64]),
+        "gkc_push_reads_device": (C.c_int, [vp, vp, vp, u64, u64]),
+        "gkc_finish_pass": (C.c_int, [vp]),
+        "gkc_partition_info": (C.c_int, [vp, u32, u32, P(u64), P(u64), P(u64)]),
+        "gkc_partition_counts": (C.c_int, [vp, u32, u32, vp, u64, P(u64)]),
+        "gkc_partition_counts_device": (C.c_int, [vp, u32, u32, P(vp), P(u64)]),
+        "gkc_histogram": (C.c_int, [vp, vp, u32]),
+        "gkc_get_stats": (C.c_int, [vp, P(Stats)]),
+        "gkc_get_timing": (C.c_int, [vp, C.c_char_p, P(C.c_double), P(u64)]),
+        "gkc_partition_superkmers": (C.c_int, [vp, u32, vp, u64, P(u64), P(u64), P(u64)]),
+        "gkc_segment_count": (C.c_int, [vp, P(u32)]),
+        "gkc_segment_export": (C.c_int, [vp, u32, P(vp), P(u32), vp, vp]),
+        "gkc_segment_import": (C.c_int, [vp, vp, vp, vp]),
+        "gkc_segments_clear": (C.c_int, [vp]),
+        "gkc_bloom_create": (C.c_int, [vp, C.c_int, u64, u32, u32, P(vp)]),
+        "gkc_bloom_destroy": (None, [vp]),
+        "gkc_bloom_nbytes": (u64, [vp]),
+        "gkc_bloom_bitsize": (u64, [vp]),
+        "gkc_bloom_insert": (C.c_int, [vp, vp, u64, u32]),
+        "gkc_bloom_insert_device": (C.c_int, [vp, vp, u64, u32]),
+        "gkc_bloom_insert_solid": (C.c_int, [vp, vp]),
+        "gkc_bloom_contains": (C.c_int, [vp, vp, u64, u32, vp]),
+        "gkc_bloom_contains8": (C.c_int, [vp, vp, u64, u32, vp]),
+        "gkc_bloom_get_array": (C.c_int, [vp, vp, u64]),
+        "gkc_bloom_set_array": (C.c_int, [vp, vp, u64]),
+        "gkc_synth_reads_device": (C.c_int, [vp, u64, u64, u64, u32, u64, u32, P(vp), P(vp)]),
+        "gkc_device_free": (C.c_int, [vp, vp]),
+        "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
+        "gkc_kmer_checksum_device": (C.c_int, [vp, vp, vp, u64, u64, P(u64), P(u64)]),
+        "gkc_result_checksum": (C.c_int, [vp, P(u64), P(u64)]),
+    }
+    for name in SYMBOLS:
+        f = getattr(L, name)          # raises AttributeError if the symbol is not exported
+        f.restype, f.argtypes = sig[name]
+    _LIB = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- host twins of device helpers (full-size parity properties) ----
+M64 = (1 << 64) - 1
+
+
+def mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+def mix64_np(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def synth_rnd_np(seed, stream, idx):
+    with np.errstate(over="ignore"):
+        base = mix64_np(np.uint64(seed) ^ (np.uint64(stream) << np.uint64(56)))
+        return mix64_np(base + np.asarray(idx, dtype=np.uint64))
+
+
+def synth_reads_np(seed, n_reads, read_len, genome_len, sub_ppm, first_read=0):
+    """numpy twin of the k_synth_reads kernel (csrc/gkc_api.hip): -> (bases uint8[n*L], offsets uint64[n+1])"""
+    i = np.repeat(np.arange(first_read, first_read + n_reads, dtype=np.uint64), read_len)
+    j = np.tile(np.arange(read_len, dtype=np.uint64), n_reads)
+    g = i * np.uint64(read_len) + j
+    u = synth_rnd_np(seed, 2, i)
+    start = (u >> np.uint64(1)) % np.uint64(genome_len - read_len + 1)
+    rev = (u & np.uint64(1)).astype(bool)
+    pos = np.where(rev, start + np.uint64(read_len - 1) - j, start + j)
+    code = (synth_rnd_np(seed, 1, pos) & np.uint64(3)).astype(np.uint32)
+    code = np.where(rev, code ^ 2, code)
+    v = synth_rnd_np(seed, 3, g)
+    sub = (v % np.uint64(1000000)) < np.uint64(sub_ppm)
+    code = np.where(sub, (code + 1 + ((v >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, code)
+    bases = np.frombuffer(b"ACTG", dtype=np.uint8)[code]
+    return bases.copy(), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+
+
+class Counter:
+    """Host-side handle over one gkc_ctx (one GPU). Mirrors the call protocol of SortingCountAlgorithm::execute
+    (reference kmer/impl/SortingCountAlgorithm.cpp:636-781): configure -> per pass: begin, push reads, finish -> fetch."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.gkc_create(device, C.byref(h))
+        if rc != 0:
+            raise GkcError("gkc_create failed (%d): %s" % (rc, (self.L.gkc_last_error(None) or b"").decode()))
+        self.h = h
+        self.k = self.m = self.nb_partitions = self.nb_passes = None
+        self._keep = []
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise GkcError("gkc error %d: %s" % (rc, (self.L.gkc_last_error(self.h) or b"").decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gkc_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, k, m, nb_partitions, repart, nb_passes=1, freq_order=None):
+        repart = np.ascontiguousarray(repart, dtype=np.uint16)
+        if repart.size != 4 ** m:
+            raise GkcError("repart must have 4^m entries")
+        fo = None if freq_order is None else np.ascontiguousarray(freq_order, dtype=np.uint32)
+        self._chk(self.L.gkc_configure(self.h, k, m, nb_partitions, nb_passes, 0 if fo is None else 1, _p(repart), _p(fo)))
+        self.k, self.m, self.nb_partitions, self.nb_passes = k, m, nb_partitions, nb_passes
+        self.rec_bytes = 16 if k <= 31 else 32
+
+    def set_solidity(self, amin=1, amax=2147483647, histo_max=10000):
+        self._chk(self.L.gkc_set_solidity(self.h, amin, amax, histo_max)); self.histo_max = histo_max
+
+    def set_max_superkmer(self, maxs):
+        self._chk(self.L.gkc_set_max_superkmer(self.h, maxs))
+
+    def begin_pass(self, p=0):
+        self._chk(self.L.gkc_begin_pass(self.h, p))
+
+    def push_reads(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8); offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._chk(self.L.gkc_push_reads(self.h, _p(bases), _p(offsets), len(offsets) - 1))
+
+    def push_reads_device(self, d_bases, d_offsets, n_reads, n_bases):
+        self._chk(self.L.gkc_push_reads_device(self.h, d_bases, d_offsets, n_reads, n_bases))
+
+    def finish_pass(self):
+        self._chk(self.L.gkc_finish_pass(self.h))
+
+    def count(self, bases, offsets):
+        """all passes over one host batch"""
+        for p in range(self.nb_passes):
+            self.begin_pass(p); self.push_reads(bases, offsets); self.finish_pass()
+
+    def partition_info(self, pass_, part):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.gkc_partition_info(self.h, pass_, part, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def partition_records(self, pass_, part):
+        """raw Count records (uint8 view)"""
+        ns, _, _ = self.partition_info(pass_, part)
+        out = np.zeros(max(1, ns * self.rec_bytes), np.uint8)
+        n = C.c_uint64()
+        self._chk(self.L.gkc_partition_counts(self.h, pass_, part, _p(out), ns, C.byref(n)))
+        return out[: ns * self.rec_bytes]
+
+    def partition(self, pass_, part):
+        """-> (lo uint64[], hi uint64[], abundance int32[])"""
+        raw = self.partition_records(pass_, part)
+        if self.rec_bytes == 16:
+            r = raw.view(np.uint64).reshape(-1, 2)
+            return r[:, 0].copy(), np.zeros(len(r), np.uint64), (r[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int32)
+        r = raw.view(np.uint64).reshape(-1, 4)
+        return r[:, 0].copy(), r[:, 1].copy(), (r[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int32)
+
+    def partition_device(self, pass_, part):
+        p = C.c_void_p(); n = C.c_uint64()
+        self._chk(self.L.gkc_partition_counts_device(self.h, pass_, part, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def all_counts(self):
+        out = {}
+        for ps in range(self.nb_passes):
+            for pt in range(self.nb_partitions):
+                lo, hi, ab = self.partition(ps, pt)
+                for a, b, c in zip(lo.tolist(), hi.tolist(), ab.tolist()):
+                    out[(b << 64) | a] = c
+        return out
+
+    def histogram(self):
+        hm = getattr(self, "histo_max", 10000)
+        h = np.zeros(hm + 1, np.uint64)
+        self._chk(self.L.gkc_histogram(self.h, _p(h), hm + 1))
+        return h
+
+    def stats(self):
+        s = Stats(); self._chk(self.L.gkc_get_stats(self.h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in Stats._fields_ if n != "reserved"}
+
+    def timing(self, name):
+        ms = C.c_double(); n = C.c_uint64()
+        self._chk(self.L.gkc_get_timing(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def partition_superkmers(self, part, cap_bytes=1 << 26):
+        out = np.zeros(cap_bytes, np.uint8)
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.gkc_partition_superkmers(self.h, part, _p(out), cap_bytes, C.byref(a), C.byref(b), C.byref(c)))
+        return out[: a.value].copy(), b.value, c.value
+
+    # ---- segments (multi-GPU exchange surface)
+    def segment_count(self):
+        n = C.c_uint32(); self._chk(self.L.gkc_segment_count(self.h, C.byref(n))); return n.value
+
+    def segment_export(self, seg):
+        p = C.c_void_p(); rb = C.c_uint32()
+        off = np.zeros(self.nb_partitions + 1, np.uint64); km = np.zeros(self.nb_partitions, np.uint64)
+        self._chk(self.L.gkc_segment_export(self.h, seg, C.byref(p), C.byref(rb), _p(off), _p(km)))
+        return p.value, rb.value, off, km
+
+    def segment_import(self, d_records, rec_offsets, kmers):
+        ro = np.ascontiguousarray(rec_offsets, dtype=np.uint64); km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        self._chk(self.L.gkc_segment_import(self.h, d_records, _p(ro), _p(km)))
+
+    def segments_clear(self):
+        self._chk(self.L.gkc_segments_clear(self.h))
+
+    # ---- synthetic input + checksums
+    def synth_reads_device(self, seed, n_reads, read_len, genome_len, sub_ppm, first_read=0):
+        b = C.c_void_p(); o = C.c_void_p()
+        self._chk(self.L.gkc_synth_reads_device(self.h, seed, first_read, n_reads, read_len, genome_len, sub_ppm, C.byref(b), C.byref(o)))
+        return b.value, o.value
+
+    def device_free(self, p):
+        self._chk(self.L.gkc_device_free(self.h, p))
+
+    def device_to_host(self, d_ptr, nbytes):
+        out = np.zeros(nbytes, np.uint8)
+        self._chk(self.L.gkc_device_to_host(self.h, _p(out), d_ptr, nbytes))
+        return out
+
+    def kmer_checksum_device(self, d_bases, d_offsets, n_reads, n_bases):
+        a = C.c_uint64(); b = C.c_uint64()
+        self._chk(self.L.gkc_kmer_checksum_device(self.h, d_bases, d_offsets, n_reads, n_bases, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def result_checksum(self):
+        a = C.c_uint64(); b = C.c_uint64()
+        self._chk(self.L.gkc_result_checksum(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+class Bloom:
+    KINDS = {"basic": 0, "cache": 1, "neighbor": 2}
+
+    def __init__(self, counter, kind, tai_bits, nb_hash, k):
+        self.c = counter; self.L = counter.L; self.k = k
+        h = C.c_void_p()
+        counter._chk(self.L.gkc_bloom_create(counter.h, self.KINDS[kind], tai_bits, nb_hash, k, C.byref(h)))
+        self.h = h; self.stride = 8 if k <= 31 else 16
+
+    def _keys(self, keys):
+        ks = [int(x) for x in keys]
+        if self.stride == 8:
+            return np.array(ks, dtype=np.uint64)
+        a = np.zeros((len(ks), 2), np.uint64)
+        a[:, 0] = [x & M64 for x in ks]; a[:, 1] = [x >> 64 for x in ks]
+        return a
+
+    def insert(self, keys):
+        a = self._keys(keys); self.c._chk(self.L.gkc_bloom_insert(self.h, _p(a), len(a), self.stride))
+
+    def insert_solid(self):
+        self.c._chk(self.L.gkc_bloom_insert_solid(self.h, self.c.h))
+
+    def contains(self, keys):
+        a = self._keys(keys); out = np.zeros(len(a), np.uint8)
+        self.c._chk(self.L.gkc_bloom_contains(self.h, _p(a), len(a), self.stride, _p(out))); return out
+
+    def contains8(self, keys):
+        a = self._keys(keys); out = np.zeros(len(a), np.uint8)
+        self.c._chk(self.L.gkc_bloom_contains8(self.h, _p(a), len(a), self.stride, _p(out))); return out
+
+    @property
+    def nbytes(self):
+        return self.L.gkc_bloom_nbytes(self.h)
+
+    @property
+    def bitsize(self):
+        return self.L.gkc_bloom_bitsize(self.h)
+
+    def array(self):
+        out = np.zeros(self.nbytes, np.uint8)
+        self.c._chk(self.L.gkc_bloom_get_array(self.h, _p(out), len(out))); return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gkc_bloom_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

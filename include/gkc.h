@@ -1,0 +1,179 @@
+/* gkc.h — C-ABI of libgkc_hip.so: the MI355X (gfx950) implementation of GATB-Core's DSK k-mer-counting hot path.
+ *
+ * This is the drop-in boundary. Everything crossing it is plain C: pointers, sizes, integers.
+ * No C++ exceptions, STL or torch types cross the ABI. Every function returns 0 on success, non-zero on error
+ * (then gkc_last_error() describes it). The host-side C++ classes in gatb-core_amd/host/ (mirrors of
+ * gatb::core::kmer::impl::SortingCountAlgorithm<span>, ICountProcessor<span>, IBloom<Item>) and the Python binding
+ * gatb-core_amd/gkc.py call nothing else.
+ *
+ * Reference citations are file:line under /root/reference/gatb-core/src/gatb/.
+ *
+ * Data conventions (identical to the reference):
+ *   nucleotide code  (c>>1)&3 : A=0 C=1 T=2 G=3, anything outside ACGTacgt is invalid   (tools/misc/api/Data.hpp:185)
+ *   k-mer integer    first nucleotide in the most significant used bits                  (kmer/impl/Model.hpp:637-657)
+ *   canonical        min(forward, reverse complement)                                    (kmer/impl/Model.hpp:294)
+ *   Count record     k<=31: 16 B {u64 value; i32 abundance; 4 B pad}
+ *                    k<=63: 32 B {u128 value (little endian); i32 abundance; 12 B pad}   (tools/misc/api/Abundance.hpp:68-129)
+ */
+#ifndef GKC_H
+#define GKC_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKC_OK            0
+#define GKC_ERR_ARG       1   /* bad argument / bad state                        */
+#define GKC_ERR_HIP       2   /* a HIP runtime call failed (message has details) */
+#define GKC_ERR_NOMEM     3   /* device or host allocation failed                */
+#define GKC_ERR_CAPACITY  4   /* caller buffer too small                         */
+#define GKC_ERR_NODEVICE  5   /* no usable gfx950 device                         */
+
+#define GKC_MINIMIZER_LEXI 0  /* -minimizer-type 0: lexicographic + KMC2 "no inner AA" rule (Model.hpp:1220-1251) */
+#define GKC_MINIMIZER_FREQ 1  /* -minimizer-type 1: (freq_order[c], c) order (Model.hpp:957-973)                  */
+
+typedef struct gkc_ctx gkc_ctx;
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Context. Replaces the per-run state of SortingCountAlgorithm<span> (kmer/impl/SortingCountAlgorithm.hpp:65-263):
+ * owns the HIP stream, every device buffer and the per-pass results.
+ * ------------------------------------------------------------------------------------------------------------- */
+int         gkc_create(int device, gkc_ctx** out);
+void        gkc_destroy(gkc_ctx* ctx);
+const char* gkc_last_error(const gkc_ctx* ctx);      /* ctx may be NULL: last error of a failed gkc_create */
+const char* gkc_version(void);
+
+/* Model + Repartitor. Replaces `Model model(k, m, cmp, freq_order)` (SortingCountAlgorithm.cpp:1251-1256, LUT built at
+ * Model.hpp:1032-1064) and `Repartitor::operator()` (kmer/impl/PartiInfo.hpp:323).
+ *   repart      u16[4^m]  minimizer value -> partition  (the table Repartitor::load reads, PartiInfo.cpp:223-262)
+ *   freq_order  u32[4^m]  or NULL; required iff minimizer_type==GKC_MINIMIZER_FREQ (RepartitionAlgorithm.cpp:311-384)
+ * k in [3,63] (k<=2 refused like SortingCountAlgorithm.cpp:662-666), m in [2,min(k-1,14)], nb_partitions in [1,65535]. */
+int gkc_configure(gkc_ctx* ctx, uint32_t k, uint32_t m, uint32_t nb_partitions, uint32_t nb_passes,
+                  int minimizer_type, const uint16_t* repart, const uint32_t* freq_order);
+
+/* Solidity window and histogram length. Replaces CountProcessorSoliditySum::check (CountProcessorSolidity.hpp:186-189,
+ * closed interval on the sum) and Histogram::inc clamping (tools/misc/impl/Histogram.hpp:92). Defaults: [1, INT32_MAX],
+ * histo_max 10000, i.e. every distinct k-mer is returned and the host's own processor chain can do the filtering. */
+int gkc_set_solidity(gkc_ctx* ctx, int32_t abundance_min, int32_t abundance_max, uint32_t histo_max);
+
+/* Super-k-mer length cap (Sequence2SuperKmer.hpp:147). 0 = reference default 28 (k<=31) / 60 (k<=63). */
+int gkc_set_max_superkmer(gkc_ctx* ctx, uint32_t maxs);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Stage A — replaces SortingCountAlgorithm::fillPartitions (SortingCountAlgorithm.cpp:1211-1344): Sequence2SuperKmer
+ * (Sequence2SuperKmer.hpp:81-159) + FillPartitions::processSuperkmer (:1081-1151) + the SuperKmerBinFiles disk shuffle
+ * (tools/storage/impl/Storage.cpp:360-430). Reads arrive as a flat ASCII buffer + CSR offsets (offsets[n_reads] ==
+ * number of bases); any number of pushes per pass. Super-k-mers whose minimizer % nb_passes != pass are dropped (:1083).
+ * ------------------------------------------------------------------------------------------------------------- */
+int gkc_begin_pass(gkc_ctx* ctx, uint32_t pass);
+int gkc_push_reads(gkc_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads);
+/* same, inputs already resident in HBM (d_bases 16-byte aligned). The buffers may be released after the call returns. */
+int gkc_push_reads_device(gkc_ctx* ctx, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases);
+
+/* Stage B — replaces SortingCountAlgorithm::fillSolidKmers (:1384-1602) = PartitionsByVectorCommand read/sort/dump
+ * (kmer/impl/PartitionsCommand.cpp:1206-1805) for every partition of the pass, plus the default processor chain
+ * histogram -> solidity -> dump (CountProcessorChain.hpp:128-135). Results stay in HBM until fetched. */
+int gkc_finish_pass(gkc_ctx* ctx);
+
+/* Result of dataset (part + pass*nb_partitions) (CountProcessorDump.hpp:131): ascending Count records of the SOLID
+ * k-mers, in the exact in-memory layout of Kmer<span>::Count so the host can pass whole arrays to
+ * Bag<Count>::insert(const Item*, len) (tools/storage/impl/CollectionHDF5Patch.hpp:262). */
+int gkc_partition_info(gkc_ctx* ctx, uint32_t pass, uint32_t part,
+                       uint64_t* n_solid, uint64_t* n_distinct, uint64_t* n_kmers);
+int gkc_partition_counts(gkc_ctx* ctx, uint32_t pass, uint32_t part, void* out_counts, uint64_t cap_records,
+                         uint64_t* n_solid);
+/* device pointer to the same records (valid until gkc_begin_pass of the same pass index or gkc_destroy) */
+int gkc_partition_counts_device(gkc_ctx* ctx, uint32_t pass, uint32_t part, const void** d_counts, uint64_t* n_solid);
+
+/* Histogram of abundances over ALL distinct k-mers (CountProcessorHistogram.hpp:173-184): histo_max+1 bins. */
+int gkc_histogram(gkc_ctx* ctx, uint64_t* out, uint32_t n_bins);
+
+/* Counters the reference reports through getInfo() (SortingCountAlgorithm.cpp:728-780, Sequence2SuperKmer.hpp:103,108) */
+typedef struct gkc_stats {
+    uint64_t kmers_nb_valid;      /* pass 0 only, like the reference                      */
+    uint64_t kmers_nb_invalid;
+    uint64_t kmers_nb_distinct;   /* summed over finished passes                          */
+    uint64_t kmers_nb_solid;
+    uint64_t nb_superkmers;       /* device records (tile boundaries may add a few splits) */
+    uint64_t nb_sequences;        /* pass 0 only                                          */
+    uint64_t nb_bases;            /* pass 0 only                                          */
+    uint64_t superkmer_bytes;     /* bytes of the device record buckets                   */
+    uint64_t oversize_buckets;    /* sub-buckets that took the global-memory sort path    */
+    uint64_t reserved[7];
+} gkc_stats;
+int gkc_get_stats(gkc_ctx* ctx, gkc_stats* out);
+
+/* Kernel timing of the last gkc_finish_pass / pushes (HIP events on the context's stream), milliseconds.
+ * names: "scan_count", "scan_emit", "expand_count", "expand_scatter", "bucket_sort", "compact", "total_stage_a", "total_stage_b" */
+int gkc_get_timing(gkc_ctx* ctx, const char* name, double* ms, uint64_t* launches);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Parity / exchange surface for the super-k-mer buckets (the device analogue of SuperKmerBinFiles).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* Partition `part` of the current pass re-encoded in the REFERENCE wire format: concatenated
+ * [u8 nbK][ceil((k+nbK-1)/4) bytes] records (Model.hpp:1386-1471, Storage.cpp:567-580). Order of records is unspecified. */
+int gkc_partition_superkmers(gkc_ctx* ctx, uint32_t part, uint8_t* out, uint64_t cap_bytes,
+                             uint64_t* n_bytes, uint64_t* n_superkmers, uint64_t* n_kmers);
+
+/* Multi-GPU: partitions are owned by ranks; the host moves each rank's buckets to their owner with one
+ * RCCL all-to-all and imports them on the owner. Records of partition p occupy rec_index in
+ * [rec_offsets[p], rec_offsets[p+1]) of the segment's arena; record_bytes is 16 (k<=31) or 32.
+ * gkc_segment_export: segment `seg` (one per push) of the current pass. d_records stays owned by the context.
+ * gkc_segment_import: adds a foreign segment; the memory stays owned by the caller and must outlive gkc_finish_pass.
+ * gkc_segments_clear: forget all segments of the current pass (frees owned arenas). */
+int gkc_segment_count(gkc_ctx* ctx, uint32_t* n_segments);
+int gkc_segment_export(gkc_ctx* ctx, uint32_t seg, const void** d_records, uint32_t* record_bytes,
+                       uint64_t* rec_offsets /* [nb_partitions+1] */, uint64_t* kmers_per_partition /* [nb_partitions] */);
+int gkc_segment_import(gkc_ctx* ctx, const void* d_records, const uint64_t* rec_offsets /* [nb_partitions+1] */,
+                       const uint64_t* kmers_per_partition /* [nb_partitions] */);
+int gkc_segments_clear(gkc_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Bloom filter of solid k-mers — replaces BloomBuilder::build / IBloom::insert (kmer/impl/BloomBuilder.hpp:102-128,
+ * 174-182) and the query side IBloom::contains / contains8 (tools/collections/impl/Bloom.hpp:211-234, 437-490,
+ * 555-828). kind: 0 "basic" (BloomSynchronized), 1 "cache" (BloomCacheCoherent), 2 "neighbor" (BloomNeighborCoherent) —
+ * the three kinds BloomFactory::createBloom can return for a k-mer item (Bloom.hpp:1254-1266).
+ * The bit array is byte-identical to the reference's getArray() for the same inserted set.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct gkc_bloom gkc_bloom;
+int      gkc_bloom_create(gkc_ctx* ctx, int kind, uint64_t tai_bits, uint32_t nb_hash, uint32_t k, gkc_bloom** out);
+void     gkc_bloom_destroy(gkc_bloom* b);
+uint64_t gkc_bloom_nbytes(const gkc_bloom* b);     /* IBloom::getSize()    */
+uint64_t gkc_bloom_bitsize(const gkc_bloom* b);    /* IBloom::getBitSize() */
+/* keys: n items, `stride` bytes apart, each starting with the k-mer value (8 B for k<=31, 16 B for k<=63): pass Count
+ * arrays with stride 16/32 or raw key arrays with stride 8/16. *_device variants take HBM-resident keys. */
+int gkc_bloom_insert(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride);
+int gkc_bloom_insert_device(gkc_bloom* b, const void* d_keys, uint64_t n, uint32_t stride);
+/* inserts every solid k-mer of every finished dataset of the context (what BloomAlgorithm::execute does, BloomAlgorithm.cpp:155-199) */
+int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* ctx);
+int gkc_bloom_contains(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out);
+int gkc_bloom_contains8(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out);  /* neighbor kind */
+int gkc_bloom_get_array(gkc_bloom* b, uint8_t* out, uint64_t cap_bytes);                               /* IBloom::getArray() */
+int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes);                            /* StorageTools::loadBloom */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Synthetic reads generated in HBM (bench / parity at full size; SURVEY §8d generator): genome of genome_len uniform
+ * bases from a counter-based hash of (seed, position); read i (global index first_read+i, so ranks can draw disjoint
+ * slices of one read stream over the same genome) starts at hash(seed,index) % (genome_len-read_len+1), is
+ * reverse-complemented with probability 1/2 and each base is substituted with probability sub_rate_ppm/1e6.
+ * Bit-identical to gatb-core_amd/gkc.py:synth_reads_np (numpy). Outputs are device pointers owned by the caller of
+ * gkc_device_free.
+ * ------------------------------------------------------------------------------------------------------------- */
+int gkc_synth_reads_device(gkc_ctx* ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                           uint64_t genome_len, uint32_t sub_rate_ppm, char** d_bases, uint64_t** d_offsets);
+int gkc_device_free(gkc_ctx* ctx, void* d_ptr);
+int gkc_device_to_host(gkc_ctx* ctx, void* dst, const void* d_src, uint64_t n_bytes);
+/* order-independent checksum of the canonical k-mer multiset of device-resident reads, computed by an independent
+ * one-thread-per-position kernel (no minimizers, no buckets): sum over valid k-mers of mix(canonical) mod 2^64, and the
+ * number of valid k-mers. Used by the full-size parity property "sum_records count*mix(value) == this". */
+int gkc_kmer_checksum_device(gkc_ctx* ctx, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads,
+                             uint64_t n_bases, uint64_t* checksum, uint64_t* n_valid);
+/* the same checksum over the finished datasets of the context: sum abundance*mix(value), sum abundance */
+int gkc_result_checksum(gkc_ctx* ctx, uint64_t* checksum, uint64_t* sum_abundance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GKC_H */

@@ -1,0 +1,258 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (ctypes binding), against the CPU oracle on the same
+seeded inputs. Bit-exact: integer/byte work. Run on the GPU box with `pytest -m gpu`."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from oracle import gko
+from tests.util import naive_counts, revcomp_int, simple_repart, synth_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gkc():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return ge.load().gkc
+
+
+def device_vs_oracle(gkc, reads, k, m, parts, passes=1, freq=None, amin=1, amax=2147483647, batches=1, rep=None,
+                     histo_max=10000):
+    bases, offs = gko.pack_reads(reads)
+    rep = simple_repart(m, parts) if rep is None else rep
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, nb_passes=passes, freq_order=freq, abundance_min=amin, abundance_max=amax,
+                  histo_max=histo_max)
+    c = gkc.Counter(0)
+    c.set_solidity(amin, amax, histo_max)
+    c.configure(k, m, parts, rep, nb_passes=passes, freq_order=freq)
+    n = len(reads)
+    for ps in range(passes):
+        c.begin_pass(ps)
+        for b in range(batches):
+            r0, r1 = n * b // batches, n * (b + 1) // batches
+            sub_off = offs[r0:r1 + 1] - offs[r0]
+            c.push_reads(bases[int(offs[r0]):int(offs[r1])], sub_off)
+        c.finish_pass()
+    for ps in range(passes):
+        for p in range(parts):
+            d = p + ps * parts
+            lo, hi, ab = c.partition(ps, p)
+            rlo, rhi, rab = ref.part(d)
+            assert np.array_equal(lo, rlo), (k, m, "dataset", d, len(lo), len(rlo))
+            assert np.array_equal(hi, rhi) and np.array_equal(ab, rab), (k, m, "dataset", d)
+            assert np.array_equal(c.partition_records(ps, p), ref.part_records(d))      # exact Count memory layout
+            ns, nd, nk = c.partition_info(ps, p)
+            assert nk == ref.part_stats(d)[0]
+    st = c.stats()
+    for key in ("kmers_nb_valid", "kmers_nb_invalid", "kmers_nb_distinct", "kmers_nb_solid", "nb_sequences"):
+        assert st[key] == ref.stats[key], (key, st[key], ref.stats[key])
+    assert np.array_equal(c.histogram(), ref.histogram())
+    return c, ref
+
+
+@pytest.mark.parametrize("k,m,parts", [(21, 10, 8), (31, 10, 16), (15, 7, 4), (9, 5, 3), (27, 8, 8), (5, 3, 2), (31, 12, 64)])
+def test_counts_bit_exact_64bit_keys(gkc, k, m, parts):
+    reads = synth_reads(3000, 20000, 150, seed=k, n_rate=0.002, ragged=True)
+    device_vs_oracle(gkc, reads, k, m, parts)
+
+
+@pytest.mark.parametrize("k,m,parts", [(63, 10, 8), (33, 9, 4), (47, 11, 16), (32, 10, 4)])
+def test_counts_bit_exact_128bit_keys(gkc, k, m, parts):
+    reads = synth_reads(2000, 20000, 150, seed=k, n_rate=0.002, ragged=True)
+    device_vs_oracle(gkc, reads, k, m, parts)
+
+
+def test_config1_plumbing_case(gkc):
+    """BASELINE configs[0]: 10k synthetic 150 bp reads, k=21, abundance-min 2"""
+    reads = synth_reads(10000, 50000, 150, seed=1)
+    c, ref = device_vs_oracle(gkc, reads, 21, 10, 8, amin=2)
+    assert ref.stats["kmers_nb_solid"] < ref.stats["kmers_nb_distinct"]
+
+
+def test_multi_batch_multi_pass_and_solidity_window(gkc):
+    reads = synth_reads(4000, 10000, 150, seed=4, n_rate=0.001, ragged=True)
+    device_vs_oracle(gkc, reads, 25, 9, 8, passes=3, batches=4, amin=2, amax=40, histo_max=30)
+
+
+def test_frequency_order_minimizers(gkc):
+    """-minimizer-type 1 (what GraphUnitigs forces, GraphUnitigs.cpp:861-870)"""
+    reads = synth_reads(3000, 15000, 150, seed=6, n_rate=0.001)
+    k, m, parts = 31, 8, 8
+    L = gko.lib()
+    counts = np.zeros(4 ** m, np.uint32)
+    for r in reads[:300]:
+        L.gko_count_mmers(r, len(r), m, counts)
+    freq = np.zeros(4 ** m, np.uint32)
+    L.gko_freq_order_from_counts(m, counts, freq)
+    device_vs_oracle(gkc, reads, k, m, parts, freq=freq)
+    device_vs_oracle(gkc, reads[:1000], 63, m, parts, freq=freq)
+
+
+def test_reference_known_answers_through_the_device(gkc, ref_vectors):
+    """TestDSK.cpp:147-305 run through the HIP path"""
+    v = ref_vectors["dsk_check1"]
+    for name, k, nks, expected in v["cases"]:
+        m = min(k - 1, 10)
+        bases, offs = gko.pack_reads(v[name])
+        c = gkc.Counter(0); c.set_solidity(nks); c.configure(k, m, 4, simple_repart(m, 4))
+        c.count(bases, offs)
+        assert c.stats()["kmers_nb_solid"] == expected, (name, k, nks)
+    v = ref_vectors["dsk_check2"]
+    bases, offs = gko.pack_reads([v["seq"]])
+    c = gkc.Counter(0); c.configure(31, 10, 4, simple_repart(10, 4)); c.count(bases, offs)
+    got = c.all_counts()
+    assert sorted(got) == sorted(v["values"]) and sum(got) & (2 ** 64 - 1) == v["checksum"]
+
+
+def test_edge_cases(gkc):
+    k, m, parts = 31, 10, 4
+    rep = simple_repart(m, parts)
+    # empty input, reads shorter than k, all-N reads, zero-length reads
+    for reads in ([], ["ACGT"], ["N" * 200], ["", "ACGTACGTAC", ""], ["A" * 30], ["ACGT" * 8 + "N" + "ACGT" * 8]):
+        device_vs_oracle(gkc, reads, k, m, parts, rep=rep)
+    # one long sequence spanning many scan tiles, with lower-case and N
+    rng = np.random.default_rng(3)
+    long = "".join(rng.choice(list("ACGTacgt"), 50000)) + "N" + "".join(rng.choice(list("ACGT"), 30000))
+    device_vs_oracle(gkc, [long, long[100:9000]], k, m, parts, rep=rep)
+    device_vs_oracle(gkc, [long], 63, m, parts, rep=rep)
+
+
+def test_oversize_buckets_low_complexity(gkc):
+    """massively repeated k-mers (poly-A, tandem repeats) overflow the LDS sort and take the global-memory path"""
+    reads = ["A" * 150] * 3000 + ["AC" * 75] * 2000 + synth_reads(500, 5000, 150, seed=8)
+    c, ref = device_vs_oracle(gkc, reads, 31, 10, 4)
+    assert c.stats()["oversize_buckets"] > 0
+    c, ref = device_vs_oracle(gkc, reads[:4000], 41, 10, 2)
+    assert c.stats()["oversize_buckets"] > 0
+
+
+def test_superkmer_buckets_match_partition_contract(gkc):
+    """A5/A6: the device buckets, re-encoded in the reference wire format and decoded by the oracle (B1), hold exactly
+    the k-mers the oracle's partitions hold (tile boundaries may split a super-k-mer; the k-mer multiset is the contract)"""
+    reads = synth_reads(1500, 10000, 150, seed=12, n_rate=0.002, ragged=True)
+    for (k, m, parts) in [(31, 10, 8), (63, 10, 4), (21, 8, 4)]:
+        bases, offs = gko.pack_reads(reads)
+        rep = simple_repart(m, parts)
+        ref = gko.Dsk(bases, offs, k, m, parts, rep)
+        c = gkc.Counter(0); c.configure(k, m, parts, rep); c.begin_pass(0); c.push_reads(bases, offs)
+        L = gko.lib()
+        for p in range(parts):
+            blob, nsk, nk = c.partition_superkmers(p)
+            assert nk == ref.part_stats(p)[0]
+            got = {}
+            off = 0; lo = np.zeros(256, np.uint64); hi = np.zeros(256, np.uint64); nbk = ctypes.c_uint(0)
+            nrec = 0
+            while off < len(blob):
+                off += L.gko_superkmer_decode(blob[off:].ctypes.data, k, lo, hi, ctypes.byref(nbk))
+                nrec += 1
+                for a, b in zip(lo[:nbk.value].tolist(), hi[:nbk.value].tolist()):
+                    key = (b << 64) | a; got[key] = got.get(key, 0) + 1
+            assert nrec == nsk and off == len(blob)
+            rlo, rhi, rab = ref.part(p)
+            exp = {(int(b) << 64) | int(a): int(cn) for a, b, cn in zip(rlo, rhi, rab)}
+            assert got == exp
+        c.finish_pass()
+
+
+@pytest.mark.parametrize("k", [11, 31, 41, 63])
+def test_bloom_bit_identical(gkc, k):
+    rng = np.random.default_rng(k)
+    keys = [int.from_bytes(rng.bytes(16), "little") & (4 ** k - 1) for _ in range(3000)]
+    others = [int.from_bytes(rng.bytes(16), "little") & (4 ** k - 1) for _ in range(2000)]
+    c = gkc.Counter(0)
+    for kind in ("basic", "cache", "neighbor"):
+        for (bits, nh) in [(3000 * 11, 7), (1 << 15, 4), (1000, 1)]:
+            ob = gko.Bloom(kind, bits, nh, k); ob.insert(keys)
+            db = gkc.Bloom(c, kind, bits, nh, k); db.insert(keys)
+            assert db.nbytes == ob.nbytes and db.bitsize == ob.bitsize
+            assert np.array_equal(db.array(), ob.array()), (kind, bits, nh)
+            assert np.array_equal(db.contains(keys + others), ob.contains(keys + others))
+            if kind == "neighbor":
+                assert np.array_equal(db.contains8(others[:500] + keys[:500]), ob.contains8(others[:500] + keys[:500]))
+            db.close()
+
+
+def test_bloom_of_solid_kmers_and_cfp_known_answer(gkc, ref_vectors):
+    """BloomAlgorithm::execute sizing + TestDebloom.cpp:133-137's 20 critical false positives, with the device filter"""
+    v = ref_vectors["debloom_k11"]; k = v["k"]
+    bases, offs = gko.pack_reads([v["seq"]])
+    c = gkc.Counter(0); c.configure(k, v["m"], 4, simple_repart(v["m"], 4)); c.count(bases, offs)
+    solid = c.all_counts()
+    lg2 = math.log(2)
+    nbits = np.float32(math.log(16 * k * (lg2 * lg2)) / (lg2 * lg2))
+    size = int(np.float32(len(solid)) * nbits); nb_hash = int(math.floor(0.7 * float(nbits)))
+    bl = gkc.Bloom(c, "basic", size, nb_hash, k)
+    bl.insert_solid()
+    mask = 4 ** k - 1
+    cand = set()
+    for x in solid:
+        for y in (x, revcomp_int(x, k)):
+            for j in range(4):
+                n = ((y << 2) | j) & mask
+                cand.add(min(n, revcomp_int(n, k)))
+    cand = sorted(cand - set(solid))
+    hits = bl.contains(cand)
+    assert {x for x, h in zip(cand, hits) if h} == set(v["cfp"])
+
+
+def test_synth_generator_and_checksum_property(gkc):
+    """device generator == numpy twin; independent checksum kernel == checksum of the counted records; sums match"""
+    c = gkc.Counter(0)
+    seed, n, L, G = 7, 20000, 150, 100000
+    db, do = c.synth_reads_device(seed, n, L, G, 10000)
+    hb = c.device_to_host(db, n * L)
+    nb, no = gkc.synth_reads_np(seed, n, L, G, 10000)
+    assert np.array_equal(hb, nb)
+    for (k, m) in [(31, 10), (63, 10)]:
+        parts = 32
+        rep = simple_repart(m, parts)
+        c.configure(k, m, parts, rep)
+        cs, nv = c.kmer_checksum_device(db, do, n, n * L)
+        c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+        rcs, rsum = c.result_checksum()
+        assert (rcs, rsum) == (cs, nv)
+        st = c.stats()
+        assert st["kmers_nb_valid"] == nv == n * (L - k + 1)
+        ref = gko.Dsk(nb, no, k, m, parts, rep)
+        for p in range(parts):
+            lo, hi, ab = c.partition(0, p)
+            rlo, rhi, rab = ref.part(p)
+            assert np.array_equal(lo, rlo) and np.array_equal(hi, rhi) and np.array_equal(ab, rab)
+            keys = (hi.astype(object) << 64) | lo.astype(object)
+            assert all(keys[i] < keys[i + 1] for i in range(len(keys) - 1))
+    c.device_free(db); c.device_free(do)
+
+
+def test_moderate_size_properties(gkc):
+    """2M reads (2.4e8 k-mers): size-independent properties — checksum of checksums, sum of abundances, strictly
+    ascending partitions, partition membership of sampled records"""
+    c = gkc.Counter(0)
+    seed, n, L, G = 11, 2_000_000, 150, 10_000_000
+    k, m, parts = 31, 10, 512
+    rep = simple_repart(m, parts)
+    c.configure(k, m, parts, rep)
+    db, do = c.synth_reads_device(seed, n, L, G, 10000)
+    cs, nv = c.kmer_checksum_device(db, do, n, n * L)
+    c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+    assert c.result_checksum() == (cs, nv)
+    st = c.stats()
+    assert st["kmers_nb_valid"] == nv == n * (L - k + 1)
+    tot = 0
+    for p in range(0, parts, 37):
+        lo, hi, ab = c.partition(0, p)
+        assert (np.diff(lo.astype(np.float64)) > 0).all() or (lo[1:] > lo[:-1]).all()
+        assert (ab >= 1).all()
+        tot += len(lo)
+        for key in lo[:: max(1, len(lo) // 20)].tolist():
+            s = "".join("ACTG"[(key >> (2 * (k - 1 - i))) & 3] for i in range(k))
+            mins, _ = gko.minimizers(s, k, m)
+            assert rep[mins[0]] == p
+    h = c.histogram()
+    assert int(h.sum()) == st["kmers_nb_distinct"]
+    assert int((h * np.arange(len(h), dtype=np.uint64)).sum()) == nv      # no abundance reaches histo_max here
+    c.device_free(db); c.device_free(do)
