@@ -67,12 +67,12 @@ static void free_pass_outputs(gkc_ctx* c, uint32_t pass)
 {
     auto it = c->pass_outputs.find(pass);
     if (it == c->pass_outputs.end()) return;
-    for (void* p : it->second) (void)hipFree(p);
+    for (void* p : it->second) c->dfree(p);
     c->pass_outputs.erase(it);
 }
 static void clear_segments(gkc_ctx* c)
 {
-    for (void* p : c->owned_arenas) (void)hipFree(p);
+    for (void* p : c->owned_arenas) c->dfree(p);
     c->owned_arenas.clear(); c->segments.clear();
 }
 
@@ -105,7 +105,8 @@ void gkc_destroy(gkc_ctx* c)
     std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first);
     for (uint32_t p : passes) free_pass_outputs(c, p);
     c->d_mkey_lut.release(); c->d_key2val.release(); c->d_repart.release(); c->d_histo.release();
-    c->d_scan_counters.release(); c->d_rsbits.release();
+    c->d_scan_counters.release(); c->d_rsbits.release(); c->d_scan_matrix.release();
+    c->pool.destroy();
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

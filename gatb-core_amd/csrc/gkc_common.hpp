@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 #include <string>
@@ -28,16 +29,45 @@ constexpr int SCAN_HALO_WORDS = 4;                             // 64 bases of lo
 constexpr int SCAN_WORDS = SCAN_TILE / 16 + SCAN_HALO_WORDS;   // 16-base words per tile
 
 // Stage B: a partition is split by key range into <= MAX_SUB sub-buckets, each sorted inside LDS.
-constexpr int MAX_SUB_BITS = 12;
-constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram / cursors: 16 KB
-constexpr int SORT_CAP_W1 = 4096;                              // keys per LDS sort, 8-byte keys (32 KB)
-constexpr int SORT_CAP_W2 = 2048;                              // keys per LDS sort, 16-byte keys (32 KB)
-constexpr int SUB_TARGET = 1024;                               // mean keys per sub-bucket the host aims at
+constexpr int MAX_SUB_BITS = 13;
+constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram / cursors: 32 KB
+constexpr int SUB_TARGET = 512;                                // mean keys per sub-bucket the host aims at (a wave sorts <= 1024 / 512)
 
 // ------------------------------------------------------------------------------------------------ device buffer
+// Caching device allocator: hipMalloc/hipFree of multi-GB buffers cost tens of ms per GB on this platform (far more than
+// the kernels that use them), so freed blocks are kept and reused by later passes of the same shape.
+struct DevPool {
+    std::multimap<size_t, void*> cache;       // free blocks by size
+    std::map<void*, size_t> live;             // blocks handed out
+    size_t cached_bytes = 0;
+    static size_t round(size_t b) { const size_t g = (size_t)2 << 20; return b < g ? ((b + 255) / 256 * 256 ? (b + 255) / 256 * 256 : 256) : (b + g - 1) / g * g; }
+    void* alloc(size_t bytes, hipError_t* err) {
+        const size_t want = round(bytes ? bytes : 1);
+        auto it = cache.lower_bound(want);
+        if (it != cache.end() && it->first <= want + want / 4 + ((size_t)1 << 20)) {       // close enough: reuse
+            void* p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess; return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, want); }   // give cached blocks back and retry
+        *err = e;
+        if (e != hipSuccess) return nullptr;
+        live[p] = want;
+        return p;
+    }
+    void free(void* p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) { (void)hipFree(p); return; }
+        cache.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
+    }
+    void trim() { for (auto& kv : cache) (void)hipFree(kv.second); cache.clear(); cached_bytes = 0; }
+    void destroy() { trim(); for (auto& kv : live) (void)hipFree(kv.first); live.clear(); }
+};
+
 struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void* p = nullptr; size_t bytes = 0; DevPool* pool = nullptr;
+    void release() { if (p) { if (pool) pool->free(p); else (void)hipFree(p); p = nullptr; bytes = 0; } }
 };
 
 // one bucketed batch of super-k-mer records (device analogue of SuperKmerBinFiles for one push)
@@ -86,20 +116,25 @@ struct gkc_ctx {
     // scratch reused across calls
     DevBuf d_scan_counters;    // u64[2P + 8]
     DevBuf d_rsbits;           // read-start bitmask
+    DevBuf d_scan_matrix;      // [2][grid][P] per-workgroup partition counts / bases (LDS-cursor scan)
     size_t key_budget = 0;     // max keys per Stage-B batch (0 = auto)
 
     void set_error(int code, const char* fmt, ...) {
         char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
         err.code = code; err.msg = buf;
     }
+    DevPool pool;
     int ensure(DevBuf& b, size_t bytes) {
         if (b.bytes >= bytes && b.p) return GKC_OK;
         b.release();
-        hipError_t e = hipMalloc(&b.p, bytes ? bytes : 16);
-        if (e != hipSuccess) { b.p = nullptr; set_error(GKC_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GKC_ERR_NOMEM; }
+        hipError_t e;
+        b.p = pool.alloc(bytes ? bytes : 16, &e); b.pool = &pool;
+        if (!b.p) { set_error(GKC_ERR_NOMEM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return GKC_ERR_NOMEM; }
         b.bytes = bytes;
         return GKC_OK;
     }
+    void* dalloc(size_t bytes) { hipError_t e; void* p = pool.alloc(bytes, &e); if (!p) set_error(GKC_ERR_NOMEM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return p; }
+    void dfree(void* p) { pool.free(p); }
 };
 
 // RAII event timer accumulating into ctx->timing[name]

@@ -13,12 +13,14 @@
 //                  sub-buckets per partition, sized so a sub-bucket fits one LDS sort); the same workgroup scans the
 //                  histogram into exact sub-bucket offsets.
 //   expand_scatter same stream again, LDS cursors (no global atomics), keys written once to their sub-bucket.
-//   bucket_sort    persistent workgroups: load one sub-bucket into LDS, bitonic sort, run-length count, abundance
-//                  histogram (LDS-aggregated), write distinct keys + counts back in place.
-//   compact        exclusive scan of solid counts, then records {value, abundance} in the reference's Count layout,
-//                  contiguous and ascending per partition (sub-buckets are key ranges, so concatenation is sorted).
-//   oversize path  sub-buckets larger than the LDS capacity (massively repeated k-mers, or too few partitions):
-//                  global-memory bitonic sort + a chunked single-workgroup run-length pass. Slow but exact.
+//   bucket_sort    one WAVE per sub-bucket: keys in registers, bitonic network (register compare-exchanges + lane-xor
+//                  shuffles, no LDS, no barrier), run-length count, abundance histogram (LDS-aggregated); distinct keys
+//                  and abundances are written back at the head of the sub-bucket's own slot range.
+//   split levels   sub-buckets larger than a wave holds (k-mers that start with their minimizer share their top bits;
+//                  repeats; too few partitions) are split again on their next key bits, keys -> keys, and re-sorted;
+//                  when no key bit is left all keys are one k-mer. Any skew terminates in <= ceil(2k/13)+1 levels.
+//   compact        slot flags (abundance != 0) -> block sums -> prefix -> records {value, abundance} in the reference's
+//                  Count layout, contiguous and ascending per partition (slot order is key order).
 #include "gkc_common.hpp"
 #include "gkc_device.hpp"
 #include <algorithm>
@@ -43,8 +45,10 @@ struct SegTable {          // device copy of the segment list
 template <int RW> __device__ __forceinline__ uint32_t rec_nt(const uint64_t (&R)[RW], uint32_t i)
 {
     if (i < 28) return (uint32_t)(R[0] >> (54 - 2 * i)) & 3u;
-    uint32_t j = i - 28;
-    return (uint32_t)(R[1 + (j >> 5)] >> (62 - 2 * (j & 31))) & 3u;
+    const uint32_t j = i - 28;
+    uint64_t w = R[1];                                    // selects instead of a dynamic register-array index (no scratch)
+    if (RW == 4) { const uint32_t q = j >> 5; w = q == 0 ? R[1] : (q == 1 ? R[RW > 2 ? 2 : 1] : R[RW > 2 ? 3 : 1]); }
+    return (uint32_t)(w >> (62 - 2 * (j & 31))) & 3u;
 }
 
 // calls f(canonical) for every k-mer of the record (B1: temp=((temp<<2)|nt)&mask, rev=((rev>>2)|(comp(nt)<<shift))&mask)
@@ -80,7 +84,7 @@ constexpr int EXPAND_THREADS = 512;
 // ------------------------------------------------------------------------------------------------ B1 expand_count
 template <int KW, int RW>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
-                                                                  uint64_t* __restrict__ sub_off)
+                                                                  uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
@@ -112,20 +116,23 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     uint32_t wpre = 0;
     for (int w = 0; w < wave; w++) wpre += s_wsum[w];
     uint32_t run = wpre + x - loc;
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) { sub_off[pd.sub_base + b + i] = pd.key_base + run; run += s_hist[b + i]; }
+    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+        b_start[pd.sub_base + b + i] = pd.key_base + run; b_n[pd.sub_base + b + i] = s_hist[b + i]; b_consumed[pd.sub_base + b + i] = (uint8_t)pd.sub_bits;
+        run += s_hist[b + i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ B3 expand_scatter
 template <int KW, int RW>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_scatter(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
-                                                                    const uint64_t* __restrict__ sub_off,
+                                                                    const uint64_t* __restrict__ b_start,
                                                                     typename KeyT<KW>::type* __restrict__ keys)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_cur[MAX_SUB];
     const PartDesc pd = parts[blockIdx.x];
     const uint32_t nsub = 1u << pd.sub_bits;
-    for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) s_cur[i] = (uint32_t)(sub_off[pd.sub_base + i] - pd.key_base);
+    for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) s_cur[i] = (uint32_t)(b_start[pd.sub_base + i] - pd.key_base);
     __syncthreads();
     key_t* out = keys + pd.key_base;
     for (uint32_t s = 0; s < segs.n_seg; s++) {
@@ -141,259 +148,341 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_scatter(const PartDes
     }
 }
 
-// ------------------------------------------------------------------------------------------------ B4 bucket_sort + RLE
+// ------------------------------------------------------------------------------------------------ B2/B3 wave sort + RLE
+// One WAVE per sub-bucket, keys in registers (KPL per lane, blocked index e = lane*KPL + r), bitonic network with
+// all-ascending comparators: in-lane steps are register compare-exchanges, cross-lane steps are lane-xor shuffles.
+// No LDS traffic, no barrier; the load is striped (coalesced) because a sort does not care about the initial order.
 constexpr int SORT_THREADS = 256;
 constexpr int HIST_LDS = 64;
 
 struct SortOut {
-    uint32_t* cnt;            // [n_keys] abundance of distinct key j of sub-bucket g at cnt[start_g + j]
-    uint32_t* n_distinct;     // [n_sub]
-    uint32_t* n_solid;        // [n_sub]
+    uint32_t* cnt;            // [n_slots] abundance of the distinct key written at the same slot (0 = empty slot)
     unsigned long long* histo; uint32_t histo_max;
-    int32_t amin, amax;
-    uint32_t* oversize_list; uint32_t* oversize_count; uint32_t oversize_cap;
+    uint32_t* over_list; uint32_t* over_count;      // buckets too large for one wave -> next level
+    unsigned long long* n_sorted;                   // [0] buckets sorted here [1] keys sorted here
 };
 
-template <int KW>
-__global__ __launch_bounds__(SORT_THREADS) void k_bucket_sort(typename KeyT<KW>::type* __restrict__ keys, const uint64_t* __restrict__ sub_off,
-                                                               uint32_t n_sub, SortOut O)
+template <int KW> struct Shfl;
+template <> struct Shfl<1> {
+    static __device__ __forceinline__ uint64_t x(uint64_t v, int m) { return (uint64_t)__shfl_xor((unsigned long long)v, m, 64); }
+    static __device__ __forceinline__ uint64_t up(uint64_t v) { return (uint64_t)__shfl_up((unsigned long long)v, 1, 64); }
+    static __device__ __forceinline__ uint64_t down(uint64_t v) { return (uint64_t)__shfl_down((unsigned long long)v, 1, 64); }
+};
+template <> struct Shfl<2> {
+    static __device__ __forceinline__ u128 x(u128 v, int m) {
+        unsigned long long lo = __shfl_xor((unsigned long long)v, m, 64), hi = __shfl_xor((unsigned long long)(v >> 64), m, 64);
+        return ((u128)hi << 64) | lo; }
+    static __device__ __forceinline__ u128 up(u128 v) {
+        unsigned long long lo = __shfl_up((unsigned long long)v, 1, 64), hi = __shfl_up((unsigned long long)(v >> 64), 1, 64);
+        return ((u128)hi << 64) | lo; }
+    static __device__ __forceinline__ u128 down(u128 v) {
+        unsigned long long lo = __shfl_down((unsigned long long)v, 1, 64), hi = __shfl_down((unsigned long long)(v >> 64), 1, 64);
+        return ((u128)hi << 64) | lo; }
+};
+
+template <int KW, int KPL>
+__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane)
 {
     typedef typename KeyT<KW>::type key_t;
-    constexpr int CAP = (KW == 1) ? SORT_CAP_W1 : SORT_CAP_W2;
-    __shared__ key_t s_k[CAP];
-    __shared__ uint16_t s_head[CAP + 1];
-    __shared__ uint32_t s_hc[HIST_LDS];
-    __shared__ uint32_t s_wsum[SORT_THREADS / 64];
-    __shared__ uint32_t s_nd, s_ns;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t < HIST_LDS) s_hc[t] = 0;
-    for (uint32_t g = blockIdx.x; g < n_sub; g += gridDim.x) {
-        const uint64_t start = sub_off[g];
-        const uint64_t n64 = sub_off[g + 1] - start;
-        __syncthreads();                                   // previous iteration fully drained (s_k, s_head reuse)
-        if (n64 == 0) { if (t == 0) { O.n_distinct[g] = 0; O.n_solid[g] = 0; } continue; }
-        if (n64 > (uint64_t)CAP) {
-            if (t == 0) {
-                O.n_distinct[g] = 0; O.n_solid[g] = 0;
-                uint32_t slot = atomicAdd(O.oversize_count, 1u);
-                if (slot < O.oversize_cap) O.oversize_list[slot] = g;
-            }
-            continue;
-        }
-        const uint32_t n = (uint32_t)n64;
-        uint32_t N = 2; while (N < n) N <<= 1;
-        for (uint32_t i = t; i < N; i += SORT_THREADS) s_k[i] = (i < n) ? keys[start + i] : KeyT<KW>::max();
-        __syncthreads();
-        // bitonic sort, all comparators ascending (mirror step then half-cleaners)
-        for (uint32_t size = 2; size <= N; size <<= 1) {
-            const uint32_t half = size >> 1;
-            for (uint32_t q = t; q < (N >> 1); q += SORT_THREADS) {
-                const uint32_t blk = q / half, off = q % half;
-                const uint32_t i = blk * size + off, j = blk * size + size - 1 - off;
-                key_t a = s_k[i], b = s_k[j];
-                if (b < a) { s_k[i] = b; s_k[j] = a; }
-            }
-            __syncthreads();
-            for (uint32_t stride = half >> 1; stride >= 1; stride >>= 1) {
-                for (uint32_t q = t; q < (N >> 1); q += SORT_THREADS) {
-                    const uint32_t i = 2 * stride * (q / stride) + (q % stride), j = i + stride;
-                    key_t a = s_k[i], b = s_k[j];
-                    if (b < a) { s_k[i] = b; s_k[j] = a; }
-                }
-                __syncthreads();
-            }
-        }
-        // run-length count (B3): heads of runs, their positions compacted into s_head
-        const uint32_t per = (n + SORT_THREADS - 1) / SORT_THREADS;
-        const uint32_t b0 = t * per;
-        uint32_t loc = 0;
-        for (uint32_t i = b0; i < b0 + per && i < n; i++) loc += (i == 0 || s_k[i] != s_k[i - 1]);
-        uint32_t x = loc;
+    constexpr int N = 64 * KPL;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-        if (lane == 63) s_wsum[wave] = x;
-        __syncthreads();
-        uint32_t wpre = 0;
-        for (int w = 0; w < wave; w++) wpre += s_wsum[w];
-        uint32_t idx = wpre + x - loc;
-        for (uint32_t i = b0; i < b0 + per && i < n; i++) if (i == 0 || s_k[i] != s_k[i - 1]) s_head[idx++] = (uint16_t)i;
-        if (t == SORT_THREADS - 1) { s_nd = idx; s_head[idx] = (uint16_t)n; s_ns = 0; }
-        __syncthreads();
-        const uint32_t nd = s_nd;
-        uint32_t solid = 0;
-        for (uint32_t j = t; j < nd; j += SORT_THREADS) {
-            const uint32_t h = s_head[j];
-            const uint32_t c = (uint32_t)s_head[j + 1] - h;
-            keys[start + j] = s_k[h];                       // in place: the whole sub-bucket already sits in LDS
-            O.cnt[start + j] = c;
-            const uint32_t hb = c >= O.histo_max ? O.histo_max : c;          // Histogram::inc (Histogram.hpp:92)
+    for (int size = 2; size <= N; size <<= 1) {
+        // mirror step: e <-> e ^ (size-1)
+        if (size <= KPL) {
+#pragma unroll
+            for (int r = 0; r < KPL; r++) { const int pr = r ^ (size - 1); if (pr > r) { key_t a = v[r], b = v[pr]; const bool sw = b < a; v[r] = sw ? b : a; v[pr] = sw ? a : b; } }
+        } else {
+            const int lmask = size / KPL - 1, top = (size / KPL) >> 1;
+            const bool low = (lane & top) == 0;
+            key_t w[KPL];
+#pragma unroll
+            for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::x(v[KPL - 1 - r], lmask); const bool ylt = y < v[r]; w[r] = (ylt == low) ? y : v[r]; }
+#pragma unroll
+            for (int r = 0; r < KPL; r++) v[r] = w[r];
+        }
+        // half cleaners: e <-> e ^ s
+#pragma unroll
+        for (int s = size >> 2; s >= 1; s >>= 1) {
+            if (s < KPL) {
+#pragma unroll
+                for (int r = 0; r < KPL; r++) if ((r & s) == 0) { key_t a = v[r], b = v[r | s]; const bool sw = b < a; v[r] = sw ? b : a; v[r | s] = sw ? a : b; }
+            } else {
+                const int ls = s / KPL;
+                const bool low = (lane & ls) == 0;
+#pragma unroll
+                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::x(v[r], ls); const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
+            }
+        }
+    }
+}
+
+// sort + run-length count one bucket of n <= 64*KPL keys held by one wave; writes distinct keys / abundances at
+// outk[start + j], O.cnt[start + j] (j-th distinct key) — ascending; slots start+nd .. start+n-1 keep abundance 0.
+template <int KW, int KPL>
+__device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                 const uint64_t start, const uint32_t n, const SortOut& O, uint32_t* s_hc, const int lane)
+{
+    typedef typename KeyT<KW>::type key_t;
+    key_t v[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[start + i] : KeyT<KW>::max(); }
+    bitonic_wave<KW, KPL>(v, lane);
+    // run-length count (B3). e = lane*KPL + r is the sorted rank
+    const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
+    const key_t next_first = Shfl<KW>::down(v[0]);
+    uint32_t headm = 0, tailm = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = lane * KPL + r;
+        const key_t pv = r ? v[r - 1] : prev_last;
+        const key_t nx = (r < KPL - 1) ? v[r + 1] : next_first;
+        const bool in = e < n;
+        headm |= (uint32_t)(in && (e == 0 || v[r] != pv)) << r;
+        tailm |= (uint32_t)(in && (e == n - 1 || v[r] != nx)) << r;
+    }
+    const uint32_t nt = __popc(tailm);
+    int lh = headm ? (int)(lane * KPL + 31 - __clz((int)headm)) : -1;
+    uint32_t x = nt; int hx = lh;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); const int hy = __shfl_up(hx, d, 64); if (lane >= d) { x += y; hx = hy > hx ? hy : hx; } }
+    uint32_t idx = x - nt;
+    int cur = __shfl_up(hx, 1, 64); if (lane == 0) cur = -1;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const int e = lane * KPL + r;
+        if ((headm >> r) & 1) cur = e;
+        if ((tailm >> r) & 1) {
+            const uint32_t c = (uint32_t)(e - cur + 1);
+            outk[start + idx] = v[r]; O.cnt[start + idx] = c; idx++;
+            const uint32_t hb = c >= O.histo_max ? O.histo_max : c;              // Histogram::inc (Histogram.hpp:92)
             if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
-            solid += ((int32_t)c >= O.amin && (int32_t)c <= O.amax);        // CountRange::includes, closed interval
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) solid += __shfl_down(solid, d, 64);
-        if (lane == 0 && solid) atomicAdd(&s_ns, solid);
-        __syncthreads();
-        if (t == 0) { O.n_distinct[g] = nd; O.n_solid[g] = s_ns; }
+    }
+}
+
+template <int KW> struct WaveCap { static constexpr int KPL_MAX = (KW == 1) ? 16 : 8; static constexpr uint32_t CAP = 64 * KPL_MAX; };
+
+template <int KW>
+__global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                             const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O)
+{
+    __shared__ uint32_t s_hc[HIST_LDS];
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    __syncthreads();
+    const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
+    uint32_t nb_done = 0; unsigned long long nk_done = 0;
+    for (uint32_t g = wave; g < n_buckets; g += n_waves) {
+        const uint32_t n = b_n[g];
+        if (n == 0) continue;
+        const uint64_t start = b_start[g];
+        if (n > WaveCap<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over_count, 1u); O.over_list[slot] = g; } continue; }
+        nb_done++; nk_done += n;
+        if (n <= 64) wave_sort_bucket<KW, 1>(src, outk, start, n, O, s_hc, lane);
+        else if (n <= 128) wave_sort_bucket<KW, 2>(src, outk, start, n, O, s_hc, lane);
+        else if (n <= 256) wave_sort_bucket<KW, 4>(src, outk, start, n, O, s_hc, lane);
+        else if (n <= 512 || KW == 2) wave_sort_bucket<KW, 8>(src, outk, start, n, O, s_hc, lane);
+        else wave_sort_bucket<KW, WaveCap<KW>::KPL_MAX>(src, outk, start, n, O, s_hc, lane);
     }
     __syncthreads();
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+    if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
 }
 
-// ------------------------------------------------------------------------------------------------ oversize path
-template <int KW>
-__global__ void k_gbitonic_step(typename KeyT<KW>::type* __restrict__ a, uint64_t n, uint64_t N, uint64_t size, uint64_t stride, int mirror)
-{
-    typedef typename KeyT<KW>::type key_t;
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= (N >> 1)) return;
-    uint64_t i, j;
-    if (mirror) { const uint64_t half = size >> 1, blk = q / half, off = q % half; i = blk * size + off; j = blk * size + size - 1 - off; }
-    else { i = 2 * stride * (q / stride) + (q % stride); j = i + stride; }
-    if (j >= n) return;                                   // virtual +inf padding never moves (all comparators ascending)
-    key_t x = a[i], y = a[j];
-    if (y < x) { a[i] = y; a[j] = x; }
-}
+// ------------------------------------------------------------------------------------------------ deeper levels
+// A bucket too large for one wave (skewed key ranges: k-mers that START with their minimizer share their top 2m bits;
+// repeats; too few partitions) is split again on its next key bits by one workgroup, keys -> keys (ping-pong buffers).
+// When no bit is left every key of the bucket is the same k-mer: one record with abundance n.
+struct SplitDesc { uint64_t start; uint32_t n; uint32_t left; uint32_t bits; uint32_t consumed; uint64_t child_base; };
 
-// chunked run-length pass over a sorted segment by ONE workgroup; writes the same outputs as k_bucket_sort
 template <int KW>
-__global__ __launch_bounds__(1024) void k_rle_big(typename KeyT<KW>::type* __restrict__ keys, uint64_t start, uint64_t n, uint32_t g, SortOut O)
+__global__ __launch_bounds__(EXPAND_THREADS) void k_split_count(const typename KeyT<KW>::type* __restrict__ src, const SplitDesc* __restrict__ descs,
+                                                                 uint64_t* __restrict__ c_start, uint32_t* __restrict__ c_n, uint8_t* __restrict__ c_consumed,
+                                                                 uint32_t* __restrict__ eff_shift)
 {
     typedef typename KeyT<KW>::type key_t;
-    __shared__ uint64_t s_w[16]; __shared__ long long s_wh[16];
-    __shared__ uint64_t s_carry_out; __shared__ long long s_carry_head; __shared__ uint32_t s_solid;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) { s_carry_out = 0; s_carry_head = -1; s_solid = 0; }
+    __shared__ uint32_t s_hist[MAX_SUB];
+    __shared__ uint32_t s_wsum[EXPAND_THREADS / 64];
+    __shared__ unsigned long long s_or[2];
+    const SplitDesc d = descs[blockIdx.x];
+    const uint32_t nsub = 1u << d.bits, mask = nsub - 1;
+    for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) s_hist[i] = 0;
+    if (threadIdx.x < 2) s_or[threadIdx.x] = 0;
     __syncthreads();
-    key_t* a = keys + start;
+    // leading bits shared by every key of the bucket carry no information: skip them (e.g. k-mers that start with
+    // their minimizer share 2m bits), so a skewed bucket resolves in one more level instead of several
+    {
+        const key_t k0 = src[d.start];
+        key_t acc = 0;
+        for (uint32_t i = threadIdx.x; i < d.n; i += EXPAND_THREADS) acc |= src[d.start + i] ^ k0;
+        unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); }
+        if ((threadIdx.x & 63) == 0) { atomicOr(&s_or[0], lo); if (KW == 2) atomicOr(&s_or[1], hi); }
+    }
+    __syncthreads();
+    uint32_t diff_bits;                                    // number of low bits that may differ between keys
+    {   const unsigned long long lo = s_or[0], hi = s_or[1];
+        diff_bits = hi ? 128 - __clzll((long long)hi) : (lo ? 64 - __clzll((long long)lo) : 0); }
+    const uint32_t left = diff_bits < d.left ? diff_bits : d.left;         // informative bits still unused
+    const uint32_t bits = d.bits < left ? d.bits : left;
+    const uint32_t shift = left - bits;
+    const uint32_t cons_child = d.consumed + (d.left - left) + bits;      // == 2k when left == bits
+    if (threadIdx.x == 0) eff_shift[blockIdx.x] = shift | (bits << 8);
+    const uint32_t m2 = bits ? ((1u << bits) - 1) : 0;
+    for (uint32_t i = threadIdx.x; i < d.n; i += EXPAND_THREADS) atomicAdd(&s_hist[(uint32_t)(src[d.start + i] >> shift) & m2], 1u);
+    __syncthreads();
+    (void)mask;
+    const uint32_t per = (nsub + EXPAND_THREADS - 1) / EXPAND_THREADS;
+    const uint32_t b = threadIdx.x * per;
+    uint32_t loc = 0;
+    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += s_hist[b + i];
+    uint32_t x = loc; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { uint32_t y = __shfl_up(x, dd, 64); if (lane >= dd) x += y; }
+    if (lane == 63) s_wsum[wave] = x;
+    __syncthreads();
+    uint32_t wpre = 0;
+    for (int w = 0; w < wave; w++) wpre += s_wsum[w];
+    uint32_t run = wpre + x - loc;
+    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+        c_start[d.child_base + b + i] = d.start + run; c_n[d.child_base + b + i] = s_hist[b + i];
+        c_consumed[d.child_base + b + i] = (uint8_t)cons_child;
+        run += s_hist[b + i];
+    }
+}
+template <int KW>
+__global__ __launch_bounds__(EXPAND_THREADS) void k_split_scatter(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ dst,
+                                                                   const SplitDesc* __restrict__ descs, const uint64_t* __restrict__ c_start,
+                                                                   const uint32_t* __restrict__ eff_shift)
+{
+    __shared__ uint32_t s_cur[MAX_SUB];
+    const SplitDesc d = descs[blockIdx.x];
+    const uint32_t es = eff_shift[blockIdx.x];
+    const uint32_t shift = es & 255, bits = es >> 8;
+    const uint32_t nsub = 1u << d.bits, mask = bits ? ((1u << bits) - 1) : 0;
+    for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) s_cur[i] = (uint32_t)(c_start[d.child_base + i] - d.start);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < d.n; i += EXPAND_THREADS) {
+        const typename KeyT<KW>::type key = src[d.start + i];
+        const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(key >> shift) & mask], 1u);
+        dst[d.start + slot] = key;
+    }
+}
+// buckets whose keys are all equal (no key bit left): one record
+template <int KW>
+__global__ void k_uniform_buckets(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk, const SplitDesc* __restrict__ descs,
+                                  uint32_t n, SortOut O)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SplitDesc d = descs[i];
+    outk[d.start] = src[d.start];
+    const uint32_t c = d.n > 0x7FFFFFFFu ? 0x7FFFFFFFu : d.n;                       // CountNumber is int32
+    O.cnt[d.start] = c;
+    atomicAdd(&O.histo[c >= O.histo_max ? O.histo_max : c], 1ULL);
+}
+__global__ void k_gather_buckets(const uint32_t* __restrict__ list, uint32_t n, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+                                 const uint8_t* __restrict__ b_consumed, uint64_t* __restrict__ o_start, uint32_t* __restrict__ o_n, uint32_t* __restrict__ o_consumed)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = list[i];
+    o_start[i] = b_start[g]; o_n[i] = b_n[g]; o_consumed[i] = b_consumed[g];
+}
+
+// ------------------------------------------------------------------------------------------------ B5 compaction by slot flags
+// cnt[slot] != 0 marks a distinct k-mer (key in keys[slot]); partitions start on COMPACT_BLK-aligned slots, so the
+// per-block prefix directly yields per-partition offsets.
+constexpr int COMPACT_THREADS = 1024, COMPACT_ITEMS = 4, COMPACT_BLK = COMPACT_THREADS * COMPACT_ITEMS;
+__global__ __launch_bounds__(COMPACT_THREADS) void k_flag_block_sums(const uint32_t* __restrict__ cnt, uint64_t n_slots, int32_t amin, int32_t amax,
+                                                                      uint64_t* __restrict__ bs_distinct, uint64_t* __restrict__ bs_solid)
+{
+    __shared__ uint32_t s_d[COMPACT_THREADS / 64], s_s[COMPACT_THREADS / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * COMPACT_BLK + (uint64_t)threadIdx.x * COMPACT_ITEMS;
+    uint32_t d = 0, s = 0;
+    if (base + COMPACT_ITEMS <= n_slots) {
+        const uint4 v = *reinterpret_cast<const uint4*>(cnt + base);
+        const uint32_t c[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) { d += c[i] != 0; s += (c[i] != 0 && (int32_t)c[i] >= amin && (int32_t)c[i] <= amax); }
+    } else {
+        for (int i = 0; i < COMPACT_ITEMS; i++) if (base + i < n_slots) { const uint32_t c = cnt[base + i]; d += c != 0; s += (c != 0 && (int32_t)c >= amin && (int32_t)c <= amax); }
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) { d += __shfl_down(d, dd, 64); s += __shfl_down(s, dd, 64); }
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_s[threadIdx.x >> 6] = s; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t td = 0, ts = 0;
+        for (int w = 0; w < COMPACT_THREADS / 64; w++) { td += s_d[w]; ts += s_s[w]; }
+        bs_distinct[blockIdx.x] = td; bs_solid[blockIdx.x] = ts;
+    }
+}
+// in-place exclusive scan of two u64 arrays of n entries (+ totals at [n]) by ONE workgroup, chunked with carry
+__global__ __launch_bounds__(1024) void k_scan2_u64(uint64_t* __restrict__ a, uint64_t* __restrict__ b, uint64_t n)
+{
+    __shared__ uint64_t s_a[16], s_b[16]; __shared__ uint64_t s_ca, s_cb;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) { s_ca = 0; s_cb = 0; }
+    __syncthreads();
     for (uint64_t c0 = 0; c0 < n; c0 += 1024) {
         const uint64_t i = c0 + t;
-        const bool in = i < n;
-        key_t me = in ? a[i] : KeyT<KW>::max();
-        const bool head = in && (i == 0 || a[i - 1] != me);
-        const bool tail = in && (i == n - 1 || a[i + 1] != me);
-        // inclusive max-scan of head positions, exclusive sum-scan of tails
-        long long hp = head ? (long long)i : -1; uint64_t tc = tail ? 1 : 0;
-        long long x = hp; uint64_t y = tc;
+        const uint64_t va = i < n ? a[i] : 0, vb = i < n ? b[i] : 0;
+        uint64_t xa = va, xb = vb;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { long long x2 = __shfl_up(x, d, 64); uint64_t y2 = __shfl_up(y, d, 64); if (lane >= d) { x = x2 > x ? x2 : x; y += y2; } }
-        if (lane == 63) { s_wh[wave] = x; s_w[wave] = y; }
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t ya = __shfl_up((unsigned long long)xa, d, 64), yb = __shfl_up((unsigned long long)xb, d, 64); if (lane >= d) { xa += ya; xb += yb; } }
+        if (lane == 63) { s_a[wave] = xa; s_b[wave] = xb; }
         __syncthreads();
-        long long ch = s_carry_head; uint64_t co = s_carry_out;
-        for (int w = 0; w < wave; w++) { ch = s_wh[w] > ch ? s_wh[w] : ch; co += s_w[w]; }
-        const long long myhead = x > ch ? x : ch;
-        const uint64_t myidx = co + y - tc;
-        __syncthreads();                                  // every a[i-1]/a[i+1] read of this chunk is done
-        if (tail) {
-            const uint64_t cnt64 = i - (uint64_t)myhead + 1;
-            const uint32_t c = cnt64 > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)cnt64;   // CountNumber is int32
-            a[myidx] = me; O.cnt[start + myidx] = c;
-            const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
-            atomicAdd(&O.histo[hb], 1ULL);
-            if ((int32_t)c >= O.amin && (int32_t)c <= O.amax) atomicAdd(&s_solid, 1u);
-        }
+        uint64_t pa = s_ca, pb = s_cb;
+        for (int w = 0; w < wave; w++) { pa += s_a[w]; pb += s_b[w]; }
+        if (i < n) { a[i] = pa + xa - va; b[i] = pb + xb - vb; }
         __syncthreads();
-        if (t == 1023) { s_carry_head = myhead; s_carry_out = myidx + tc; }
+        if (t == 1023) { s_ca = pa + xa; s_cb = pb + xb; }
         __syncthreads();
     }
-    if (t == 0) { O.n_distinct[g] = (uint32_t)s_carry_out; O.n_solid[g] = s_solid; }
+    if (t == 0) { a[n] = s_ca; b[n] = s_cb; }
 }
-
-// ------------------------------------------------------------------------------------------------ scans / gather / compact
-// out[i] = sum_{j<i} in[j]  (u32 -> u64), n+1 outputs; three small kernels
-constexpr int SCAN_BLK = 1024, SCAN_ITEMS = 4;
-__global__ __launch_bounds__(SCAN_BLK) void k_scan_block_sums(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ block_sums)
-{
-    __shared__ uint64_t s[SCAN_BLK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLK * SCAN_ITEMS + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint64_t v = 0;
-    for (int i = 0; i < SCAN_ITEMS; i++) if (base + i < n) v += in[base + i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint64_t tot = 0; for (int w = 0; w < SCAN_BLK / 64; w++) tot += s[w]; block_sums[blockIdx.x] = tot; }
-}
-__global__ void k_scan_serial(uint64_t* __restrict__ a, uint64_t n)     // exclusive, in place, tiny n (#blocks)
-{
-    if (threadIdx.x || blockIdx.x) return;
-    uint64_t run = 0;
-    for (uint64_t i = 0; i < n; i++) { uint64_t v = a[i]; a[i] = run; run += v; }
-    a[n] = run;
-}
-__global__ __launch_bounds__(SCAN_BLK) void k_scan_final(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ block_sums,
-                                                          uint64_t* __restrict__ out)
-{
-    __shared__ uint64_t s[SCAN_BLK / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLK * SCAN_ITEMS + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS]; uint64_t loc = 0;
-    for (int i = 0; i < SCAN_ITEMS; i++) { v[i] = (base + i < n) ? in[base + i] : 0; loc += v[i]; }
-    uint64_t x = loc; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint64_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-    if (lane == 63) s[wave] = x;
-    __syncthreads();
-    uint64_t run = block_sums[blockIdx.x];
-    for (int w = 0; w < wave; w++) run += s[w];
-    run += x - loc;
-    for (int i = 0; i < SCAN_ITEMS; i++) { if (base + i < n) out[base + i] = run; run += v[i]; }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_BLK - 1) out[n] = block_sums[gridDim.x];
-}
-
-// per-partition totals: distinct (sum over its sub-buckets) and the solid offset of its first sub-bucket
-__global__ void k_part_totals(const PartDesc* __restrict__ parts, uint32_t n_parts, const uint32_t* __restrict__ n_distinct,
-                              const uint64_t* __restrict__ solid_off, uint64_t* __restrict__ out /* [n_parts][2] */)
-{
-    __shared__ uint64_t s[4];
-    const PartDesc pd = parts[blockIdx.x];
-    const uint32_t nsub = 1u << pd.sub_bits;
-    uint64_t v = 0;
-    for (uint32_t i = threadIdx.x; i < nsub; i += blockDim.x) v += n_distinct[pd.sub_base + i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { out[2 * blockIdx.x] = s[0] + s[1] + s[2] + s[3]; out[2 * blockIdx.x + 1] = solid_off[pd.sub_base]; }
-}
-
 // B5 dump: Count records {value, abundance} (Abundance.hpp:68-129), solid only, ascending
 template <int KW>
-__global__ __launch_bounds__(SORT_THREADS) void k_compact(const typename KeyT<KW>::type* __restrict__ keys, const uint32_t* __restrict__ cnt,
-                                                           const uint64_t* __restrict__ sub_off, const uint32_t* __restrict__ n_distinct,
-                                                           const uint64_t* __restrict__ solid_off, uint32_t n_sub,
-                                                           int32_t amin, int32_t amax, uint64_t* __restrict__ out)
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_flags(const typename KeyT<KW>::type* __restrict__ keys, const uint32_t* __restrict__ cnt, uint64_t n_slots,
+                                                                    const uint64_t* __restrict__ bp_solid, int32_t amin, int32_t amax, uint64_t* __restrict__ out)
 {
-    __shared__ uint32_t s_wsum[SORT_THREADS / 64];
+    __shared__ uint32_t s_w[COMPACT_THREADS / 64];
+    constexpr int OW = (KW == 1) ? 2 : 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    constexpr int OW = (KW == 1) ? 2 : 4;                   // u64 words per Count record
-    for (uint32_t g = blockIdx.x; g < n_sub; g += gridDim.x) {
-        const uint32_t nd = n_distinct[g];
-        const uint64_t start = sub_off[g];
-        uint64_t obase = solid_off[g];
-        for (uint32_t c0 = 0; c0 < nd; c0 += SORT_THREADS) {
-            const uint32_t j = c0 + t;
-            uint32_t c = 0; typename KeyT<KW>::type key = 0;
-            bool ok = false;
-            if (j < nd) { c = cnt[start + j]; key = keys[start + j]; ok = ((int32_t)c >= amin && (int32_t)c <= amax); }
-            uint32_t x = ok;
+    const uint64_t base = (uint64_t)blockIdx.x * COMPACT_BLK + (uint64_t)t * COMPACT_ITEMS;
+    uint32_t c[COMPACT_ITEMS]; uint32_t ok = 0, loc = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-            __syncthreads();
-            if (lane == 63) s_wsum[wave] = x;
-            __syncthreads();
-            uint32_t pre = 0, tot = 0;
-            for (int w = 0; w < SORT_THREADS / 64; w++) { if (w < wave) pre += s_wsum[w]; tot += s_wsum[w]; }
-            if (ok) {
-                uint64_t* o = out + (obase + pre + x - 1) * OW;
-                if (KW == 1) { *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2((uint64_t)key, (uint64_t)c); }
-                else {
-                    *reinterpret_cast<ulonglong2*>(o) = make_ulonglong2((uint64_t)key, (uint64_t)((u128)key >> 64));
-                    *reinterpret_cast<ulonglong2*>(o + 2) = make_ulonglong2((uint64_t)c, 0ULL);
-                }
-            }
-            obase += tot;
+    for (int i = 0; i < COMPACT_ITEMS; i++) {
+        c[i] = (base + i < n_slots) ? cnt[base + i] : 0;
+        const bool o = c[i] != 0 && (int32_t)c[i] >= amin && (int32_t)c[i] <= amax;       // CountRange::includes (closed interval)
+        ok |= (uint32_t)o << i; loc += o;
+    }
+    uint32_t x = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int w = 0; w < wave; w++) pre += s_w[w];
+    uint64_t o = bp_solid[blockIdx.x] + pre + x - loc;
+#pragma unroll
+    for (int i = 0; i < COMPACT_ITEMS; i++) if ((ok >> i) & 1) {
+        const typename KeyT<KW>::type key = keys[base + i];
+        uint64_t* dst = out + o * OW; o++;
+        if (KW == 1) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2((uint64_t)key, (uint64_t)c[i]);
+        else {
+            *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2((uint64_t)key, (uint64_t)((u128)key >> 64));
+            *reinterpret_cast<ulonglong2*>(dst + 2) = make_ulonglong2((uint64_t)c[i], 0ULL);
         }
     }
+}
+__global__ void k_gather_u64(const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, const uint64_t* __restrict__ idx, uint32_t n, uint64_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[2 * i] = a[idx[i]]; out[2 * i + 1] = b[idx[i]];
 }
 
 // checksum of a Count-record array: sum abundance * mix(value), sum abundance
@@ -415,127 +504,181 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 }
 
 // ------------------------------------------------------------------------------------------------ host orchestration
+struct BatchBufs {
+    DevBuf pd, keysA, keysB, cnt, b_start[2], b_n[2], b_cons[2], over, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &misc, &bs_d, &bs_s,
+                                        &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot };
+                     for (DevBuf* d : all) d->release(); }
+};
+
 template <int KW, int RW>
 static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, const std::vector<uint64_t>& part_keys,
                        const SegTable& segs, std::vector<void*>& outputs)
 {
     typedef typename KeyT<KW>::type key_t;
-    constexpr int CAP = (KW == 1) ? SORT_CAP_W1 : SORT_CAP_W2;
     const uint32_t nb = (uint32_t)batch_parts.size();
     const uint32_t k = c->k;
     // --- host-built tables (sizes are known exactly from Stage A)
     std::vector<PartDesc> pd(nb);
-    uint64_t n_keys = 0, n_sub = 0;
+    std::vector<uint64_t> pblk(nb + 1);
+    uint64_t n_slots = 0, n_sub = 0;
+    const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t np = part_keys[batch_parts[i]];
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
         uint32_t bits = 0;
-        const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;
         while (bits < (uint32_t)MAX_SUB_BITS && bits < 2 * k && (np >> bits) > target) bits++;
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
-        pd[i].key_base = n_keys; pd[i].sub_base = n_sub;
-        n_keys += np; n_sub += (1ull << bits);
+        pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
+        pblk[i] = n_slots / COMPACT_BLK;
+        n_slots += (np + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;      // partitions start on compaction-block boundaries
+        n_sub += (1ull << bits);
     }
+    pblk[nb] = n_slots / COMPACT_BLK;
     if (n_sub >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "too many sub-buckets in one batch");
-    DevBuf d_pd, d_keys, d_cnt, d_suboff, d_nd, d_ns, d_soloff, d_bsum, d_over, d_ptot;
-    auto cleanup = [&]() { d_pd.release(); d_keys.release(); d_cnt.release(); d_suboff.release(); d_nd.release(); d_ns.release();
-                           d_soloff.release(); d_bsum.release(); d_over.release(); d_ptot.release(); };
-#define CB_TRY(expr) do { int rc__ = (expr); if (rc__ != GKC_OK) { cleanup(); return rc__; } } while (0)
-#define CB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); c->set_error(GKC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); return GKC_ERR_HIP; } } while (0)
-    CB_TRY(c->ensure(d_pd, nb * sizeof(PartDesc)));
-    CB_TRY(c->ensure(d_keys, (size_t)std::max<uint64_t>(n_keys, 1) * sizeof(key_t)));
-    CB_TRY(c->ensure(d_cnt, (size_t)std::max<uint64_t>(n_keys, 1) * 4));
-    CB_TRY(c->ensure(d_suboff, (size_t)(n_sub + 1) * 8));
-    CB_TRY(c->ensure(d_nd, (size_t)n_sub * 4));
-    CB_TRY(c->ensure(d_ns, (size_t)n_sub * 4));
-    CB_TRY(c->ensure(d_soloff, (size_t)(n_sub + 1) * 8));
-    const uint64_t n_scan_blocks = (n_sub + (uint64_t)SCAN_BLK * SCAN_ITEMS - 1) / ((uint64_t)SCAN_BLK * SCAN_ITEMS);
-    CB_TRY(c->ensure(d_bsum, (size_t)(n_scan_blocks + 1) * 8));
-    const uint32_t over_cap = 1u << 20;
-    CB_TRY(c->ensure(d_over, (size_t)(over_cap + 1) * 4));
-    CB_TRY(c->ensure(d_ptot, (size_t)nb * 16));
-    CB_HIP(hipMemcpyAsync(d_pd.p, pd.data(), nb * sizeof(PartDesc), hipMemcpyHostToDevice, c->stream));
-    CB_HIP(hipMemcpyAsync((uint64_t*)d_suboff.p + n_sub, &n_keys, 8, hipMemcpyHostToDevice, c->stream));
-    CB_HIP(hipMemsetAsync(d_over.p, 0, (size_t)(over_cap + 1) * 4, c->stream));
-    uint32_t* over_list = (uint32_t*)d_over.p + 1; uint32_t* over_count = (uint32_t*)d_over.p;
+    const uint64_t n_blocks = n_slots / COMPACT_BLK;
+    BatchBufs B;
+#define CB_TRY(expr) do { int rc__ = (expr); if (rc__ != GKC_OK) { B.release(); return rc__; } } while (0)
+#define CB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { B.release(); c->set_error(GKC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); return GKC_ERR_HIP; } } while (0)
+    CB_TRY(c->ensure(B.pd, nb * sizeof(PartDesc)));
+    CB_TRY(c->ensure(B.keysA, (size_t)std::max<uint64_t>(n_slots, 1) * sizeof(key_t)));
+    CB_TRY(c->ensure(B.cnt, (size_t)std::max<uint64_t>(n_slots, 1) * 4));
+    CB_TRY(c->ensure(B.b_start[0], (size_t)n_sub * 8)); CB_TRY(c->ensure(B.b_n[0], (size_t)n_sub * 4)); CB_TRY(c->ensure(B.b_cons[0], (size_t)n_sub));
+    CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4));
+    CB_TRY(c->ensure(B.misc, 64));
+    CB_TRY(c->ensure(B.bs_d, (size_t)(n_blocks + 1) * 8)); CB_TRY(c->ensure(B.bs_s, (size_t)(n_blocks + 1) * 8));
+    CB_TRY(c->ensure(B.pidx, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.ptot, (size_t)(nb + 1) * 16));
+    CB_HIP(hipMemcpyAsync(B.pd.p, pd.data(), nb * sizeof(PartDesc), hipMemcpyHostToDevice, c->stream));
+    CB_HIP(hipMemcpyAsync(B.pidx.p, pblk.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    CB_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)std::max<uint64_t>(n_slots, 1) * 4, c->stream));
+    CB_HIP(hipMemsetAsync(B.misc.p, 0, 64, c->stream));
 
     {   ScopedTimer tm(c, "expand_count");
-        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, c->stream, (const PartDesc*)d_pd.p, segs, k, (uint64_t*)d_suboff.p);
+        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, c->stream, (const PartDesc*)B.pd.p, segs, k,
+                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
-        hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, c->stream, (const PartDesc*)d_pd.p, segs, k,
-                           (const uint64_t*)d_suboff.p, (key_t*)d_keys.p);
+        hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, c->stream, (const PartDesc*)B.pd.p, segs, k,
+                           (const uint64_t*)B.b_start[0].p, (key_t*)B.keysA.p);
         CB_HIP(hipGetLastError());
     }
     SortOut O{};
-    O.cnt = (uint32_t*)d_cnt.p; O.n_distinct = (uint32_t*)d_nd.p; O.n_solid = (uint32_t*)d_ns.p;
-    O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max; O.amin = c->amin; O.amax = c->amax;
-    O.oversize_list = over_list; O.oversize_count = over_count; O.oversize_cap = over_cap;
-    const uint32_t sort_grid = (uint32_t)std::min<uint64_t>(n_sub, 256 * 8);
-    {   ScopedTimer tm(c, "bucket_sort");
-        hipLaunchKernelGGL((k_bucket_sort<KW>), dim3(sort_grid), dim3(SORT_THREADS), 0, c->stream, (key_t*)d_keys.p, (const uint64_t*)d_suboff.p, (uint32_t)n_sub, O);
-        CB_HIP(hipGetLastError());
-    }
-    // --- oversize sub-buckets (rare): global bitonic sort + chunked RLE
-    uint32_t n_over = 0;
-    CB_HIP(hipMemcpyAsync(&n_over, over_count, 4, hipMemcpyDeviceToHost, c->stream));
-    CB_HIP(hipStreamSynchronize(c->stream));
-    if (n_over > over_cap) { cleanup(); GKC_FAIL(c, GKC_ERR_ARG, "more than %u oversize sub-buckets: use more partitions", over_cap); }
-    if (n_over) {
-        ScopedTimer tm(c, "oversize_sort");
-        std::vector<uint32_t> ol(n_over);
-        CB_HIP(hipMemcpy(ol.data(), over_list, (size_t)n_over * 4, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> so(2);
-        for (uint32_t g : ol) {
-            CB_HIP(hipMemcpy(so.data(), (uint64_t*)d_suboff.p + g, 16, hipMemcpyDeviceToHost));
-            const uint64_t start = so[0], n = so[1] - so[0];
-            uint64_t N = 2; while (N < n) N <<= 1;
-            key_t* a = (key_t*)d_keys.p + start;
-            const unsigned blocks = (unsigned)(((N >> 1) + 255) / 256);
-            for (uint64_t size = 2; size <= N; size <<= 1) {
-                hipLaunchKernelGGL((k_gbitonic_step<KW>), dim3(blocks), dim3(256), 0, c->stream, a, n, N, size, (uint64_t)0, 1);
-                for (uint64_t stride = size >> 2; stride >= 1; stride >>= 1)
-                    hipLaunchKernelGGL((k_gbitonic_step<KW>), dim3(blocks), dim3(256), 0, c->stream, a, n, N, size, stride, 0);
-            }
-            hipLaunchKernelGGL((k_rle_big<KW>), dim3(1), dim3(1024), 0, c->stream, (key_t*)d_keys.p, start, n, g, O);
+    O.cnt = (uint32_t*)B.cnt.p; O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max;
+    O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1;
+    O.n_sorted = (unsigned long long*)B.misc.p;
+
+    // --- levels: sort what fits one wave, split the rest on the next key bits, repeat
+    int cur = 0;                                 // bucket arrays b_*[cur]
+    uint64_t n_buckets = n_sub;
+    key_t* src = (key_t*)B.keysA.p;
+    for (int level = 1; n_buckets > 0; level++) {
+        CB_HIP(hipMemsetAsync(B.over.p, 0, 4, c->stream));
+        {   ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
+            const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
+            hipLaunchKernelGGL((k_wave_sort<KW>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
             CB_HIP(hipGetLastError());
         }
-        c->stats_now().oversize_buckets += n_over;
-    }
-    // --- solid offsets, per-partition totals, output allocation, compaction
-    uint64_t total_solid = 0;
-    std::vector<uint64_t> ptot((size_t)nb * 2);
-    {   ScopedTimer tm(c, "compact");
-        hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)n_scan_blocks), dim3(SCAN_BLK), 0, c->stream, (const uint32_t*)d_ns.p, n_sub, (uint64_t*)d_bsum.p);
-        hipLaunchKernelGGL(k_scan_serial, dim3(1), dim3(1), 0, c->stream, (uint64_t*)d_bsum.p, n_scan_blocks);
-        hipLaunchKernelGGL(k_scan_final, dim3((unsigned)n_scan_blocks), dim3(SCAN_BLK), 0, c->stream, (const uint32_t*)d_ns.p, n_sub, (const uint64_t*)d_bsum.p, (uint64_t*)d_soloff.p);
-        hipLaunchKernelGGL(k_part_totals, dim3(nb), dim3(256), 0, c->stream, (const PartDesc*)d_pd.p, nb, (const uint32_t*)d_nd.p, (const uint64_t*)d_soloff.p, (uint64_t*)d_ptot.p);
-        CB_HIP(hipGetLastError());
-        CB_HIP(hipMemcpyAsync(&total_solid, (uint64_t*)d_soloff.p + n_sub, 8, hipMemcpyDeviceToHost, c->stream));
-        CB_HIP(hipMemcpyAsync(ptot.data(), d_ptot.p, (size_t)nb * 16, hipMemcpyDeviceToHost, c->stream));
+        uint32_t n_over = 0;
+        CB_HIP(hipMemcpyAsync(&n_over, B.over.p, 4, hipMemcpyDeviceToHost, c->stream));
         CB_HIP(hipStreamSynchronize(c->stream));
-        constexpr int OW = (KW == 1) ? 2 : 4;
-        void* out = nullptr;
-        hipError_t e = hipMalloc(&out, (size_t)std::max<uint64_t>(total_solid, 1) * OW * 8);
-        if (e != hipSuccess) { cleanup(); GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of %llu Count records failed: %s", (unsigned long long)total_solid, hipGetErrorString(e)); }
-        outputs.push_back(out);
-        hipLaunchKernelGGL((k_compact<KW>), dim3(sort_grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)d_keys.p, (const uint32_t*)d_cnt.p,
-                           (const uint64_t*)d_suboff.p, (const uint32_t*)d_nd.p, (const uint64_t*)d_soloff.p, (uint32_t)n_sub, c->amin, c->amax, (uint64_t*)out);
+        if (!n_over) break;
+        ScopedTimer tm(c, "split_levels");
+        // fetch (start, n, consumed bits) of the oversize buckets
+        CB_TRY(c->ensure(B.g_start, (size_t)n_over * 8)); CB_TRY(c->ensure(B.g_n, (size_t)n_over * 4)); CB_TRY(c->ensure(B.g_cons, (size_t)n_over * 4));
+        hipLaunchKernelGGL(k_gather_buckets, dim3((n_over + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)O.over_list, n_over,
+                           (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p,
+                           (uint64_t*)B.g_start.p, (uint32_t*)B.g_n.p, (uint32_t*)B.g_cons.p);
+        std::vector<uint64_t> h_start(n_over); std::vector<uint32_t> h_n(n_over), h_cons(n_over);
+        CB_HIP(hipMemcpyAsync(h_start.data(), B.g_start.p, (size_t)n_over * 8, hipMemcpyDeviceToHost, c->stream));
+        CB_HIP(hipMemcpyAsync(h_n.data(), B.g_n.p, (size_t)n_over * 4, hipMemcpyDeviceToHost, c->stream));
+        CB_HIP(hipMemcpyAsync(h_cons.data(), B.g_cons.p, (size_t)n_over * 4, hipMemcpyDeviceToHost, c->stream));
+        CB_HIP(hipStreamSynchronize(c->stream));
+        std::vector<SplitDesc> split, uni;
+        uint64_t n_child = 0;
+        for (uint32_t i = 0; i < n_over; i++) {
+            SplitDesc d{}; d.start = h_start[i]; d.n = h_n[i]; d.consumed = h_cons[i];
+            const uint32_t left = 2 * k - d.consumed;
+            if (left == 0) { uni.push_back(d); continue; }
+            // deeper levels see clustered keys (that is why the bucket was oversize): split 8x finer than the mean asks for
+            uint32_t bits = 1;
+            while (bits < (uint32_t)MAX_SUB_BITS && bits < left && (d.n >> bits) > target) bits++;
+            bits = std::min<uint32_t>(std::min<uint32_t>(bits + 3, (uint32_t)MAX_SUB_BITS), left);
+            d.bits = bits; d.left = left; d.child_base = n_child; n_child += (1ull << bits);
+            split.push_back(d);
+        }
+        c->stats_now().oversize_buckets += n_over;
+        if (getenv("GKC_VERBOSE")) {
+            uint64_t kk = 0, mx = 0; for (uint32_t i = 0; i < n_over; i++) { kk += h_n[i]; mx = std::max<uint64_t>(mx, h_n[i]); }
+            fprintf(stderr, "[gkc] level %d: %llu buckets sorted from, %u oversize (%llu keys, max %llu), %zu uniform, %llu children\n", level,
+                    (unsigned long long)n_buckets, n_over, (unsigned long long)kk, (unsigned long long)mx, uni.size(), (unsigned long long)n_child);
+        }
+        if (n_child >= (1ULL << 31)) { B.release(); GKC_FAIL(c, GKC_ERR_ARG, "too many sub-buckets while splitting: use more partitions"); }
+        key_t* dst = src;
+        if (!uni.empty()) {
+            CB_TRY(c->ensure(B.descs, uni.size() * sizeof(SplitDesc)));
+            CB_HIP(hipMemcpyAsync(B.descs.p, uni.data(), uni.size() * sizeof(SplitDesc), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL((k_uniform_buckets<KW>), dim3((unsigned)((uni.size() + 255) / 256)), dim3(256), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const SplitDesc*)B.descs.p, (uint32_t)uni.size(), O);
+            CB_HIP(hipGetLastError());
+            CB_HIP(hipStreamSynchronize(c->stream));
+        }
+        const int nxt = cur ^ 1;
+        if (!split.empty()) {
+            if (!B.keysB.p) CB_TRY(c->ensure(B.keysB, (size_t)n_slots * sizeof(key_t)));
+            dst = (src == (key_t*)B.keysA.p) ? (key_t*)B.keysB.p : (key_t*)B.keysA.p;
+            CB_TRY(c->ensure(B.descs, split.size() * sizeof(SplitDesc)));
+            CB_TRY(c->ensure(B.effs, split.size() * 4));
+            CB_TRY(c->ensure(B.b_start[nxt], (size_t)n_child * 8)); CB_TRY(c->ensure(B.b_n[nxt], (size_t)n_child * 4)); CB_TRY(c->ensure(B.b_cons[nxt], (size_t)n_child));
+            if (B.over.bytes < (size_t)(n_child + 1) * 4) { CB_TRY(c->ensure(B.over, (size_t)(n_child + 1) * 4)); O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1; }
+            CB_HIP(hipMemcpyAsync(B.descs.p, split.data(), split.size() * sizeof(SplitDesc), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL((k_split_count<KW>), dim3((unsigned)split.size()), dim3(EXPAND_THREADS), 0, c->stream, (const key_t*)src, (const SplitDesc*)B.descs.p,
+                               (uint64_t*)B.b_start[nxt].p, (uint32_t*)B.b_n[nxt].p, (uint8_t*)B.b_cons[nxt].p, (uint32_t*)B.effs.p);
+            hipLaunchKernelGGL((k_split_scatter<KW>), dim3((unsigned)split.size()), dim3(EXPAND_THREADS), 0, c->stream, (const key_t*)src, dst, (const SplitDesc*)B.descs.p,
+                               (const uint64_t*)B.b_start[nxt].p, (const uint32_t*)B.effs.p);
+            CB_HIP(hipGetLastError());
+            CB_HIP(hipStreamSynchronize(c->stream));     // descs / host vectors are reused next level
+        }
+        cur = nxt; n_buckets = n_child; src = dst;
+    }
+
+    // --- compaction: per-block (distinct, solid) sums -> prefix -> Count records
+    uint64_t total_solid = 0;
+    std::vector<uint64_t> ptot((size_t)(nb + 1) * 2);
+    {   ScopedTimer tm(c, "compact");
+        if (n_blocks) {
+            hipLaunchKernelGGL(k_flag_block_sums, dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const uint32_t*)B.cnt.p, n_slots, c->amin, c->amax,
+                               (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p);
+        }
+        hipLaunchKernelGGL(k_scan2_u64, dim3(1), dim3(1024), 0, c->stream, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks);
+        hipLaunchKernelGGL(k_gather_u64, dim3((nb + 1 + 255) / 256), dim3(256), 0, c->stream, (const uint64_t*)B.bs_d.p, (const uint64_t*)B.bs_s.p,
+                           (const uint64_t*)B.pidx.p, nb + 1, (uint64_t*)B.ptot.p);
         CB_HIP(hipGetLastError());
+        CB_HIP(hipMemcpyAsync(ptot.data(), B.ptot.p, (size_t)(nb + 1) * 16, hipMemcpyDeviceToHost, c->stream));
+        CB_HIP(hipStreamSynchronize(c->stream));
+        total_solid = ptot[2 * nb + 1];
+        constexpr int OW = (KW == 1) ? 2 : 4;
+        void* out = c->dalloc((size_t)std::max<uint64_t>(total_solid, 1) * OW * 8);
+        if (!out) { B.release(); return GKC_ERR_NOMEM; }
+        outputs.push_back(out);
+        if (n_blocks) {
+            hipLaunchKernelGGL((k_compact_flags<KW>), dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const key_t*)B.keysA.p, (const uint32_t*)B.cnt.p, n_slots,
+                               (const uint64_t*)B.bs_s.p, c->amin, c->amax, (uint64_t*)out);
+            CB_HIP(hipGetLastError());
+        }
         CB_HIP(hipStreamSynchronize(c->stream));
         for (uint32_t i = 0; i < nb; i++) {
             Dataset& D = c->datasets[(size_t)c->pass * c->nb_partitions + batch_parts[i]];
-            const uint64_t s0 = ptot[2 * i + 1], s1 = (i + 1 < nb) ? ptot[2 * (i + 1) + 1] : total_solid;
+            const uint64_t s0 = ptot[2 * i + 1], s1 = ptot[2 * (i + 1) + 1];
             D.d_counts = (const uint8_t*)out + s0 * OW * 8;
-            D.n_solid = s1 - s0; D.n_distinct = ptot[2 * i]; D.n_kmers = part_keys[batch_parts[i]]; D.done = true;
+            D.n_solid = s1 - s0; D.n_distinct = ptot[2 * (i + 1)] - ptot[2 * i]; D.n_kmers = part_keys[batch_parts[i]]; D.done = true;
             c->stats_now().kmers_nb_distinct += D.n_distinct; c->stats_now().kmers_nb_solid += D.n_solid;
         }
     }
-    cleanup();
+    B.release();
 #undef CB_TRY
 #undef CB_HIP
-    (void)CAP;
     return GKC_OK;
 }
 
@@ -566,8 +709,9 @@ int gkc_count_pass(gkc_ctx* c)
     if (!budget) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-        // per key: key + 4 B count + (solid) Count record; keep a third of the free memory for outputs
-        const size_t per_key = (c->key_words == 1 ? 8 : 16) + 4;
+        free_b += c->pool.cached_bytes;                      // blocks parked in the caching allocator are reusable
+        // per key slot: key (x2 if a level-2 split is needed) + 4 B abundance; keep a third of the free memory for outputs
+        const size_t per_key = 2 * (c->key_words == 1 ? 8 : 16) + 4;
         budget = std::max<size_t>((free_b / 3) / per_key, (size_t)1 << 20);
         budget = std::min<size_t>(budget, (size_t)3 << 30);
     }

@@ -21,6 +21,7 @@
 //   The pass runs twice per batch (count, then emit at exact offsets): no bucket can overflow whatever the skew.
 #include "gkc_common.hpp"
 #include "gkc_device.hpp"
+#include <algorithm>
 
 struct ScanParams {
     const uint8_t* bases; uint64_t n_bases;
@@ -31,6 +32,11 @@ struct ScanParams {
     const uint16_t* repart; uint32_t nb_passes, pass;
     unsigned long long* cnt_rec; unsigned long long* cnt_kmers; unsigned long long* cursor;
     uint64_t* arena;
+    int dbg_noatomic;             // GKC_DEBUG_NOATOMIC=1: timing experiment only (wrong results)
+    uint64_t n_tiles; uint32_t n_parts;
+    unsigned long long* wg_cnt;          // LDSPART count: [grid][P] packed (k-mers << 32 | records) of this workgroup
+    const unsigned long long* wg_base;   // LDSPART emit : [grid][P] records of earlier workgroups in the partition
+    const unsigned long long* rec_off;   // LDSPART emit : [P] first record of the partition in the arena
     unsigned long long* gstats;   // [0] valid k-mers [1] invalid k-mers [2] records emitted/counted
 };
 
@@ -45,29 +51,48 @@ __global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_
     atomicOr(&bits[g >> 5], 1u << (g & 31));
 }
 
+// LDS index of per-position arrays: thread t owns positions 16t..16t+15; one pad word per 16 entries makes the lane
+// stride 17 dwords, so the 32 lanes of an LDS access group hit 32 different banks (stride 16 would be a 16-way conflict)
+#define MKI(p) ((p) + ((p) >> 4))
 constexpr int BE_PAD = 12;   // zero words after the tile planes so record extraction may read past the halo
 
-template <bool EMIT, int RW>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
+// LDSPART: persistent workgroups with a static tile assignment (tile = blockIdx.x, += gridDim.x, identical in the count
+// and the emit launch). Per-partition counters / record cursors live in LDS (64-bit LDS atomics): the count launch
+// leaves a [workgroup][partition] matrix, a tiny prefix kernel turns it into private record ranges, and the emit launch
+// needs no global atomic at all. !LDSPART (nb_partitions too large for LDS): global atomics per record.
+template <bool EMIT, int RW, bool LDSPART>
+__global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_part[];
     __shared__ uint32_t s_be[SCAN_WORDS + BE_PAD];
     __shared__ uint32_t s_le[SCAN_WORDS + BE_PAD];
     __shared__ uint16_t s_bad[SCAN_WORDS + 8];
     __shared__ uint32_t s_rs[SCAN_TILE / 32 + 8];
-    __shared__ uint32_t s_mk[SCAN_TILE + 16 * SCAN_HALO_WORDS + 16];
-    __shared__ uint32_t s_end[SCAN_TILE];
+    __shared__ uint32_t s_mk[MKI(SCAN_TILE + 16 * SCAN_HALO_WORDS + 16)];   // padded: see MKI
+    __shared__ uint32_t s_end[MKI(SCAN_TILE)];
     __shared__ uint32_t s_lastmz[SCAN_THREADS], s_firstmz[SCAN_THREADS + 1];
     __shared__ uint8_t  s_lastvalid[SCAN_THREADS], s_firstvalid[SCAN_THREADS + 1];
     __shared__ int      s_wavecarry[SCAN_THREADS / 64];
     __shared__ unsigned long long s_stat[3];
 
     const int t = threadIdx.x;
-    const uint64_t t0 = (uint64_t)blockIdx.x * SCAN_TILE;
     const uint32_t k = P.k, m = P.m;
 
     if (t < 3) s_stat[t] = 0;
     if (t < BE_PAD) { s_be[SCAN_WORDS + t] = 0; s_le[SCAN_WORDS + t] = 0; }
     if (t < 8) s_bad[SCAN_WORDS + t] = 0;
+    if (LDSPART) {
+        for (uint32_t p = t; p < P.n_parts; p += SCAN_THREADS)
+            s_part[p] = EMIT ? (P.rec_off[p] + P.wg_base[(uint64_t)blockIdx.x * P.n_parts + p]) : 0ULL;
+    }
+    uint32_t nv_acc = 0, ni_acc = 0, n_rec = 0;
+
+  for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+    const uint64_t t0 = tile * SCAN_TILE;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));                                // keep per-lane address math inside the loop: hoisting it
+                                                               // (LICM) costs ~150 VGPRs and halves the occupancy
+    __syncthreads();                                           // LDS of the previous tile fully consumed
 
     // ---- step 0: ASCII -> bit planes (A1) ----
     for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
@@ -120,7 +145,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
                 a = (a >> 1) & a & P.mask_ma1;                // "AA" anywhere but as prefix (KMC2 rule)
                 key = a ? P.mmask : c;
             }
-            s_mk[16 * w + j] = key;
+            s_mk[17 * w + j] = key;
         }
     }
     __syncthreads();
@@ -132,24 +157,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
     uint32_t mz[16];
     if (Wn >= 16) {
         uint32_t core = P.default_key;                        // the default minimizer 4^m-1 takes part (Model.hpp:1260)
-        for (uint32_t i = 15; i < Wn; i++) { uint32_t v = s_mk[p0 + i]; core = v < core ? v : core; }
+        for (uint32_t i = 15; i < Wn; i++) { uint32_t v = s_mk[MKI(p0 + i)]; core = v < core ? v : core; }
         uint32_t suf = 0xFFFFFFFFu;
         uint32_t sufL[16];
         sufL[15] = suf;
 #pragma unroll
-        for (int j = 14; j >= 0; j--) { uint32_t v = s_mk[p0 + j]; suf = v < suf ? v : suf; sufL[j] = suf; }
+        for (int j = 14; j >= 0; j--) { uint32_t v = s_mk[MKI(p0 + j)]; suf = v < suf ? v : suf; sufL[j] = suf; }
         uint32_t pre = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             uint32_t r = sufL[j] < core ? sufL[j] : core;
             mz[j] = pre < r ? pre : r;
-            uint32_t v = s_mk[p0 + Wn + j]; pre = v < pre ? v : pre;
+            uint32_t v = s_mk[MKI(p0 + Wn + j)]; pre = v < pre ? v : pre;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             uint32_t best = P.default_key;
-            for (uint32_t i = 0; i < Wn; i++) { uint32_t v = s_mk[p0 + j + i]; best = v < best ? v : best; }
+            for (uint32_t i = 0; i < Wn; i++) { uint32_t v = s_mk[MKI(p0 + j + i)]; best = v < best ? v : best; }
             mz[j] = best;
         }
     }
@@ -212,7 +237,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
     // ---- step 5: emit one record per run end (A4 cap, A5 pass filter + partition, A6 bucket write) ----
     // run ends are first compacted per thread into LDS (own 16 slots), so the divergent emission loop runs
     // max-over-lanes(#ends) times instead of 16
-    uint32_t n_rec = 0;
     {
         int ls = carry, n_end = 0;
         const bool nxt_valid = s_firstvalid[t + 1] != 0;       // t==255: sentinel (tile end)
@@ -230,26 +254,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
             const bool is_end = v && (boundary || (d1 % maxs) == 0);
             if (is_end) {
                 const int start = ls + ((p - ls) / maxs) * maxs;
-                s_mk[p0 + n_end] = mz[j];                                    // own slots; s_mk is dead after step 2
-                s_end[p0 + n_end] = (uint32_t)start | ((uint32_t)(p - start + 1) << 16);
+                s_mk[MKI(p0) + n_end] = mz[j];                                    // own slots; s_mk is dead after step 2
+                s_end[MKI(p0) + n_end] = (uint32_t)start | ((uint32_t)(p - start + 1) << 16);
                 n_end++;
             }
         }
 #pragma unroll 1
         for (int e = 0; e < n_end; e++) {
-            const uint32_t info = s_end[p0 + e];
+            const uint32_t info = s_end[MKI(p0) + e];
             const int start = (int)(info & 0xFFFFu);
             const uint32_t nbk = info >> 16;
-            const uint32_t key = s_mk[p0 + e];
+            const uint32_t key = s_mk[MKI(p0) + e];
             const uint32_t value = P.freq_mode ? P.key2val[key] : key;
             if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
             const uint32_t part = P.repart[value];
             n_rec++;
             if (!EMIT) {
-                atomicAdd(&P.cnt_rec[part], 1ULL);
-                atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk);
+                if (P.dbg_noatomic) continue;
+                if (LDSPART) atomicAdd(&s_part[part], ((unsigned long long)nbk << 32) | 1ULL);
+                else { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
             } else {
-                const unsigned long long slot = atomicAdd(&P.cursor[part], 1ULL);
+                const unsigned long long slot = LDSPART ? atomicAdd(&s_part[part], 1ULL) : atomicAdd(&P.cursor[part], 1ULL);
                 // 2-bit plane, left-aligned at `start`
                 const int w0 = start >> 4, sh = 2 * (start & 15);
                 uint64_t A[RW + 1];
@@ -278,31 +303,57 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile(ScanParams P)
         }
     }
 
+    nv_acc += __popc(validmask); ni_acc += __popc(existsmask & ~validmask);
+  }   // tile loop
+
     // ---- statistics (Sequence2SuperKmer.hpp:103,108) ----
     {
-        uint32_t nv = __popc(validmask), ni = __popc(existsmask & ~validmask);
+        uint32_t nv = nv_acc, ni = ni_acc;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { nv += __shfl_down(nv, d, 64); ni += __shfl_down(ni, d, 64); n_rec += __shfl_down(n_rec, d, 64); }
         if ((t & 63) == 0) { atomicAdd(&s_stat[0], (unsigned long long)nv); atomicAdd(&s_stat[1], (unsigned long long)ni); atomicAdd(&s_stat[2], (unsigned long long)n_rec); }
         __syncthreads();
         if (t < 3 && s_stat[t]) atomicAdd(&P.gstats[t], s_stat[t]);
     }
+    if (LDSPART && !EMIT) {
+        for (uint32_t p = t; p < P.n_parts; p += SCAN_THREADS) P.wg_cnt[(uint64_t)blockIdx.x * P.n_parts + p] = s_part[p];
+    }
+}
+
+// per-partition prefix over workgroups: base[w][p] = records of workgroups < w; totals per partition
+__global__ void k_wg_prefix(const unsigned long long* __restrict__ wg_cnt, uint32_t n_wg, uint32_t n_parts,
+                            unsigned long long* __restrict__ wg_base, unsigned long long* __restrict__ tot_rec, unsigned long long* __restrict__ tot_km)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    unsigned long long run = 0, km = 0;
+    for (uint32_t w = 0; w < n_wg; w++) {
+        const unsigned long long v = wg_cnt[(uint64_t)w * n_parts + p];
+        wg_base[(uint64_t)w * n_parts + p] = run;
+        run += v & 0xFFFFFFFFULL; km += v >> 32;
+    }
+    tot_rec[p] = run; tot_km[p] = km;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, uint64_t n_tiles)
+static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart, unsigned grid_n, size_t dyn_lds)
 {
-    dim3 grid((unsigned)n_tiles), block(SCAN_THREADS);
+    dim3 grid(grid_n), block(SCAN_THREADS);
+#define GKC_LAUNCH(E, R, L) hipLaunchKernelGGL((k_scan_tile<E, R, L>), grid, block, dyn_lds, c->stream, P)
     if (c->record_bytes == 16) {
-        if (emit) hipLaunchKernelGGL((k_scan_tile<true, 2>), grid, block, 0, c->stream, P);
-        else      hipLaunchKernelGGL((k_scan_tile<false, 2>), grid, block, 0, c->stream, P);
+        if (ldspart) { if (emit) GKC_LAUNCH(true, 2, true); else GKC_LAUNCH(false, 2, true); }
+        else         { if (emit) GKC_LAUNCH(true, 2, false); else GKC_LAUNCH(false, 2, false); }
     } else {
-        if (emit) hipLaunchKernelGGL((k_scan_tile<true, 4>), grid, block, 0, c->stream, P);
-        else      hipLaunchKernelGGL((k_scan_tile<false, 4>), grid, block, 0, c->stream, P);
+        if (ldspart) { if (emit) GKC_LAUNCH(true, 4, true); else GKC_LAUNCH(false, 4, true); }
+        else         { if (emit) GKC_LAUNCH(true, 4, false); else GKC_LAUNCH(false, 4, false); }
     }
+#undef GKC_LAUNCH
     GKC_HIP(c, hipGetLastError());
     return GKC_OK;
 }
+
+constexpr uint32_t SCAN_LDS_PARTS_MAX = 8192;      // 64 KB of LDS cursors at most
+constexpr size_t SCAN_STATIC_LDS = 40 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
 
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
 {
@@ -324,11 +375,23 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         hipLaunchKernelGGL(k_mark_read_starts, g, b, 0, c->stream, d_offsets, n_entries, (uint32_t*)c->d_rsbits.p);
         GKC_HIP(c, hipGetLastError());
     }
-    // counters: [0..P) records, [P..2P) k-mers, [2P..3P) cursors, [3P..3P+4) stats
+    // geometry: persistent workgroups when the partition cursors fit in LDS
+    const bool ldspart = Pn <= SCAN_LDS_PARTS_MAX && getenv("GKC_SCAN_GLOBAL_ATOMICS") == nullptr;
+    const size_t dyn_lds = ldspart ? (size_t)Pn * 8 : 0;
+    unsigned grid_n;
+    if (ldspart) {
+        int cus = 256; hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        unsigned per_cu = (unsigned)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (SCAN_STATIC_LDS + dyn_lds)));
+        grid_n = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)cus * per_cu);
+    } else grid_n = (unsigned)std::min<uint64_t>(n_tiles, 1u << 20);
+
+    // counters: [0..P) records, [P..2P) k-mers, [2P..3P) cursors / rec_off, [3P..3P+4) stats
     const size_t n_cnt = (size_t)3 * Pn + 4;
     GKC_TRY(c->ensure(c->d_scan_counters, n_cnt * 8));
     GKC_HIP(c, hipMemsetAsync(c->d_scan_counters.p, 0, n_cnt * 8, c->stream));
     unsigned long long* cnt = (unsigned long long*)c->d_scan_counters.p;
+    if (ldspart) GKC_TRY(c->ensure(c->d_scan_matrix, (size_t)2 * grid_n * Pn * 8));
 
     ScanParams P{};
     P.bases = (const uint8_t*)d_bases; P.n_bases = n_bases; P.rsbits = (const uint32_t*)c->d_rsbits.p;
@@ -340,9 +403,19 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     P.repart = (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
     P.cnt_rec = cnt; P.cnt_kmers = cnt + Pn; P.cursor = cnt + 2 * (size_t)Pn; P.gstats = cnt + 3 * (size_t)Pn;
     P.arena = nullptr;
+    P.dbg_noatomic = getenv("GKC_DEBUG_NOATOMIC") != nullptr;
+    P.n_tiles = n_tiles; P.n_parts = Pn;
+    P.wg_cnt = ldspart ? (unsigned long long*)c->d_scan_matrix.p : nullptr;
+    P.wg_base = ldspart ? (unsigned long long*)c->d_scan_matrix.p + (size_t)grid_n * Pn : nullptr;
+    P.rec_off = cnt + 2 * (size_t)Pn;
 
     {   ScopedTimer tm(c, "scan_count");
-        GKC_TRY(launch_scan(c, P, false, n_tiles));
+        GKC_TRY(launch_scan(c, P, false, ldspart, grid_n, dyn_lds));
+        if (ldspart) {
+            hipLaunchKernelGGL(k_wg_prefix, dim3((Pn + 255) / 256), dim3(256), 0, c->stream, P.wg_cnt, grid_n, Pn,
+                               (unsigned long long*)P.wg_base, cnt, cnt + Pn);
+            GKC_HIP(c, hipGetLastError());
+        }
     }
     std::vector<unsigned long long> h(n_cnt);
     GKC_HIP(c, hipMemcpyAsync(h.data(), cnt, n_cnt * 8, hipMemcpyDeviceToHost, c->stream));
@@ -358,15 +431,15 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
 
     void* arena = nullptr;
     if (total) {
-        hipError_t e = hipMalloc(&arena, (size_t)total * c->record_bytes);
-        if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of %llu super-k-mer records failed: %s", (unsigned long long)total, hipGetErrorString(e));
+        arena = c->dalloc((size_t)total * c->record_bytes);
+        if (!arena) return GKC_ERR_NOMEM;
         c->owned_arenas.push_back(arena);
-        // cursors start at the exact partition offsets
+        // cursors (global-atomic mode) / partition offsets (LDS mode) start at the exact partition offsets
         GKC_HIP(c, hipMemcpyAsync(cnt + 2 * (size_t)Pn, seg.rec_off.data(), (size_t)Pn * 8, hipMemcpyHostToDevice, c->stream));
         GKC_HIP(c, hipMemsetAsync(cnt + 3 * (size_t)Pn, 0, 4 * 8, c->stream));
         P.arena = (uint64_t*)arena;
         {   ScopedTimer tm(c, "scan_emit");
-            GKC_TRY(launch_scan(c, P, true, n_tiles));
+            GKC_TRY(launch_scan(c, P, true, ldspart, grid_n, dyn_lds));
         }
     }
     seg.d_records = arena;
