@@ -6,7 +6,7 @@ Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by t
 Rank 0 prints ONE JSON line. metric = BASELINE.json's "distinct k-mers/s at k=31".
 
 N=1 workload = BASELINE configs[1] shape (k=31, synthetic 150 bp reads, 30x coverage, 1 % substitutions, single pass,
-no Bloom), --reads per GPU (default 2e7 so the default run finishes in minutes; --reads 100000000 is the full config).
+no Bloom), --reads per GPU (default 10^8 = the full config; a step takes < 1 s).
 N>1: weak scaling — every rank scans its own --reads reads; super-k-mer buckets are routed to the partition's owner
 rank with one RCCL all-to-all (torch.distributed, backend nccl == RCCL), each rank counts the partitions it owns.
 """
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=20_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (default = BASELINE configs[1]: 10^8)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
@@ -126,7 +126,7 @@ def main():
         step()
     sync()
     # per-kernel timers are HIP events on the context's own stream, accumulated inside the library
-    names = ["scan_count", "scan_emit", "expand_count", "expand_scatter", "bucket_sort", "compact", "oversize_sort",
+    names = ["scan_count", "scan_emit", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_deep", "split_levels", "compact",
              "total_stage_a", "total_stage_b"]
     base = {nme: c.timing(nme) for nme in names}
     t0 = time.perf_counter()

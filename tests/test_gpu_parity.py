@@ -256,3 +256,78 @@ def test_moderate_size_properties(gkc):
     assert int(h.sum()) == st["kmers_nb_distinct"]
     assert int((h * np.arange(len(h), dtype=np.uint64)).sum()) == nv      # no abundance reaches histo_max here
     c.device_free(db); c.device_free(do)
+
+
+def test_two_owner_shards_on_one_gpu(gkc):
+    """multi-GPU data flow on one device: two contexts scan one half of the reads each, their buckets are routed to the
+    partition owners exactly as dist.py does (slices of the arena -> foreign segments), each owner counts its partitions;
+    the union must equal the oracle's single-process result"""
+    import torch
+    ge.load()
+    from gatb_core_amd import dist as gd
+    reads = synth_reads(4000, 20000, 150, seed=21, n_rate=0.001, ragged=True)
+    k, m, parts, world = 31, 10, 8, 2
+    rep = simple_repart(m, parts)
+    bases, offs = gko.pack_reads(reads)
+    ref = gko.Dsk(bases, offs, k, m, parts, rep)
+    ctxs = [gkc.Counter(0) for _ in range(world)]
+    exports = []
+    half = len(reads) // 2
+    for r, c in enumerate(ctxs):
+        c.configure(k, m, parts, rep)
+        c.begin_pass(0)
+        r0, r1 = (0, half) if r == 0 else (half, len(reads))
+        c.push_reads(bases[int(offs[r0]):int(offs[r1])], offs[r0:r1 + 1] - offs[r0])
+        ptr, rb, off, km = c.segment_export(0)
+        t = torch.as_tensor(gd.DevArray(ptr, int(off[-1]) * rb), device="cuda").clone()     # "send buffer"
+        exports.append((t, rb, off.astype(np.int64), km.astype(np.int64)))
+    ranges = gd.owner_ranges(parts, world)
+    keep = []
+    for r, c in enumerate(ctxs):
+        c.segments_clear()
+        lo, hi = ranges[r]
+        for (t, rb, off, km) in exports:                       # chunk from every source rank
+            chunk = t[off[lo] * rb: off[hi] * rb].clone(); keep.append(chunk)
+            ro = np.zeros(parts + 1, np.int64); ro[lo + 1:hi + 1] = off[lo + 1:hi + 1] - off[lo]; ro[hi + 1:] = ro[hi]
+            kk = np.zeros(parts, np.int64); kk[lo:hi] = km[lo:hi]
+            if ro[-1]:
+                c.segment_import(chunk.data_ptr(), ro.astype(np.uint64), kk.astype(np.uint64))
+        c.finish_pass()
+    torch.cuda.synchronize()
+    tot_distinct = 0
+    for r, c in enumerate(ctxs):
+        lo, hi = ranges[r]
+        for p in range(parts):
+            lo_, hi_, ab = c.partition(0, p)
+            if lo <= p < hi:
+                rlo, rhi, rab = ref.part(p)
+                assert np.array_equal(lo_, rlo) and np.array_equal(ab, rab)
+            else:
+                assert len(lo_) == 0
+        tot_distinct += c.stats()["kmers_nb_distinct"]
+    assert tot_distinct == ref.stats["kmers_nb_distinct"]
+    assert sum(c.stats()["kmers_nb_valid"] for c in ctxs) == ref.stats["kmers_nb_valid"]
+
+
+def test_distributed_counter_world1_rccl(gkc):
+    """DistributedCounter over the real backend (nccl == RCCL) with one rank: zero-copy arena view, all_gather +
+    all_to_all_single on the device, foreign-segment import"""
+    import os, socket, torch
+    import torch.distributed as dist
+    ge.load()
+    from gatb_core_amd import dist as gd
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        reads = synth_reads(3000, 20000, 150, seed=5)
+        k, m, parts = 31, 10, 16
+        rep = simple_repart(m, parts)
+        bases, offs = gko.pack_reads(reads)
+        ref = gko.Dsk(bases, offs, k, m, parts, rep)
+        c = gkc.Counter(0); c.configure(k, m, parts, rep)
+        dc = gd.DistributedCounter(c, 0, 1, parts)
+        c.begin_pass(0); c.push_reads(bases, offs); dc.exchange(); c.finish_pass()
+        assert c.all_counts() == ref.all_counts()
+    finally:
+        dist.destroy_process_group()
