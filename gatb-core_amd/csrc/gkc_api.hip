@@ -237,6 +237,47 @@ int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint6
     return rc;
 }
 
+// host-buffer helper shared by the sampling entry points
+static int upload_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, DevBuf& db, DevBuf& dof, uint64_t* n_bases)
+{
+    if (!offsets || offsets[0] != 0) GKC_FAIL(c, GKC_ERR_ARG, "offsets[0] must be 0");
+    *n_bases = offsets[n_reads];
+    GKC_TRY(c->ensure(db, (size_t)*n_bases + 64));
+    int rc = c->ensure(dof, (size_t)(n_reads + 1) * 8);
+    if (rc != GKC_OK) { db.release(); return rc; }
+    hipError_t e = hipSuccess;
+    if (*n_bases) e = hipMemcpyAsync(db.p, bases, (size_t)*n_bases, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dof.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { db.release(); dof.release(); GKC_FAIL(c, GKC_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e)); }
+    return GKC_OK;
+}
+
+int gkc_sample_minimizers(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t* superkmers_per_minim, uint64_t* kmers_per_minim)
+{
+    if (!c || !superkmers_per_minim || !kmers_per_minim) return GKC_ERR_ARG;
+    if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "gkc_configure must be called first (any repartition table)");
+    GKC_HIP(c, hipSetDevice(c->device));
+    DevBuf db, dof; uint64_t nb = 0;
+    GKC_TRY(upload_reads(c, bases, offsets, n_reads, db, dof, &nb));
+    int rc = gkc_scan_sample(c, (const char*)db.p, (const uint64_t*)dof.p, n_reads, nb, superkmers_per_minim, kmers_per_minim);
+    (void)hipStreamSynchronize(c->stream);
+    db.release(); dof.release();
+    return rc;
+}
+
+int gkc_count_mmers(gkc_ctx* c, uint32_t m, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t* counts)
+{
+    if (!c || !counts) return GKC_ERR_ARG;
+    if (m < 2 || m > 14) GKC_FAIL(c, GKC_ERR_ARG, "m must be in [2,14]");
+    GKC_HIP(c, hipSetDevice(c->device));
+    DevBuf db, dof; uint64_t nb = 0;
+    GKC_TRY(upload_reads(c, bases, offsets, n_reads, db, dof, &nb));
+    int rc = gkc_scan_count_mmers(c, m, (const char*)db.p, (const uint64_t*)dof.p, n_reads, counts);
+    (void)hipStreamSynchronize(c->stream);
+    db.release(); dof.release();
+    return rc;
+}
+
 int gkc_finish_pass(gkc_ctx* c)
 {
     if (!c) return GKC_ERR_ARG;

@@ -33,6 +33,7 @@ struct ScanParams {
     unsigned long long* cnt_rec; unsigned long long* cnt_kmers; unsigned long long* cursor;
     uint64_t* arena;
     int dbg_noatomic;             // GKC_DEBUG_NOATOMIC=1: timing experiment only (wrong results)
+    int identity_part;            // sampling mode: the 'partition' of a super-k-mer is its minimizer value (4^m bins)
     uint64_t n_tiles; uint32_t n_parts;
     unsigned long long* wg_cnt;          // LDSPART count: [grid][P] packed (k-mers << 32 | records) of this workgroup
     const unsigned long long* wg_base;   // LDSPART emit : [grid][P] records of earlier workgroups in the partition
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
             const uint32_t key = s_mk[MKI(p0) + e];
             const uint32_t value = P.freq_mode ? P.key2val[key] : key;
             if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
-            const uint32_t part = P.repart[value];
+            const uint32_t part = P.identity_part ? value : P.repart[value];
             n_rec++;
             if (!EMIT) {
                 if (P.dbg_noatomic) continue;
@@ -444,6 +445,80 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     }
     seg.d_records = arena;
     c->segments.push_back(std::move(seg));
+    return GKC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RepartitorAlgorithm support (kmer/impl/RepartitionAlgorithm.cpp:395-475 SampleRepart): per-minimizer super-k-mer and
+// k-mer counts of a sample of reads, computed by the same scan kernel with "partition = minimizer value".
+// ------------------------------------------------------------------------------------------------
+int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases,
+                    uint64_t* h_superkmers, uint64_t* h_kmers)
+{
+    const uint64_t nm = 1ULL << (2 * c->m);
+    const uint64_t n_tiles = (n_bases + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_tiles == 0) return GKC_OK;
+    if (n_tiles >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "sample too large");
+    const size_t rs_words = (size_t)(n_tiles * SCAN_TILE / 32 + 64);
+    GKC_TRY(c->ensure(c->d_rsbits, rs_words * 4));
+    GKC_HIP(c, hipMemsetAsync(c->d_rsbits.p, 0, rs_words * 4, c->stream));
+    hipLaunchKernelGGL(k_mark_read_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, c->stream, d_offsets, n_reads + 1, (uint32_t*)c->d_rsbits.p);
+    DevBuf cnt; GKC_TRY(c->ensure(cnt, (size_t)(2 * nm + 4) * 8));
+    hipError_t e = hipMemsetAsync(cnt.p, 0, (size_t)(2 * nm + 4) * 8, c->stream);
+    ScanParams P{};
+    P.bases = (const uint8_t*)d_bases; P.n_bases = n_bases; P.rsbits = (const uint32_t*)c->d_rsbits.p;
+    P.k = c->k; P.m = c->m; P.nb_mm = c->k - c->m + 1; P.maxs = c->maxs;
+    P.mmask = (uint32_t)(nm - 1);
+    P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
+    P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
+    P.mkey_lut = (const uint32_t*)c->d_mkey_lut.p; P.key2val = (const uint32_t*)c->d_key2val.p; P.default_key = c->default_key;
+    P.repart = (const uint16_t*)c->d_repart.p; P.nb_passes = 1; P.pass = 0;
+    P.cnt_rec = (unsigned long long*)cnt.p; P.cnt_kmers = P.cnt_rec + nm; P.cursor = nullptr; P.gstats = P.cnt_rec + 2 * nm;
+    P.identity_part = 1; P.n_tiles = n_tiles; P.n_parts = 0;
+    int rc = (e == hipSuccess) ? launch_scan(c, P, false, false, (unsigned)std::min<uint64_t>(n_tiles, 1u << 20), 0) : GKC_ERR_HIP;
+    if (rc == GKC_OK) {
+        std::vector<uint64_t> a(nm), b(nm);
+        e = hipMemcpyAsync(a.data(), cnt.p, nm * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(b.data(), (uint64_t*)cnt.p + nm, nm * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) for (uint64_t i = 0; i < nm; i++) { h_superkmers[i] += a[i]; h_kmers[i] += b[i]; }
+    }
+    cnt.release();
+    if (rc != GKC_OK) return rc;
+    if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "minimizer sampling failed: %s", hipGetErrorString(e));
+    return GKC_OK;
+}
+
+// MmersFrequency (RepartitionAlgorithm.cpp:88-120): occurrences of every canonical m-mer at VALID m-mer positions
+__global__ void k_count_mmers(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint64_t n_reads, uint32_t m,
+                              unsigned int* __restrict__ counts)
+{
+    const uint32_t mask = (uint32_t)((1ULL << (2 * m)) - 1);
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = offsets[r], e = offsets[r + 1];
+        uint32_t fw = 0, rv = 0, good = 0;
+        for (uint64_t g = b; g < e; g++) {
+            const uint32_t ch = bases[g];
+            if (nt_valid(ch)) { const uint32_t code = nt_code(ch); fw = ((fw << 2) | code) & mask; rv = (rv >> 2) | ((code ^ 2u) << (2 * (m - 1))); good++; }
+            else { good = 0; fw = 0; rv = 0; }
+            if (good >= m) atomicAdd(&counts[fw < rv ? fw : rv], 1u);
+        }
+    }
+}
+int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t* h_counts)
+{
+    const uint64_t nm = 1ULL << (2 * m);
+    DevBuf cnt; GKC_TRY(c->ensure(cnt, nm * 4));
+    hipError_t e = hipMemcpyAsync(cnt.p, h_counts, nm * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_count_mmers, dim3((unsigned)std::min<uint64_t>((n_reads + 255) / 256 + 1, 8192)), dim3(256), 0, c->stream,
+                           (const uint8_t*)d_bases, d_offsets, n_reads, m, (unsigned int*)cnt.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_counts, cnt.p, nm * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cnt.release();
+    if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "m-mer counting failed: %s", hipGetErrorString(e));
     return GKC_OK;
 }
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
     "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_synth_reads_device", "gkc_device_free",
-    "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum",
+    "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
         "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
         "gkc_kmer_checksum_device": (C.c_int, [vp, vp, vp, u64, u64, P(u64), P(u64)]),
         "gkc_result_checksum": (C.c_int, [vp, P(u64), P(u64)]),
+        "gkc_sample_minimizers": (C.c_int, [vp, vp, vp, u64, vp, vp]),
+        "gkc_count_mmers": (C.c_int, [vp, u32, vp, vp, u64, vp]),
     }
     for name in SYMBOLS:
         f = getattr(L, name)          # raises AttributeError if the symbol is not exported
@@ -267,6 +269,19 @@ class Counter:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.L.gkc_partition_superkmers(self.h, part, _p(out), cap_bytes, C.byref(a), C.byref(b), C.byref(c)))
         return out[: a.value].copy(), b.value, c.value
+
+    # ---- Repartitor sampling
+    def sample_minimizers(self, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8); offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nsk = np.zeros(4 ** self.m, np.uint64); nk = np.zeros(4 ** self.m, np.uint64)
+        self._chk(self.L.gkc_sample_minimizers(self.h, _p(bases), _p(offsets), len(offsets) - 1, _p(nsk), _p(nk)))
+        return nsk, nk
+
+    def count_mmers(self, m, bases, offsets):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8); offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        cnt = np.zeros(4 ** m, np.uint32)
+        self._chk(self.L.gkc_count_mmers(self.h, m, _p(bases), _p(offsets), len(offsets) - 1, _p(cnt)))
+        return cnt
 
     # ---- segments (multi-GPU exchange surface)
     def segment_count(self):

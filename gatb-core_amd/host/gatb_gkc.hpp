@@ -1,0 +1,631 @@
+// gatb_gkc.hpp — C++ host side of the MI355X DSK hot path, mirroring the reference's plug-in API for this path.
+//
+// Same namespaces, class names, method names, argument meaning and error behaviour as the reference classes the path sits
+// behind, so a test written against gatb::core::kmer::impl reads the same here:
+//   Kmer<span>::{Type,Count}        kmer/impl/Model.hpp:89-1592, tools/misc/api/Abundance.hpp:68-129
+//   ICountProcessor<span>           kmer/api/ICountProcessor.hpp:92-185          (full call protocol preserved)
+//   CountProcessor{Histogram,SoliditySum,Dump,Chain}   kmer/impl/CountProcessor*.hpp
+//   Repartitor                      kmer/impl/PartiInfo.hpp:292-387, PartiInfo.cpp:48-295
+//   Configuration                   kmer/impl/Configuration.hpp:38-117
+//   SortingCountAlgorithm<span>     kmer/impl/SortingCountAlgorithm.hpp:65-263, .cpp:525-781
+//   IBloom<Item> / BloomFactory     tools/collections/impl/Bloom.hpp:113-168, 1240-1282
+//   system::Exception               system/api/Exception.hpp:59-100
+// Everything below the API is the C-ABI of libgkc_hip.so (include/gkc.h); no algorithmic work is done on the host:
+// the host only builds the repartition table from device-computed statistics (as the reference does on its host) and
+// forwards the counted records to the processors in ascending order.
+//
+// Not mirrored (out of scope): bank parsers (a minimal in-memory / FASTA-FASTQ reader is provided so the
+// examples run), the Storage/HDF5 layer (CountProcessorDump keeps the partitions in memory and can write raw
+// `Count` arrays + the `minimRepart` byte stream), OptionsParser/Properties trees (a flat string map is used).
+#pragma once
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/gkc.h"
+
+namespace gatb { namespace core {
+
+namespace system {
+/** printf-style exception (system/api/Exception.hpp:59-100) */
+class Exception {
+public:
+    Exception() {}
+    Exception(const char* fmt, ...) { char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap); _message = buf; }
+    const char* getMessage() const { return _message.c_str(); }
+protected:
+    std::string _message;
+};
+/** intrusive reference counting (system/api/ISmartPointer.hpp:97-115) */
+class SmartPointer {
+public:
+    SmartPointer() : _ref(0) {}
+    virtual ~SmartPointer() {}
+    void use() { _ref++; }
+    void forget() { if (--_ref <= 0) delete this; }
+private:
+    int _ref;
+};
+}  // namespace system
+
+typedef int32_t CountNumber;                       // system/api/types.hpp:49
+typedef std::vector<CountNumber> CountVector;
+
+namespace tools { namespace misc {
+/** flat property set standing in for IProperties (keys are the reference's STR_* strings, StringsRepository.hpp:115-180) */
+class Properties {
+public:
+    void setInt(const std::string& k, int64_t v) { _m[k] = std::to_string(v); }
+    void setStr(const std::string& k, const std::string& v) { _m[k] = v; }
+    int64_t getInt(const std::string& k) const { auto it = _m.find(k); if (it == _m.end()) throw system::Exception("Empty property '%s'", k.c_str()); return atoll(it->second.c_str()); }
+    std::string getStr(const std::string& k) const { auto it = _m.find(k); if (it == _m.end()) throw system::Exception("Empty property '%s'", k.c_str()); return it->second; }
+    bool has(const std::string& k) const { return _m.count(k) != 0; }
+    void add(const std::string& k, const char* fmt, ...) { char buf[256]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap); _m[k] = buf; }
+    const std::map<std::string, std::string>& map() const { return _m; }
+private:
+    std::map<std::string, std::string> _m;
+};
+typedef Properties IProperties;
+}}  // namespace tools::misc
+
+#define STR_KMER_SIZE            "-kmer-size"
+#define STR_KMER_ABUNDANCE_MIN   "-abundance-min"
+#define STR_KMER_ABUNDANCE_MAX   "-abundance-max"
+#define STR_MINIMIZER_SIZE       "-minimizer-size"
+#define STR_MINIMIZER_TYPE       "-minimizer-type"
+#define STR_REPARTITION_TYPE     "-repartition-type"
+#define STR_MAX_MEMORY           "-max-memory"
+#define STR_HISTOGRAM_MAX        "-histo-max"
+#define STR_URI_OUTPUT           "-out"
+#define STR_NB_PARTITIONS        "-nb-partitions"      /* extension: force the partition count (0 = derive) */
+#define STR_NB_PASSES            "-nb-passes"          /* extension: force the pass count (default 1)       */
+#define STR_GPU_DEVICE           "-gpu"                /* extension: HIP device index                       */
+
+// ------------------------------------------------------------------------------------------------ bank (minimal)
+namespace bank {
+struct Sequence { const char* data; size_t size; const char* getDataBuffer() const { return data; } size_t getDataSize() const { return size; } };
+/** IBank restricted to what the hot path needs (bank/api/IBank.hpp:78-158): a flat base buffer + offsets */
+class IBank : public system::SmartPointer {
+public:
+    virtual ~IBank() {}
+    virtual const std::vector<char>& bases() const = 0;
+    virtual const std::vector<uint64_t>& offsets() const = 0;     // n+1 entries
+    int64_t getNbItems() const { return (int64_t)offsets().size() - 1; }
+    uint64_t getSize() const { return offsets().back(); }
+    void estimate(uint64_t& number, uint64_t& totalSize, uint64_t& maxSize) const {
+        number = (uint64_t)getNbItems(); totalSize = getSize(); maxSize = 0;
+        for (size_t i = 0; i + 1 < offsets().size(); i++) maxSize = std::max<uint64_t>(maxSize, offsets()[i + 1] - offsets()[i]);
+    }
+};
+/** BankStrings (bank/impl/BankStrings.hpp): sequences given as C strings */
+class BankStrings : public IBank {
+public:
+    BankStrings() { _off.push_back(0); }
+    BankStrings(const char* s, ...) { _off.push_back(0); va_list ap; va_start(ap, s); for (const char* p = s; p; p = va_arg(ap, const char*)) add(p); va_end(ap); }
+    BankStrings(const char* seqs[], size_t n) { _off.push_back(0); for (size_t i = 0; i < n; i++) add(seqs[i]); }
+    explicit BankStrings(const std::vector<std::string>& v) { _off.push_back(0); for (auto& s : v) add(s.c_str()); }
+    void add(const char* s) { size_t n = strlen(s); _bases.insert(_bases.end(), s, s + n); _off.push_back(_bases.size()); }
+    const std::vector<char>& bases() const { return _bases; }
+    const std::vector<uint64_t>& offsets() const { return _off; }
+protected:
+    std::vector<char> _bases; std::vector<uint64_t> _off;
+};
+/** plain FASTA / FASTQ reader (uncompressed); multi-line FASTA records are concatenated */
+class BankFasta : public BankStrings {
+public:
+    explicit BankFasta(const std::string& path) {
+        std::ifstream in(path);
+        if (!in) throw system::Exception("Unable to open file '%s'", path.c_str());
+        std::string line, cur; bool fastq = false, have = false; int fq = 0;
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!have && line.empty()) continue;
+            if (!have) { fastq = line[0] == '@'; have = true; }
+            if (fastq) { if (fq == 1) add(line.c_str()); fq = (fq + 1) & 3; }
+            else if (!line.empty() && line[0] == '>') { if (!cur.empty()) { add(cur.c_str()); cur.clear(); } }
+            else cur += line;
+        }
+        if (!fastq && !cur.empty()) add(cur.c_str());
+    }
+};
+}  // namespace bank
+
+namespace kmer { namespace impl {
+
+// ------------------------------------------------------------------------------------------------ k-mer integer + Count
+/** LargeInt<1> / LargeInt<2> as used by the path (tools/math/LargeInt1.pri, LargeInt2.pri): value semantics + toString */
+template <int W> struct LargeInt;
+template <> struct LargeInt<1> {
+    uint64_t value;
+    LargeInt() : value(0) {}
+    LargeInt(uint64_t v) : value(v) {}
+    uint64_t getVal() const { return value; }
+    void setVal(uint64_t v) { value = v; }
+    bool operator<(const LargeInt& o) const { return value < o.value; }
+    bool operator==(const LargeInt& o) const { return value == o.value; }
+    bool operator!=(const LargeInt& o) const { return value != o.value; }
+    LargeInt& operator+=(const LargeInt& o) { value += o.value; return *this; }
+    static size_t getSize() { return 64; }
+    static const char* getName() { return "LargeInt<1>"; }
+    std::string toString(size_t k) const { std::string s(k, 'A'); uint64_t t = value; for (size_t i = k; i-- > 0;) { s[i] = "ACTG"[t & 3]; t >>= 2; } return s; }
+};
+template <> struct LargeInt<2> {
+    unsigned __int128 value;
+    LargeInt() : value(0) {}
+    LargeInt(uint64_t v) : value(v) {}
+    uint64_t getVal() const { return (uint64_t)value; }
+    void setVal(uint64_t v) { value = v; }
+    bool operator<(const LargeInt& o) const { return value < o.value; }
+    bool operator==(const LargeInt& o) const { return value == o.value; }
+    bool operator!=(const LargeInt& o) const { return value != o.value; }
+    LargeInt& operator+=(const LargeInt& o) { value += o.value; return *this; }
+    static size_t getSize() { return 128; }
+    static const char* getName() { return "LargeInt<2>"; }
+    std::string toString(size_t k) const { std::string s(k, 'A'); unsigned __int128 t = value; for (size_t i = k; i-- > 0;) { s[i] = "ACTG"[(unsigned)(t & 3)]; t >>= 2; } return s; }
+};
+
+#define KMER_DEFAULT_SPAN 32
+template <size_t span = KMER_DEFAULT_SPAN> struct Kmer {
+    typedef LargeInt<(span + 31) / 32> Type;                       // Model.hpp:100
+    /** {value, abundance}: 16 bytes (span 32) / 32 bytes (span 64) — the layout libgkc_hip.so returns (Abundance.hpp:68-129) */
+    struct Count {
+        Type value; CountNumber abundance;
+        uint32_t _pad[sizeof(Type) == 8 ? 1 : 3];                  // explicit, zeroed: records are byte-reproducible on disk
+        Count() : abundance(0) { for (auto& x : _pad) x = 0; }
+        Count(const Type& v, CountNumber a) : value(v), abundance(a) { for (auto& x : _pad) x = 0; }
+        const Type& getValue() const { return value; }
+        CountNumber getAbundance() const { return abundance; }
+        bool operator<(const Count& o) const { return value < o.value; }
+    };
+};
+static_assert(sizeof(Kmer<32>::Count) == 16, "Count layout must match the device records (k<=31)");
+static_assert(sizeof(Kmer<64>::Count) == 32, "Count layout must match the device records (k<=63)");
+
+// ------------------------------------------------------------------------------------------------ Configuration
+/** kmer/impl/Configuration.hpp:38-117 (fields the hot path reads) */
+struct Configuration {
+    size_t _kmerSize = 0, _minim_size = 0, _repartitionType = 0, _minimizerType = 0;
+    uint64_t _max_memory = 0, _estimateSeqNb = 0, _estimateSeqTotalSize = 0, _estimateSeqMaxSize = 0, _kmersNb = 0, _volume = 0;
+    uint32_t _nb_passes = 1, _nb_partitions = 0;
+    CountNumber _abundance_min = 1, _abundance_max = 2147483647; uint32_t _histo_max = 10000;
+    size_t _nb_banks = 1; bool _isComputed = false;
+};
+
+// ------------------------------------------------------------------------------------------------ Repartitor
+/** minimizer -> partition table (PartiInfo.hpp:292-387). The builders restate PartiInfo.cpp:48-218 on statistics that were
+ *  computed ON THE DEVICE (gkc_sample_minimizers); `save`/`load` use the byte layout of Repartitor::save (PartiInfo.cpp:271-295)
+ *  in a plain file instead of an HDF5 stream. */
+class Repartitor : public system::SmartPointer {
+public:
+    typedef uint16_t Value;
+    Repartitor(int nbpart = 0, int minimsize = 0, int nbPass = 1) : _nbpart((uint16_t)nbpart), _mm(minimsize), _nb_minims(1ULL << (2 * minimsize)), _nbPass((uint16_t)nbPass) {}
+    Value operator()(uint64_t minimizer_value) const { return _repart_table[minimizer_value]; }
+    uint16_t getNbPasses() const { return _nbPass; }
+    uint16_t getNbPartitions() const { return _nbpart; }
+    uint64_t getNbMinimizers() const { return _nb_minims; }
+    const std::vector<Value>& getTable() const { return _repart_table; }
+    const uint32_t* getMinimizerFrequencies() const { return _freq_order.empty() ? nullptr : _freq_order.data(); }
+    void setMinimizerFrequencies(const std::vector<uint32_t>& f) { _freq_order = f; }
+
+    /** largest bin into the emptiest partition (computeDistrib, PartiInfo.cpp:48-106). Weights = k-mers per minimizer. */
+    void computeDistrib(const std::vector<uint64_t>& weight) {
+        _repart_table.assign(_nb_minims, 0);
+        std::vector<std::pair<uint64_t, uint64_t>> bins(_nb_minims);
+        for (uint64_t i = 0; i < _nb_minims; i++) bins[i] = { weight[i], i };
+        std::stable_sort(bins.begin(), bins.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a.first > b.first; });
+        typedef std::pair<uint64_t, uint32_t> slot;                 // (space used, partition)
+        std::vector<slot> heap; for (uint32_t j = 0; j < _nbpart; j++) heap.push_back({ 0, j });
+        auto cmp = [](const slot& a, const slot& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        for (uint64_t c = 0; c < _nb_minims; c++) {
+            std::pop_heap(heap.begin(), heap.end(), cmp); slot s = heap.back(); heap.pop_back();
+            _repart_table[bins[c].second] = (Value)s.second; s.first += bins[c].first;
+            heap.push_back(s); std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+    }
+    /** keeps minimizers in lexicographic order (justGroupLexi, PartiInfo.cpp:185-218; what bcalm2 needs) */
+    void justGroupLexi(const std::vector<uint64_t>& nbKmers) {
+        _repart_table.assign(_nb_minims, (Value)(_nbpart - 1));
+        uint64_t sum = 0; for (uint64_t v : nbKmers) sum += v;
+        const uint64_t mean = sum / _nbpart; uint64_t acc = 0, j = 0;
+        for (uint64_t i = 0; i < _nb_minims; i++) {
+            _repart_table[i] = (Value)std::min<uint64_t>(j, _nbpart - 1);        // the reference may write j == nbpart here; clamped
+            acc += nbKmers[i];
+            if (acc > mean) { acc = 0; if (j < _nbpart) j++; }
+        }
+    }
+    /** frequency order grouping (justGroup, PartiInfo.cpp:131-183): counts = sorted (count, m-mer) pairs */
+    void justGroup(const std::vector<uint64_t>& nbKmers, const std::vector<std::pair<uint32_t, uint32_t>>& counts) {
+        _repart_table.assign(_nb_minims, (Value)(_nbpart - 1));
+        uint64_t sum = 0; for (uint64_t v : nbKmers) sum += v;
+        const uint64_t mean = sum / _nbpart; uint64_t acc = 0, j = 0;
+        for (auto& c : counts) {
+            _repart_table[c.second] = (Value)std::min<uint64_t>(j, _nbpart - 1);
+            acc += nbKmers[c.second];
+            if (acc > mean) { acc = 0; if (j < _nbpart) j++; }
+        }
+    }
+    /** byte stream of Repartitor::save: u16 nbpart; u64 nb_minims; u16 nbPass; u16 table[]; u8 hasFreq; u32 magic (+ freq file) */
+    void save(const std::string& path) const {
+        std::ofstream os(path, std::ios::binary);
+        const uint32_t magic = 0x12345678; const uint8_t hasf = !_freq_order.empty();
+        os.write((const char*)&_nbpart, 2); os.write((const char*)&_nb_minims, 8); os.write((const char*)&_nbPass, 2);
+        os.write((const char*)_repart_table.data(), 2 * _nb_minims); os.write((const char*)&hasf, 1); os.write((const char*)&magic, 4);
+        if (hasf) { std::ofstream of(path + ".minimFrequency", std::ios::binary); of.write((const char*)_freq_order.data(), 4 * _nb_minims); of.write((const char*)&magic, 4); }
+    }
+    void load(const std::string& path) {
+        std::ifstream is(path, std::ios::binary);
+        if (!is) throw system::Exception("Unable to load Repartitor (minimRepart) '%s'", path.c_str());
+        uint8_t hasf = 0; uint32_t magic = 0;
+        is.read((char*)&_nbpart, 2); is.read((char*)&_nb_minims, 8); is.read((char*)&_nbPass, 2);
+        _repart_table.resize(_nb_minims); is.read((char*)_repart_table.data(), 2 * _nb_minims);
+        is.read((char*)&hasf, 1); is.read((char*)&magic, 4);
+        if (magic != 0x12345678) throw system::Exception("Unable to load Repartitor (minimRepart), possibly due to bad format.");
+        _mm = 0; while ((1ULL << (2 * _mm)) < _nb_minims) _mm++;
+        if (hasf) { std::ifstream f(path + ".minimFrequency", std::ios::binary); _freq_order.resize(_nb_minims); f.read((char*)_freq_order.data(), 4 * _nb_minims); }
+    }
+    void setTable(const std::vector<Value>& t) { _repart_table = t; }
+private:
+    uint16_t _nbpart; int _mm; uint64_t _nb_minims; uint16_t _nbPass;
+    std::vector<Value> _repart_table; std::vector<uint32_t> _freq_order;
+};
+
+// ------------------------------------------------------------------------------------------------ ICountProcessor + defaults
+/** plug-in protocol of the counting stage (kmer/api/ICountProcessor.hpp:92-185): identical calls in identical order */
+template <size_t span = KMER_DEFAULT_SPAN>
+class ICountProcessor : public system::SmartPointer {
+public:
+    typedef typename Kmer<span>::Type Type;
+    virtual void begin(const Configuration& config) = 0;
+    virtual void end() = 0;
+    virtual void beginPass(size_t passId) = 0;
+    virtual void endPass(size_t passId) = 0;
+    virtual ICountProcessor* clone() = 0;
+    virtual void finishClones(std::vector<ICountProcessor<span>*>& clones) = 0;
+    virtual void beginPart(size_t passId, size_t partId, size_t cacheSize, const char* name) = 0;
+    virtual void endPart(size_t passId, size_t partId) = 0;
+    virtual bool process(size_t partId, const Type& kmer, const CountVector& count, CountNumber sum = 0) = 0;
+    virtual std::string getName() const = 0;
+    virtual tools::misc::Properties getProperties() const { return tools::misc::Properties(); }
+    /** EXTENSION (bulk sink): processors that can take a whole ascending Count[] block at once override
+     *  this; the default forwards record by record to process(), so custom processors keep working unchanged. */
+    virtual void processBulk(size_t partId, const typename Kmer<span>::Count* counts, size_t n) {
+        CountVector v(1);
+        for (size_t i = 0; i < n; i++) { v[0] = counts[i].abundance; process(partId, counts[i].value, v, counts[i].abundance); }
+    }
+};
+
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorAbstract : public ICountProcessor<span> {
+public:
+    void begin(const Configuration&) {}
+    void end() {}
+    void beginPass(size_t) {}
+    void endPass(size_t) {}
+    void finishClones(std::vector<ICountProcessor<span>*>&) {}
+    void beginPart(size_t, size_t, size_t, const char*) {}
+    void endPart(size_t, size_t) {}
+};
+
+/** CountProcessorHistogram (kmer/impl/CountProcessorHistogram.hpp:173-184; Histogram::inc, Histogram.hpp:92) */
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorHistogram : public CountProcessorAbstract<span> {
+public:
+    typedef typename Kmer<span>::Type Type;
+    explicit CountProcessorHistogram(size_t histoMax = 10000, std::vector<uint64_t>* shared = nullptr)
+        : _length(histoMax), _own(histoMax + 1, 0), _shared(shared ? shared : &_own) {}
+    ICountProcessor<span>* clone() { return new CountProcessorHistogram(_length, _shared); }
+    bool process(size_t, const Type&, const CountVector&, CountNumber sum) { (*_shared)[(size_t)sum >= _length ? _length : (size_t)sum]++; return true; }
+    std::string getName() const { return "histogram"; }
+    const std::vector<uint64_t>& getHistogram() const { return *_shared; }
+private:
+    size_t _length; std::vector<uint64_t> _own; std::vector<uint64_t>* _shared;
+};
+
+/** CountProcessorSoliditySum (kmer/impl/CountProcessorSolidity.hpp:60-190): closed interval test on the sum */
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorSoliditySum : public CountProcessorAbstract<span> {
+public:
+    typedef typename Kmer<span>::Type Type;
+    struct Totals { uint64_t total = 0, ok = 0; };
+    CountProcessorSoliditySum(CountNumber amin, CountNumber amax, Totals* shared = nullptr) : _min(amin), _max(amax), _shared(shared ? shared : &_own) {}
+    ICountProcessor<span>* clone() { return new CountProcessorSoliditySum(_min, _max, _shared); }
+    bool process(size_t, const Type&, const CountVector&, CountNumber sum) { _shared->total++; const bool ok = sum >= _min && sum <= _max; if (ok) _shared->ok++; return ok; }
+    std::string getName() const { return "sum"; }
+    tools::misc::Properties getProperties() const {
+        tools::misc::Properties p; p.add("kmers_nb_distinct", "%llu", (unsigned long long)_shared->total); p.add("kmers_nb_solid", "%llu", (unsigned long long)_shared->ok);
+        p.add("kmers_nb_weak", "%llu", (unsigned long long)(_shared->total - _shared->ok)); return p; }
+    const Totals& totals() const { return *_shared; }
+private:
+    CountNumber _min, _max; Totals _own; Totals* _shared;
+};
+
+/** CountProcessorDump (kmer/impl/CountProcessorDump.hpp:60-180): dataset index = part + pass*nb_partitions (:131);
+ *  nb_partitions*nb_passes datasets exist even if empty (:85-95). Datasets are kept in memory (the reference appends them
+ *  to dsk/solid/<i> through BagCache -> HDF5); saveRaw() writes each one as a raw Count[] file. */
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorDump : public CountProcessorAbstract<span> {
+public:
+    typedef typename Kmer<span>::Type Type; typedef typename Kmer<span>::Count Count;
+    typedef std::vector<std::vector<Count>> Store;
+    explicit CountProcessorDump(size_t kmerSize, Store* shared = nullptr, size_t nbParts = 0) : _kmerSize(kmerSize), _shared(shared ? shared : &_own), _nbPartsPerPass(nbParts), _cur(0) {}
+    void begin(const Configuration& config) { _nbPartsPerPass = config._nb_partitions; _shared->assign((size_t)config._nb_partitions * config._nb_passes, std::vector<Count>()); }
+    ICountProcessor<span>* clone() { return new CountProcessorDump(_kmerSize, _shared, _nbPartsPerPass); }
+    void beginPart(size_t passId, size_t partId, size_t, const char*) { _cur = partId + passId * _nbPartsPerPass; }
+    bool process(size_t, const Type& kmer, const CountVector&, CountNumber sum) { (*_shared)[_cur].push_back(Count(kmer, sum)); return true; }
+    void processBulk(size_t, const Count* counts, size_t n) { auto& d = (*_shared)[_cur]; d.insert(d.end(), counts, counts + n); }
+    std::string getName() const { return "dump"; }
+    const Store& getSolidCounts() const { return *_shared; }
+    uint64_t getNbItems() const { uint64_t n = 0; for (auto& d : *_shared) n += d.size(); return n; }
+    void saveRaw(const std::string& prefix) const {
+        for (size_t i = 0; i < _shared->size(); i++) { std::ofstream os(prefix + ".solid." + std::to_string(i), std::ios::binary); os.write((const char*)(*_shared)[i].data(), (*_shared)[i].size() * sizeof(Count)); }
+    }
+private:
+    size_t _kmerSize; Store _own; Store* _shared; size_t _nbPartsPerPass; size_t _cur;
+};
+
+/** CountProcessorChain (kmer/impl/CountProcessorChain.hpp:60-160): a k-mer goes down the chain while processors return true */
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorChain : public ICountProcessor<span> {
+public:
+    typedef typename Kmer<span>::Type Type;
+    CountProcessorChain(const std::vector<ICountProcessor<span>*>& items) : _items(items) { for (auto* i : _items) i->use(); }
+    ~CountProcessorChain() { for (auto* i : _items) i->forget(); }
+    void begin(const Configuration& c) { for (auto* i : _items) i->begin(c); }
+    void end() { for (auto* i : _items) i->end(); }
+    void beginPass(size_t p) { for (auto* i : _items) i->beginPass(p); }
+    void endPass(size_t p) { for (auto* i : _items) i->endPass(p); }
+    ICountProcessor<span>* clone() { std::vector<ICountProcessor<span>*> c; for (auto* i : _items) c.push_back(i->clone()); return new CountProcessorChain(c); }
+    void finishClones(std::vector<ICountProcessor<span>*>& clones) {
+        for (size_t i = 0; i < _items.size(); i++) { std::vector<ICountProcessor<span>*> sub; for (auto* c : clones) if (auto* ch = dynamic_cast<CountProcessorChain*>(c)) sub.push_back(ch->_items[i]); _items[i]->finishClones(sub); }
+    }
+    void beginPart(size_t a, size_t b, size_t c, const char* n) { for (auto* i : _items) i->beginPart(a, b, c, n); }
+    void endPart(size_t a, size_t b) { for (auto* i : _items) i->endPart(a, b); }
+    bool process(size_t partId, const Type& kmer, const CountVector& count, CountNumber sum = 0) {
+        if (sum == 0) for (CountNumber c : count) sum += c;
+        bool res = true;
+        for (size_t i = 0; res && i < _items.size(); i++) res = _items[i]->process(partId, kmer, count, sum);
+        return res;
+    }
+    std::string getName() const { return "chain"; }
+    const std::vector<ICountProcessor<span>*>& items() const { return _items; }
+    template <class T> T* get() const { for (auto* i : _items) if (T* t = dynamic_cast<T*>(i)) return t; return nullptr; }
+private:
+    std::vector<ICountProcessor<span>*> _items;
+};
+
+// ------------------------------------------------------------------------------------------------ SortingCountAlgorithm
+/** DSK driver on the GPU. Same constructors / execute() / accessors as kmer/impl/SortingCountAlgorithm.hpp:85-192.
+ *  execute() = configure (Configuration + Repartitor if not injected, .cpp:525-625) -> processors begin -> per pass:
+ *  fillPartitions (Stage A on the device) -> fillSolidKmers (Stage B on the device, then one clone per partition fed in
+ *  ascending k-mer order: beginPart / process... / endPart, finishClones) -> processors end; getInfo() keys as :728-780. */
+template <size_t span = KMER_DEFAULT_SPAN>
+class SortingCountAlgorithm {
+public:
+    typedef typename Kmer<span>::Type Type; typedef typename Kmer<span>::Count Count;
+    typedef ICountProcessor<span> CountProcessor;
+
+    static tools::misc::IProperties* getDefaultProperties() {     // SortingCountAlgorithm.cpp:202-236 defaults
+        auto* p = new tools::misc::IProperties();
+        p->setInt(STR_KMER_SIZE, 31); p->setInt(STR_KMER_ABUNDANCE_MIN, 2); p->setInt(STR_KMER_ABUNDANCE_MAX, 2147483647);
+        p->setInt(STR_MINIMIZER_SIZE, 10); p->setInt(STR_MINIMIZER_TYPE, 0); p->setInt(STR_REPARTITION_TYPE, 0);
+        p->setInt(STR_MAX_MEMORY, 5000); p->setInt(STR_HISTOGRAM_MAX, 10000); p->setStr(STR_URI_OUTPUT, "");
+        p->setInt(STR_NB_PARTITIONS, 0); p->setInt(STR_NB_PASSES, 1); p->setInt(STR_GPU_DEVICE, 0);
+        return p;
+    }
+    SortingCountAlgorithm(bank::IBank* bank, tools::misc::IProperties* params)
+        : _bank(bank), _params(*params), _repartitor(nullptr), _ctx(nullptr) { _bank->use(); }
+    SortingCountAlgorithm(bank::IBank* bank, const Configuration& config, Repartitor* repartitor, std::vector<CountProcessor*> processors, tools::misc::IProperties* params)
+        : _bank(bank), _params(*params), _config(config), _repartitor(repartitor), _processors(processors), _ctx(nullptr) {
+        _bank->use(); if (_repartitor) _repartitor->use(); for (auto* p : _processors) p->use();
+    }
+    ~SortingCountAlgorithm() {
+        if (_ctx) gkc_destroy(_ctx);
+        _bank->forget(); if (_repartitor) _repartitor->forget(); for (auto* p : _processors) p->forget();
+    }
+    void addProcessor(CountProcessor* p) { p->use(); _processors.push_back(p); }
+    size_t getProcessorNumber() const { return _processors.size(); }
+    CountProcessor* getProcessor(size_t i) { return _processors[i]; }
+    const Configuration& getConfig() const { return _config; }
+    Repartitor* getRepartitor() { return _repartitor; }
+    const tools::misc::Properties* getInfo() const { return &_info; }
+    /** solid counts of the default dump processor (getSolidCounts(), .hpp:168) */
+    const typename CountProcessorDump<span>::Store& getSolidCounts() {
+        for (auto* p : _processors) { if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(p)) if (auto* d = ch->template get<CountProcessorDump<span>>()) return d->getSolidCounts();
+                                      if (auto* d = dynamic_cast<CountProcessorDump<span>*>(p)) return d->getSolidCounts(); }
+        throw system::Exception("no dump processor");
+    }
+    gkc_ctx* context() { return _ctx; }
+
+    void execute() {
+        configure();
+        const uint32_t P = _config._nb_partitions;
+        for (auto* p : _processors) p->begin(_config);
+        const auto& bases = _bank->bases(); const auto& offs = _bank->offsets();
+        std::vector<Count> buf; std::vector<typename Kmer<32>::Count> narrow;
+        for (uint32_t pass = 0; pass < _config._nb_passes; pass++) {
+            check(gkc_begin_pass(_ctx, pass));
+            check(gkc_push_reads(_ctx, bases.data(), offs.data(), offs.size() - 1));                 // fillPartitions
+            check(gkc_finish_pass(_ctx));                                                             // fillSolidKmers (device part)
+            for (auto* proc : _processors) {
+                proc->beginPass(pass);
+                std::vector<CountProcessor*> clones;
+                for (uint32_t p = 0; p < P; p++) {
+                    uint64_t ns = 0, nd = 0, nk = 0;
+                    check(gkc_partition_info(_ctx, pass, p, &ns, &nd, &nk));
+                    buf.resize(ns);
+                    uint64_t got = 0;
+                    if (sizeof(Count) == 32 && _config._kmerSize <= 31) {
+                        // span 64 instantiated with k <= 31 (the reference's unit tests do it): the device keys are 64-bit
+                        // (its key width follows k, like the reference's run-time Integer dispatch); widen the records here
+                        narrow.resize(ns);
+                        check(gkc_partition_counts(_ctx, pass, p, narrow.data(), ns, &got));
+                        for (uint64_t i = 0; i < got; i++) { buf[i].value.setVal(narrow[i].value.getVal()); buf[i].abundance = narrow[i].abundance; }
+                    } else
+                    check(gkc_partition_counts(_ctx, pass, p, buf.data(), ns, &got));
+                    CountProcessor* clone = proc->clone(); clone->use(); clones.push_back(clone);
+                    clone->beginPart(pass, p, 4096, "vector");
+                    clone->processBulk(p, buf.data(), (size_t)got);                                   // ascending k-mer order
+                    clone->endPart(pass, p);
+                }
+                proc->finishClones(clones);
+                for (auto* c : clones) c->forget();
+                proc->endPass(pass);
+            }
+        }
+        for (auto* p : _processors) p->end();
+        gkc_stats st; check(gkc_get_stats(_ctx, &st));
+        _info.add("kmers_nb_valid", "%llu", (unsigned long long)st.kmers_nb_valid);
+        _info.add("kmers_nb_invalid", "%llu", (unsigned long long)st.kmers_nb_invalid);
+        _info.add("nb_partitions", "%u", P); _info.add("nb_passes", "%u", _config._nb_passes);
+        _info.add("nb_superkmers", "%llu", (unsigned long long)st.nb_superkmers);
+        _info.add("seq_number", "%llu", (unsigned long long)st.nb_sequences);
+        // the solidity processor sees every distinct k-mer (the device returns all of them; filtering is the chain's job)
+        for (auto* p : _processors) if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(p)) if (auto* s = ch->template get<CountProcessorSoliditySum<span>>()) {
+            _info.add("kmers_nb_distinct", "%llu", (unsigned long long)s->totals().total); _info.add("kmers_nb_solid", "%llu", (unsigned long long)s->totals().ok); }
+        if (!_info.has("kmers_nb_distinct")) { _info.add("kmers_nb_distinct", "%llu", (unsigned long long)st.kmers_nb_distinct); _info.add("kmers_nb_solid", "%llu", (unsigned long long)st.kmers_nb_solid); }
+    }
+
+    /** default chain histogram -> solidity -> dump (getDefaultProcessorVector, SortingCountAlgorithm.cpp:376-400) */
+    static CountProcessor* getDefaultProcessor(const Configuration& c) {
+        std::vector<CountProcessor*> items;
+        items.push_back(new CountProcessorHistogram<span>(c._histo_max));
+        items.push_back(new CountProcessorSoliditySum<span>(c._abundance_min, c._abundance_max));
+        items.push_back(new CountProcessorDump<span>(c._kmerSize));
+        return new CountProcessorChain<span>(items);
+    }
+
+private:
+    void check(int rc) { if (rc != GKC_OK) throw system::Exception("gkc error %d: %s", rc, gkc_last_error(_ctx)); }
+
+    /** configure(), SortingCountAlgorithm.cpp:525-625 + ConfigurationAlgorithm.cpp:245-467 (GPU-aware partition count) */
+    void configure() {
+        if (!_config._isComputed) {
+            _config._kmerSize = (size_t)_params.getInt(STR_KMER_SIZE);
+            if (_config._kmerSize <= 2) throw system::Exception("Error: kmer size should be > 2");          // .cpp:662-666 (exit(1) there)
+            if (_config._kmerSize >= span) throw system::Exception("Type '%s' has too low precision (%d bits) for the required %d kmer size",
+                                                                   Type::getName(), (int)Type::getSize(), (int)_config._kmerSize);       // Model.hpp:398-404
+            size_t m = (size_t)_params.getInt(STR_MINIMIZER_SIZE);
+            if (m == 0) m = 8;                                                                              // ConfigurationAlgorithm.cpp:249-251
+            _config._minim_size = std::min(_config._kmerSize - 1, m);
+            _config._minimizerType = (size_t)_params.getInt(STR_MINIMIZER_TYPE); _config._repartitionType = (size_t)_params.getInt(STR_REPARTITION_TYPE);
+            _config._abundance_min = (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MIN); _config._abundance_max = (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MAX);
+            _config._histo_max = (uint32_t)_params.getInt(STR_HISTOGRAM_MAX); _config._max_memory = (uint64_t)_params.getInt(STR_MAX_MEMORY);
+            _bank->estimate(_config._estimateSeqNb, _config._estimateSeqTotalSize, _config._estimateSeqMaxSize);
+            const uint64_t total = _config._estimateSeqTotalSize, nseq = _config._estimateSeqNb, k = _config._kmerSize;
+            _config._kmersNb = total > nseq * (k - 1) ? total - nseq * (k - 1) : 0;                       // ConfigurationAlgorithm.cpp:308-319
+            _config._nb_passes = _params.has(STR_NB_PASSES) ? (uint32_t)std::max<int64_t>(1, _params.getInt(STR_NB_PASSES)) : 1;
+            uint32_t forced = _params.has(STR_NB_PARTITIONS) ? (uint32_t)_params.getInt(STR_NB_PARTITIONS) : 0;
+            // GPU-aware sizing: a partition should hold ~3M k-mers (fits one Stage-B workgroup's sub-bucket fan-out); the scan keeps
+            // its partition cursors in LDS up to 8192 partitions
+            uint64_t want = forced ? forced : std::max<uint64_t>(4, (_config._kmersNb / _config._nb_passes + 2999999) / 3000000);
+            if (!forced) { uint64_t p2 = 4; while (p2 < want) p2 <<= 1; want = std::min<uint64_t>(p2, 8192); }
+            _config._nb_partitions = (uint32_t)std::min<uint64_t>(want, 65535);
+            _config._isComputed = true;
+        }
+        int rc = gkc_create((int)(_params.has(STR_GPU_DEVICE) ? _params.getInt(STR_GPU_DEVICE) : 0), &_ctx);
+        if (rc != GKC_OK) throw system::Exception("gkc_create failed (%d): %s", rc, gkc_last_error(nullptr));
+        const size_t m = _config._minim_size; const uint32_t P = _config._nb_partitions;
+        if (!_repartitor) { _repartitor = buildRepartitor(m, P); _repartitor->use(); }
+        if (_processors.empty()) { CountProcessor* p = getDefaultProcessor(_config); p->use(); _processors.push_back(p); }
+        // the device returns every distinct k-mer; histogram / solidity / dump stay in the processor chain (drop-in behaviour)
+        check(gkc_set_solidity(_ctx, 1, 2147483647, _config._histo_max));
+        check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, P, _config._nb_passes, _repartitor->getMinimizerFrequencies() ? GKC_MINIMIZER_FREQ : GKC_MINIMIZER_LEXI,
+                            _repartitor->getTable().data(), _repartitor->getMinimizerFrequencies()));
+    }
+
+    /** RepartitorAlgorithm::execute (RepartitionAlgorithm.cpp:287-492): sample statistics on the device, tables on the host */
+    Repartitor* buildRepartitor(size_t m, uint32_t P) {
+        const auto& bases = _bank->bases(); const auto& offs = _bank->offsets();
+        const uint64_t nseq = offs.size() - 1, nm = 1ULL << (2 * m);
+        Repartitor* rep = new Repartitor((int)P, (int)m, (int)_config._nb_passes);
+        std::vector<uint16_t> dummy(nm, 0);
+        std::vector<std::pair<uint32_t, uint32_t>> counts;
+        std::vector<uint32_t> freq;
+        if (_config._minimizerType == 1) {                                                                  // computeFrequencies (:311-384)
+            uint64_t ns = std::min<uint64_t>((uint64_t)(nseq * 0.05), 50000000ULL); if (ns == 0) ns = 1; ns = std::min<uint64_t>(ns + 1, nseq);
+            std::vector<uint32_t> mc(nm, 0);
+            check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, 1, 1, GKC_MINIMIZER_LEXI, dummy.data(), nullptr));
+            check(gkc_count_mmers(_ctx, (uint32_t)m, bases.data(), offs.data(), ns, mc.data()));
+            for (uint64_t i = 0; i < nm; i++) if (mc[i] > 0) counts.push_back({ mc[i], (uint32_t)i });
+            std::sort(counts.begin(), counts.end());
+            freq.assign(nm, (uint32_t)nm);
+            for (size_t i = 0; i < counts.size(); i++) freq[counts[i].second] = (uint32_t)i;
+            freq[nm - 1] = (uint32_t)(nm - 1);
+            rep->setMinimizerFrequencies(freq);
+        }
+        // computeRepartition (:395-475): super-k-mer statistics of a sample prefix of the bank
+        uint64_t ns = std::max<uint64_t>((uint64_t)(nseq * 0.05), 1000000ULL); ns = std::min<uint64_t>(ns, nseq);
+        std::vector<uint64_t> nsk(nm, 0), nk(nm, 0);
+        check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, 1, 1, freq.empty() ? GKC_MINIMIZER_LEXI : GKC_MINIMIZER_FREQ, dummy.data(), freq.empty() ? nullptr : freq.data()));
+        check(gkc_sample_minimizers(_ctx, bases.data(), offs.data(), ns, nsk.data(), nk.data()));
+        if (_config._minimizerType == 1) rep->justGroup(nk, counts);
+        else { rep->computeDistrib(nk); if (_config._repartitionType == 1) rep->justGroupLexi(nk); }
+        return rep;
+    }
+
+    bank::IBank* _bank; tools::misc::Properties _params; Configuration _config; Repartitor* _repartitor;
+    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx;
+};
+
+}}  // namespace kmer::impl
+
+// ------------------------------------------------------------------------------------------------ Bloom
+namespace tools { namespace collections { namespace impl {
+enum BloomKind { BLOOM_NONE, BLOOM_BASIC, BLOOM_CACHE, BLOOM_NEIGHBOR, BLOOM_DEFAULT };
+/** IBloom<Item> (tools/collections/impl/Bloom.hpp:113-168) backed by the device filter. insert()/contains() take one item to keep
+ *  the interface; the bulk overloads are what a GPU wants and what BloomBuilder::build (BloomBuilder.hpp:102-128) maps to. */
+template <typename Item> class IBloom : public system::SmartPointer {
+public:
+    virtual ~IBloom() {}
+    virtual void insert(const Item& item) = 0;
+    virtual bool contains(const Item& item) = 0;
+    virtual uint8_t contains8(const Item& item) = 0;          // std::bitset<8> in the reference: bit j = neighbour j
+    virtual uint8_t contains4(const Item& item, bool right) = 0;
+    virtual std::vector<uint8_t> getArray() = 0;
+    virtual uint64_t getSize() = 0;
+    virtual uint64_t getBitSize() = 0;
+    virtual size_t getNbHash() const = 0;
+    virtual std::string getName() const = 0;
+};
+template <typename Item> class BloomDevice : public IBloom<Item> {
+public:
+    BloomDevice(gkc_ctx* ctx, BloomKind kind, uint64_t tai_bloom, size_t nbHash, size_t kmerSize) : _ctx(ctx), _kind(kind), _nbHash(nbHash), _b(nullptr) {
+        const int kd = kind == BLOOM_BASIC ? 0 : (kind == BLOOM_CACHE || kind == BLOOM_DEFAULT) ? 1 : 2;
+        if (kind == BLOOM_NONE) throw system::Exception("unknown Bloom kind");
+        if (gkc_bloom_create(ctx, kd, tai_bloom, (uint32_t)nbHash, (uint32_t)kmerSize, &_b) != GKC_OK) throw system::Exception("%s", gkc_last_error(ctx));
+    }
+    ~BloomDevice() { gkc_bloom_destroy(_b); }
+    void insert(const Item& item) { chk(gkc_bloom_insert(_b, &item, 1, sizeof(Item))); }
+    void insert(const Item* items, size_t n) { chk(gkc_bloom_insert(_b, items, n, sizeof(Item))); }
+    /** every solid k-mer of a counted context (BloomAlgorithm::execute, BloomAlgorithm.cpp:155-199) */
+    void insertSolid(gkc_ctx* counted) { chk(gkc_bloom_insert_solid(_b, counted)); }
+    bool contains(const Item& item) { uint8_t r = 0; chk(gkc_bloom_contains(_b, &item, 1, sizeof(Item), &r)); return r != 0; }
+    void contains(const Item* items, size_t n, uint8_t* out) { chk(gkc_bloom_contains(_b, items, n, sizeof(Item), out)); }
+    uint8_t contains8(const Item& item) { uint8_t r = 0; chk(gkc_bloom_contains8(_b, &item, 1, sizeof(Item), &r)); return r; }
+    void contains8(const Item* items, size_t n, uint8_t* out) { chk(gkc_bloom_contains8(_b, items, n, sizeof(Item), out)); }
+    uint8_t contains4(const Item& item, bool right) { uint8_t r = contains8(item); return right ? (r & 15) : (r >> 4); }
+    std::vector<uint8_t> getArray() { std::vector<uint8_t> a(getSize()); chk(gkc_bloom_get_array(_b, a.data(), a.size())); return a; }
+    uint64_t getSize() { return gkc_bloom_nbytes(_b); }
+    uint64_t getBitSize() { return gkc_bloom_bitsize(_b); }
+    size_t getNbHash() const { return _nbHash; }
+    std::string getName() const { return _kind == BLOOM_BASIC ? "basic" : (_kind == BLOOM_NEIGHBOR ? "neighbor" : "cache"); }
+private:
+    void chk(int rc) { if (rc != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx)); }
+    gkc_ctx* _ctx; BloomKind _kind; size_t _nbHash; gkc_bloom* _b;
+};
+/** BloomFactory::createBloom (Bloom.hpp:1254-1266) */
+struct BloomFactory {
+    template <typename Item> static IBloom<Item>* createBloom(gkc_ctx* ctx, BloomKind kind, uint64_t tai_bloom, size_t nbHash, size_t kmerSize) {
+        return new BloomDevice<Item>(ctx, kind, tai_bloom, nbHash, kmerSize);
+    }
+};
+}}}  // namespace tools::collections::impl
+
+}}  // namespace gatb::core

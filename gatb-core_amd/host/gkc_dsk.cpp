@@ -1,0 +1,36 @@
+// gkc_dsk — minimal command line over SortingCountAlgorithm<span> (the role tools/dbgh5.cpp plays for the count-only case):
+//   gkc_dsk -in reads.fa|fq -kmer-size 31 [-abundance-min 2] [-minimizer-size 10] [-minimizer-type 0|1] [-nb-partitions N] -out prefix
+// writes prefix.solid.<dataset> (raw Count[] records, ascending), prefix.minimRepart, prefix.histo, prefix.info
+#include "gatb_gkc.hpp"
+#include <iostream>
+using namespace gatb::core;
+using namespace gatb::core::kmer::impl;
+
+template <size_t span> static int run(tools::misc::IProperties* params, const std::string& in, const std::string& out)
+{
+    SortingCountAlgorithm<span> dsk(new bank::BankFasta(in), params);
+    dsk.execute();
+    for (auto& kv : dsk.getInfo()->map()) std::cout << kv.first << " : " << kv.second << std::endl;
+    if (!out.empty()) {
+        auto* chain = dynamic_cast<CountProcessorChain<span>*>(dsk.getProcessor(0));
+        if (chain) {
+            chain->template get<CountProcessorDump<span>>()->saveRaw(out);
+            std::ofstream h(out + ".histo"); const auto& hv = chain->template get<CountProcessorHistogram<span>>()->getHistogram();
+            for (size_t i = 1; i < hv.size(); i++) if (hv[i]) h << i << "\t" << hv[i] << "\n";
+        }
+        dsk.getRepartitor()->save(out + ".minimRepart");
+        std::ofstream info(out + ".info"); for (auto& kv : dsk.getInfo()->map()) info << kv.first << "\t" << kv.second << "\n";
+    }
+    return 0;
+}
+int main(int argc, char** argv)
+{
+    tools::misc::IProperties* params = SortingCountAlgorithm<32>::getDefaultProperties();
+    std::string in, out;
+    for (int i = 1; i + 1 < argc; i += 2) { std::string k = argv[i], v = argv[i + 1]; if (k == "-in") in = v; else if (k == "-out") { out = v; params->setStr(k, v); } else params->setStr(k, v); }
+    if (in.empty()) { std::cerr << "usage: gkc_dsk -in reads.fa -kmer-size 31 [-abundance-min 2] -out prefix" << std::endl; return 2; }
+    try {
+        const size_t k = (size_t)params->getInt(STR_KMER_SIZE);
+        return k <= 31 ? run<32>(params, in, out) : run<64>(params, in, out);            // Integer::apply / setVariant (tools/math/Integer.hpp:58-90)
+    } catch (system::Exception& e) { std::cerr << "EXCEPTION: " << e.getMessage() << std::endl; return 1; }
+}

@@ -62,6 +62,19 @@ int gkc_set_solidity(gkc_ctx* ctx, int32_t abundance_min, int32_t abundance_max,
 int gkc_set_max_superkmer(gkc_ctx* ctx, uint32_t maxs);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Repartitor sampling — device side of RepartitorAlgorithm (kmer/impl/RepartitionAlgorithm.cpp:287-492). The tables
+ * themselves (computeDistrib / justGroup / justGroupLexi, kmer/impl/PartiInfo.cpp:48-218, and the frequency ranking,
+ * RepartitionAlgorithm.cpp:352-380) are built by the host from these statistics, like the reference does.
+ *   gkc_sample_minimizers : per minimizer value, number of super-k-mers and of k-mers of the sample under the CURRENT model
+ *                           (PartiInfo::incSuperKmer_per_minimBin); arrays of 4^m u64, ACCUMULATED into.
+ *   gkc_count_mmers       : occurrences of every canonical m-mer at valid positions (MmersFrequency functor, :88-120);
+ *                           u32[4^m], ACCUMULATED into.
+ * ------------------------------------------------------------------------------------------------------------- */
+int gkc_sample_minimizers(gkc_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                          uint64_t* superkmers_per_minim, uint64_t* kmers_per_minim);
+int gkc_count_mmers(gkc_ctx* ctx, uint32_t m, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t* counts);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Stage A — replaces SortingCountAlgorithm::fillPartitions (SortingCountAlgorithm.cpp:1211-1344): Sequence2SuperKmer
  * (Sequence2SuperKmer.hpp:81-159) + FillPartitions::processSuperkmer (:1081-1151) + the SuperKmerBinFiles disk shuffle
  * (tools/storage/impl/Storage.cpp:360-430). Reads arrive as a flat ASCII buffer + CSR offsets (offsets[n_reads] ==

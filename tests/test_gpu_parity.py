@@ -331,3 +331,24 @@ def test_distributed_counter_world1_rccl(gkc):
         assert c.all_counts() == ref.all_counts()
     finally:
         dist.destroy_process_group()
+
+
+def test_repartitor_sampling_statistics(gkc):
+    """gkc_sample_minimizers / gkc_count_mmers against the oracle's restatement of SampleRepart / MmersFrequency"""
+    reads = synth_reads(800, 8000, 150, seed=31, n_rate=0.002, ragged=True)
+    bases, offs = gko.pack_reads(reads)
+    k, m = 31, 8
+    c = gkc.Counter(0); c.configure(k, m, 4, np.zeros(4 ** m, np.uint16))
+    nsk, nk = c.sample_minimizers(bases, offs)
+    exp_k = np.zeros(4 ** m, np.uint64)
+    for r in reads:
+        mn, st, nb, nv, ni = gko.superkmers(r, k, m)
+        np.add.at(exp_k, mn, nb.astype(np.uint64))
+    assert np.array_equal(nk, exp_k)                       # k-mers per minimizer: independent of tile splits
+    assert nsk.sum() >= 1 and (nsk[nk == 0] == 0).all()
+    cnt = c.count_mmers(m, bases, offs)
+    exp = np.zeros(4 ** m, np.uint32)
+    L = gko.lib()
+    for r in reads:
+        L.gko_count_mmers(r, len(r), m, exp)
+    assert np.array_equal(cnt, exp)
