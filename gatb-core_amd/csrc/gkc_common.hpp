@@ -31,7 +31,8 @@ constexpr int SCAN_WORDS = SCAN_TILE / 16 + SCAN_HALO_WORDS;   // 16-base words 
 // Stage B: a partition is split by key range into <= MAX_SUB sub-buckets, each sorted inside LDS.
 constexpr int MAX_SUB_BITS = 13;
 constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram / cursors: 32 KB
-constexpr int SUB_TARGET = 512;                                // mean keys per sub-bucket the host aims at (a wave sorts <= 1024 / 512)
+constexpr int SUB_TARGET = 512;                                // mean keys per level-1 bucket: a wave sorts <= 1024 / 512 straight from HBM;
+                                                               // denser buckets (<= 6144 / 3072) are split + sorted inside LDS, larger ones in HBM
 
 // ------------------------------------------------------------------------------------------------ device buffer
 // Caching device allocator: hipMalloc/hipFree of multi-GB buffers cost tens of ms per GB on this platform (far more than

@@ -158,7 +158,8 @@ constexpr int HIST_LDS = 64;
 struct SortOut {
     uint32_t* cnt;            // [n_slots] abundance of the distinct key written at the same slot (0 = empty slot)
     unsigned long long* histo; uint32_t histo_max;
-    uint32_t* over_list; uint32_t* over_count;      // buckets too large for one wave -> next level
+    uint32_t* over_list; uint32_t* over_count;      // buckets too large for one wave -> k_lds_sort
+    uint32_t* over2_list; uint32_t* over2_count;    // buckets too large for LDS (or pathological inside it) -> HBM split level
     unsigned long long* n_sorted;                   // [0] buckets sorted here [1] keys sorted here
 };
 
@@ -219,13 +220,14 @@ __device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], 
 // sort + run-length count one bucket of n <= 64*KPL keys held by one wave; writes distinct keys / abundances at
 // outk[start + j], O.cnt[start + j] (j-th distinct key) — ascending; slots start+nd .. start+n-1 keep abundance 0.
 template <int KW, int KPL>
-__device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+__device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* src /* first key of the bucket: LDS or global */,
+                                                 typename KeyT<KW>::type* __restrict__ outk,
                                                  const uint64_t start, const uint32_t n, const SortOut& O, uint32_t* s_hc, const int lane)
 {
     typedef typename KeyT<KW>::type key_t;
     key_t v[KPL];
 #pragma unroll
-    for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[start + i] : KeyT<KW>::max(); }
+    for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[i] : KeyT<KW>::max(); }
     bitonic_wave<KW, KPL>(v, lane);
     // run-length count (B3). e = lane*KPL + r is the sorted rank
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
@@ -260,8 +262,23 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     }
 }
 
-template <int KW> struct WaveCap { static constexpr int KPL_MAX = (KW == 1) ? 16 : 8; static constexpr uint32_t CAP = 64 * KPL_MAX; };
+// inside k_lds_sort a wave register-sorts up to 512 (u64) / 256 (u128) keys; larger fine groups are split again inside LDS.
+// k_wave_sort (whole small buckets straight from HBM) goes up to 1024 / 512.
+template <int KW> struct WaveCap { static constexpr int KPL_MAX = (KW == 1) ? 8 : 4; static constexpr uint32_t CAP = 64 * KPL_MAX; };
+template <int KW> struct WaveCapBig { static constexpr int KPL_MAX = (KW == 1) ? 16 : 8; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 
+template <int KW, int KPLMAX>
+__device__ __forceinline__ void wave_sort_dispatch(const typename KeyT<KW>::type* src, typename KeyT<KW>::type* __restrict__ outk, const uint64_t start,
+                                                   const uint32_t n, const SortOut& O, uint32_t* s_hc, const int lane)
+{
+    if (n <= 64) wave_sort_bucket<KW, 1>(src, outk, start, n, O, s_hc, lane);
+    else if (n <= 128) wave_sort_bucket<KW, 2>(src, outk, start, n, O, s_hc, lane);
+    else if (n <= 256 || KPLMAX == 4) wave_sort_bucket<KW, 4>(src, outk, start, n, O, s_hc, lane);
+    else if (n <= 512 || KPLMAX == 8) wave_sort_bucket<KW, (KPLMAX >= 8 ? 8 : 4)>(src, outk, start, n, O, s_hc, lane);
+    else wave_sort_bucket<KW, KPLMAX>(src, outk, start, n, O, s_hc, lane);
+}
+
+// one WAVE per small bucket, straight from HBM (no LDS, no barrier)
 template <int KW>
 __global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                              const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O)
@@ -276,17 +293,154 @@ __global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<
         const uint32_t n = b_n[g];
         if (n == 0) continue;
         const uint64_t start = b_start[g];
-        if (n > WaveCap<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over_count, 1u); O.over_list[slot] = g; } continue; }
+        if (n > WaveCapBig<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over_count, 1u); O.over_list[slot] = g; } continue; }
         nb_done++; nk_done += n;
-        if (n <= 64) wave_sort_bucket<KW, 1>(src, outk, start, n, O, s_hc, lane);
-        else if (n <= 128) wave_sort_bucket<KW, 2>(src, outk, start, n, O, s_hc, lane);
-        else if (n <= 256) wave_sort_bucket<KW, 4>(src, outk, start, n, O, s_hc, lane);
-        else if (n <= 512 || KW == 2) wave_sort_bucket<KW, 8>(src, outk, start, n, O, s_hc, lane);
-        else wave_sort_bucket<KW, WaveCap<KW>::KPL_MAX>(src, outk, start, n, O, s_hc, lane);
+        wave_sort_dispatch<KW, WaveCapBig<KW>::KPL_MAX>(src + start, outk, start, n, O, s_hc, lane);
     }
     __syncthreads();
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
     if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
+}
+
+// One WORKGROUP per bucket of up to LDS_CAP keys (a key-range slice of a partition): the keys are read from HBM once
+// (coalesced, into registers) and split on their next informative bits into <=256 fine groups INSIDE LDS (LDS histogram,
+// LDS cursors, in-place because the keys sit in registers while they are re-placed). Fine groups still too large for a
+// wave (a dense cluster: k-mers starting with the same minimizer, a repeat family) are split again the same way, still in
+// LDS; a group whose keys are all equal is one k-mer. Then every wave register-sorts and run-length-counts fine groups
+// (~100 keys: a 128-key bitonic network has 28 stages, a 1024-key one 55). No level below the first costs HBM traffic.
+// Only buckets with more than LDS_CAP keys go to the HBM split levels below.
+constexpr int LDS_THREADS = 512;
+template <int KW> struct LdsCap { static constexpr int CAP = (KW == 1) ? 6144 : 3072; static constexpr int KPT = CAP / LDS_THREADS; };
+constexpr uint32_t FINE_TARGET = 320, FINE_MAX_BITS = 8, FINE_NF = 1024, FINE_NP = 64;
+__device__ __forceinline__ uint32_t gpack(uint32_t off, uint32_t cnt, uint32_t uni) { return off | (cnt << 13) | (uni << 27); }
+
+template <int KW>
+__global__ __launch_bounds__(LDS_THREADS, 4) void k_lds_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                            const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+                                                            const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
+{
+    typedef typename KeyT<KW>::type key_t;
+    constexpr int CAP = LdsCap<KW>::CAP, KPT = LdsCap<KW>::KPT;
+    __shared__ key_t s_keys[CAP];
+    __shared__ uint32_t s_hist[1 << FINE_MAX_BITS], s_off[(1 << FINE_MAX_BITS) + 1];
+    __shared__ uint32_t s_final[FINE_NF], s_pend[FINE_NP];
+    __shared__ unsigned long long s_or[2];
+    __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ uint32_t s_nfinal, s_npend, s_big;
+    if (threadIdx.x < HIST_LDS) s_hc[threadIdx.x] = 0;
+    uint32_t nb_done = 0; unsigned long long nk_done = 0;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));                              // keep per-lane address math inside the loop (no LICM register blow-up)
+        const int lane = t & 63, wave = t >> 6;
+        const uint32_t g = list[li];
+        const uint32_t n = b_n[g];
+        if (n == 0) continue;
+        const uint64_t start = b_start[g];
+        if (n > (uint32_t)CAP) { if (t == 0) { const uint32_t slot = atomicAdd(O.over2_count, 1u); O.over2_list[slot] = g; } continue; }
+        __syncthreads();                                         // LDS of the previous bucket fully consumed
+        if (t == 0) { s_nfinal = 0; s_npend = 1; s_pend[0] = gpack(0, n, 0); s_big = 0; }
+        bool first = true;
+        for (;;) {
+            __syncthreads();
+            const uint32_t np = s_npend;
+            if (np == 0 || s_big) break;
+            const uint32_t rg = s_pend[np - 1];
+            const uint32_t off = rg & 8191u, cnt = (rg >> 13) & 16383u;
+            __syncthreads();
+            if (t == 0) s_npend = np - 1;
+            if (t < 2) s_or[t] = 0;
+            if (t < (1 << FINE_MAX_BITS)) s_hist[t] = 0;
+            if (first && cnt <= WaveCap<KW>::CAP) {              // small bucket: straight to a wave, from LDS like the others
+                for (uint32_t i = t; i < cnt; i += LDS_THREADS) s_keys[i] = src[start + i];
+                if (t == 0) { s_final[0] = gpack(0, cnt, 0); s_nfinal = 1; }
+                first = false;
+                continue;
+            }
+            // 1. keys of the range -> registers; which low bits differ at all?
+            key_t kr[KPT];
+            const key_t k0 = first ? src[start] : s_keys[off];
+            key_t acc = 0;
+#pragma unroll
+            for (int i = 0; i < KPT; i++) {
+                const uint32_t idx = i * LDS_THREADS + t;
+                if (idx < cnt) { kr[i] = first ? src[start + idx] : s_keys[off + idx]; acc |= kr[i] ^ k0; }
+            }
+            {   unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { lo |= __shfl_down(lo, d, 64); hi |= __shfl_down(hi, d, 64); }
+                __syncthreads();                                 // every load of the range is done; s_or / s_hist are reset
+                if (lane == 0) { atomicOr(&s_or[0], lo); if (KW == 2) atomicOr(&s_or[1], hi); }
+            }
+            __syncthreads();
+            uint32_t diff_bits;
+            {   const unsigned long long lo = s_or[0], hi = s_or[1];
+                diff_bits = hi ? 128 - __clzll((long long)hi) : (lo ? 64 - __clzll((long long)lo) : 0); }
+            if (diff_bits == 0) {                                // one k-mer, cnt times
+                if (first) for (uint32_t i = t; i < 1; i += LDS_THREADS) s_keys[off] = k0;
+                if (t == 0) { const uint32_t q = s_nfinal; if (q < FINE_NF) { s_final[q] = gpack(off, cnt, 1); s_nfinal = q + 1; } else s_big = 1; }
+                first = false;
+                continue;
+            }
+            uint32_t b2 = 1;
+            while (b2 < FINE_MAX_BITS && b2 < diff_bits && (cnt >> b2) > FINE_TARGET) b2++;
+            const uint32_t shift2 = diff_bits - b2, m2 = (1u << b2) - 1, ngrp = 1u << b2;
+            // 2. LDS histogram of the fine groups
+#pragma unroll
+            for (int i = 0; i < KPT; i++) { const uint32_t idx = i * LDS_THREADS + t; if (idx < cnt) atomicAdd(&s_hist[(uint32_t)(kr[i] >> shift2) & m2], 1u); }
+            __syncthreads();
+            // 3. exclusive scan (wave 0: 4 bins per lane) -> group offsets
+            if (wave == 0) {
+                uint32_t c[4], loc = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { c[i] = s_hist[lane * 4 + i]; loc += c[i]; }
+                uint32_t x = loc;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+                uint32_t run = x - loc;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { s_off[lane * 4 + i] = run; run += c[i]; }
+                if (lane == 63) s_off[256] = run;
+            }
+            __syncthreads();
+            if (t < (1 << FINE_MAX_BITS)) s_hist[t] = s_off[t];    // cursors
+            __syncthreads();
+            // 4. re-place the keys group-contiguously inside the same LDS range (they are all in registers)
+#pragma unroll
+            for (int i = 0; i < KPT; i++) {
+                const uint32_t idx = i * LDS_THREADS + t;
+                if (idx < cnt) { const uint32_t slot = atomicAdd(&s_hist[(uint32_t)(kr[i] >> shift2) & m2], 1u); s_keys[off + slot] = kr[i]; }
+            }
+            // 5. children: small enough -> final list, else pending
+            if ((uint32_t)t < ngrp) {
+                const uint32_t c = s_off[t + 1] - s_off[t];
+                if (c) {
+                    if (c <= WaveCap<KW>::CAP) { const uint32_t q = atomicAdd(&s_nfinal, 1u); if (q < FINE_NF) s_final[q] = gpack(off + s_off[t], c, 0); else s_big = 1; }
+                    else { const uint32_t q = atomicAdd(&s_npend, 1u); if (q < FINE_NP) s_pend[q] = gpack(off + s_off[t], c, 0); else s_big = 1; }
+                }
+            }
+            first = false;
+        }
+        if (s_big) { if (t == 0) { const uint32_t slot = atomicAdd(O.over2_count, 1u); O.over2_list[slot] = g; } continue; }
+        // 6. every wave sorts + counts fine groups out of LDS
+        const uint32_t nf = s_nfinal < FINE_NF ? s_nfinal : FINE_NF;
+        for (uint32_t i = wave; i < nf; i += LDS_THREADS / 64) {
+            const uint32_t f = s_final[i];
+            const uint32_t off = f & 8191u, cnt = (f >> 13) & 16383u;
+            if (f >> 27) {
+                if (lane == 0) {
+                    const uint32_t c = cnt;
+                    outk[start + off] = s_keys[off]; O.cnt[start + off] = c;
+                    const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
+                    if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
+                }
+            } else wave_sort_dispatch<KW, WaveCap<KW>::KPL_MAX>(s_keys + off, outk, start + off, cnt, O, s_hc, lane);
+        }
+        nb_done++; nk_done += n;
+    }
+    __syncthreads();
+    if (threadIdx.x < HIST_LDS && s_hc[threadIdx.x]) atomicAdd(&O.histo[threadIdx.x], (unsigned long long)s_hc[threadIdx.x]);
+    if (threadIdx.x == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
 }
 
 // ------------------------------------------------------------------------------------------------ deeper levels
@@ -505,8 +659,8 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, b_start[2], b_n[2], b_cons[2], over, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
-    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &misc, &bs_d, &bs_s,
+    DevBuf pd, keysA, keysB, cnt, b_start[2], b_n[2], b_cons[2], over, over2, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &misc, &bs_d, &bs_s,
                                         &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot };
                      for (DevBuf* d : all) d->release(); }
 };
@@ -522,12 +676,13 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     std::vector<PartDesc> pd(nb);
     std::vector<uint64_t> pblk(nb + 1);
     uint64_t n_slots = 0, n_sub = 0;
-    const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;
+    const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;       // mean keys of a level-1 bucket (sorted inside LDS)
+    const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t np = part_keys[batch_parts[i]];
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
         uint32_t bits = 0;
-        while (bits < (uint32_t)MAX_SUB_BITS && bits < 2 * k && (np >> bits) > target) bits++;
+        while (bits < max_bits1 && bits < 2 * k && (np >> bits) > target) bits++;
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pblk[i] = n_slots / COMPACT_BLK;
@@ -544,7 +699,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     CB_TRY(c->ensure(B.keysA, (size_t)std::max<uint64_t>(n_slots, 1) * sizeof(key_t)));
     CB_TRY(c->ensure(B.cnt, (size_t)std::max<uint64_t>(n_slots, 1) * 4));
     CB_TRY(c->ensure(B.b_start[0], (size_t)n_sub * 8)); CB_TRY(c->ensure(B.b_n[0], (size_t)n_sub * 4)); CB_TRY(c->ensure(B.b_cons[0], (size_t)n_sub));
-    CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4));
+    CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over2, (size_t)(n_sub + 1) * 4));
     CB_TRY(c->ensure(B.misc, 64));
     CB_TRY(c->ensure(B.bs_d, (size_t)(n_blocks + 1) * 8)); CB_TRY(c->ensure(B.bs_s, (size_t)(n_blocks + 1) * 8));
     CB_TRY(c->ensure(B.pidx, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.ptot, (size_t)(nb + 1) * 16));
@@ -566,6 +721,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     SortOut O{};
     O.cnt = (uint32_t*)B.cnt.p; O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max;
     O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1;
+    O.over2_count = (uint32_t*)B.over2.p; O.over2_list = (uint32_t*)B.over2.p + 1;
     O.n_sorted = (unsigned long long*)B.misc.p;
 
     // --- levels: sort what fits one wave, split the rest on the next key bits, repeat
@@ -574,20 +730,31 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     key_t* src = (key_t*)B.keysA.p;
     for (int level = 1; n_buckets > 0; level++) {
         CB_HIP(hipMemsetAsync(B.over.p, 0, 4, c->stream));
+        CB_HIP(hipMemsetAsync(B.over2.p, 0, 4, c->stream));
         {   ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
             const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
             hipLaunchKernelGGL((k_wave_sort<KW>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
             CB_HIP(hipGetLastError());
         }
+        uint32_t n_mid = 0;
+        CB_HIP(hipMemcpyAsync(&n_mid, B.over.p, 4, hipMemcpyDeviceToHost, c->stream));
+        CB_HIP(hipStreamSynchronize(c->stream));
+        if (!n_mid) break;
+        {   ScopedTimer tm(c, "bucket_sort_lds");                 // mid-size buckets: split + sort inside LDS
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_mid, 256 * 8);
+            hipLaunchKernelGGL((k_lds_sort<KW>), dim3(grid), dim3(LDS_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, O);
+            CB_HIP(hipGetLastError());
+        }
         uint32_t n_over = 0;
-        CB_HIP(hipMemcpyAsync(&n_over, B.over.p, 4, hipMemcpyDeviceToHost, c->stream));
+        CB_HIP(hipMemcpyAsync(&n_over, B.over2.p, 4, hipMemcpyDeviceToHost, c->stream));
         CB_HIP(hipStreamSynchronize(c->stream));
         if (!n_over) break;
         ScopedTimer tm(c, "split_levels");
         // fetch (start, n, consumed bits) of the oversize buckets
         CB_TRY(c->ensure(B.g_start, (size_t)n_over * 8)); CB_TRY(c->ensure(B.g_n, (size_t)n_over * 4)); CB_TRY(c->ensure(B.g_cons, (size_t)n_over * 4));
-        hipLaunchKernelGGL(k_gather_buckets, dim3((n_over + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)O.over_list, n_over,
+        hipLaunchKernelGGL(k_gather_buckets, dim3((n_over + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)O.over2_list, n_over,
                            (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p,
                            (uint64_t*)B.g_start.p, (uint32_t*)B.g_n.p, (uint32_t*)B.g_cons.p);
         std::vector<uint64_t> h_start(n_over); std::vector<uint32_t> h_n(n_over), h_cons(n_over);
@@ -604,7 +771,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             // deeper levels see clustered keys (that is why the bucket was oversize): split 8x finer than the mean asks for
             uint32_t bits = 1;
             while (bits < (uint32_t)MAX_SUB_BITS && bits < left && (d.n >> bits) > target) bits++;
-            bits = std::min<uint32_t>(std::min<uint32_t>(bits + 3, (uint32_t)MAX_SUB_BITS), left);
+            bits = std::min<uint32_t>(std::min<uint32_t>(bits + 2, (uint32_t)MAX_SUB_BITS), left);
             d.bits = bits; d.left = left; d.child_base = n_child; n_child += (1ull << bits);
             split.push_back(d);
         }
@@ -632,6 +799,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             CB_TRY(c->ensure(B.effs, split.size() * 4));
             CB_TRY(c->ensure(B.b_start[nxt], (size_t)n_child * 8)); CB_TRY(c->ensure(B.b_n[nxt], (size_t)n_child * 4)); CB_TRY(c->ensure(B.b_cons[nxt], (size_t)n_child));
             if (B.over.bytes < (size_t)(n_child + 1) * 4) { CB_TRY(c->ensure(B.over, (size_t)(n_child + 1) * 4)); O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1; }
+            if (B.over2.bytes < (size_t)(n_child + 1) * 4) { CB_TRY(c->ensure(B.over2, (size_t)(n_child + 1) * 4)); O.over2_count = (uint32_t*)B.over2.p; O.over2_list = (uint32_t*)B.over2.p + 1; }
             CB_HIP(hipMemcpyAsync(B.descs.p, split.data(), split.size() * sizeof(SplitDesc), hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL((k_split_count<KW>), dim3((unsigned)split.size()), dim3(EXPAND_THREADS), 0, c->stream, (const key_t*)src, (const SplitDesc*)B.descs.p,
                                (uint64_t*)B.b_start[nxt].p, (uint32_t*)B.b_n[nxt].p, (uint8_t*)B.b_cons[nxt].p, (uint32_t*)B.effs.p);
