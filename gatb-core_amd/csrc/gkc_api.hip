@@ -184,7 +184,7 @@ int gkc_set_solidity(gkc_ctx* c, int32_t amin, int32_t amax, uint32_t histo_max)
 int gkc_set_max_superkmer(gkc_ctx* c, uint32_t maxs)
 {
     if (!c) return GKC_ERR_ARG;
-    c->maxs = maxs;
+    c->maxs = maxs == 1 ? 2 : maxs;            // the cap division uses a multiply-high reciprocal that needs maxs >= 2
     if (c->configured) { const uint32_t def = c->k <= 31 ? 28 : 60; if (c->maxs == 0 || c->maxs > def) c->maxs = def; }
     return GKC_OK;
 }

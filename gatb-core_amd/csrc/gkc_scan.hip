@@ -26,7 +26,7 @@
 struct ScanParams {
     const uint8_t* bases; uint64_t n_bases;
     const uint32_t* rsbits;
-    uint32_t k, m, nb_mm, maxs, mmask, mask_ma1;
+    uint32_t k, m, nb_mm, maxs, maxs_magic, mmask, mask_ma1;   // maxs_magic = ceil(2^32 / maxs): d / maxs == umulhi(d, magic) for d < 2^13
     int freq_mode;
     const uint32_t* mkey_lut; const uint32_t* key2val; uint32_t default_key;
     const uint16_t* repart; uint32_t nb_passes, pass;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
     __shared__ uint16_t s_bad[SCAN_WORDS + 8];
     __shared__ uint32_t s_rs[SCAN_TILE / 32 + 8];
     __shared__ uint32_t s_mk[MKI(SCAN_TILE + 16 * SCAN_HALO_WORDS + 16)];   // padded: see MKI
-    __shared__ uint32_t s_end[MKI(SCAN_TILE)];
+    __shared__ uint16_t s_end[MKI(SCAN_TILE)];                             // per run end: (nbK-1) << 4 | j
     __shared__ uint32_t s_lastmz[SCAN_THREADS], s_firstmz[SCAN_THREADS + 1];
     __shared__ uint8_t  s_lastvalid[SCAN_THREADS], s_firstvalid[SCAN_THREADS + 1];
     __shared__ int      s_wavecarry[SCAN_THREADS / 64];
@@ -115,15 +115,26 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
                 dw[q] = x;
             }
         }
-        uint32_t be = 0, le = 0, bad = 0;
+        // SWAR: 4 bases per 32-bit word (A1: code = (c>>1)&3, valid iff (c & 0xDF) in {A,C,G,T})
+        uint32_t le = 0, bad = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            uint32_t c = (dw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            uint32_t code = nt_code(c);
-            be |= code << (30 - 2 * j);
-            le |= code << (2 * j);
-            bad |= (nt_valid(c) ^ 1u) << j;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t wv = dw[q];
+            uint32_t c4 = (wv >> 1) & 0x03030303u;
+            c4 = (c4 | (c4 >> 6)) & 0x000F000Fu;
+            c4 = (c4 | (c4 >> 12)) & 0xFFu;                                     // c0 | c1<<2 | c2<<4 | c3<<6
+            le |= c4 << (8 * q);
+            const uint32_t u = wv & 0xDFDFDFDFu;
+            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // 0x80 where the byte is non-zero
+            uint32_t b4 = nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u);
+            b4 >>= 7;
+            b4 = (b4 | (b4 >> 7) | (b4 >> 14) | (b4 >> 21)) & 0xFu;
+            bad |= b4 << (4 * q);
         }
+        uint32_t be = le;                                                        // reverse the 16 two-bit groups
+        be = ((be >> 2) & 0x33333333u) | ((be & 0x33333333u) << 2);
+        be = ((be >> 4) & 0x0F0F0F0Fu) | ((be & 0x0F0F0F0Fu) << 4);
+        be = __builtin_bswap32(be);
         s_be[w] = be; s_le[w] = le; s_bad[w] = (uint16_t)bad;
     }
     for (int i = t; i < SCAN_TILE / 32 + 8; i += SCAN_THREADS) s_rs[i] = P.rsbits[t0 / 32 + i];
@@ -181,25 +192,36 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
     }
 
     // ---- step 3: which positions hold a k-mer, and which of those are valid (A2) ----
-    uint32_t existsmask = 0, validmask = 0;
+    // window-OR of the invalid / read-start bit planes over k (k-1) positions for all 16 positions of the thread at once:
+    // doubling (windows 1,2,4,...,32) on a 128-bit value, then the binary decomposition of the window length.
+    uint32_t existsmask, validmask;
     {
         const int q = t >> 1, off = (t & 1) * 16;
         uint64_t rlo = (uint64_t)s_rs[q] | ((uint64_t)s_rs[q + 1] << 32);
         uint64_t rhi = (uint64_t)s_rs[q + 2] | ((uint64_t)s_rs[q + 3] << 32);
         if (off) { rlo = (rlo >> 16) | (rhi << 48); rhi >>= 16; }
+        rlo = (rlo >> 1) | (rhi << 63); rhi >>= 1;            // read starts matter inside (g, g+k-1]: shift by one, window k-1
         uint64_t blo = (uint64_t)s_bad[t] | ((uint64_t)s_bad[t + 1] << 16) | ((uint64_t)s_bad[t + 2] << 32) | ((uint64_t)s_bad[t + 3] << 48);
         uint64_t bhi = (uint64_t)s_bad[t + 4] | ((uint64_t)s_bad[t + 5] << 16) | ((uint64_t)s_bad[t + 6] << 32) | ((uint64_t)s_bad[t + 7] << 48);
-        const uint64_t maskk = (1ULL << k) - 1;               // k <= 63
-        const uint64_t maskk1 = (1ULL << (k - 1)) - 1;
+        auto window_or16 = [](uint64_t lo, uint64_t hi, uint32_t len) -> uint32_t {
+            // returns bits j=0..15 : OR of input bits j .. j+len-1   (len in [0,63])
+            uint32_t acc = 0, ofs = 0;
+            uint64_t alo = lo, ahi = hi;                      // window 1
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            uint64_t g = t0 + p0 + j;
-            bool ex = (g + k <= P.n_bases) && (((rlo >> 1) & maskk1) == 0);   // no read start inside (g, g+k-1]
-            bool va = ex && ((blo & maskk) == 0);                             // no invalid character inside [g, g+k-1]
-            existsmask |= (uint32_t)ex << j; validmask |= (uint32_t)va << j;
-            rlo = (rlo >> 1) | (rhi << 63); rhi >>= 1;
-            blo = (blo >> 1) | (bhi << 63); bhi >>= 1;
-        }
+            for (uint32_t p = 1; p <= 32; p <<= 1) {
+                if (len & p) { acc |= (uint32_t)(ofs ? ((alo >> ofs) | (ahi << (64 - ofs))) : alo); ofs += p; }
+                const uint64_t nlo = alo | ((alo >> p) | (ahi << (64 - p))), nhi = ahi | (ahi >> p);   // window 2p
+                alo = nlo; ahi = nhi;
+            }
+            return acc & 0xFFFFu;
+        };
+        const uint32_t rsany = window_or16(rlo, rhi, k - 1);
+        const uint32_t badany = window_or16(blo, bhi, k);
+        // k-mers may not run past the end of the batch
+        const long long lim = (long long)P.n_bases - (long long)k - (long long)(t0 + p0);      // last j that still fits
+        const uint32_t fits = lim >= 15 ? 0xFFFFu : (lim < 0 ? 0u : ((2u << (uint32_t)lim) - 1u));
+        existsmask = ~rsany & fits;
+        validmask = existsmask & ~badany;
     }
 
     // ---- step 4: natural super-k-mer starts and the workgroup-wide "last start" max-scan (A4) ----
@@ -251,20 +273,24 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
             bool boundary;
             if (j < 15) boundary = !((validmask >> (j + 1)) & 1) || ((nsmask >> (j + 1)) & 1);
             else boundary = !nxt_valid || (nxt_mz != mz[15]);
-            const int d1 = p + 1 - ls;
-            const bool is_end = v && (boundary || (d1 % maxs) == 0);
+            // run length so far and its position inside the cap: exact division by the launch constant `maxs` through a
+            // multiply-high (a hardware integer division here would be ~1/3 of the kernel's instructions)
+            const uint32_t d0 = (uint32_t)(p - ls);                           // < tile size whenever v is set
+            const uint32_t q0 = __umulhi(d0, P.maxs_magic);
+            const uint32_t r0 = d0 - q0 * (uint32_t)maxs;                    // (p - ls) % maxs
+            const bool is_end = v && (boundary || r0 + 1 == (uint32_t)maxs);
             if (is_end) {
-                const int start = ls + ((p - ls) / maxs) * maxs;
+                const int start = ls + (int)(q0 * (uint32_t)maxs);
                 s_mk[MKI(p0) + n_end] = mz[j];                                    // own slots; s_mk is dead after step 2
-                s_end[MKI(p0) + n_end] = (uint32_t)start | ((uint32_t)(p - start + 1) << 16);
+                s_end[MKI(p0) + n_end] = (uint16_t)(((uint32_t)(p - start) << 4) | (uint32_t)j);
                 n_end++;
             }
         }
 #pragma unroll 1
         for (int e = 0; e < n_end; e++) {
             const uint32_t info = s_end[MKI(p0) + e];
-            const int start = (int)(info & 0xFFFFu);
-            const uint32_t nbk = info >> 16;
+            const uint32_t nbk = (info >> 4) + 1;
+            const int start = p0 + (int)(info & 15u) - (int)(info >> 4);
             const uint32_t key = s_mk[MKI(p0) + e];
             const uint32_t value = P.freq_mode ? P.key2val[key] : key;
             if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
@@ -354,7 +380,7 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
 }
 
 constexpr uint32_t SCAN_LDS_PARTS_MAX = 8192;      // 64 KB of LDS cursors at most
-constexpr size_t SCAN_STATIC_LDS = 40 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
+constexpr size_t SCAN_STATIC_LDS = 32 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
 
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
 {
@@ -396,7 +422,7 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
 
     ScanParams P{};
     P.bases = (const uint8_t*)d_bases; P.n_bases = n_bases; P.rsbits = (const uint32_t*)c->d_rsbits.p;
-    P.k = c->k; P.m = c->m; P.nb_mm = c->k - c->m + 1; P.maxs = c->maxs;
+    P.k = c->k; P.m = c->m; P.nb_mm = c->k - c->m + 1; P.maxs = c->maxs; P.maxs_magic = (uint32_t)(((1ULL << 32) + c->maxs - 1) / c->maxs);
     P.mmask = (uint32_t)((1ULL << (2 * c->m)) - 1);
     P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
     P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
@@ -467,7 +493,7 @@ int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, 
     hipError_t e = hipMemsetAsync(cnt.p, 0, (size_t)(2 * nm + 4) * 8, c->stream);
     ScanParams P{};
     P.bases = (const uint8_t*)d_bases; P.n_bases = n_bases; P.rsbits = (const uint32_t*)c->d_rsbits.p;
-    P.k = c->k; P.m = c->m; P.nb_mm = c->k - c->m + 1; P.maxs = c->maxs;
+    P.k = c->k; P.m = c->m; P.nb_mm = c->k - c->m + 1; P.maxs = c->maxs; P.maxs_magic = (uint32_t)(((1ULL << 32) + c->maxs - 1) / c->maxs);
     P.mmask = (uint32_t)(nm - 1);
     P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
     P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
