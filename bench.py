@@ -161,13 +161,23 @@ def main():
         dom = max(alg, key=lambda n_: ktime[n_][0])
         dom_ms = ktime[dom][0] / max(1, args.steps)            # per step (a step may launch the kernel once per Stage-B batch)
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        workload = ("k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions" % (k, n_reads, m, parts))
+        traffic = None
+        kname = {"scan_count": "k_scan_tile<false, 2, true>", "scan_emit": "k_scan_tile<true, 2, true>", "expand_count": "k_expand_count<1, 2>",
+                 "expand_scatter": "k_expand_scatter<1, 2>", "bucket_sort": "k_wave_sort<1>", "bucket_sort_lds": "k_lds_sort<1>", "compact": "k_compact_flags<1>"}
+        try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), only if they were taken on this exact workload
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == workload and kname.get(dom) in pt["kernels"]:
+                traffic = pt["kernels"][kname[dom]]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+        launches_per_step = max(1, ktime[dom][1] // max(1, args.steps))
         out = {
             "metric": "distinct k-mers/s at k=%d" % k, "value": value, "unit": "distinct k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if k <= 31 else "u128",
             "data": "synthetic (device generator, seeded; 150 bp reads, 30x, 1% substitutions)",
-            "config": {"workload": "k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions"
-                                   % (k, n_reads, m, parts),
+            "config": {"workload": workload,
                        "reads_per_gpu": n_reads, "partitions": parts, "valid_kmers": valid, "distinct_kmers": distinct,
                        "valid_kmers_per_s": valid / (dt / args.steps), "gbases_per_s": n_bases * world / (dt / args.steps) / 1e9,
                        "mean_kmers_per_superkmer": nbar, "distinct_ratio": d,
@@ -175,8 +185,10 @@ def main():
                        "model_GBps": valid / world * algorithmic_bytes_per_kmer(k, L, nbar, d) / (dt / args.steps) / 1e9,
                        "kernel_ms_per_step": {n_: round(ktime[n_][0] / args.steps, 3) for n_ in names}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "launch_ms": dom_ms, "algorithmic_bytes_per_step": alg[dom]},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch)" if traffic else None,
+                         "launches_per_step": int(launches_per_step), "launch_ms": dom_ms / launches_per_step,
+                         "algorithmic_bytes_per_launch": alg[dom] / launches_per_step},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(k, m, min(parts, 256), repart_for_bench(m, min(parts, 256)))

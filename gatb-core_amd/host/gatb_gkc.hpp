@@ -628,4 +628,53 @@ struct BloomFactory {
 };
 }}}  // namespace tools::collections::impl
 
+// ------------------------------------------------------------------------------------------------ BloomAlgorithm (C5)
+namespace kmer { namespace impl {
+enum DebloomKind { DEBLOOM_NONE, DEBLOOM_ORIGINAL, DEBLOOM_CASCADING, DEBLOOM_DEFAULT };
+static const double gkc_debloom_rvalues[129][2] = {
+#include "../../include/gkc_debloom_rvalues.inc"
+};
+/** DebloomAlgorithm<span>::getNbBitsPerKmer (kmer/impl/DebloomAlgorithm.cpp:628-660) */
+inline float getNbBitsPerKmer(size_t kmerSize, DebloomKind debloomKind) {
+    static double lg2 = log(2);
+    float nbitsPerKmer = 0;
+    if (kmerSize > 128 && debloomKind == DEBLOOM_CASCADING) throw system::Exception("kmer size %d too big for cascading bloom filters", (int)kmerSize);
+    switch (debloomKind) {
+        case DEBLOOM_CASCADING: nbitsPerKmer = (float)gkc_debloom_rvalues[kmerSize][1]; break;
+        default: nbitsPerKmer = (float)(log(16 * kmerSize * (lg2 * lg2)) / (lg2 * lg2)); break;
+    }
+    if (nbitsPerKmer == 0) nbitsPerKmer = 1;
+    return nbitsPerKmer;
+}
+/** BloomAlgorithm<span>::execute (kmer/impl/BloomAlgorithm.cpp:155-199): Bloom filter of the solid k-mers of a counted context.
+ *  size = (u64)(nbSolid * nbitsPerKmer) in float arithmetic, nbHash = floor(0.7 * nbits), 1000 bits if empty; every solid
+ *  k-mer is inserted ON THE DEVICE straight from the result buffers (BloomBuilder::build, BloomBuilder.hpp:102-128). */
+template <size_t span = KMER_DEFAULT_SPAN>
+class BloomAlgorithm {
+public:
+    typedef typename Kmer<span>::Type Type;
+    BloomAlgorithm(gkc_ctx* countedCtx, size_t kmerSize, float nbitsPerKmer, tools::collections::impl::BloomKind kind = tools::collections::impl::BLOOM_DEFAULT)
+        : _ctx(countedCtx), _kmerSize(kmerSize), _nbitsPerKmer(nbitsPerKmer), _kind(kind), _bloom(nullptr) {}
+    ~BloomAlgorithm() { if (_bloom) _bloom->forget(); }
+    void execute() {
+        gkc_stats st; if (gkc_get_stats(_ctx, &st) != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx));
+        const uint64_t solidKmersNb = st.kmers_nb_solid;
+        const float NBITS_PER_KMER = _nbitsPerKmer;
+        uint64_t estimatedBloomSize = (uint64_t)(solidKmersNb * NBITS_PER_KMER);
+        const size_t nbHash = (size_t)(int)floorf(0.7 * NBITS_PER_KMER);
+        if (estimatedBloomSize == 0) estimatedBloomSize = 1000;
+        auto* b = new tools::collections::impl::BloomDevice<Type>(_ctx, _kind, estimatedBloomSize, nbHash, _kmerSize);
+        b->use(); _bloom = b;
+        b->insertSolid(_ctx);
+        _info.add("kind", "%s", b->getName().c_str()); _info.add("bitsize", "%llu", (unsigned long long)b->getBitSize());
+        _info.add("nb_hash", "%d", (int)nbHash); _info.add("nbits_per_kmer", "%f", _nbitsPerKmer);
+    }
+    tools::collections::impl::IBloom<Type>* getBloom() { return _bloom; }
+    const tools::misc::Properties* getInfo() const { return &_info; }
+private:
+    gkc_ctx* _ctx; size_t _kmerSize; float _nbitsPerKmer; tools::collections::impl::BloomKind _kind;
+    tools::collections::impl::IBloom<Type>* _bloom; tools::misc::Properties _info;
+};
+}}  // namespace kmer::impl
+
 }}  // namespace gatb::core

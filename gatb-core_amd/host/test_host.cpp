@@ -123,6 +123,30 @@ template <size_t span> static void bloom_test(size_t k)
     gkc_destroy(ctx);
 }
 
+// TestDebloom.cpp:84-137 sizing through BloomAlgorithm: k=11, DEBLOOM_ORIGINAL, BLOOM_BASIC -> 130 solid k-mers,
+// size = (u64)(130 * nbits) = 1200 bits, 6 hash functions; plus the cascading table entry used by dbgh5's default.
+static void bloom_algorithm_test()
+{
+    const char* seq = "CGCTACAGCAGCTAGTTCATCATTGTTTATCAATGATAAAATATAATAAGCTAAAAGGAAACTATAAATA"
+                      "ACCATGTATAATTATAAGTAGGTACCTATTTTTTTATTTTAAACTGAAATTCAATATTATATAGGCAAAG";
+    IProperties* params = SortingCountAlgorithm<32>::getDefaultProperties();
+    params->setInt(STR_KMER_SIZE, 11); params->setInt(STR_MINIMIZER_SIZE, 8); params->setInt(STR_KMER_ABUNDANCE_MIN, 1);
+    SortingCountAlgorithm<32> sortingCount(new bank::BankStrings(seq, NULL), params);
+    sortingCount.execute();
+    CHECK(sortingCount.getInfo()->getInt("kmers_nb_solid") == 130);
+    float nbits = getNbBitsPerKmer(11, DEBLOOM_ORIGINAL);
+    BloomAlgorithm<32> bloom(sortingCount.context(), 11, nbits, BLOOM_BASIC);
+    bloom.execute();
+    CHECK(bloom.getInfo()->getInt("nb_hash") == 6);
+    CHECK(bloom.getBloom()->getBitSize() == 1200);
+    CHECK(bloom.getBloom()->getSize() == 1 + 1200 / 8);
+    size_t miss = 0;
+    for (auto& part : sortingCount.getSolidCounts()) for (auto& c : part) miss += !bloom.getBloom()->contains(c.value);
+    CHECK(miss == 0);
+    CHECK(getNbBitsPerKmer(31, DEBLOOM_CASCADING) > 5 && getNbBitsPerKmer(31, DEBLOOM_CASCADING) < 20);
+    delete params;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) { std::cerr << "usage: test_host vectors.txt" << std::endl; return 2; }
@@ -140,6 +164,7 @@ int main(int argc, char** argv)
             }
         }
         protocol_test();
+        bloom_algorithm_test();
         bloom_test<32>(31); bloom_test<64>(47);
         // error behaviour: k too small is refused, k >= span is refused (Model.hpp:398-404)
         bool threw = false;
