@@ -105,7 +105,7 @@ void gkc_destroy(gkc_ctx* c)
     std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first);
     for (uint32_t p : passes) free_pass_outputs(c, p);
     c->d_mkey_lut.release(); c->d_key2val.release(); c->d_repart.release(); c->d_histo.release();
-    c->d_scan_counters.release(); c->d_rsbits.release(); c->d_scan_matrix.release();
+    c->d_scan_counters.release(); c->d_rsbits.release(); c->d_scan_matrix.release(); c->d_desc.release(); c->d_desc_tile.release();
     c->pool.destroy();
     (void)hipStreamDestroy(c->stream);
     delete c;

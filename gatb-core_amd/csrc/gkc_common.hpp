@@ -117,7 +117,8 @@ struct gkc_ctx {
     // scratch reused across calls
     DevBuf d_scan_counters;    // u64[2P + 8]
     DevBuf d_rsbits;           // read-start bitmask
-    DevBuf d_scan_matrix;      // [2][grid][P] per-workgroup partition counts / bases (LDS-cursor scan)
+    DevBuf d_scan_matrix;      // [grid][P] per-workgroup partition bases (u64) + counts (u32) (LDS-counter scan)
+    DevBuf d_desc, d_desc_tile; // record descriptors of the count pass, per-tile (offset,count)
     size_t key_budget = 0;     // max keys per Stage-B batch (0 = auto)
 
     void set_error(int code, const char* fmt, ...) {

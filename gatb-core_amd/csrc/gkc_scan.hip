@@ -35,9 +35,10 @@ struct ScanParams {
     int dbg_noatomic;             // GKC_DEBUG_NOATOMIC=1: timing experiment only (wrong results)
     int identity_part;            // sampling mode: the 'partition' of a super-k-mer is its minimizer value (4^m bins)
     uint64_t n_tiles; uint32_t n_parts;
-    unsigned long long* wg_cnt;          // LDSPART count: [grid][P] packed (k-mers << 32 | records) of this workgroup
-    const unsigned long long* wg_base;   // LDSPART emit : [grid][P] records of earlier workgroups in the partition
+    uint32_t* wg_cnt;                    // LDSPART count: [grid][P] records of this workgroup
+    const unsigned long long* wg_base;   // LDSPART emit : [grid][P] first arena slot of this workgroup in the partition
     const unsigned long long* rec_off;   // LDSPART emit : [P] first record of the partition in the arena
+    uint32_t* desc; uint32_t desc_cap_wg; uint2* desc_tile; uint32_t* desc_overflow;   // record descriptors written by the count pass
     unsigned long long* gstats;   // [0] valid k-mers [1] invalid k-mers [2] records emitted/counted
 };
 
@@ -57,6 +58,77 @@ __global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_
 #define MKI(p) ((p) + ((p) >> 4))
 constexpr int BE_PAD = 12;   // zero words after the tile planes so record extraction may read past the halo
 
+// builds the 16/32-byte record of the super-k-mer that starts at tile-local position `start` (nbk k-mers) from the
+// big-endian 2-bit plane in LDS and stores it at arena slot `slot`
+template <int RW>
+__device__ __forceinline__ void store_record(const uint32_t* s_be, int start, uint32_t nbk, uint32_t k, uint64_t* arena, unsigned long long slot)
+{
+    const int w0 = start >> 4, sh = 2 * (start & 15);
+    uint64_t A[RW + 1];
+#pragma unroll
+    for (int i = 0; i <= RW; i++) A[i] = ((uint64_t)s_be[w0 + 2 * i] << 32) | s_be[w0 + 2 * i + 1];
+    uint64_t B[RW];
+#pragma unroll
+    for (int i = 0; i < RW; i++) B[i] = sh ? ((A[i] << sh) | (A[i + 1] >> (64 - sh))) : A[i];
+    uint64_t R[RW];
+    R[0] = ((uint64_t)nbk << 56) | (B[0] >> 8);
+#pragma unroll
+    for (int i = 1; i < RW; i++) R[i] = (B[i - 1] << 56) | (B[i] >> 8);
+    // zero everything after the k+nbK-1 nucleotides of this super-k-mer
+    const int n = (int)k + (int)nbk - 1;
+    if (n < 28) R[0] &= ~((1ULL << (56 - 2 * n)) - 1);
+#pragma unroll
+    for (int i = 1; i < RW; i++) {
+        const int have = n - 28 - 32 * (i - 1);       // nucleotides of word i that belong to the record
+        if (have <= 0) R[i] = 0;
+        else if (have < 32) R[i] &= ~((1ULL << (64 - 2 * have)) - 1);
+    }
+    uint64_t* dst = arena + slot * RW;
+#pragma unroll
+    for (int i = 0; i < RW; i += 2) *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(R[i], R[i + 1]);
+}
+
+// 16 ASCII bases (4 dwords) -> little-endian 2-bit word + invalid mask (A1), SWAR
+__device__ __forceinline__ void encode16(const uint32_t (&dw)[4], uint32_t& le, uint32_t& bad)
+{
+    le = 0; bad = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t wv = dw[q];
+        uint32_t c4 = (wv >> 1) & 0x03030303u;
+        c4 = (c4 | (c4 >> 6)) & 0x000F000Fu;
+        c4 = (c4 | (c4 >> 12)) & 0xFFu;                                     // c0 | c1<<2 | c2<<4 | c3<<6
+        le |= c4 << (8 * q);
+        const uint32_t u = wv & 0xDFDFDFDFu;
+        auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // 0x80 where the byte is non-zero
+        uint32_t b4 = nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u);
+        b4 >>= 7;
+        b4 = (b4 | (b4 >> 7) | (b4 >> 14) | (b4 >> 21)) & 0xFu;
+        bad |= b4 << (4 * q);
+    }
+}
+__device__ __forceinline__ uint32_t rev2bit(uint32_t x)                         // reverse the 16 two-bit groups
+{
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+__device__ __forceinline__ void load16(const uint8_t* bases, uint64_t g0, uint64_t n_bases, uint32_t (&dw)[4])
+{
+    if (g0 + 16 <= n_bases) {
+        const uint4 v = *reinterpret_cast<const uint4*>(bases + g0);
+        dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const uint64_t g = g0 + 4 * q + b; const uint32_t c = (g < n_bases) ? bases[g] : 0u; x |= c << (8 * b); }
+            dw[q] = x;
+        }
+    }
+}
+
 // LDSPART: persistent workgroups with a static tile assignment (tile = blockIdx.x, += gridDim.x, identical in the count
 // and the emit launch). Per-partition counters / record cursors live in LDS (64-bit LDS atomics): the count launch
 // leaves a [workgroup][partition] matrix, a tiny prefix kernel turns it into private record ranges, and the emit launch
@@ -64,7 +136,7 @@ constexpr int BE_PAD = 12;   // zero words after the tile planes so record extra
 template <bool EMIT, int RW, bool LDSPART>
 __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_part[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_part[];       // per-partition record counter of this workgroup (4 B)
     __shared__ uint32_t s_be[SCAN_WORDS + BE_PAD];
     __shared__ uint32_t s_le[SCAN_WORDS + BE_PAD];
     __shared__ uint16_t s_bad[SCAN_WORDS + 8];
@@ -75,16 +147,18 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
     __shared__ uint8_t  s_lastvalid[SCAN_THREADS], s_firstvalid[SCAN_THREADS + 1];
     __shared__ int      s_wavecarry[SCAN_THREADS / 64];
     __shared__ unsigned long long s_stat[3];
+    __shared__ uint32_t s_toff, s_tcnt;
 
     const int t = threadIdx.x;
     const uint32_t k = P.k, m = P.m;
 
     if (t < 3) s_stat[t] = 0;
+    if (t == 0) { s_toff = 0; s_tcnt = 0; }
     if (t < BE_PAD) { s_be[SCAN_WORDS + t] = 0; s_le[SCAN_WORDS + t] = 0; }
     if (t < 8) s_bad[SCAN_WORDS + t] = 0;
     if (LDSPART) {
         for (uint32_t p = t; p < P.n_parts; p += SCAN_THREADS)
-            s_part[p] = EMIT ? (P.rec_off[p] + P.wg_base[(uint64_t)blockIdx.x * P.n_parts + p]) : 0ULL;
+            s_part[p] = 0u;
     }
     uint32_t nv_acc = 0, ni_acc = 0, n_rec = 0;
 
@@ -97,44 +171,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
 
     // ---- step 0: ASCII -> bit planes (A1) ----
     for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
-        uint64_t g0 = t0 + 16ull * w;
-        uint32_t dw[4];
-        if (g0 + 16 <= P.n_bases) {
-            uint4 v = *reinterpret_cast<const uint4*>(P.bases + g0);
-            dw[0] = v.x; dw[1] = v.y; dw[2] = v.z; dw[3] = v.w;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t x = 0;
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    uint64_t g = g0 + 4 * q + b;
-                    uint32_t c = (g < P.n_bases) ? P.bases[g] : 0u;
-                    x |= c << (8 * b);
-                }
-                dw[q] = x;
-            }
-        }
-        // SWAR: 4 bases per 32-bit word (A1: code = (c>>1)&3, valid iff (c & 0xDF) in {A,C,G,T})
-        uint32_t le = 0, bad = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t wv = dw[q];
-            uint32_t c4 = (wv >> 1) & 0x03030303u;
-            c4 = (c4 | (c4 >> 6)) & 0x000F000Fu;
-            c4 = (c4 | (c4 >> 12)) & 0xFFu;                                     // c0 | c1<<2 | c2<<4 | c3<<6
-            le |= c4 << (8 * q);
-            const uint32_t u = wv & 0xDFDFDFDFu;
-            auto nz = [](uint32_t v) { return (((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // 0x80 where the byte is non-zero
-            uint32_t b4 = nz(u ^ 0x41414141u) & nz(u ^ 0x43434343u) & nz(u ^ 0x47474747u) & nz(u ^ 0x54545454u);
-            b4 >>= 7;
-            b4 = (b4 | (b4 >> 7) | (b4 >> 14) | (b4 >> 21)) & 0xFu;
-            bad |= b4 << (4 * q);
-        }
-        uint32_t be = le;                                                        // reverse the 16 two-bit groups
-        be = ((be >> 2) & 0x33333333u) | ((be & 0x33333333u) << 2);
-        be = ((be >> 4) & 0x0F0F0F0Fu) | ((be & 0x0F0F0F0Fu) << 4);
-        be = __builtin_bswap32(be);
+        uint32_t dw[4], le, bad;
+        load16(P.bases, t0 + 16ull * w, P.n_bases, dw);
+        encode16(dw, le, bad);
+        const uint32_t be = rev2bit(le);
         s_be[w] = be; s_le[w] = le; s_bad[w] = (uint16_t)bad;
     }
     for (int i = t; i < SCAN_TILE / 32 + 8; i += SCAN_THREADS) s_rs[i] = P.rsbits[t0 / 32 + i];
@@ -286,8 +326,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
                 n_end++;
             }
         }
+        // descriptor stream of the count pass (LDSPART): (partition, nbK, start) per record, so that the emit pass does
+        // not have to recompute minimizers. Slots are reserved per thread; filtered-out records leave a ~0 hole.
+        uint32_t dbase = 0; bool dstore = false;
+        if (!EMIT && LDSPART && P.desc && n_end) {
+            dbase = s_toff + atomicAdd(&s_tcnt, (uint32_t)n_end);
+            dstore = dbase + (uint32_t)n_end <= P.desc_cap_wg;
+            if (!dstore) *P.desc_overflow = 1u;
+        }
 #pragma unroll 1
         for (int e = 0; e < n_end; e++) {
+            if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = 0xFFFFFFFFu;
             const uint32_t info = s_end[MKI(p0) + e];
             const uint32_t nbk = (info >> 4) + 1;
             const int start = p0 + (int)(info & 15u) - (int)(info >> 4);
@@ -298,39 +347,23 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
             n_rec++;
             if (!EMIT) {
                 if (P.dbg_noatomic) continue;
-                if (LDSPART) atomicAdd(&s_part[part], ((unsigned long long)nbk << 32) | 1ULL);
-                else { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
+                if (LDSPART) {
+                    atomicAdd(&s_part[part], 1u);
+                    if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = (part << 18) | ((nbk - 1) << 12) | (uint32_t)start;
+                } else { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
             } else {
-                const unsigned long long slot = LDSPART ? atomicAdd(&s_part[part], 1ULL) : atomicAdd(&P.cursor[part], 1ULL);
-                // 2-bit plane, left-aligned at `start`
-                const int w0 = start >> 4, sh = 2 * (start & 15);
-                uint64_t A[RW + 1];
-#pragma unroll
-                for (int i = 0; i <= RW; i++) A[i] = ((uint64_t)s_be[w0 + 2 * i] << 32) | s_be[w0 + 2 * i + 1];
-                uint64_t B[RW];
-#pragma unroll
-                for (int i = 0; i < RW; i++) B[i] = sh ? ((A[i] << sh) | (A[i + 1] >> (64 - sh))) : A[i];
-                uint64_t R[RW];
-                R[0] = ((uint64_t)nbk << 56) | (B[0] >> 8);
-#pragma unroll
-                for (int i = 1; i < RW; i++) R[i] = (B[i - 1] << 56) | (B[i] >> 8);
-                // zero everything after the k+nbK-1 nucleotides of this super-k-mer
-                const int n = (int)k + (int)nbk - 1;
-                if (n < 28) R[0] &= ~((1ULL << (56 - 2 * n)) - 1);
-#pragma unroll
-                for (int i = 1; i < RW; i++) {
-                    const int have = n - 28 - 32 * (i - 1);       // nucleotides of word i that belong to the record
-                    if (have <= 0) R[i] = 0;
-                    else if (have < 32) R[i] &= ~((1ULL << (64 - 2 * have)) - 1);
-                }
-                uint64_t* dst = P.arena + slot * RW;
-#pragma unroll
-                for (int i = 0; i < RW; i += 2) *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(R[i], R[i + 1]);
+                const unsigned long long slot = LDSPART ? (P.wg_base[(uint64_t)blockIdx.x * P.n_parts + part] + atomicAdd(&s_part[part], 1u))
+                                                        : atomicAdd(&P.cursor[part], 1ULL);
+                store_record<RW>(s_be, start, nbk, k, P.arena, slot);
             }
         }
     }
 
     nv_acc += __popc(validmask); ni_acc += __popc(existsmask & ~validmask);
+    if (!EMIT && LDSPART && P.desc) {                          // close the tile's descriptor range
+        __syncthreads();
+        if (t == 0) { P.desc_tile[tile] = make_uint2(s_toff, s_tcnt); s_toff += s_tcnt; s_tcnt = 0; }
+    }
   }   // tile loop
 
     // ---- statistics (Sequence2SuperKmer.hpp:103,108) ----
@@ -347,22 +380,77 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
     }
 }
 
-// per-partition prefix over workgroups: base[w][p] = records of workgroups < w; totals per partition
-__global__ void k_wg_prefix(const unsigned long long* __restrict__ wg_cnt, uint32_t n_wg, uint32_t n_parts,
-                            unsigned long long* __restrict__ wg_base, unsigned long long* __restrict__ tot_rec, unsigned long long* __restrict__ tot_km)
+// Emit pass driven by the count pass's descriptors: only the big-endian 2-bit plane is rebuilt (no m-mer keys, no window
+// minimum, no scans); one thread per record builds and stores it at its exact slot (LDS counter + private base).
+template <int RW>
+__global__ __launch_bounds__(SCAN_THREADS) void k_emit_desc(ScanParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_part[];
+    __shared__ uint32_t s_be[SCAN_WORDS + BE_PAD];
+    if (threadIdx.x < BE_PAD) s_be[SCAN_WORDS + threadIdx.x] = 0;
+    for (uint32_t p = threadIdx.x; p < P.n_parts; p += SCAN_THREADS) s_part[p] = 0u;
+    const unsigned long long* base = P.wg_base + (uint64_t)blockIdx.x * P.n_parts;
+    const uint32_t* desc = P.desc + (uint64_t)blockIdx.x * P.desc_cap_wg;
+    for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        const uint64_t t0 = tile * SCAN_TILE;
+        __syncthreads();
+        for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
+            uint32_t dw[4], le, bad;
+            load16(P.bases, t0 + 16ull * w, P.n_bases, dw);
+            encode16(dw, le, bad);
+            s_be[w] = rev2bit(le);
+        }
+        __syncthreads();
+        const uint2 td = P.desc_tile[tile];
+        for (uint32_t i = t; i < td.y; i += SCAN_THREADS) {
+            const uint32_t d = desc[td.x + i];
+            if (d == 0xFFFFFFFFu) continue;
+            const uint32_t part = d >> 18, nbk = ((d >> 12) & 63u) + 1u; const int start = (int)(d & 4095u);
+            const unsigned long long slot = base[part] + atomicAdd(&s_part[part], 1u);
+            store_record<RW>(s_be, start, nbk, P.k, P.arena, slot);
+        }
+    }
+}
+
+// per-partition prefix over workgroups: base[w][p] = records of workgroups < w (partition-relative); totals per partition
+__global__ void k_wg_prefix(const uint32_t* __restrict__ wg_cnt, uint32_t n_wg, uint32_t n_parts,
+                            unsigned long long* __restrict__ wg_base, unsigned long long* __restrict__ tot_rec)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_parts) return;
-    unsigned long long run = 0, km = 0;
+    unsigned long long run = 0;
     for (uint32_t w = 0; w < n_wg; w++) {
-        const unsigned long long v = wg_cnt[(uint64_t)w * n_parts + p];
+        const uint32_t v = wg_cnt[(uint64_t)w * n_parts + p];
         wg_base[(uint64_t)w * n_parts + p] = run;
-        run += v & 0xFFFFFFFFULL; km += v >> 32;
+        run += v;
     }
-    tot_rec[p] = run; tot_km[p] = km;
+    tot_rec[p] = run;
+}
+// base[w][p] += rec_off[p]: absolute arena slots
+__global__ void k_wg_base_abs(unsigned long long* __restrict__ wg_base, const unsigned long long* __restrict__ rec_off, uint32_t n_parts, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wg_base[i] += rec_off[i % n_parts];
+}
+// k-mers per partition = sum of nbK over its records (the count pass only counts records, 4 B of LDS per partition)
+template <int RW>
+__global__ void k_partition_kmers(const uint64_t* __restrict__ arena, const unsigned long long* __restrict__ rec_off, const unsigned long long* __restrict__ tot_rec,
+                                  unsigned long long* __restrict__ out)
+{
+    __shared__ unsigned long long s[4];
+    const uint32_t p = blockIdx.x;
+    const uint64_t r0 = rec_off[p], n = tot_rec[p];
+    unsigned long long v = 0;
+    for (uint64_t r = threadIdx.x; r < n; r += blockDim.x) v += arena[(r0 + r) * RW] >> 56;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[p] = s[0] + s[1] + s[2] + s[3];
 }
 
-// ------------------------------------------------------------------------------------------------ host side
 static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart, unsigned grid_n, size_t dyn_lds)
 {
     dim3 grid(grid_n), block(SCAN_THREADS);
@@ -379,7 +467,7 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
     return GKC_OK;
 }
 
-constexpr uint32_t SCAN_LDS_PARTS_MAX = 8192;      // 64 KB of LDS cursors at most
+constexpr uint32_t SCAN_LDS_PARTS_MAX = 16384;     // 64 KB of LDS counters at most
 constexpr size_t SCAN_STATIC_LDS = 32 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
 
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
@@ -404,7 +492,7 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     }
     // geometry: persistent workgroups when the partition cursors fit in LDS
     const bool ldspart = Pn <= SCAN_LDS_PARTS_MAX && getenv("GKC_SCAN_GLOBAL_ATOMICS") == nullptr;
-    const size_t dyn_lds = ldspart ? (size_t)Pn * 8 : 0;
+    const size_t dyn_lds = ldspart ? (size_t)Pn * 4 : 0;
     unsigned grid_n;
     if (ldspart) {
         int cus = 256; hipDeviceProp_t prop;
@@ -418,7 +506,7 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     GKC_TRY(c->ensure(c->d_scan_counters, n_cnt * 8));
     GKC_HIP(c, hipMemsetAsync(c->d_scan_counters.p, 0, n_cnt * 8, c->stream));
     unsigned long long* cnt = (unsigned long long*)c->d_scan_counters.p;
-    if (ldspart) GKC_TRY(c->ensure(c->d_scan_matrix, (size_t)2 * grid_n * Pn * 8));
+    if (ldspart) GKC_TRY(c->ensure(c->d_scan_matrix, (size_t)grid_n * Pn * 12));      // [G][P] u64 bases, then [G][P] u32 counts
 
     ScanParams P{};
     P.bases = (const uint8_t*)d_bases; P.n_bases = n_bases; P.rsbits = (const uint32_t*)c->d_rsbits.p;
@@ -432,15 +520,27 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     P.arena = nullptr;
     P.dbg_noatomic = getenv("GKC_DEBUG_NOATOMIC") != nullptr;
     P.n_tiles = n_tiles; P.n_parts = Pn;
-    P.wg_cnt = ldspart ? (unsigned long long*)c->d_scan_matrix.p : nullptr;
-    P.wg_base = ldspart ? (unsigned long long*)c->d_scan_matrix.p + (size_t)grid_n * Pn : nullptr;
+    P.wg_base = ldspart ? (unsigned long long*)c->d_scan_matrix.p : nullptr;
+    P.wg_cnt = ldspart ? (uint32_t*)((unsigned long long*)c->d_scan_matrix.p + (size_t)grid_n * Pn) : nullptr;
     P.rec_off = cnt + 2 * (size_t)Pn;
+    // descriptor stream (count pass -> emit pass): DESC_PER_TILE u32 per tile on average, per-workgroup regions
+    const bool use_desc = ldspart && Pn <= 16384 && getenv("GKC_SCAN_NO_DESC") == nullptr;
+    if (use_desc) {
+        const uint64_t tiles_per_wg = (n_tiles + grid_n - 1) / grid_n;
+        const uint64_t cap = tiles_per_wg * 640;
+        if (cap < (1ULL << 32)) {
+            GKC_TRY(c->ensure(c->d_desc, (size_t)grid_n * cap * 4));
+            GKC_TRY(c->ensure(c->d_desc_tile, (size_t)n_tiles * 8));
+            P.desc = (uint32_t*)c->d_desc.p; P.desc_cap_wg = (uint32_t)cap; P.desc_tile = (uint2*)c->d_desc_tile.p;
+            P.desc_overflow = (uint32_t*)(cnt + 3 * (size_t)Pn + 3);
+        }
+    }
 
     {   ScopedTimer tm(c, "scan_count");
         GKC_TRY(launch_scan(c, P, false, ldspart, grid_n, dyn_lds));
         if (ldspart) {
-            hipLaunchKernelGGL(k_wg_prefix, dim3((Pn + 255) / 256), dim3(256), 0, c->stream, P.wg_cnt, grid_n, Pn,
-                               (unsigned long long*)P.wg_base, cnt, cnt + Pn);
+            hipLaunchKernelGGL(k_wg_prefix, dim3((Pn + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)P.wg_cnt, grid_n, Pn,
+                               (unsigned long long*)P.wg_base, cnt);
             GKC_HIP(c, hipGetLastError());
         }
     }
@@ -466,7 +566,29 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         GKC_HIP(c, hipMemsetAsync(cnt + 3 * (size_t)Pn, 0, 4 * 8, c->stream));
         P.arena = (uint64_t*)arena;
         {   ScopedTimer tm(c, "scan_emit");
+            if (ldspart) {
+                const uint64_t nn = (uint64_t)grid_n * Pn;
+                hipLaunchKernelGGL(k_wg_base_abs, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, (unsigned long long*)P.wg_base,
+                                   (const unsigned long long*)(cnt + 2 * (size_t)Pn), Pn, nn);
+            }
+            if (P.desc && h[3 * (size_t)Pn + 3] == 0) {          // descriptors complete: light emit kernel
+                if (c->record_bytes == 16) hipLaunchKernelGGL((k_emit_desc<2>), dim3(grid_n), dim3(SCAN_THREADS), dyn_lds, c->stream, P);
+                else                       hipLaunchKernelGGL((k_emit_desc<4>), dim3(grid_n), dim3(SCAN_THREADS), dyn_lds, c->stream, P);
+                GKC_HIP(c, hipGetLastError());
+            } else
             GKC_TRY(launch_scan(c, P, true, ldspart, grid_n, dyn_lds));
+            if (ldspart) {          // k-mers per partition (Stage B sizes its key buffers from them)
+                GKC_HIP(c, hipMemcpyAsync(cnt, h.data(), (size_t)Pn * 8, hipMemcpyHostToDevice, c->stream));       // tot_rec back (cnt[0..P) was reused)
+                if (c->record_bytes == 16) hipLaunchKernelGGL((k_partition_kmers<2>), dim3(Pn), dim3(256), 0, c->stream, (const uint64_t*)arena,
+                                                              (const unsigned long long*)(cnt + 2 * (size_t)Pn), (const unsigned long long*)cnt, cnt + Pn);
+                else                       hipLaunchKernelGGL((k_partition_kmers<4>), dim3(Pn), dim3(256), 0, c->stream, (const uint64_t*)arena,
+                                                              (const unsigned long long*)(cnt + 2 * (size_t)Pn), (const unsigned long long*)cnt, cnt + Pn);
+                GKC_HIP(c, hipGetLastError());
+                std::vector<unsigned long long> hk(Pn);
+                GKC_HIP(c, hipMemcpyAsync(hk.data(), cnt + Pn, (size_t)Pn * 8, hipMemcpyDeviceToHost, c->stream));
+                GKC_HIP(c, hipStreamSynchronize(c->stream));
+                for (uint32_t p = 0; p < Pn; p++) seg.nkmers[p] = hk[p];
+            }
         }
     }
     seg.d_records = arena;
