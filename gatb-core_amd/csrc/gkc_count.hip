@@ -148,7 +148,11 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_scatter(const PartDes
     }
 }
 
+__device__ __forceinline__ uint32_t count_at(const uint8_t* cnt8, const uint32_t* cnt32, uint64_t slot, uint32_t b) { return b == 255u ? cnt32[slot] : b; }
+
 // ------------------------------------------------------------------------------------------------ B2/B3 wave sort + RLE
+struct SortOut;
+__device__ __forceinline__ void put_count(const SortOut& O, uint64_t slot, uint32_t c);
 // One WAVE per sub-bucket, keys in registers (KPL per lane, blocked index e = lane*KPL + r), bitonic network with
 // all-ascending comparators: in-lane steps are register compare-exchanges, cross-lane steps are lane-xor shuffles.
 // No LDS traffic, no barrier; the load is striped (coalesced) because a sort does not care about the initial order.
@@ -156,12 +160,20 @@ constexpr int SORT_THREADS = 256;
 constexpr int HIST_LDS = 64;
 
 struct SortOut {
-    uint32_t* cnt;            // [n_slots] abundance of the distinct key written at the same slot (0 = empty slot)
+    uint8_t* cnt8;            // [n_slots] abundance of the distinct key written at the same slot, saturated at 255 (0 = empty slot)
+    uint32_t* cnt32;          // [n_slots] full abundance, written (and later read) only where cnt8 == 255: the flag/abundance
+                              // plane costs 1 byte per slot of HBM traffic instead of 4
     unsigned long long* histo; uint32_t histo_max;
     uint32_t* over_list; uint32_t* over_count;      // buckets too large for one wave -> k_lds_sort
     uint32_t* over2_list; uint32_t* over2_count;    // buckets too large for LDS (or pathological inside it) -> HBM split level
     unsigned long long* n_sorted;                   // [0] buckets sorted here [1] keys sorted here
 };
+
+__device__ __forceinline__ void put_count(const SortOut& O, uint64_t slot, uint32_t c)
+{
+    O.cnt8[slot] = (uint8_t)(c < 255u ? c : 255u);
+    if (c >= 255u) O.cnt32[slot] = c;
+}
 
 template <int KW> struct Shfl;
 template <> struct Shfl<1> {
@@ -255,7 +267,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
         if ((headm >> r) & 1) cur = e;
         if ((tailm >> r) & 1) {
             const uint32_t c = (uint32_t)(e - cur + 1);
-            outk[start + idx] = v[r]; O.cnt[start + idx] = c; idx++;
+            outk[start + idx] = v[r]; put_count(O, start + idx, c); idx++;
             const uint32_t hb = c >= O.histo_max ? O.histo_max : c;              // Histogram::inc (Histogram.hpp:92)
             if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
         }
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(LDS_THREADS, 4) void k_lds_sort(const typename KeyT
             if (f >> 27) {
                 if (lane == 0) {
                     const uint32_t c = cnt;
-                    outk[start + off] = s_keys[off]; O.cnt[start + off] = c;
+                    outk[start + off] = s_keys[off]; put_count(O, start + off, c);
                     const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
                     if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
                 }
@@ -533,7 +545,7 @@ __global__ void k_uniform_buckets(const typename KeyT<KW>::type* __restrict__ sr
     const SplitDesc d = descs[i];
     outk[d.start] = src[d.start];
     const uint32_t c = d.n > 0x7FFFFFFFu ? 0x7FFFFFFFu : d.n;                       // CountNumber is int32
-    O.cnt[d.start] = c;
+    put_count(O, d.start, c);
     atomicAdd(&O.histo[c >= O.histo_max ? O.histo_max : c], 1ULL);
 }
 __global__ void k_gather_buckets(const uint32_t* __restrict__ list, uint32_t n, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
@@ -549,19 +561,17 @@ __global__ void k_gather_buckets(const uint32_t* __restrict__ list, uint32_t n, 
 // cnt[slot] != 0 marks a distinct k-mer (key in keys[slot]); partitions start on COMPACT_BLK-aligned slots, so the
 // per-block prefix directly yields per-partition offsets.
 constexpr int COMPACT_THREADS = 1024, COMPACT_ITEMS = 4, COMPACT_BLK = COMPACT_THREADS * COMPACT_ITEMS;
-__global__ __launch_bounds__(COMPACT_THREADS) void k_flag_block_sums(const uint32_t* __restrict__ cnt, uint64_t n_slots, int32_t amin, int32_t amax,
-                                                                      uint64_t* __restrict__ bs_distinct, uint64_t* __restrict__ bs_solid)
+__global__ __launch_bounds__(COMPACT_THREADS) void k_flag_block_sums(const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ cnt32, uint64_t n_slots,
+                                                                      int32_t amin, int32_t amax, uint64_t* __restrict__ bs_distinct, uint64_t* __restrict__ bs_solid)
 {
     __shared__ uint32_t s_d[COMPACT_THREADS / 64], s_s[COMPACT_THREADS / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * COMPACT_BLK + (uint64_t)threadIdx.x * COMPACT_ITEMS;
+    const uint64_t base = (uint64_t)blockIdx.x * COMPACT_BLK + (uint64_t)threadIdx.x * COMPACT_ITEMS;      // n_slots is a multiple of COMPACT_BLK
     uint32_t d = 0, s = 0;
-    if (base + COMPACT_ITEMS <= n_slots) {
-        const uint4 v = *reinterpret_cast<const uint4*>(cnt + base);
-        const uint32_t c[4] = { v.x, v.y, v.z, v.w };
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(cnt8 + base);
 #pragma unroll
-        for (int i = 0; i < 4; i++) { d += c[i] != 0; s += (c[i] != 0 && (int32_t)c[i] >= amin && (int32_t)c[i] <= amax); }
-    } else {
-        for (int i = 0; i < COMPACT_ITEMS; i++) if (base + i < n_slots) { const uint32_t c = cnt[base + i]; d += c != 0; s += (c != 0 && (int32_t)c >= amin && (int32_t)c <= amax); }
+    for (int i = 0; i < 4; i++) {
+        const uint32_t b = (v >> (8 * i)) & 255u;
+        if (b) { const uint32_t c = count_at(cnt8, cnt32, base + i, b); d++; s += ((int32_t)c >= amin && (int32_t)c <= amax); }
     }
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) { d += __shfl_down(d, dd, 64); s += __shfl_down(s, dd, 64); }
@@ -599,7 +609,8 @@ __global__ __launch_bounds__(1024) void k_scan2_u64(uint64_t* __restrict__ a, ui
 }
 // B5 dump: Count records {value, abundance} (Abundance.hpp:68-129), solid only, ascending
 template <int KW>
-__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_flags(const typename KeyT<KW>::type* __restrict__ keys, const uint32_t* __restrict__ cnt, uint64_t n_slots,
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_flags(const typename KeyT<KW>::type* __restrict__ keys, const uint8_t* __restrict__ cnt8,
+                                                                    const uint32_t* __restrict__ cnt32, uint64_t n_slots,
                                                                     const uint64_t* __restrict__ bp_solid, int32_t amin, int32_t amax, uint64_t* __restrict__ out)
 {
     __shared__ uint32_t s_w[COMPACT_THREADS / 64];
@@ -607,9 +618,11 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_flags(const typenam
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * COMPACT_BLK + (uint64_t)t * COMPACT_ITEMS;
     uint32_t c[COMPACT_ITEMS]; uint32_t ok = 0, loc = 0;
+    const uint32_t v4 = *reinterpret_cast<const uint32_t*>(cnt8 + base);                 // n_slots is a multiple of COMPACT_BLK
 #pragma unroll
     for (int i = 0; i < COMPACT_ITEMS; i++) {
-        c[i] = (base + i < n_slots) ? cnt[base + i] : 0;
+        const uint32_t b = (v4 >> (8 * i)) & 255u;
+        c[i] = b ? count_at(cnt8, cnt32, base + i, b) : 0u;
         const bool o = c[i] != 0 && (int32_t)c[i] >= amin && (int32_t)c[i] <= amax;       // CountRange::includes (closed interval)
         ok |= (uint32_t)o << i; loc += o;
     }
@@ -659,8 +672,8 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, b_start[2], b_n[2], b_cons[2], over, over2, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
-    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &misc, &bs_d, &bs_s,
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &misc, &bs_d, &bs_s,
                                         &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot };
                      for (DevBuf* d : all) d->release(); }
 };
@@ -697,7 +710,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
 #define CB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { B.release(); c->set_error(GKC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); return GKC_ERR_HIP; } } while (0)
     CB_TRY(c->ensure(B.pd, nb * sizeof(PartDesc)));
     CB_TRY(c->ensure(B.keysA, (size_t)std::max<uint64_t>(n_slots, 1) * sizeof(key_t)));
-    CB_TRY(c->ensure(B.cnt, (size_t)std::max<uint64_t>(n_slots, 1) * 4));
+    CB_TRY(c->ensure(B.cnt, (size_t)std::max<uint64_t>(n_slots, 1) * 4)); CB_TRY(c->ensure(B.cnt8, (size_t)std::max<uint64_t>(n_slots, 4)));
     CB_TRY(c->ensure(B.b_start[0], (size_t)n_sub * 8)); CB_TRY(c->ensure(B.b_n[0], (size_t)n_sub * 4)); CB_TRY(c->ensure(B.b_cons[0], (size_t)n_sub));
     CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over2, (size_t)(n_sub + 1) * 4));
     CB_TRY(c->ensure(B.misc, 64));
@@ -705,7 +718,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     CB_TRY(c->ensure(B.pidx, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.ptot, (size_t)(nb + 1) * 16));
     CB_HIP(hipMemcpyAsync(B.pd.p, pd.data(), nb * sizeof(PartDesc), hipMemcpyHostToDevice, c->stream));
     CB_HIP(hipMemcpyAsync(B.pidx.p, pblk.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    CB_HIP(hipMemsetAsync(B.cnt.p, 0, (size_t)std::max<uint64_t>(n_slots, 1) * 4, c->stream));
+    CB_HIP(hipMemsetAsync(B.cnt8.p, 0, (size_t)std::max<uint64_t>(n_slots, 4), c->stream));
     CB_HIP(hipMemsetAsync(B.misc.p, 0, 64, c->stream));
 
     {   ScopedTimer tm(c, "expand_count");
@@ -719,7 +732,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipGetLastError());
     }
     SortOut O{};
-    O.cnt = (uint32_t*)B.cnt.p; O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max;
+    O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max;
     O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1;
     O.over2_count = (uint32_t*)B.over2.p; O.over2_list = (uint32_t*)B.over2.p + 1;
     O.n_sorted = (unsigned long long*)B.misc.p;
@@ -816,7 +829,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     std::vector<uint64_t> ptot((size_t)(nb + 1) * 2);
     {   ScopedTimer tm(c, "compact");
         if (n_blocks) {
-            hipLaunchKernelGGL(k_flag_block_sums, dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const uint32_t*)B.cnt.p, n_slots, c->amin, c->amax,
+            hipLaunchKernelGGL(k_flag_block_sums, dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, n_slots, c->amin, c->amax,
                                (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p);
         }
         hipLaunchKernelGGL(k_scan2_u64, dim3(1), dim3(1024), 0, c->stream, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks);
@@ -831,7 +844,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         if (!out) { B.release(); return GKC_ERR_NOMEM; }
         outputs.push_back(out);
         if (n_blocks) {
-            hipLaunchKernelGGL((k_compact_flags<KW>), dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const key_t*)B.keysA.p, (const uint32_t*)B.cnt.p, n_slots,
+            hipLaunchKernelGGL((k_compact_flags<KW>), dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const key_t*)B.keysA.p, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, n_slots,
                                (const uint64_t*)B.bs_s.p, c->amin, c->amax, (uint64_t*)out);
             CB_HIP(hipGetLastError());
         }
