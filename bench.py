@@ -81,8 +81,9 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_dist = world > 1 or os.environ.get("GKC_FORCE_DIST") == "1"       # GKC_FORCE_DIST=1: exercise the exchange path with one rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     gkc = ge.load().gkc
@@ -103,7 +104,7 @@ def main():
     d_bases, d_offs = c.synth_reads_device(2, n_reads, L, genome, 10000, first_read=rank * n_reads)
     n_bases = n_reads * L
 
-    if world > 1:
+    if use_dist:
         from gatb_core_amd import dist as gdist          # noqa
         runner = gdist.DistributedCounter(c, rank, world, parts)
     else:
@@ -118,7 +119,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +197,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     c.device_free(d_bases); c.device_free(d_offs)
-    if world > 1:
+    if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
 

@@ -8,7 +8,8 @@ reads the files back). Here the same hand-over is ONE all-to-all of the device s
   * every rank scans its own slice of the reads (Stage A) into per-partition buckets (gkc_push_reads*);
   * partition p is owned by rank p // (P / world)  (contiguous ranges, so the bytes for one destination are ONE contiguous
     slice of the bucket arena — nothing is packed or copied before the send);
-  * a small all-gather of the per-partition record / k-mer counts, then all_to_all_single of the arena bytes;
+  * a small all-gather of the per-partition record / k-mer counts, then the all-to-all of the arena bytes (one batch of
+    point-to-point messages below 2 GiB each — larger single transfers are corrupted by this RCCL/torch stack);
   * every rank imports the chunks it received as foreign segments (gkc_segment_import) and counts the partitions it
     owns (Stage B, gkc_finish_pass). Results stay sharded by partition; no further collective.
 
@@ -36,7 +37,11 @@ def owner_ranges(nb_partitions, world):
     return [(r * per, (r + 1) * per) for r in range(world)]
 
 
-def exchange_buckets(send, rec_off, kmers, record_bytes, rank, world, group=None):
+CHUNK_BYTES = 1 << 30      # per (source, destination) message: RCCL / torch silently corrupt transfers of 2 GiB and more (measured on
+                           # this stack: all_to_all_single of >= 2^31 bytes per peer returns wrong data), so every message stays below
+
+
+def exchange_buckets(send, rec_off, kmers, record_bytes, rank, world, group=None, chunk_bytes=None):
     """Routes bucket bytes to the owners.
 
     send      uint8 tensor: this rank's bucket arena (partition-major), on the device of the process group's backend
@@ -59,7 +64,24 @@ def exchange_buckets(send, rec_off, kmers, record_bytes, rank, world, group=None
     out_split = [int(rec_cnt[s, lo:hi].sum()) * record_bytes for s in range(world)]
     recv = torch.empty(sum(out_split), dtype=torch.uint8, device=dev)
     assert sum(in_split) == send.numel(), (sum(in_split), send.numel())
-    dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    # all-to-all as one batch of point-to-point messages (what RCCL's all-to-all is underneath), chunked below 2 GiB;
+    # the local slice is a plain device copy
+    ch = int(chunk_bytes or CHUNK_BYTES) // record_bytes * record_bytes
+    in_off = np.concatenate([[0], np.cumsum(in_split)]); out_off = np.concatenate([[0], np.cumsum(out_split)])
+    ops = []
+    for peer in range(world):
+        s_sl = send[int(in_off[peer]):int(in_off[peer + 1])]
+        r_sl = recv[int(out_off[peer]):int(out_off[peer + 1])]
+        if peer == rank:
+            r_sl.copy_(s_sl)
+            continue
+        for c0 in range(0, s_sl.numel(), ch):
+            ops.append(dist.P2POp(dist.isend, s_sl[c0:c0 + ch], peer, group))
+        for c0 in range(0, r_sl.numel(), ch):
+            ops.append(dist.P2POp(dist.irecv, r_sl[c0:c0 + ch], peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     # 3) per-source tables for gkc_segment_import
     chunks = []
     pos = 0

@@ -32,7 +32,7 @@ def _make_records(rank, P, rb, seed):
     return recs, rec_off, kmers.astype(np.int64)
 
 
-def _worker(rank, world, port, P, rb, q):
+def _worker(rank, world, port, P, rb, q, chunk=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -40,7 +40,7 @@ def _worker(rank, world, port, P, rb, q):
         from gatb_core_amd import dist as gd
         recs, rec_off, kmers = _make_records(rank, P, rb, 100)
         send = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy())
-        recv, chunks = gd.exchange_buckets(send, rec_off, kmers, rb, rank, world)
+        recv, chunks = gd.exchange_buckets(send, rec_off, kmers, rb, rank, world, chunk_bytes=chunk)
         lo, hi = gd.owner_ranges(P, world)[rank]
         got = recv.numpy().view(np.uint64).reshape(-1, rb // 8)
         ok = True
@@ -64,13 +64,14 @@ def _worker(rank, world, port, P, rb, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("P,rb", [(8, 16), (6, 32)])
-def test_bucket_exchange_world2_gloo(P, rb):
+@pytest.mark.parametrize("P,rb,chunk", [(8, 16, None), (6, 32, None), (8, 16, 96)])
+def test_bucket_exchange_world2_gloo(P, rb, chunk):
+    """chunk=96 bytes forces several point-to-point messages per peer (the >= 2 GiB work-around path)"""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, P, rb, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, P, rb, q, chunk)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
