@@ -77,6 +77,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything else that writes to fd 1 (RCCL prints its version banner there)
+    # is routed to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,7 +201,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(k, m, min(parts, 256), repart_for_bench(m, min(parts, 256)))
         elif world == 1:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     c.device_free(d_bases); c.device_free(d_offs)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
