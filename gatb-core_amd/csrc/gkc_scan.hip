@@ -385,11 +385,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
 template <int RW>
 __global__ __launch_bounds__(SCAN_THREADS) void k_emit_desc(ScanParams P)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_part[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cur[];   // absolute arena cursor per partition (this kernel's
+                                                                                 // static LDS is tiny, so 8 B per partition fit; a
+                                                                                 // per-record gather of the base from HBM/L2 would
+                                                                                 // triple the kernel's read traffic)
     __shared__ uint32_t s_be[SCAN_WORDS + BE_PAD];
     if (threadIdx.x < BE_PAD) s_be[SCAN_WORDS + threadIdx.x] = 0;
-    for (uint32_t p = threadIdx.x; p < P.n_parts; p += SCAN_THREADS) s_part[p] = 0u;
-    const unsigned long long* base = P.wg_base + (uint64_t)blockIdx.x * P.n_parts;
+    uint32_t* s_km = reinterpret_cast<uint32_t*>(s_cur + P.n_parts);              // k-mers per partition of this workgroup
+    for (uint32_t p = threadIdx.x; p < P.n_parts; p += SCAN_THREADS) { s_cur[p] = P.wg_base[(uint64_t)blockIdx.x * P.n_parts + p]; s_km[p] = 0u; }
     const uint32_t* desc = P.desc + (uint64_t)blockIdx.x * P.desc_cap_wg;
     for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         int t = threadIdx.x;
@@ -408,10 +411,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_emit_desc(ScanParams P)
             const uint32_t d = desc[td.x + i];
             if (d == 0xFFFFFFFFu) continue;
             const uint32_t part = d >> 18, nbk = ((d >> 12) & 63u) + 1u; const int start = (int)(d & 4095u);
-            const unsigned long long slot = base[part] + atomicAdd(&s_part[part], 1u);
+            const unsigned long long slot = atomicAdd(&s_cur[part], 1ULL);
+            atomicAdd(&s_km[part], nbk);
             store_record<RW>(s_be, start, nbk, P.k, P.arena, slot);
         }
     }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < P.n_parts; p += SCAN_THREADS) if (s_km[p]) atomicAdd(&P.cnt_kmers[p], (unsigned long long)s_km[p]);
 }
 
 // per-partition prefix over workgroups: base[w][p] = records of workgroups < w (partition-relative); totals per partition
@@ -571,15 +577,16 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
                 hipLaunchKernelGGL(k_wg_base_abs, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, (unsigned long long*)P.wg_base,
                                    (const unsigned long long*)(cnt + 2 * (size_t)Pn), Pn, nn);
             }
-            if (P.desc && h[3 * (size_t)Pn + 3] == 0) {          // descriptors complete: light emit kernel
-                if (c->record_bytes == 16) hipLaunchKernelGGL((k_emit_desc<2>), dim3(grid_n), dim3(SCAN_THREADS), dyn_lds, c->stream, P);
-                else                       hipLaunchKernelGGL((k_emit_desc<4>), dim3(grid_n), dim3(SCAN_THREADS), dyn_lds, c->stream, P);
+            const bool light = P.desc && h[3 * (size_t)Pn + 3] == 0;
+            if (light) {                                          // descriptors complete: light emit kernel (also sums k-mers per partition)
+                if (c->record_bytes == 16) hipLaunchKernelGGL((k_emit_desc<2>), dim3(grid_n), dim3(SCAN_THREADS), (size_t)Pn * 12, c->stream, P);
+                else                       hipLaunchKernelGGL((k_emit_desc<4>), dim3(grid_n), dim3(SCAN_THREADS), (size_t)Pn * 12, c->stream, P);
                 GKC_HIP(c, hipGetLastError());
             } else
             GKC_TRY(launch_scan(c, P, true, ldspart, grid_n, dyn_lds));
             if (ldspart) {          // k-mers per partition (Stage B sizes its key buffers from them)
-                GKC_HIP(c, hipMemcpyAsync(cnt, h.data(), (size_t)Pn * 8, hipMemcpyHostToDevice, c->stream));       // tot_rec back (cnt[0..P) was reused)
-                if (c->record_bytes == 16) hipLaunchKernelGGL((k_partition_kmers<2>), dim3(Pn), dim3(256), 0, c->stream, (const uint64_t*)arena,
+                if (light) { /* accumulated by k_emit_desc into cnt[P..2P) */ }
+                else if (c->record_bytes == 16) hipLaunchKernelGGL((k_partition_kmers<2>), dim3(Pn), dim3(256), 0, c->stream, (const uint64_t*)arena,
                                                               (const unsigned long long*)(cnt + 2 * (size_t)Pn), (const unsigned long long*)cnt, cnt + Pn);
                 else                       hipLaunchKernelGGL((k_partition_kmers<4>), dim3(Pn), dim3(256), 0, c->stream, (const uint64_t*)arena,
                                                               (const unsigned long long*)(cnt + 2 * (size_t)Pn), (const unsigned long long*)cnt, cnt + Pn);
