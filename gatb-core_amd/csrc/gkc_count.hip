@@ -175,15 +175,43 @@ __device__ __forceinline__ void put_count(const SortOut& O, uint64_t slot, uint3
     if (c >= 255u) O.cnt32[slot] = c;
 }
 
+// lane-xor exchange with a COMPILE-TIME mask. Masks that stay inside a 16-lane row and map onto a DPP control (xor 1, 2, 3 =
+// quad_perm; xor 7 = row_half_mirror; xor 15 = row_mirror; xor 8 = row_ror:8) are VALU moves with no LDS-crossbar round trip;
+// xor 4 (two banked row shifts), xor 16 / 32 (gfx950 v_permlane16_swap / v_permlane32_swap + select) and 31 / 63 are available
+// behind GKC_PERMLANE_SWAP (verified on the GPU, tools/dpp_check/dpp_check.hip) but measured slower than ds_bpermute here.
+#ifndef GKC_PERMLANE_SWAP
+#define GKC_PERMLANE_SWAP 0      // measured: with the swaps the network turns VALU-bound and gets slower; ds_bpermute overlaps on the LDS pipe
+#endif
+template <int M> __device__ __forceinline__ uint32_t lane_xor32(uint32_t v)
+{
+    if constexpr (M == 1)       return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    else if constexpr (M == 2)  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    else if constexpr (M == 3)  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xF, 0xF, true);    // quad_perm [3,2,1,0]
+    else if constexpr (M == 7)  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    else if constexpr (M == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    else if constexpr (M == 8)  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true);   // row_ror:8
+    else if constexpr (M == 4 && GKC_PERMLANE_SWAP) {                                                      // two banked row shifts
+        const uint32_t r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                        // row_shl:4 -> banks 0,2
+        return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);                                    // row_shr:4 -> banks 1,3
+    } else if constexpr (M == 16 && GKC_PERMLANE_SWAP) {                                                     // gfx950 v_permlane16_swap
+        const auto p = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane_id() & 16) ? p[0] : p[1];
+    } else if constexpr (M == 32 && GKC_PERMLANE_SWAP) {                                                     // gfx950 v_permlane32_swap
+        const auto p = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane_id() & 32) ? p[0] : p[1];
+    } else if constexpr (M == 31 && GKC_PERMLANE_SWAP) return lane_xor32<16>(lane_xor32<15>(v));
+    else if constexpr (M == 63 && GKC_PERMLANE_SWAP) return lane_xor32<32>(lane_xor32<31>(v));
+    else                        return (uint32_t)__shfl_xor((int)v, M, 64);
+}
 template <int KW> struct Shfl;
 template <> struct Shfl<1> {
-    static __device__ __forceinline__ uint64_t x(uint64_t v, int m) { return (uint64_t)__shfl_xor((unsigned long long)v, m, 64); }
+    template <int M> static __device__ __forceinline__ uint64_t x(uint64_t v) { return ((uint64_t)lane_xor32<M>((uint32_t)(v >> 32)) << 32) | lane_xor32<M>((uint32_t)v); }
     static __device__ __forceinline__ uint64_t up(uint64_t v) { return (uint64_t)__shfl_up((unsigned long long)v, 1, 64); }
     static __device__ __forceinline__ uint64_t down(uint64_t v) { return (uint64_t)__shfl_down((unsigned long long)v, 1, 64); }
 };
 template <> struct Shfl<2> {
-    static __device__ __forceinline__ u128 x(u128 v, int m) {
-        unsigned long long lo = __shfl_xor((unsigned long long)v, m, 64), hi = __shfl_xor((unsigned long long)(v >> 64), m, 64);
+    template <int M> static __device__ __forceinline__ u128 x(u128 v) {
+        const uint64_t lo = Shfl<1>::x<M>((uint64_t)v), hi = Shfl<1>::x<M>((uint64_t)(v >> 64));
         return ((u128)hi << 64) | lo; }
     static __device__ __forceinline__ u128 up(u128 v) {
         unsigned long long lo = __shfl_up((unsigned long long)v, 1, 64), hi = __shfl_up((unsigned long long)(v >> 64), 1, 64);
@@ -193,41 +221,49 @@ template <> struct Shfl<2> {
         return ((u128)hi << 64) | lo; }
 };
 
-template <int KW, int KPL>
-__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane)
-{
-    typedef typename KeyT<KW>::type key_t;
-    constexpr int N = 64 * KPL;
+// bitonic network over N = 64*KPL keys (blocked index e = lane*KPL + r), all comparators ascending, as compile-time recursion so
+// that every lane mask is a template constant
+template <int KW, int KPL, int S> struct HalfClean {                    // e <-> e ^ S, then S/2, ..., 1
+    static __device__ __forceinline__ void run(typename KeyT<KW>::type (&v)[KPL], const int lane) {
+        typedef typename KeyT<KW>::type key_t;
+        if constexpr (S >= 1) {
+            if constexpr (S < KPL) {
 #pragma unroll
-    for (int size = 2; size <= N; size <<= 1) {
-        // mirror step: e <-> e ^ (size-1)
-        if (size <= KPL) {
-#pragma unroll
-            for (int r = 0; r < KPL; r++) { const int pr = r ^ (size - 1); if (pr > r) { key_t a = v[r], b = v[pr]; const bool sw = b < a; v[r] = sw ? b : a; v[pr] = sw ? a : b; } }
-        } else {
-            const int lmask = size / KPL - 1, top = (size / KPL) >> 1;
-            const bool low = (lane & top) == 0;
-            key_t w[KPL];
-#pragma unroll
-            for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::x(v[KPL - 1 - r], lmask); const bool ylt = y < v[r]; w[r] = (ylt == low) ? y : v[r]; }
-#pragma unroll
-            for (int r = 0; r < KPL; r++) v[r] = w[r];
-        }
-        // half cleaners: e <-> e ^ s
-#pragma unroll
-        for (int s = size >> 2; s >= 1; s >>= 1) {
-            if (s < KPL) {
-#pragma unroll
-                for (int r = 0; r < KPL; r++) if ((r & s) == 0) { key_t a = v[r], b = v[r | s]; const bool sw = b < a; v[r] = sw ? b : a; v[r | s] = sw ? a : b; }
+                for (int r = 0; r < KPL; r++) if ((r & S) == 0) { key_t a = v[r], b = v[r | S]; const bool sw = b < a; v[r] = sw ? b : a; v[r | S] = sw ? a : b; }
             } else {
-                const int ls = s / KPL;
-                const bool low = (lane & ls) == 0;
+                constexpr int LS = S / KPL;
+                const bool low = (lane & LS) == 0;
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::x(v[r], ls); const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
+                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LS>(v[r]); const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
             }
+            HalfClean<KW, KPL, S / 2>::run(v, lane);
         }
     }
-}
+};
+template <int KW, int KPL, int SIZE> struct BitonicMerge {              // sorted runs of SIZE/2 -> sorted runs of SIZE
+    static __device__ __forceinline__ void run(typename KeyT<KW>::type (&v)[KPL], const int lane) {
+        typedef typename KeyT<KW>::type key_t;
+        if constexpr (SIZE >= 2) {
+            BitonicMerge<KW, KPL, SIZE / 2>::run(v, lane);
+            // mirror step: e <-> e ^ (SIZE-1)
+            if constexpr (SIZE <= KPL) {
+#pragma unroll
+                for (int r = 0; r < KPL; r++) { const int pr = r ^ (SIZE - 1); if (pr > r) { key_t a = v[r], b = v[pr]; const bool sw = b < a; v[r] = sw ? b : a; v[pr] = sw ? a : b; } }
+            } else {
+                constexpr int LMASK = SIZE / KPL - 1, TOP = (SIZE / KPL) >> 1;
+                const bool low = (lane & TOP) == 0;
+                key_t w[KPL];
+#pragma unroll
+                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LMASK>(v[KPL - 1 - r]); const bool ylt = y < v[r]; w[r] = (ylt == low) ? y : v[r]; }
+#pragma unroll
+                for (int r = 0; r < KPL; r++) v[r] = w[r];
+            }
+            HalfClean<KW, KPL, SIZE / 4>::run(v, lane);
+        }
+    }
+};
+template <int KW, int KPL>
+__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane) { BitonicMerge<KW, KPL, 64 * KPL>::run(v, lane); }
 
 // sort + run-length count one bucket of n <= 64*KPL keys held by one wave; writes distinct keys / abundances at
 // outk[start + j], O.cnt[start + j] (j-th distinct key) — ascending; slots start+nd .. start+n-1 keep abundance 0.
@@ -727,7 +763,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
-        hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, c->stream, (const PartDesc*)B.pd.p, segs, k,
+        const size_t pad_lds = getenv("GKC_SCATTER_PAD_LDS") ? (size_t)atoi(getenv("GKC_SCATTER_PAD_LDS")) * 1024 : 0;   // experiment: fewer resident workgroups
+        hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), pad_lds, c->stream, (const PartDesc*)B.pd.p, segs, k,
                            (const uint64_t*)B.b_start[0].p, (key_t*)B.keysA.p);
         CB_HIP(hipGetLastError());
     }
