@@ -41,7 +41,15 @@ struct DevPool {
     std::multimap<size_t, void*> cache;       // free blocks by size
     std::map<void*, size_t> live;             // blocks handed out
     size_t cached_bytes = 0;
-    static size_t round(size_t b) { const size_t g = (size_t)2 << 20; return b < g ? ((b + 255) / 256 * 256 ? (b + 255) / 256 * 256 : 256) : (b + g - 1) / g * g; }
+    // size classes: 256 B granules below 2 MB, 2 MB granules up to 64 MB, then 16 classes per octave (<= 6.25 % slack) so that the
+    // slightly different buffer sizes of successive Stage-B batches / passes land in the same class and are reused
+    static size_t round(size_t b) {
+        if (b < ((size_t)2 << 20)) return (b + 255) / 256 * 256 ? (b + 255) / 256 * 256 : 256;
+        if (b < ((size_t)64 << 20)) { const size_t g = (size_t)2 << 20; return (b + g - 1) / g * g; }
+        int lg = 63 - __builtin_clzll((unsigned long long)b);
+        const size_t g = (size_t)1 << (lg - 4);
+        return (b + g - 1) / g * g;
+    }
     void* alloc(size_t bytes, hipError_t* err) {
         const size_t want = round(bytes ? bytes : 1);
         auto it = cache.lower_bound(want);
@@ -50,7 +58,13 @@ struct DevPool {
         }
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, want); }   // give cached blocks back and retry
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (it != cache.end()) {                                   // out of memory: any cached block that is large enough will do
+                p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess; return p;
+            }
+            trim(); e = hipMalloc(&p, want);                           // give cached blocks back and retry
+        }
         *err = e;
         if (e != hipSuccess) return nullptr;
         live[p] = want;

@@ -922,24 +922,27 @@ int gkc_count_pass(gkc_ctx* c)
     if (e1 != hipSuccess || e2 != hipSuccess) { d_recptr.release(); d_recoff.release(); GKC_FAIL(c, GKC_ERR_HIP, "segment table upload failed"); }
     SegTable segs{ (const uint8_t* const*)d_recptr.p, (const uint64_t*)d_recoff.p, n_seg, Pn };
 
-    // batches of consecutive partitions bounded by the key budget
-    size_t budget = c->key_budget;
-    if (!budget) {
+    // batches of consecutive partitions bounded by a key budget that is re-derived from the free HBM before every batch
+    // (results of earlier batches stay resident). Per key slot: key (x2: a split level may need the ping-pong buffer), 5 B of
+    // abundance planes, and room for its Count record.
+    const size_t per_key = 2 * (c->key_words == 1 ? 8 : 16) + 5 + (c->key_words == 1 ? 16 : 32);
+    auto budget_now = [&]() -> size_t {
+        if (c->key_budget) return c->key_budget;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
         free_b += c->pool.cached_bytes;                      // blocks parked in the caching allocator are reusable
-        // per key slot: key (x2 if a level-2 split is needed) + 4 B abundance; keep a third of the free memory for outputs
-        const size_t per_key = 2 * (c->key_words == 1 ? 8 : 16) + 4;
-        budget = std::max<size_t>((free_b / 3) / per_key, (size_t)1 << 20);
-        budget = std::min<size_t>(budget, (size_t)3 << 30);
-    }
+        size_t b = (size_t)((double)free_b * 0.85) / per_key;
+        b = std::max<size_t>(b, (size_t)1 << 20);
+        return std::min<size_t>(b, (size_t)3 << 30);
+    };
     std::vector<void*>& outputs = c->pass_outputs[c->pass];
     std::vector<uint32_t> batch; uint64_t acc = 0;
     rc = GKC_OK;
+    size_t budget = budget_now();
     auto flush = [&]() -> int {
         if (batch.empty()) return GKC_OK;
         int r = (c->key_words == 1) ? count_batch<1, 2>(c, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, batch, part_keys, segs, outputs);
-        batch.clear(); acc = 0; return r;
+        batch.clear(); acc = 0; budget = budget_now(); return r;
     };
     for (uint32_t p = 0; p < Pn && rc == GKC_OK; p++) {
         if (!batch.empty() && acc + part_keys[p] > budget) rc = flush();

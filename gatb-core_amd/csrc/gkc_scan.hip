@@ -600,6 +600,7 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     }
     seg.d_records = arena;
     c->segments.push_back(std::move(seg));
+    c->d_desc.release(); c->d_desc_tile.release();             // back to the pool: Stage B may reuse the space
     return GKC_OK;
 }
 
