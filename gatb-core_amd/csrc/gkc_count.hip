@@ -166,6 +166,7 @@ struct SortOut {
     unsigned long long* histo; uint32_t histo_max;
     uint32_t* over_list; uint32_t* over_count;      // buckets too large for one wave -> k_lds_sort
     uint32_t* over2_list; uint32_t* over2_count;    // buckets too large for LDS (or pathological inside it) -> HBM split level
+    uint32_t* over3_list; uint32_t* over3_count;    // buckets too large for the double-size wave network -> k_lds_sort
     unsigned long long* n_sorted;                   // [0] buckets sorted here [1] keys sorted here
 };
 
@@ -348,6 +349,30 @@ __global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<
     __syncthreads();
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
     if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
+}
+
+// second tier: buckets up to twice the first tier's size (2048 / 1024 keys), one wave each with a double-size network; only
+// ~10 % of the keys come here, so the lower occupancy of this kernel (64+ key registers) does not touch the first tier
+template <int KW> struct WaveCapHuge { static constexpr int KPL = (KW == 1) ? 32 : 16; static constexpr uint32_t CAP = 64 * KPL; };
+template <int KW>
+__global__ __launch_bounds__(SORT_THREADS) void k_wave_sort_big(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                                 const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+                                                                 const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
+{
+    __shared__ uint32_t s_hc[HIST_LDS];
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    __syncthreads();
+    const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
+    for (uint32_t li = wave; li < n_list; li += n_waves) {
+        const uint32_t g = list[li];
+        const uint32_t n = b_n[g];
+        const uint64_t start = b_start[g];
+        if (n > WaveCapHuge<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over3_count, 1u); O.over3_list[slot] = g; } continue; }
+        wave_sort_bucket<KW, WaveCapHuge<KW>::KPL>(src + start, outk, start, n, O, s_hc, lane);
+    }
+    __syncthreads();
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
 }
 
 // One WORKGROUP per bucket of up to LDS_CAP keys (a key-range slice of a partition): the keys are read from HBM once
@@ -708,8 +733,8 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
-    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &misc, &bs_d, &bs_s,
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &over3, &misc, &bs_d, &bs_s,
                                         &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot };
                      for (DevBuf* d : all) d->release(); }
 };
@@ -748,7 +773,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     CB_TRY(c->ensure(B.keysA, (size_t)std::max<uint64_t>(n_slots, 1) * sizeof(key_t)));
     CB_TRY(c->ensure(B.cnt, (size_t)std::max<uint64_t>(n_slots, 1) * 4)); CB_TRY(c->ensure(B.cnt8, (size_t)std::max<uint64_t>(n_slots, 4)));
     CB_TRY(c->ensure(B.b_start[0], (size_t)n_sub * 8)); CB_TRY(c->ensure(B.b_n[0], (size_t)n_sub * 4)); CB_TRY(c->ensure(B.b_cons[0], (size_t)n_sub));
-    CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over2, (size_t)(n_sub + 1) * 4));
+    CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over2, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over3, (size_t)(n_sub + 1) * 4));
     CB_TRY(c->ensure(B.misc, 64));
     CB_TRY(c->ensure(B.bs_d, (size_t)(n_blocks + 1) * 8)); CB_TRY(c->ensure(B.bs_s, (size_t)(n_blocks + 1) * 8));
     CB_TRY(c->ensure(B.pidx, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.ptot, (size_t)(nb + 1) * 16));
@@ -772,6 +797,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max;
     O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1;
     O.over2_count = (uint32_t*)B.over2.p; O.over2_list = (uint32_t*)B.over2.p + 1;
+    O.over3_count = (uint32_t*)B.over3.p; O.over3_list = (uint32_t*)B.over3.p + 1;
     O.n_sorted = (unsigned long long*)B.misc.p;
 
     // --- levels: sort what fits one wave, split the rest on the next key bits, repeat
@@ -781,6 +807,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     for (int level = 1; n_buckets > 0; level++) {
         CB_HIP(hipMemsetAsync(B.over.p, 0, 4, c->stream));
         CB_HIP(hipMemsetAsync(B.over2.p, 0, 4, c->stream));
+        CB_HIP(hipMemsetAsync(B.over3.p, 0, 4, c->stream));
         {   ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
             const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
             hipLaunchKernelGGL((k_wave_sort<KW>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
@@ -791,10 +818,20 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipMemcpyAsync(&n_mid, B.over.p, 4, hipMemcpyDeviceToHost, c->stream));
         CB_HIP(hipStreamSynchronize(c->stream));
         if (!n_mid) break;
-        {   ScopedTimer tm(c, "bucket_sort_lds");                 // mid-size buckets: split + sort inside LDS
-            const unsigned grid = (unsigned)std::min<uint64_t>(n_mid, 256 * 8);
-            hipLaunchKernelGGL((k_lds_sort<KW>), dim3(grid), dim3(LDS_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+        uint32_t n_mid2 = 0;
+        {   ScopedTimer tm(c, "bucket_sort_big");                 // up to 2x the first tier: double-size wave network
+            const unsigned grid = (unsigned)std::min<uint64_t>((n_mid + 3) / 4, 256 * 16);
+            hipLaunchKernelGGL((k_wave_sort_big<KW>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, O);
+            CB_HIP(hipGetLastError());
+            CB_HIP(hipMemcpyAsync(&n_mid2, B.over3.p, 4, hipMemcpyDeviceToHost, c->stream));
+            CB_HIP(hipStreamSynchronize(c->stream));
+        }
+        if (!n_mid2) break;
+        {   ScopedTimer tm(c, "bucket_sort_lds");                 // denser buckets: split + sort inside LDS
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_mid2, 256 * 8);
+            hipLaunchKernelGGL((k_lds_sort<KW>), dim3(grid), dim3(LDS_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, O);
             CB_HIP(hipGetLastError());
         }
         uint32_t n_over = 0;
@@ -850,6 +887,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             CB_TRY(c->ensure(B.b_start[nxt], (size_t)n_child * 8)); CB_TRY(c->ensure(B.b_n[nxt], (size_t)n_child * 4)); CB_TRY(c->ensure(B.b_cons[nxt], (size_t)n_child));
             if (B.over.bytes < (size_t)(n_child + 1) * 4) { CB_TRY(c->ensure(B.over, (size_t)(n_child + 1) * 4)); O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1; }
             if (B.over2.bytes < (size_t)(n_child + 1) * 4) { CB_TRY(c->ensure(B.over2, (size_t)(n_child + 1) * 4)); O.over2_count = (uint32_t*)B.over2.p; O.over2_list = (uint32_t*)B.over2.p + 1; }
+            if (B.over3.bytes < (size_t)(n_child + 1) * 4) { CB_TRY(c->ensure(B.over3, (size_t)(n_child + 1) * 4)); O.over3_count = (uint32_t*)B.over3.p; O.over3_list = (uint32_t*)B.over3.p + 1; }
             CB_HIP(hipMemcpyAsync(B.descs.p, split.data(), split.size() * sizeof(SplitDesc), hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL((k_split_count<KW>), dim3((unsigned)split.size()), dim3(EXPAND_THREADS), 0, c->stream, (const key_t*)src, (const SplitDesc*)B.descs.p,
                                (uint64_t*)B.b_start[nxt].p, (uint32_t*)B.b_n[nxt].p, (uint8_t*)B.b_cons[nxt].p, (uint32_t*)B.effs.p);
