@@ -106,8 +106,8 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     const uint32_t per = (nsub + EXPAND_THREADS - 1) / EXPAND_THREADS;       // <= 8
     const uint32_t b = threadIdx.x * per;
     uint32_t loc = 0;
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += s_hist[b + i];
-    uint32_t x = loc;
+    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += (s_hist[b + i] + 1u) & ~1u;     // every sub-bucket starts on an even slot:
+    uint32_t x = loc;                                                                          // the scatter writes keys in 16-byte pairs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     uint32_t run = wpre + x - loc;
     for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
         b_start[pd.sub_base + b + i] = pd.key_base + run; b_n[pd.sub_base + b + i] = s_hist[b + i]; b_consumed[pd.sub_base + b + i] = (uint8_t)pd.sub_bits;
-        run += s_hist[b + i];
+        run += (s_hist[b + i] + 1u) & ~1u;
     }
 }
 
@@ -149,6 +149,46 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_scatter(const PartDes
 }
 
 __device__ __forceinline__ uint32_t count_at(const uint8_t* cnt8, const uint32_t* cnt32, uint64_t slot, uint32_t b) { return b == 255u ? cnt32[slot] : b; }
+
+// B1 (8-byte keys): same stream, but keys leave the workgroup in 16-byte PAIRS. A single 8-byte store to one of 8192 open
+// sub-buckets never combines in L2 (measured: 3.3x write amplification, ~1 fabric write transaction of 32 B per key), so each
+// sub-bucket has a one-key parking slot in LDS: a key either parks (CAS EMPTY -> key) or takes the parked key out (CAS key ->
+// EMPTY) and the two are written with one aligned 16-byte store -> half the write transactions. Lock-free: every attempt
+// either succeeds or lost to another thread's success, nobody waits on anybody. Leftover parked keys are flushed at the end.
+constexpr int PAIR_THREADS = 1024;
+__global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
+                                                                       const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub] parked key or EMPTY
+    const PartDesc pd = parts[blockIdx.x];
+    const uint32_t nsub = 1u << pd.sub_bits;
+    uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + nsub);                     // [nsub] next free slot of the sub-bucket
+    constexpr unsigned long long EMPTY = ~0ULL;
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { s_pend[i] = EMPTY; s_cur[i] = (uint32_t)(b_start[pd.sub_base + i] - pd.key_base); }
+    __syncthreads();
+    uint64_t* out = keys + pd.key_base;
+    for (uint32_t s = 0; s < segs.n_seg; s++) {
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const uint8_t* base = segs.rec[s];
+        for (uint64_t r = r0 + threadIdx.x; r < r1; r += PAIR_THREADS) {
+            uint64_t R[2]; load_rec<2>(base, r, R);
+            for_each_kmer<1, 2>(R, k, [&](uint64_t c) {
+                const uint32_t q = (uint32_t)(c >> pd.shift);
+                for (;;) {
+                    const unsigned long long cur = *reinterpret_cast<volatile unsigned long long*>(&s_pend[q]);
+                    if (cur == EMPTY) { if (atomicCAS(&s_pend[q], EMPTY, (unsigned long long)c) == EMPTY) break; }
+                    else if (atomicCAS(&s_pend[q], cur, EMPTY) == cur) {
+                        const uint32_t p = atomicAdd(&s_cur[q], 2u);
+                        *reinterpret_cast<ulonglong2*>(out + p) = make_ulonglong2(cur, (unsigned long long)c);
+                        break;
+                    }
+                }
+            });
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[s_cur[i]] = v; }
+}
 
 // ------------------------------------------------------------------------------------------------ B2/B3 wave sort + RLE
 struct SortOut;
@@ -760,7 +800,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pblk[i] = n_slots / COMPACT_BLK;
-        n_slots += (np + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;      // partitions start on compaction-block boundaries
+        n_slots += (np + (1ull << bits) + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;      // partitions start on compaction-block boundaries;
+                                                                                             // + one pad slot per sub-bucket (even starts)
         n_sub += (1ull << bits);
     }
     pblk[nb] = n_slots / COMPACT_BLK;
@@ -788,8 +829,14 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
-        const size_t pad_lds = getenv("GKC_SCATTER_PAD_LDS") ? (size_t)atoi(getenv("GKC_SCATTER_PAD_LDS")) * 1024 : 0;   // experiment: fewer resident workgroups
-        hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), pad_lds, c->stream, (const PartDesc*)B.pd.p, segs, k,
+        if (KW == 1 && getenv("GKC_SCATTER_NO_PAIR") == nullptr) {
+            const size_t lds = (size_t)MAX_SUB * 12;
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds, c->stream, (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p);
+        } else
+        hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, c->stream, (const PartDesc*)B.pd.p, segs, k,
                            (const uint64_t*)B.b_start[0].p, (key_t*)B.keysA.p);
         CB_HIP(hipGetLastError());
     }
