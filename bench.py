@@ -159,7 +159,7 @@ def main():
         rec_bytes = 16 if k <= 31 else 32; key_bytes = 8 if k <= 31 else 16
         alg = {
             "scan_count": n_bases * 1.0,
-            "scan_emit": n_bases * 1.0 + st["nb_superkmers"] * rec_bytes,
+            "scan_emit": n_bases * 1.0 + st["nb_superkmers"] * (rec_bytes + 4),
             "expand_count": st["nb_superkmers"] * rec_bytes,
             "expand_scatter": st["nb_superkmers"] * rec_bytes + keys_per_rank * key_bytes,
             "bucket_sort": keys_per_rank * key_bytes + (distinct / world) * (key_bytes + 4),
@@ -170,8 +170,8 @@ def main():
         achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         workload = ("k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions" % (k, n_reads, m, parts))
         traffic = None
-        kname = {"scan_count": "k_scan_tile<false, 2, true>", "scan_emit": "k_scan_tile<true, 2, true>", "expand_count": "k_expand_count<1, 2>",
-                 "expand_scatter": "k_expand_scatter<1, 2>", "bucket_sort": "k_wave_sort<1>", "bucket_sort_lds": "k_lds_sort<1>", "compact": "k_compact_flags<1>"}
+        kname = {"scan_count": "k_scan_tile<false, 2, true>", "scan_emit": "k_emit_desc<2>", "expand_count": "k_expand_count<1, 2>",
+                 "expand_scatter": "k_expand_scatter_pair", "bucket_sort": "k_wave_sort<1>", "bucket_sort_lds": "k_lds_sort<1>", "compact": "k_compact_flags<1>"}
         try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), only if they were taken on this exact workload
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload and kname.get(dom) in pt["kernels"]:
