@@ -79,6 +79,28 @@ template <int RW> __device__ __forceinline__ void load_rec(const uint8_t* base, 
     for (int i = 0; i < RW; i += 2) { ulonglong2 v = p[i / 2]; R[i] = v.x; R[i + 1] = v.y; }
 }
 
+// 16-byte record as a left-aligned bit string (120 bits = 60 nt): the 64-bit window that starts at nucleotide i
+__device__ __forceinline__ uint64_t rec_window(uint64_t s_hi, uint64_t s_lo, uint32_t i)
+{
+    const uint32_t s = 2 * i;                                   // 0..54
+    return (s_hi << s) | ((s_lo >> 1) >> (63 - s));
+}
+
+// k <= 31, 16-byte records: k-mer i is a window of the record's bit string (no per-nucleotide setup loop); the reverse
+// complement rolls: the nucleotide entering at the right is the low 2 bits of the new window
+template <class F>
+__device__ __forceinline__ void for_each_kmer16(const uint64_t (&R)[2], uint32_t k, F f)
+{
+    const uint64_t s_hi = (R[0] << 8) | (R[1] >> 56), s_lo = R[1] << 8;
+    const uint32_t nbk = (uint32_t)(R[0] >> 56), down = 64 - 2 * k, sh = 2 * (k - 1);
+    uint64_t fw = s_hi >> down, rv = revcomp64(fw, k);
+    for (uint32_t i = 0; i < nbk; i++) {
+        f(fw < rv ? fw : rv);
+        fw = rec_window(s_hi, s_lo, i + 1) >> down;
+        rv = (rv >> 2) | ((uint64_t)(((uint32_t)fw & 3u) ^ 2u) << sh);
+    }
+}
+
 constexpr int EXPAND_THREADS = 512;
 
 // ------------------------------------------------------------------------------------------------ B1 expand_count
@@ -96,6 +118,12 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     for (uint32_t s = 0; s < segs.n_seg; s++) {
         const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         const uint8_t* base = segs.rec[s];
+        if constexpr (KW == 1 && RW == 2) {
+            for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
+                uint64_t R[2]; load_rec<2>(base, r, R);
+                for_each_kmer16(R, k, [&](uint64_t c) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
+            }
+        } else
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
             for_each_kmer<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
@@ -156,6 +184,12 @@ __device__ __forceinline__ uint32_t count_at(const uint8_t* cnt8, const uint32_t
 // EMPTY) and the two are written with one aligned 16-byte store -> half the write transactions. Lock-free: every attempt
 // either succeeds or lost to another thread's success, nobody waits on anybody. Leftover parked keys are flushed at the end.
 constexpr int PAIR_THREADS = 1024;
+
+// LDS cost model (tools/lds_bench, random slots in a 64 KB table, per wave instruction): read64 18 clk, cas64 21 clk, exch64 12 clk,
+// add32 with return 10 clk, add32 without 6 clk — random 8-byte LDS accesses run at ~3-5 lanes/clk, so the protocol uses the cheapest
+// primitive only: EXCHANGES. A thread holding key h first swaps EMPTY into the slot: a key came out -> the two leave as a pair.
+// Nothing came out -> it swaps h in: EMPTY came out -> parked; a key came out (someone parked in between) -> it now holds
+// that key instead and starts over. Keys are conserved by every exchange, nobody waits on anybody; 1.5 exchanges per key.
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys)
 {
@@ -169,19 +203,28 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     uint64_t* out = keys + pd.key_base;
     for (uint32_t s = 0; s < segs.n_seg; s++) {
         const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
-        const uint8_t* base = segs.rec[s];
-        for (uint64_t r = r0 + threadIdx.x; r < r1; r += PAIR_THREADS) {
-            uint64_t R[2]; load_rec<2>(base, r, R);
-            for_each_kmer<1, 2>(R, k, [&](uint64_t c) {
+        const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+        uint64_t r = r0 + threadIdx.x;
+        ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
+        for (; r < r1; r += PAIR_THREADS) {
+            const uint64_t R[2] = {nx.x, nx.y};
+            if (r + PAIR_THREADS < r1) nx = recs[r + PAIR_THREADS];                  // next record in flight while this one is expanded
+            for_each_kmer16(R, k, [&](uint64_t c) {
                 const uint32_t q = (uint32_t)(c >> pd.shift);
+                unsigned long long h = c;
                 for (;;) {
-                    const unsigned long long cur = *reinterpret_cast<volatile unsigned long long*>(&s_pend[q]);
-                    if (cur == EMPTY) { if (atomicCAS(&s_pend[q], EMPTY, (unsigned long long)c) == EMPTY) break; }
-                    else if (atomicCAS(&s_pend[q], cur, EMPTY) == cur) {
+                    const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
+                    if (y != EMPTY) {
                         const uint32_t p = atomicAdd(&s_cur[q], 2u);
-                        *reinterpret_cast<ulonglong2*>(out + p) = make_ulonglong2(cur, (unsigned long long)c);
+#ifdef GKC_EXP_NOSTORE
+                        if (c == 0x123456789ULL)
+#endif
+                        *reinterpret_cast<ulonglong2*>(out + p) = make_ulonglong2(y, h);
                         break;
                     }
+                    const unsigned long long z = atomicExch(&s_pend[q], h);
+                    if (z == EMPTY) break;
+                    h = z;
                 }
             });
         }
@@ -317,7 +360,9 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     key_t v[KPL];
 #pragma unroll
     for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[i] : KeyT<KW>::max(); }
+#ifndef GKC_EXP_NOSORT
     bitonic_wave<KW, KPL>(v, lane);
+#endif
     // run-length count (B3). e = lane*KPL + r is the sorted rank
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
     const key_t next_first = Shfl<KW>::down(v[0]);
@@ -852,6 +897,17 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     uint64_t n_buckets = n_sub;
     key_t* src = (key_t*)B.keysA.p;
     for (int level = 1; n_buckets > 0; level++) {
+        if (getenv("GKC_VERBOSE")) {             // diagnostic: bucket-size distribution of this level
+            std::vector<uint32_t> hn(n_buckets);
+            CB_HIP(hipMemcpyAsync(hn.data(), B.b_n[cur].p, (size_t)n_buckets * 4, hipMemcpyDeviceToHost, c->stream));
+            CB_HIP(hipStreamSynchronize(c->stream));
+            const uint32_t edges[] = {0, 64, 128, 256, 512, 1024, 2048, 6144, 0xffffffffu};
+            uint64_t nb_[9] = {0}, nk_[9] = {0};
+            for (uint32_t v : hn) { int e = 0; while (v > edges[e]) e++; nb_[e]++; nk_[e] += v; }
+            fprintf(stderr, "[gkc] level %d sizes:", level);
+            for (int e = 0; e < 9; e++) fprintf(stderr, " <=%u: %llu b / %llu k;", edges[e], (unsigned long long)nb_[e], (unsigned long long)nk_[e]);
+            fprintf(stderr, "\n");
+        }
         CB_HIP(hipMemsetAsync(B.over.p, 0, 4, c->stream));
         CB_HIP(hipMemsetAsync(B.over2.p, 0, 4, c->stream));
         CB_HIP(hipMemsetAsync(B.over3.p, 0, 4, c->stream));

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO = os.path.join(CSRC, "libgkc_hip.so")
+SO = os.environ.get("GKC_LIB") or os.path.join(CSRC, "libgkc_hip.so")      # GKC_LIB: an experiment build of the same library (tools/build_variant.sh)
 _LIB = None
 
 SYMBOLS = [

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds an experiment variant of libgkc_hip.so with extra -D flags (timing experiments: a phase disabled, another tile size ...).
+#   tools/build_variant.sh NAME -DGKC_EXP_NOSORT=1 ...   ->  gatb-core_amd/csrc/variants/libgkc_hip_NAME.so
+# Run with GKC_LIB=<that file> python bench.py ...   Variants are never shipped or tested; results of a variant may be wrong by design.
+set -e
+cd "$(dirname "$0")/../gatb-core_amd/csrc"
+name=$1; shift
+mkdir -p variants/$name
+for f in gkc_api gkc_scan gkc_count gkc_bloom; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c $f.hip -o variants/$name/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libgkc_hip_$name.so variants/$name/*.o
+echo built variants/libgkc_hip_$name.so
