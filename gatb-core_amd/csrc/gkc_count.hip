@@ -101,6 +101,35 @@ __device__ __forceinline__ void for_each_kmer16(const uint64_t (&R)[2], uint32_t
     }
 }
 
+// 32 <= k <= 63, 32-byte records (248-bit string, 124 nt): the same with a 128-bit window
+template <class F>
+__device__ __forceinline__ void for_each_kmer32(const uint64_t (&R)[4], uint32_t k, F f)
+{
+    const uint64_t S0 = (R[0] << 8) | (R[1] >> 56), S1 = (R[1] << 8) | (R[2] >> 56), S2 = (R[2] << 8) | (R[3] >> 56), S3 = R[3] << 8;
+    const uint32_t nbk = (uint32_t)(R[0] >> 56), down = 128 - 2 * k, sh = 2 * (k - 1);
+    auto window = [&](uint32_t i) -> u128 {                       // bits [2i, 2i+128) of the string; 2i <= 118
+        const uint32_t s = 2 * i, t = s & 63;
+        const bool j = s >= 64;
+        const uint64_t A = j ? S1 : S0, B = j ? S2 : S1, C = j ? S3 : S2;
+        const uint64_t hi = (A << t) | ((B >> 1) >> (63 - t)), lo = (B << t) | ((C >> 1) >> (63 - t));
+        return ((u128)hi << 64) | lo;
+    };
+    u128 fw = window(0) >> down, rv = revcomp128(fw, k);
+    for (uint32_t i = 0; i < nbk; i++) {
+        f(fw < rv ? fw : rv);
+        fw = window(i + 1) >> down;
+        rv = (rv >> 2) | ((u128)(((uint32_t)fw & 3u) ^ 2u) << sh);
+    }
+}
+// record width -> fastest k-mer walk (the generic per-nucleotide for_each_kmer stays as the reference restatement for other widths)
+template <int KW, int RW, class F>
+__device__ __forceinline__ void for_each_kmer_fast(const uint64_t (&R)[RW], uint32_t k, F f)
+{
+    if constexpr (KW == 1 && RW == 2) for_each_kmer16(R, k, f);
+    else if constexpr (KW == 2 && RW == 4) { if (k >= 32) for_each_kmer32(R, k, f); else for_each_kmer<KW, RW>(R, k, f); }
+    else for_each_kmer<KW, RW>(R, k, f);
+}
+
 constexpr int EXPAND_THREADS = 512;
 
 // ------------------------------------------------------------------------------------------------ B1 expand_count
@@ -118,15 +147,9 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     for (uint32_t s = 0; s < segs.n_seg; s++) {
         const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         const uint8_t* base = segs.rec[s];
-        if constexpr (KW == 1 && RW == 2) {
-            for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
-                uint64_t R[2]; load_rec<2>(base, r, R);
-                for_each_kmer16(R, k, [&](uint64_t c) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
-            }
-        } else
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
-            for_each_kmer<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
+            for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
         }
     }
     __syncthreads();
@@ -134,8 +157,8 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     const uint32_t per = (nsub + EXPAND_THREADS - 1) / EXPAND_THREADS;       // <= 8
     const uint32_t b = threadIdx.x * per;
     uint32_t loc = 0;
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += (s_hist[b + i] + 1u) & ~1u;     // every sub-bucket starts on an even slot:
-    uint32_t x = loc;                                                                          // the scatter writes keys in 16-byte pairs
+    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += (s_hist[b + i] + 3u) & ~3u;     // every sub-bucket starts on a multiple of 4 slots:
+    uint32_t x = loc;                                                                          // the scatter writes 8-byte keys in aligned 32-byte quads
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     uint32_t run = wpre + x - loc;
     for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
         b_start[pd.sub_base + b + i] = pd.key_base + run; b_n[pd.sub_base + b + i] = s_hist[b + i]; b_consumed[pd.sub_base + b + i] = (uint8_t)pd.sub_bits;
-        run += (s_hist[b + i] + 1u) & ~1u;
+        run += (s_hist[b + i] + 3u) & ~3u;
     }
 }
 
@@ -168,7 +191,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_scatter(const PartDes
         const uint8_t* base = segs.rec[s];
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
-            for_each_kmer<KW, RW>(R, k, [&](key_t c) {
+            for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) {
                 const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(c >> pd.shift)], 1u);
                 out[slot] = c;
             });
@@ -231,6 +254,78 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[s_cur[i]] = v; }
+}
+
+// B1, 32-byte version. With the expansion itself cheap the pair kernel is bound by its 16-byte stores: a sub-bucket's next pair arrives
+// long after its line left L2, so every pair costs a whole 32-byte HBM write atom (PMC: 2 x the algorithmic bytes). Here a sub-bucket
+// parks up to THREE keys (slots s0..s2) and the fourth arrival leaves with all of them as one aligned 32-byte quad. That needs 32 B of
+// LDS per sub-bucket, so a workgroup owns 4096 sub-buckets: a partition split 8192 ways is expanded by TWO workgroups, each keeping the
+// k-mers of its half of the key range (the expansion is a fraction of the kernel). Exchange-only protocol, keys conserved by every step:
+// deposit = swap the held key into s0, s1, s2 in turn until EMPTY comes out (then it is parked); three keys came out instead -> all
+// three slots were full: swap EMPTY into the three slots and leave with what came out + the held key. Fewer than 3 came out (two
+// collectors raced): those keys go one by one to the BACK of the bucket (quads fill it from the front, singles from the back; the bucket
+// size is exact, the two cursors meet).
+constexpr int QUAD_THREADS = 1024, QUAD_SUB = 4096;
+__global__ __launch_bounds__(QUAD_THREADS) void k_expand_scatter_quad(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
+                                                                       const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+                                                                       uint64_t* __restrict__ keys, uint32_t halves_log2)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_slot[];       // [3][QUAD_SUB] parked keys or EMPTY
+    uint32_t* s_front = reinterpret_cast<uint32_t*>(s_slot + 3 * QUAD_SUB);           // [QUAD_SUB] next quad of the sub-bucket
+    uint32_t* s_back = s_front + QUAD_SUB;                                            // [QUAD_SUB] one past the next single (counts down)
+    const PartDesc pd = parts[blockIdx.x >> halves_log2];
+    const uint32_t nsub = 1u << pd.sub_bits;
+    const uint32_t half = blockIdx.x & ((1u << halves_log2) - 1), q0 = half * QUAD_SUB;
+    if (q0 >= nsub) return;
+    const uint32_t nq = min(nsub - q0, (uint32_t)QUAD_SUB);
+    constexpr unsigned long long EMPTY = ~0ULL;
+    for (uint32_t i = threadIdx.x; i < QUAD_SUB; i += QUAD_THREADS) {
+        s_slot[i] = EMPTY; s_slot[QUAD_SUB + i] = EMPTY; s_slot[2 * QUAD_SUB + i] = EMPTY;
+        if (i < nq) { const uint32_t st = (uint32_t)(b_start[pd.sub_base + q0 + i] - pd.key_base); s_front[i] = st; s_back[i] = st + b_n[pd.sub_base + q0 + i]; }
+    }
+    __syncthreads();
+    uint64_t* out = keys + pd.key_base;
+    const bool all_mine = nsub <= (uint32_t)QUAD_SUB;
+    for (uint32_t s = 0; s < segs.n_seg; s++) {
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+        uint64_t r = r0 + threadIdx.x;
+        ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
+        for (; r < r1; r += QUAD_THREADS) {
+            const uint64_t R[2] = {nx.x, nx.y};
+            if (r + QUAD_THREADS < r1) nx = recs[r + QUAD_THREADS];                  // next record in flight while this one is expanded
+            for_each_kmer16(R, k, [&](uint64_t c) {
+                const uint32_t q = (uint32_t)(c >> pd.shift) - q0;
+                if (!all_mine && q >= (uint32_t)QUAD_SUB) return;                     // the other workgroup's half of the key range
+                unsigned long long h = c, z;
+                z = atomicExch(&s_slot[q], h); if (z == EMPTY) return; h = z;
+                z = atomicExch(&s_slot[QUAD_SUB + q], h); if (z == EMPTY) return; h = z;
+                z = atomicExch(&s_slot[2 * QUAD_SUB + q], h); if (z == EMPTY) return; h = z;
+                const unsigned long long a = atomicExch(&s_slot[q], EMPTY), b = atomicExch(&s_slot[QUAD_SUB + q], EMPTY),
+                                         d = atomicExch(&s_slot[2 * QUAD_SUB + q], EMPTY);
+                if (a != EMPTY && b != EMPTY && d != EMPTY) {
+                    const uint32_t p = atomicAdd(&s_front[q], 4u);
+#ifdef GKC_EXP_NOSTORE
+                    if (c == 0x123456789ULL)
+#endif
+                    {   ulonglong2* o = reinterpret_cast<ulonglong2*>(out + p);
+                        o[0] = make_ulonglong2(a, b); o[1] = make_ulonglong2(d, h); }
+                } else {
+                    const uint32_t m = 1u + (a != EMPTY) + (b != EMPTY) + (d != EMPTY);
+                    uint32_t p = atomicSub(&s_back[q], m) - m;
+                    out[p++] = h;
+                    if (a != EMPTY) out[p++] = a;
+                    if (b != EMPTY) out[p++] = b;
+                    if (d != EMPTY) out[p++] = d;
+                }
+            });
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nq; i += QUAD_THREADS) {
+        uint32_t p = s_back[i];
+        for (int j = 0; j < 3; j++) { const unsigned long long v = s_slot[j * QUAD_SUB + i]; if (v != EMPTY) out[--p] = v; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ B2/B3 wave sort + RLE
@@ -413,8 +508,11 @@ __device__ __forceinline__ void wave_sort_dispatch(const typename KeyT<KW>::type
 }
 
 // one WAVE per small bucket, straight from HBM (no LDS, no barrier)
+#ifndef GKC_WS_WAVES
+#define GKC_WS_WAVES 5      // waves per SIMD the register budget is cut for: 3 (151 VGPRs) 98 ms, 4: 87 ms, 5: 84 ms, 6: 85 ms per 1.2e10 keys
+#endif
 template <int KW>
-__global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+__global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                              const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O)
 {
     __shared__ uint32_t s_hc[HIST_LDS];
@@ -423,10 +521,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<
     __syncthreads();
     const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
     uint32_t nb_done = 0; unsigned long long nk_done = 0;
+    uint32_t n_next = wave < n_buckets ? b_n[wave] : 0; uint64_t start_next = wave < n_buckets ? b_start[wave] : 0;
     for (uint32_t g = wave; g < n_buckets; g += n_waves) {
-        const uint32_t n = b_n[g];
+        const uint32_t n = n_next; const uint64_t start = start_next;
+        if (g + n_waves < n_buckets) { n_next = b_n[g + n_waves]; start_next = b_start[g + n_waves]; }     // next bucket's descriptor in flight during this sort
         if (n == 0) continue;
-        const uint64_t start = b_start[g];
         if (n > WaveCapBig<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over_count, 1u); O.over_list[slot] = g; } continue; }
         nb_done++; nk_done += n;
         wave_sort_dispatch<KW, WaveCapBig<KW>::KPL_MAX>(src + start, outk, start, n, O, s_hc, lane);
@@ -439,8 +538,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_wave_sort(const typename KeyT<
 // second tier: buckets up to twice the first tier's size (2048 / 1024 keys), one wave each with a double-size network; only
 // ~10 % of the keys come here, so the lower occupancy of this kernel (64+ key registers) does not touch the first tier
 template <int KW> struct WaveCapHuge { static constexpr int KPL = (KW == 1) ? 32 : 16; static constexpr uint32_t CAP = 64 * KPL; };
+#ifndef GKC_WSB_WAVES
+#define GKC_WSB_WAVES 3     // 2 (214 VGPRs): 16.3 ms, 3: 13.4 ms, 4: 13.2 ms
+#endif
 template <int KW>
-__global__ __launch_bounds__(SORT_THREADS) void k_wave_sort_big(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+__global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                                  const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                                  const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
 {
@@ -468,12 +570,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_wave_sort_big(const typename K
 // (~100 keys: a 128-key bitonic network has 28 stages, a 1024-key one 55). No level below the first costs HBM traffic.
 // Only buckets with more than LDS_CAP keys go to the HBM split levels below.
 constexpr int LDS_THREADS = 512;
+#ifndef GKC_LDS_WAVES
+#define GKC_LDS_WAVES 4
+#endif
 template <int KW> struct LdsCap { static constexpr int CAP = (KW == 1) ? 6144 : 3072; static constexpr int KPT = CAP / LDS_THREADS; };
 constexpr uint32_t FINE_TARGET = 320, FINE_MAX_BITS = 8, FINE_NF = 1024, FINE_NP = 64;
 __device__ __forceinline__ uint32_t gpack(uint32_t off, uint32_t cnt, uint32_t uni) { return off | (cnt << 13) | (uni << 27); }
 
 template <int KW>
-__global__ __launch_bounds__(LDS_THREADS, 4) void k_lds_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+__global__ __launch_bounds__(LDS_THREADS, GKC_LDS_WAVES) void k_lds_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                             const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                             const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
 {
@@ -730,23 +835,28 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_flag_block_sums(const uint8
     }
 }
 // in-place exclusive scan of two u64 arrays of n entries (+ totals at [n]) by ONE workgroup, chunked with carry
+constexpr int SCAN2_ITEMS = 8;                  // consecutive elements per thread and round: one workgroup, n / 8192 rounds
 __global__ __launch_bounds__(1024) void k_scan2_u64(uint64_t* __restrict__ a, uint64_t* __restrict__ b, uint64_t n)
 {
     __shared__ uint64_t s_a[16], s_b[16]; __shared__ uint64_t s_ca, s_cb;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) { s_ca = 0; s_cb = 0; }
     __syncthreads();
-    for (uint64_t c0 = 0; c0 < n; c0 += 1024) {
-        const uint64_t i = c0 + t;
-        const uint64_t va = i < n ? a[i] : 0, vb = i < n ? b[i] : 0;
-        uint64_t xa = va, xb = vb;
+    for (uint64_t c0 = 0; c0 < n; c0 += 1024 * SCAN2_ITEMS) {
+        const uint64_t i0 = c0 + (uint64_t)t * SCAN2_ITEMS;
+        uint64_t va[SCAN2_ITEMS], vb[SCAN2_ITEMS], ta = 0, tb = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN2_ITEMS; j++) { va[j] = i0 + j < n ? a[i0 + j] : 0; vb[j] = i0 + j < n ? b[i0 + j] : 0; ta += va[j]; tb += vb[j]; }
+        uint64_t xa = ta, xb = tb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint64_t ya = __shfl_up((unsigned long long)xa, d, 64), yb = __shfl_up((unsigned long long)xb, d, 64); if (lane >= d) { xa += ya; xb += yb; } }
         if (lane == 63) { s_a[wave] = xa; s_b[wave] = xb; }
         __syncthreads();
         uint64_t pa = s_ca, pb = s_cb;
         for (int w = 0; w < wave; w++) { pa += s_a[w]; pb += s_b[w]; }
-        if (i < n) { a[i] = pa + xa - va; b[i] = pb + xb - vb; }
+        uint64_t ra = pa + xa - ta, rb = pb + xb - tb;
+#pragma unroll
+        for (int j = 0; j < SCAN2_ITEMS; j++) if (i0 + j < n) { a[i0 + j] = ra; b[i0 + j] = rb; ra += va[j]; rb += vb[j]; }
         __syncthreads();
         if (t == 1023) { s_ca = pa + xa; s_cb = pb + xb; }
         __syncthreads();
@@ -845,8 +955,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pblk[i] = n_slots / COMPACT_BLK;
-        n_slots += (np + (1ull << bits) + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;      // partitions start on compaction-block boundaries;
-                                                                                             // + one pad slot per sub-bucket (even starts)
+        n_slots += (np + (3ull << bits) + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;      // partitions start on compaction-block boundaries;
+                                                                                             // + up to 3 pad slots per sub-bucket (starts on multiples of 4)
         n_sub += (1ull << bits);
     }
     pblk[nb] = n_slots / COMPACT_BLK;
@@ -874,7 +984,15 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
-        if (KW == 1 && getenv("GKC_SCATTER_NO_PAIR") == nullptr) {
+        if (KW == 1 && getenv("GKC_SCATTER_QUAD") != nullptr) {           // measured slower (double expansion + 3-slot protocol: 119 vs 96 ms), kept for experiments
+            const size_t lds = (size_t)QUAD_SUB * 32;
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+            uint32_t max_bits = 0; for (uint32_t i = 0; i < nb; i++) max_bits = std::max(max_bits, pd[i].sub_bits);
+            uint32_t hl2 = 0; while (((uint32_t)QUAD_SUB << hl2) < (1u << max_bits)) hl2++;
+            hipLaunchKernelGGL(k_expand_scatter_quad, dim3(nb << hl2), dim3(QUAD_THREADS), lds, c->stream, (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start[0].p, (const uint32_t*)B.b_n[0].p, (uint64_t*)B.keysA.p, hl2);
+        } else if (KW == 1 && getenv("GKC_SCATTER_NO_PAIR") == nullptr) {
             const size_t lds = (size_t)MAX_SUB * 12;
             static bool attr_set = false;
             if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
