@@ -342,9 +342,9 @@ struct SortOut {
     uint32_t* cnt32;          // [n_slots] full abundance, written (and later read) only where cnt8 == 255: the flag/abundance
                               // plane costs 1 byte per slot of HBM traffic instead of 4
     unsigned long long* histo; uint32_t histo_max;
-    uint32_t* over_list; uint32_t* over_count;      // buckets too large for one wave -> k_lds_sort
-    uint32_t* over2_list; uint32_t* over2_count;    // buckets too large for LDS (or pathological inside it) -> HBM split level
-    uint32_t* over3_list; uint32_t* over3_count;    // buckets too large for the double-size wave network -> k_lds_sort
+    uint32_t* over_list; uint32_t* over_count;      // buckets too large for the first wave tier -> k_wave_sort_big
+    uint32_t* over2_list; uint32_t* over2_count;    // buckets too large for the workgroup tier -> HBM split level
+    uint32_t* over3_list; uint32_t* over3_count;    // buckets too large for the double-size wave network -> k_wg_sort
     unsigned long long* n_sorted;                   // [0] buckets sorted here [1] keys sorted here
 };
 
@@ -491,8 +491,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     }
 }
 
-// inside k_lds_sort a wave register-sorts up to 512 (u64) / 256 (u128) keys; larger fine groups are split again inside LDS.
-// k_wave_sort (whole small buckets straight from HBM) goes up to 1024 / 512.
+// register capacity of the wave tiers: k_wave_sort up to 1024 (u64) / 512 (u128) keys, k_wave_sort_big twice that
 template <int KW> struct WaveCap { static constexpr int KPL_MAX = (KW == 1) ? 8 : 4; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 template <int KW> struct WaveCapBig { static constexpr int KPL_MAX = (KW == 1) ? 16 : 8; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 
@@ -562,148 +561,103 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(c
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
 }
 
-// One WORKGROUP per bucket of up to LDS_CAP keys (a key-range slice of a partition): the keys are read from HBM once
-// (coalesced, into registers) and split on their next informative bits into <=256 fine groups INSIDE LDS (LDS histogram,
-// LDS cursors, in-place because the keys sit in registers while they are re-placed). Fine groups still too large for a
-// wave (a dense cluster: k-mers starting with the same minimizer, a repeat family) are split again the same way, still in
-// LDS; a group whose keys are all equal is one k-mer. Then every wave register-sorts and run-length-counts fine groups
-// (~100 keys: a 128-key bitonic network has 28 stages, a 1024-key one 55). No level below the first costs HBM traffic.
-// Only buckets with more than LDS_CAP keys go to the HBM split levels below.
-constexpr int LDS_THREADS = 512;
-#ifndef GKC_LDS_WAVES
-#define GKC_LDS_WAVES 4
-#endif
-template <int KW> struct LdsCap { static constexpr int CAP = (KW == 1) ? 6144 : 3072; static constexpr int KPT = CAP / LDS_THREADS; };
-constexpr uint32_t FINE_TARGET = 320, FINE_MAX_BITS = 8, FINE_NF = 1024, FINE_NP = 64;
-__device__ __forceinline__ uint32_t gpack(uint32_t off, uint32_t cnt, uint32_t uni) { return off | (cnt << 13) | (uni << 27); }
-
-template <int KW>
-__global__ __launch_bounds__(LDS_THREADS, GKC_LDS_WAVES) void k_lds_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
-                                                            const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
-                                                            const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
+// Buckets beyond one wave's registers: a WORKGROUP of NW waves holds the bucket in registers (64*KPL keys per wave). Every wave
+// runs the wave network on its part; the merges across waves are the same bitonic steps with the partner in another wave, exchanged
+// through LDS at the SAME (register, lane) coordinate (mirror step: the reflected one) — consecutive lanes touch consecutive LDS
+// words, no bank conflict, and only log2(NW)*(log2(NW)+1)/2 of the stages cross waves (3 for 4 waves, 6 for 8); the half-cleaners
+// below 64*KPL stay inside the waves. Then one run-length count across the workgroup. No data-dependent LDS traffic at all
+// (tools/lds_bench: a random 8-byte LDS access costs 5x a conflict-free one), unlike a split inside LDS.
+template <int KW, int NW, int KPL>
+__global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                        const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+                                                        const uint32_t* __restrict__ list, uint32_t n_list, uint32_t n_min, uint32_t n_max_all /* 0, or: report buckets beyond every tier */, SortOut O)
 {
     typedef typename KeyT<KW>::type key_t;
-    constexpr int CAP = LdsCap<KW>::CAP, KPT = LdsCap<KW>::KPT;
-    __shared__ key_t s_keys[CAP];
-    __shared__ uint32_t s_hist[1 << FINE_MAX_BITS], s_off[(1 << FINE_MAX_BITS) + 1];
-    __shared__ uint32_t s_final[FINE_NF], s_pend[FINE_NP];
-    __shared__ unsigned long long s_or[2];
+    constexpr uint32_t CAPW = 64 * KPL, CAP = NW * CAPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    key_t* s_x = reinterpret_cast<key_t*>(s_raw);                 // [NW][KPL][64] exchange buffer
+    __shared__ key_t s_first[NW], s_last[NW];
+    __shared__ uint32_t s_tails[NW]; __shared__ int s_head[NW];
     __shared__ uint32_t s_hc[HIST_LDS];
-    __shared__ uint32_t s_nfinal, s_npend, s_big;
-    if (threadIdx.x < HIST_LDS) s_hc[threadIdx.x] = 0;
-    uint32_t nb_done = 0; unsigned long long nk_done = 0;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < HIST_LDS) s_hc[t] = 0;
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        int t = threadIdx.x;
-        asm volatile("" : "+v"(t));                              // keep per-lane address math inside the loop (no LICM register blow-up)
-        const int lane = t & 63, wave = t >> 6;
         const uint32_t g = list[li];
         const uint32_t n = b_n[g];
-        if (n == 0) continue;
+        if (n_max_all && n > n_max_all && t == 0) { const uint32_t slot = atomicAdd(O.over2_count, 1u); O.over2_list[slot] = g; }
+        if (n <= n_min || n > CAP) continue;                      // another tier's bucket
         const uint64_t start = b_start[g];
-        if (n > (uint32_t)CAP) { if (t == 0) { const uint32_t slot = atomicAdd(O.over2_count, 1u); O.over2_list[slot] = g; } continue; }
-        __syncthreads();                                         // LDS of the previous bucket fully consumed
-        if (t == 0) { s_nfinal = 0; s_npend = 1; s_pend[0] = gpack(0, n, 0); s_big = 0; }
-        bool first = true;
-        for (;;) {
-            __syncthreads();
-            const uint32_t np = s_npend;
-            if (np == 0 || s_big) break;
-            const uint32_t rg = s_pend[np - 1];
-            const uint32_t off = rg & 8191u, cnt = (rg >> 13) & 16383u;
-            __syncthreads();
-            if (t == 0) s_npend = np - 1;
-            if (t < 2) s_or[t] = 0;
-            if (t < (1 << FINE_MAX_BITS)) s_hist[t] = 0;
-            if (first && cnt <= WaveCap<KW>::CAP) {              // small bucket: straight to a wave, from LDS like the others
-                for (uint32_t i = t; i < cnt; i += LDS_THREADS) s_keys[i] = src[start + i];
-                if (t == 0) { s_final[0] = gpack(0, cnt, 0); s_nfinal = 1; }
-                first = false;
-                continue;
-            }
-            // 1. keys of the range -> registers; which low bits differ at all?
-            key_t kr[KPT];
-            const key_t k0 = first ? src[start] : s_keys[off];
-            key_t acc = 0;
+        key_t v[KPL];
 #pragma unroll
-            for (int i = 0; i < KPT; i++) {
-                const uint32_t idx = i * LDS_THREADS + t;
-                if (idx < cnt) { kr[i] = first ? src[start + idx] : s_keys[off + idx]; acc |= kr[i] ^ k0; }
-            }
-            {   unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
+        for (int r = 0; r < KPL; r++) { const uint32_t i = w * CAPW + r * 64 + lane; v[r] = i < n ? src[start + i] : KeyT<KW>::max(); }
+        bitonic_wave<KW, KPL>(v, lane);
+        key_t* mine = s_x + (size_t)w * CAPW;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { lo |= __shfl_down(lo, d, 64); hi |= __shfl_down(hi, d, 64); }
-                __syncthreads();                                 // every load of the range is done; s_or / s_hist are reset
-                if (lane == 0) { atomicOr(&s_or[0], lo); if (KW == 2) atomicOr(&s_or[1], hi); }
-            }
-            __syncthreads();
-            uint32_t diff_bits;
-            {   const unsigned long long lo = s_or[0], hi = s_or[1];
-                diff_bits = hi ? 128 - __clzll((long long)hi) : (lo ? 64 - __clzll((long long)lo) : 0); }
-            if (diff_bits == 0) {                                // one k-mer, cnt times
-                if (first) for (uint32_t i = t; i < 1; i += LDS_THREADS) s_keys[off] = k0;
-                if (t == 0) { const uint32_t q = s_nfinal; if (q < FINE_NF) { s_final[q] = gpack(off, cnt, 1); s_nfinal = q + 1; } else s_big = 1; }
-                first = false;
-                continue;
-            }
-            uint32_t b2 = 1;
-            while (b2 < FINE_MAX_BITS && b2 < diff_bits && (cnt >> b2) > FINE_TARGET) b2++;
-            const uint32_t shift2 = diff_bits - b2, m2 = (1u << b2) - 1, ngrp = 1u << b2;
-            // 2. LDS histogram of the fine groups
+        for (int SZ = 2; SZ <= NW; SZ <<= 1) {                    // merge sorted runs of SZ/2 waves into runs of SZ waves
+            {   // mirror step: element E <-> E ^ (SZ*CAPW - 1): wave w ^ (SZ-1), register KPL-1-r, lane 63-lane
+                __syncthreads();
 #pragma unroll
-            for (int i = 0; i < KPT; i++) { const uint32_t idx = i * LDS_THREADS + t; if (idx < cnt) atomicAdd(&s_hist[(uint32_t)(kr[i] >> shift2) & m2], 1u); }
-            __syncthreads();
-            // 3. exclusive scan (wave 0: 4 bins per lane) -> group offsets
-            if (wave == 0) {
-                uint32_t c[4], loc = 0;
+                for (int r = 0; r < KPL; r++) mine[r * 64 + lane] = v[r];
+                __syncthreads();
+                const key_t* other = s_x + (size_t)(w ^ (SZ - 1)) * CAPW;
+                const bool low = (w & (SZ >> 1)) == 0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) { c[i] = s_hist[lane * 4 + i]; loc += c[i]; }
-                uint32_t x = loc;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-                uint32_t run = x - loc;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { s_off[lane * 4 + i] = run; run += c[i]; }
-                if (lane == 63) s_off[256] = run;
+                for (int r = 0; r < KPL; r++) { const key_t y = other[(KPL - 1 - r) * 64 + (63 - lane)]; const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
             }
-            __syncthreads();
-            if (t < (1 << FINE_MAX_BITS)) s_hist[t] = s_off[t];    // cursors
-            __syncthreads();
-            // 4. re-place the keys group-contiguously inside the same LDS range (they are all in registers)
 #pragma unroll
-            for (int i = 0; i < KPT; i++) {
-                const uint32_t idx = i * LDS_THREADS + t;
-                if (idx < cnt) { const uint32_t slot = atomicAdd(&s_hist[(uint32_t)(kr[i] >> shift2) & m2], 1u); s_keys[off + slot] = kr[i]; }
+            for (int S = SZ >> 2; S >= 1; S >>= 1) {              // half-cleaners whose partner is another wave: w ^ S, same register and lane
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < KPL; r++) mine[r * 64 + lane] = v[r];
+                __syncthreads();
+                const key_t* other = s_x + (size_t)(w ^ S) * CAPW;
+                const bool low = (w & S) == 0;
+#pragma unroll
+                for (int r = 0; r < KPL; r++) { const key_t y = other[r * 64 + lane]; const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
             }
-            // 5. children: small enough -> final list, else pending
-            if ((uint32_t)t < ngrp) {
-                const uint32_t c = s_off[t + 1] - s_off[t];
-                if (c) {
-                    if (c <= WaveCap<KW>::CAP) { const uint32_t q = atomicAdd(&s_nfinal, 1u); if (q < FINE_NF) s_final[q] = gpack(off + s_off[t], c, 0); else s_big = 1; }
-                    else { const uint32_t q = atomicAdd(&s_npend, 1u); if (q < FINE_NP) s_pend[q] = gpack(off + s_off[t], c, 0); else s_big = 1; }
-                }
-            }
-            first = false;
+            HalfClean<KW, KPL, CAPW / 2>::run(v, lane);           // the rest of the merge stays inside the wave
         }
-        if (s_big) { if (t == 0) { const uint32_t slot = atomicAdd(O.over2_count, 1u); O.over2_list[slot] = g; } continue; }
-        // 6. every wave sorts + counts fine groups out of LDS
-        const uint32_t nf = s_nfinal < FINE_NF ? s_nfinal : FINE_NF;
-        for (uint32_t i = wave; i < nf; i += LDS_THREADS / 64) {
-            const uint32_t f = s_final[i];
-            const uint32_t off = f & 8191u, cnt = (f >> 13) & 16383u;
-            if (f >> 27) {
-                if (lane == 0) {
-                    const uint32_t c = cnt;
-                    outk[start + off] = s_keys[off]; put_count(O, start + off, c);
-                    const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
-                    if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
-                }
-            } else wave_sort_dispatch<KW, WaveCap<KW>::KPL_MAX>(s_keys + off, outk, start + off, cnt, O, s_hc, lane);
+        // run-length count across the workgroup; E = w*CAPW + lane*KPL + r is the sorted rank
+        if (lane == 0) s_first[w] = v[0];
+        if (lane == 63) s_last[w] = v[KPL - 1];
+        __syncthreads();
+        key_t prev_last = Shfl<KW>::up(v[KPL - 1]), next_first = Shfl<KW>::down(v[0]);
+        if (lane == 0 && w > 0) prev_last = s_last[w - 1];
+        if (lane == 63 && w < NW - 1) next_first = s_first[w + 1];
+        const uint32_t E0 = w * CAPW + lane * KPL;
+        uint32_t headm = 0, tailm = 0;
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const uint32_t e = E0 + r;
+            const key_t pv = r ? v[r - 1] : prev_last;
+            const key_t nx = (r < KPL - 1) ? v[r + 1] : next_first;
+            const bool in = e < n;
+            headm |= (uint32_t)(in && (e == 0 || v[r] != pv)) << r;
+            tailm |= (uint32_t)(in && (e == n - 1 || v[r] != nx)) << r;
         }
-        nb_done++; nk_done += n;
+        const uint32_t nt = __popc(tailm);
+        int lh = headm ? (int)(E0 + 31 - __clz((int)headm)) : -1;
+        uint32_t x = nt; int hx = lh;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); const int hy = __shfl_up(hx, d, 64); if (lane >= d) { x += y; hx = hy > hx ? hy : hx; } }
+        if (lane == 63) { s_tails[w] = x; s_head[w] = hx; }
+        __syncthreads();
+        uint32_t idx = x - nt; int cur = __shfl_up(hx, 1, 64); if (lane == 0) cur = -1;
+        for (int ww = 0; ww < w; ww++) { idx += s_tails[ww]; cur = s_head[ww] > cur ? s_head[ww] : cur; }
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+            const int e = (int)E0 + r;
+            if ((headm >> r) & 1) cur = e;
+            if ((tailm >> r) & 1) {
+                const uint32_t c = (uint32_t)(e - cur + 1);
+                outk[start + idx] = v[r]; put_count(O, start + idx, c); idx++;
+                const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
+                if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
+            }
+        }
     }
     __syncthreads();
-    if (threadIdx.x < HIST_LDS && s_hc[threadIdx.x]) atomicAdd(&O.histo[threadIdx.x], (unsigned long long)s_hc[threadIdx.x]);
-    if (threadIdx.x == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
 }
 
 // ------------------------------------------------------------------------------------------------ deeper levels
@@ -1049,10 +1003,24 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             CB_HIP(hipStreamSynchronize(c->stream));
         }
         if (!n_mid2) break;
-        {   ScopedTimer tm(c, "bucket_sort_lds");                 // denser buckets: split + sort inside LDS
-            const unsigned grid = (unsigned)std::min<uint64_t>(n_mid2, 256 * 8);
-            hipLaunchKernelGGL((k_lds_sort<KW>), dim3(grid), dim3(LDS_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
-                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, O);
+        {
+            ScopedTimer tm(c, "bucket_sort_wg");                  // beyond one wave: workgroups of 4 / 8 waves, merges across waves through LDS
+            constexpr int K1 = WaveCapHuge<KW>::KPL / 2;
+            constexpr uint32_t C0 = WaveCapHuge<KW>::CAP, C1 = 4 * 64 * K1, C2 = 8 * 64 * K1;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 4, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C1 * sizeof(key_t)));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 8, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C2 * sizeof(key_t)));
+                attr_set = true;
+            }
+            // measured (ms per 1.2e10 keys, wg tier + HBM split levels + their sorts): up to 4096 keys here: 40, up to 8192: 44, none: 47
+            const uint32_t wg_max = getenv("GKC_WG_MAX") ? (uint32_t)atoi(getenv("GKC_WG_MAX")) : C1;     // buckets beyond go to the HBM split
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_mid2, 256 * 4);
+            hipLaunchKernelGGL((k_wg_sort<KW, 4, K1>), dim3(grid), dim3(256), C1 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, wg_max >= C1 ? C0 : 0xffffffffu, std::max(wg_max, C0), O);
+            if (wg_max > C1)
+            hipLaunchKernelGGL((k_wg_sort<KW, 8, K1>), dim3(grid), dim3(512), C2 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, C1, 0u, O);
             CB_HIP(hipGetLastError());
         }
         uint32_t n_over = 0;
