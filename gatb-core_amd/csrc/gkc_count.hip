@@ -400,34 +400,49 @@ template <> struct Shfl<2> {
         return ((u128)hi << 64) | lo; }
 };
 
+// In-lane compare-exchange. F (8-byte keys only): the keys of the bucket carry the exponent tag of a double in their 12 top bits (see
+// TAG64 below), so they are positive normal doubles whose order is the integer order, and the exchange is the two native 64-bit
+// instructions v_min_f64 / v_max_f64 instead of a 64-bit compare and four selects. Cross-lane steps compare the same bit patterns as integers.
+constexpr uint64_t TAG64 = 0x4330000000000000ULL, TAG64_MANT = 0x000FFFFFFFFFFFFFULL;
+template <int KW, bool F> __device__ __forceinline__ void ce_inlane(typename KeyT<KW>::type& a, typename KeyT<KW>::type& b)
+{
+    if constexpr (F && KW == 1) {
+        const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+        double lo, hi;
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+        a = (uint64_t)__double_as_longlong(lo); b = (uint64_t)__double_as_longlong(hi);
+    } else { const typename KeyT<KW>::type x = a, y = b; const bool sw = y < x; a = sw ? y : x; b = sw ? x : y; }
+}
+
 // bitonic network over N = 64*KPL keys (blocked index e = lane*KPL + r), all comparators ascending, as compile-time recursion so
 // that every lane mask is a template constant
-template <int KW, int KPL, int S> struct HalfClean {                    // e <-> e ^ S, then S/2, ..., 1
+template <int KW, int KPL, int S, bool F = false> struct HalfClean {                    // e <-> e ^ S, then S/2, ..., 1
     static __device__ __forceinline__ void run(typename KeyT<KW>::type (&v)[KPL], const int lane) {
         typedef typename KeyT<KW>::type key_t;
         if constexpr (S >= 1) {
             if constexpr (S < KPL) {
 #pragma unroll
-                for (int r = 0; r < KPL; r++) if ((r & S) == 0) { key_t a = v[r], b = v[r | S]; const bool sw = b < a; v[r] = sw ? b : a; v[r | S] = sw ? a : b; }
+                for (int r = 0; r < KPL; r++) if ((r & S) == 0) ce_inlane<KW, F>(v[r], v[r | S]);
             } else {
                 constexpr int LS = S / KPL;
                 const bool low = (lane & LS) == 0;
 #pragma unroll
                 for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LS>(v[r]); const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
             }
-            HalfClean<KW, KPL, S / 2>::run(v, lane);
+            HalfClean<KW, KPL, S / 2, F>::run(v, lane);
         }
     }
 };
-template <int KW, int KPL, int SIZE> struct BitonicMerge {              // sorted runs of SIZE/2 -> sorted runs of SIZE
+template <int KW, int KPL, int SIZE, bool F = false> struct BitonicMerge {              // sorted runs of SIZE/2 -> sorted runs of SIZE
     static __device__ __forceinline__ void run(typename KeyT<KW>::type (&v)[KPL], const int lane) {
         typedef typename KeyT<KW>::type key_t;
         if constexpr (SIZE >= 2) {
-            BitonicMerge<KW, KPL, SIZE / 2>::run(v, lane);
+            BitonicMerge<KW, KPL, SIZE / 2, F>::run(v, lane);
             // mirror step: e <-> e ^ (SIZE-1)
             if constexpr (SIZE <= KPL) {
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const int pr = r ^ (SIZE - 1); if (pr > r) { key_t a = v[r], b = v[pr]; const bool sw = b < a; v[r] = sw ? b : a; v[pr] = sw ? a : b; } }
+                for (int r = 0; r < KPL; r++) { const int pr = r ^ (SIZE - 1); if (pr > r) ce_inlane<KW, F>(v[r], v[pr]); }
             } else {
                 constexpr int LMASK = SIZE / KPL - 1, TOP = (SIZE / KPL) >> 1;
                 const bool low = (lane & TOP) == 0;
@@ -437,26 +452,32 @@ template <int KW, int KPL, int SIZE> struct BitonicMerge {              // sorte
 #pragma unroll
                 for (int r = 0; r < KPL; r++) v[r] = w[r];
             }
-            HalfClean<KW, KPL, SIZE / 4>::run(v, lane);
+            HalfClean<KW, KPL, SIZE / 4, F>::run(v, lane);
         }
     }
 };
-template <int KW, int KPL>
-__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane) { BitonicMerge<KW, KPL, 64 * KPL>::run(v, lane); }
+template <int KW, int KPL, bool F = false>
+__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane) { BitonicMerge<KW, KPL, 64 * KPL, F>::run(v, lane); }
 
 // sort + run-length count one bucket of n <= 64*KPL keys held by one wave; writes distinct keys / abundances at
 // outk[start + j], O.cnt[start + j] (j-th distinct key) — ascending; slots start+nd .. start+n-1 keep abundance 0.
-template <int KW, int KPL>
+template <int KW, int KPL, bool F = false>
 __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* src /* first key of the bucket: LDS or global */,
                                                  typename KeyT<KW>::type* __restrict__ outk,
                                                  const uint64_t start, const uint32_t n, const SortOut& O, uint32_t* s_hc, const int lane)
 {
     typedef typename KeyT<KW>::type key_t;
     key_t v[KPL];
+    key_t top = 0;                                               // F: the 12 top bits every key of the bucket shares (replaced by the tag while sorting)
 #pragma unroll
     for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[i] : KeyT<KW>::max(); }
+    if constexpr (F && KW == 1) {
+        top = src[0] & ~TAG64_MANT;
+#pragma unroll
+        for (int r = 0; r < KPL; r++) v[r] = (v[r] & TAG64_MANT) | TAG64;          // padding (all ones) becomes TAG64_PAD: above every key
+    }
 #ifndef GKC_EXP_NOSORT
-    bitonic_wave<KW, KPL>(v, lane);
+    bitonic_wave<KW, KPL, F>(v, lane);
 #endif
     // run-length count (B3). e = lane*KPL + r is the sorted rank
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
@@ -484,7 +505,8 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
         if ((headm >> r) & 1) cur = e;
         if ((tailm >> r) & 1) {
             const uint32_t c = (uint32_t)(e - cur + 1);
-            outk[start + idx] = v[r]; put_count(O, start + idx, c); idx++;
+            if constexpr (F && KW == 1) outk[start + idx] = (v[r] & TAG64_MANT) | top; else outk[start + idx] = v[r];
+            put_count(O, start + idx, c); idx++;
             const uint32_t hb = c >= O.histo_max ? O.histo_max : c;              // Histogram::inc (Histogram.hpp:92)
             if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
         }
@@ -495,22 +517,22 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
 template <int KW> struct WaveCap { static constexpr int KPL_MAX = (KW == 1) ? 8 : 4; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 template <int KW> struct WaveCapBig { static constexpr int KPL_MAX = (KW == 1) ? 16 : 8; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 
-template <int KW, int KPLMAX>
+template <int KW, int KPLMAX, bool F = false>
 __device__ __forceinline__ void wave_sort_dispatch(const typename KeyT<KW>::type* src, typename KeyT<KW>::type* __restrict__ outk, const uint64_t start,
                                                    const uint32_t n, const SortOut& O, uint32_t* s_hc, const int lane)
 {
-    if (n <= 64) wave_sort_bucket<KW, 1>(src, outk, start, n, O, s_hc, lane);
-    else if (n <= 128) wave_sort_bucket<KW, 2>(src, outk, start, n, O, s_hc, lane);
-    else if (n <= 256 || KPLMAX == 4) wave_sort_bucket<KW, 4>(src, outk, start, n, O, s_hc, lane);
-    else if (n <= 512 || KPLMAX == 8) wave_sort_bucket<KW, (KPLMAX >= 8 ? 8 : 4)>(src, outk, start, n, O, s_hc, lane);
-    else wave_sort_bucket<KW, KPLMAX>(src, outk, start, n, O, s_hc, lane);
+    if (n <= 64) wave_sort_bucket<KW, 1, F>(src, outk, start, n, O, s_hc, lane);
+    else if (n <= 128) wave_sort_bucket<KW, 2, F>(src, outk, start, n, O, s_hc, lane);
+    else if (n <= 256 || KPLMAX == 4) wave_sort_bucket<KW, 4, F>(src, outk, start, n, O, s_hc, lane);
+    else if (n <= 512 || KPLMAX == 8) wave_sort_bucket<KW, (KPLMAX >= 8 ? 8 : 4), F>(src, outk, start, n, O, s_hc, lane);
+    else wave_sort_bucket<KW, KPLMAX, F>(src, outk, start, n, O, s_hc, lane);
 }
 
 // one WAVE per small bucket, straight from HBM (no LDS, no barrier)
 #ifndef GKC_WS_WAVES
 #define GKC_WS_WAVES 5      // waves per SIMD the register budget is cut for: 3 (151 VGPRs) 98 ms, 4: 87 ms, 5: 84 ms, 6: 85 ms per 1.2e10 keys
 #endif
-template <int KW>
+template <int KW, bool F>
 __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                              const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O)
 {
@@ -527,7 +549,7 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const 
         if (n == 0) continue;
         if (n > WaveCapBig<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over_count, 1u); O.over_list[slot] = g; } continue; }
         nb_done++; nk_done += n;
-        wave_sort_dispatch<KW, WaveCapBig<KW>::KPL_MAX>(src + start, outk, start, n, O, s_hc, lane);
+        wave_sort_dispatch<KW, WaveCapBig<KW>::KPL_MAX, F>(src + start, outk, start, n, O, s_hc, lane);
     }
     __syncthreads();
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
@@ -540,7 +562,7 @@ template <int KW> struct WaveCapHuge { static constexpr int KPL = (KW == 1) ? 32
 #ifndef GKC_WSB_WAVES
 #define GKC_WSB_WAVES 3     // 2 (214 VGPRs): 16.3 ms, 3: 13.4 ms, 4: 13.2 ms
 #endif
-template <int KW>
+template <int KW, bool F>
 __global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                                  const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                                  const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
@@ -555,7 +577,7 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(c
         const uint32_t n = b_n[g];
         const uint64_t start = b_start[g];
         if (n > WaveCapHuge<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over3_count, 1u); O.over3_list[slot] = g; } continue; }
-        wave_sort_bucket<KW, WaveCapHuge<KW>::KPL>(src + start, outk, start, n, O, s_hc, lane);
+        wave_sort_bucket<KW, WaveCapHuge<KW>::KPL, F>(src + start, outk, start, n, O, s_hc, lane);
     }
     __syncthreads();
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
@@ -567,7 +589,7 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(c
 // words, no bank conflict, and only log2(NW)*(log2(NW)+1)/2 of the stages cross waves (3 for 4 waves, 6 for 8); the half-cleaners
 // below 64*KPL stay inside the waves. Then one run-length count across the workgroup. No data-dependent LDS traffic at all
 // (tools/lds_bench: a random 8-byte LDS access costs 5x a conflict-free one), unlike a split inside LDS.
-template <int KW, int NW, int KPL>
+template <int KW, int NW, int KPL, bool F>
 __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                         const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                         const uint32_t* __restrict__ list, uint32_t n_list, uint32_t n_min, uint32_t n_max_all /* 0, or: report buckets beyond every tier */, SortOut O)
@@ -590,7 +612,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
         key_t v[KPL];
 #pragma unroll
         for (int r = 0; r < KPL; r++) { const uint32_t i = w * CAPW + r * 64 + lane; v[r] = i < n ? src[start + i] : KeyT<KW>::max(); }
-        bitonic_wave<KW, KPL>(v, lane);
+        key_t top = 0;
+        if constexpr (F && KW == 1) {
+            top = src[start] & ~TAG64_MANT;
+#pragma unroll
+            for (int r = 0; r < KPL; r++) v[r] = (v[r] & TAG64_MANT) | TAG64;
+        }
+        bitonic_wave<KW, KPL, F>(v, lane);
         key_t* mine = s_x + (size_t)w * CAPW;
 #pragma unroll
         for (int SZ = 2; SZ <= NW; SZ <<= 1) {                    // merge sorted runs of SZ/2 waves into runs of SZ waves
@@ -615,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
 #pragma unroll
                 for (int r = 0; r < KPL; r++) { const key_t y = other[r * 64 + lane]; const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
             }
-            HalfClean<KW, KPL, CAPW / 2>::run(v, lane);           // the rest of the merge stays inside the wave
+            HalfClean<KW, KPL, CAPW / 2, F>::run(v, lane);        // the rest of the merge stays inside the wave
         }
         // run-length count across the workgroup; E = w*CAPW + lane*KPL + r is the sorted rank
         if (lane == 0) s_first[w] = v[0];
@@ -650,7 +678,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
             if ((headm >> r) & 1) cur = e;
             if ((tailm >> r) & 1) {
                 const uint32_t c = (uint32_t)(e - cur + 1);
-                outk[start + idx] = v[r]; put_count(O, start + idx, c); idx++;
+                if constexpr (F && KW == 1) outk[start + idx] = (v[r] & TAG64_MANT) | top; else outk[start + idx] = v[r];
+                put_count(O, start + idx, c); idx++;
                 const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
                 if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
             }
@@ -965,6 +994,10 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     O.n_sorted = (unsigned long long*)B.misc.p;
 
     // --- levels: sort what fits one wave, split the rest on the next key bits, repeat
+    uint32_t min_bits1 = 64; for (uint32_t i = 0; i < nb; i++) min_bits1 = std::min(min_bits1, pd[i].sub_bits);
+    // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
+    const bool tag = KW == 1 && 2 * k - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
+    constexpr bool FT = KW == 1;
     int cur = 0;                                 // bucket arrays b_*[cur]
     uint64_t n_buckets = n_sub;
     key_t* src = (key_t*)B.keysA.p;
@@ -985,7 +1018,9 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipMemsetAsync(B.over3.p, 0, 4, c->stream));
         {   ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
             const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
-            hipLaunchKernelGGL((k_wave_sort<KW>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+            if (tag) hipLaunchKernelGGL((k_wave_sort<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
+            else hipLaunchKernelGGL((k_wave_sort<KW, false>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
             CB_HIP(hipGetLastError());
         }
@@ -996,7 +1031,9 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         uint32_t n_mid2 = 0;
         {   ScopedTimer tm(c, "bucket_sort_big");                 // up to 2x the first tier: double-size wave network
             const unsigned grid = (unsigned)std::min<uint64_t>((n_mid + 3) / 4, 256 * 16);
-            hipLaunchKernelGGL((k_wave_sort_big<KW>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+            if (tag) hipLaunchKernelGGL((k_wave_sort_big<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, O);
+            else hipLaunchKernelGGL((k_wave_sort_big<KW, false>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, O);
             CB_HIP(hipGetLastError());
             CB_HIP(hipMemcpyAsync(&n_mid2, B.over3.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1009,18 +1046,25 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             constexpr uint32_t C0 = WaveCapHuge<KW>::CAP, C1 = 4 * 64 * K1, C2 = 8 * 64 * K1;
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 4, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C1 * sizeof(key_t)));
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 8, K1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C2 * sizeof(key_t)));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 4, K1, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C1 * sizeof(key_t)));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 4, K1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C1 * sizeof(key_t)));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 8, K1, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C2 * sizeof(key_t)));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wg_sort<KW, 8, K1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(C2 * sizeof(key_t)));
                 attr_set = true;
             }
             // measured (ms per 1.2e10 keys, wg tier + HBM split levels + their sorts): up to 4096 keys here: 40, up to 8192: 44, none: 47
             const uint32_t wg_max = getenv("GKC_WG_MAX") ? (uint32_t)atoi(getenv("GKC_WG_MAX")) : C1;     // buckets beyond go to the HBM split
             const unsigned grid = (unsigned)std::min<uint64_t>(n_mid2, 256 * 4);
-            hipLaunchKernelGGL((k_wg_sort<KW, 4, K1>), dim3(grid), dim3(256), C1 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+            if (tag) hipLaunchKernelGGL((k_wg_sort<KW, 4, K1, FT>), dim3(grid), dim3(256), C1 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, wg_max >= C1 ? C0 : 0xffffffffu, std::max(wg_max, C0), O);
-            if (wg_max > C1)
-            hipLaunchKernelGGL((k_wg_sort<KW, 8, K1>), dim3(grid), dim3(512), C2 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+            else hipLaunchKernelGGL((k_wg_sort<KW, 4, K1, false>), dim3(grid), dim3(256), C1 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, wg_max >= C1 ? C0 : 0xffffffffu, std::max(wg_max, C0), O);
+            if (wg_max > C1) {
+            if (tag) hipLaunchKernelGGL((k_wg_sort<KW, 8, K1, FT>), dim3(grid), dim3(512), C2 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, C1, 0u, O);
+            else hipLaunchKernelGGL((k_wg_sort<KW, 8, K1, false>), dim3(grid), dim3(512), C2 * sizeof(key_t), c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over3_list, n_mid2, C1, 0u, O);
+            }
             CB_HIP(hipGetLastError());
         }
         uint32_t n_over = 0;
