@@ -21,10 +21,15 @@ struct gkc_error { int code; std::string msg; };
 #define GKC_TRY(expr) do { int rc_ = (expr); if (rc_ != GKC_OK) return rc_; } while (0)
 
 // ------------------------------------------------------------------------------------------------ geometry
-// Stage A tile: one 256-thread workgroup scans TILE k-mer start positions (16 per thread) plus a halo.
-constexpr int SCAN_THREADS = 256;
+// Stage A tile: one 512-thread workgroup scans TILE k-mer start positions (16 per thread) plus a halo. 512 threads share one set of
+// per-partition LDS counters (16 KB at 4096 partitions): 2 workgroups = 16 waves per CU fit in LDS, with 256 threads only 12 did
+// (measured: scan 64 -> 54 ms).
+constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_PER_THREAD = 16;
-constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;      // 4096 positions
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;      // 8192 positions
+constexpr int DESC_START_BITS = 13, DESC_NBK_BITS = 6;         // record descriptor: [partition : 13][nbK-1 : 6][start in tile : 13]
+static_assert(SCAN_TILE == (1 << DESC_START_BITS), "descriptor start field");
+constexpr uint32_t DESC_PARTS_MAX = 1u << (32 - DESC_START_BITS - DESC_NBK_BITS);
 constexpr int SCAN_HALO_WORDS = 4;                             // 64 bases of look-ahead (k<=63)
 constexpr int SCAN_WORDS = SCAN_TILE / 16 + SCAN_HALO_WORDS;   // 16-base words per tile
 

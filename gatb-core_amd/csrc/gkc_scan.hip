@@ -9,7 +9,7 @@
 //   A6 SuperKmer::save + SuperKmerBinFiles      kmer/impl/Model.hpp:1386-1471, tools/storage/impl/Storage.cpp:360-580
 //
 // MI355X design (not a translation of the per-thread rolling loop of the reference):
-//   * one 256-thread workgroup per tile of 4096 k-mer start positions; ASCII is read once with coalesced 16-byte loads
+//   * one 512-thread workgroup per tile of 8192 k-mer start positions; ASCII is read once with coalesced 16-byte loads
 //     and turned into three bit-planes in LDS (big-endian 2-bit, little-endian 2-bit, invalid mask);
 //   * the minimizer order key of every m-mer is computed position-parallel (lexicographic/KMC2 order: pure ALU, the
 //     reverse complement comes from the little-endian plane for free; frequency order: one 4-byte gather from an
@@ -134,7 +134,7 @@ __device__ __forceinline__ void load16(const uint8_t* bases, uint64_t g0, uint64
 // leaves a [workgroup][partition] matrix, a tiny prefix kernel turns it into private record ranges, and the emit launch
 // needs no global atomic at all. !LDSPART (nb_partitions too large for LDS): global atomics per record.
 template <bool EMIT, int RW, bool LDSPART>
-__global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
+__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_part[];       // per-partition record counter of this workgroup (4 B)
     __shared__ uint32_t s_be[SCAN_WORDS + BE_PAD];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 3) void k_scan_tile(ScanParams P)
                 if (P.dbg_noatomic) continue;
                 if (LDSPART) {
                     atomicAdd(&s_part[part], 1u);
-                    if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = (part << 18) | ((nbk - 1) << 12) | (uint32_t)start;
+                    if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = (part << (DESC_START_BITS + DESC_NBK_BITS)) | ((nbk - 1) << DESC_START_BITS) | (uint32_t)start;
                 } else { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
             } else {
                 const unsigned long long slot = LDSPART ? (P.wg_base[(uint64_t)blockIdx.x * P.n_parts + part] + atomicAdd(&s_part[part], 1u))
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_emit_desc(ScanParams P)
         for (uint32_t i = t; i < td.y; i += SCAN_THREADS) {
             const uint32_t d = desc[td.x + i];
             if (d == 0xFFFFFFFFu) continue;
-            const uint32_t part = d >> 18, nbk = ((d >> 12) & 63u) + 1u; const int start = (int)(d & 4095u);
+            const uint32_t part = d >> (DESC_START_BITS + DESC_NBK_BITS), nbk = ((d >> DESC_START_BITS) & ((1u << DESC_NBK_BITS) - 1)) + 1u; const int start = (int)(d & (uint32_t)(SCAN_TILE - 1));
             const unsigned long long slot = atomicAdd(&s_cur[part], 1ULL);
             atomicAdd(&s_km[part], nbk);
             store_record<RW>(s_be, start, nbk, P.k, P.arena, slot);
@@ -474,7 +474,7 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
 }
 
 constexpr uint32_t SCAN_LDS_PARTS_MAX = 16384;     // 64 KB of LDS counters at most
-constexpr size_t SCAN_STATIC_LDS = 32 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
+constexpr size_t SCAN_STATIC_LDS = 64 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
 
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
 {
@@ -530,10 +530,10 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     P.wg_cnt = ldspart ? (uint32_t*)((unsigned long long*)c->d_scan_matrix.p + (size_t)grid_n * Pn) : nullptr;
     P.rec_off = cnt + 2 * (size_t)Pn;
     // descriptor stream (count pass -> emit pass): DESC_PER_TILE u32 per tile on average, per-workgroup regions
-    const bool use_desc = ldspart && Pn <= 16384 && getenv("GKC_SCAN_NO_DESC") == nullptr;
+    const bool use_desc = ldspart && Pn <= DESC_PARTS_MAX && getenv("GKC_SCAN_NO_DESC") == nullptr;
     if (use_desc) {
         const uint64_t tiles_per_wg = (n_tiles + grid_n - 1) / grid_n;
-        const uint64_t cap = tiles_per_wg * 640;
+        const uint64_t cap = tiles_per_wg * (SCAN_TILE * 5 / 32);
         if (cap < (1ULL << 32)) {
             GKC_TRY(c->ensure(c->d_desc, (size_t)grid_n * cap * 4));
             GKC_TRY(c->ensure(c->d_desc_tile, (size_t)n_tiles * 8));
