@@ -795,27 +795,35 @@ __global__ void k_gather_buckets(const uint32_t* __restrict__ list, uint32_t n, 
 // cnt[slot] != 0 marks a distinct k-mer (key in keys[slot]); partitions start on COMPACT_BLK-aligned slots, so the
 // per-block prefix directly yields per-partition offsets.
 constexpr int COMPACT_THREADS = 1024, COMPACT_ITEMS = 4, COMPACT_BLK = COMPACT_THREADS * COMPACT_ITEMS;
-__global__ __launch_bounds__(COMPACT_THREADS) void k_flag_block_sums(const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ cnt32, uint64_t n_slots,
-                                                                      int32_t amin, int32_t amax, uint64_t* __restrict__ bs_distinct, uint64_t* __restrict__ bs_solid)
+// one WAVE per compaction block (4096 flag bytes = 64 lanes x 4 x 16-byte loads), no LDS, no barrier
+constexpr int BSUM_THREADS = 256;
+__global__ __launch_bounds__(BSUM_THREADS) void k_flag_block_sums(const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ cnt32, uint64_t n_blocks,
+                                                                   int32_t amin, int32_t amax, uint64_t* __restrict__ bs_distinct, uint64_t* __restrict__ bs_solid)
 {
-    __shared__ uint32_t s_d[COMPACT_THREADS / 64], s_s[COMPACT_THREADS / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * COMPACT_BLK + (uint64_t)threadIdx.x * COMPACT_ITEMS;      // n_slots is a multiple of COMPACT_BLK
+    static_assert(COMPACT_BLK == 64 * 4 * 16, "one wave covers a block with four 16-byte loads per lane");
+    const uint64_t blk = (uint64_t)blockIdx.x * (BSUM_THREADS / 64) + (threadIdx.x >> 6);
+    if (blk >= n_blocks) return;
+    const int lane = threadIdx.x & 63;
+    const bool all_solid = amin <= 1 && amax == 0x7fffffff;
     uint32_t d = 0, s = 0;
-    const uint32_t v = *reinterpret_cast<const uint32_t*>(cnt8 + base);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t b = (v >> (8 * i)) & 255u;
-        if (b) { const uint32_t c = count_at(cnt8, cnt32, base + i, b); d++; s += ((int32_t)c >= amin && (int32_t)c <= amax); }
+    for (int j = 0; j < 4; j++) {
+        const uint64_t base = blk * COMPACT_BLK + (uint64_t)(j * 64 + lane) * 16;
+        const uint4 q = *reinterpret_cast<const uint4*>(cnt8 + base);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 255u;
+            if (b) {
+                d++;
+                if (!all_solid) { const uint32_t c = count_at(cnt8, cnt32, base + i, b); s += ((int32_t)c >= amin && (int32_t)c <= amax); }
+            }
+        }
     }
+    if (all_solid) s = d;
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) { d += __shfl_down(d, dd, 64); s += __shfl_down(s, dd, 64); }
-    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_s[threadIdx.x >> 6] = s; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t td = 0, ts = 0;
-        for (int w = 0; w < COMPACT_THREADS / 64; w++) { td += s_d[w]; ts += s_s[w]; }
-        bs_distinct[blockIdx.x] = td; bs_solid[blockIdx.x] = ts;
-    }
+    if (lane == 0) { bs_distinct[blk] = d; bs_solid[blk] = s; }
 }
 // in-place exclusive scan of two u64 arrays of n entries (+ totals at [n]) by ONE workgroup, chunked with carry
 constexpr int SCAN2_ITEMS = 8;                  // consecutive elements per thread and round: one workgroup, n / 8192 rounds
@@ -1137,7 +1145,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     std::vector<uint64_t> ptot((size_t)(nb + 1) * 2);
     {   ScopedTimer tm(c, "compact");
         if (n_blocks) {
-            hipLaunchKernelGGL(k_flag_block_sums, dim3((unsigned)n_blocks), dim3(COMPACT_THREADS), 0, c->stream, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, n_slots, c->amin, c->amax,
+            hipLaunchKernelGGL(k_flag_block_sums, dim3((unsigned)((n_blocks + BSUM_THREADS / 64 - 1) / (BSUM_THREADS / 64))), dim3(BSUM_THREADS), 0, c->stream, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, n_blocks, c->amin, c->amax,
                                (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p);
         }
         hipLaunchKernelGGL(k_scan2_u64, dim3(1), dim3(1024), 0, c->stream, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks);
