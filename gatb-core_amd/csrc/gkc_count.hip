@@ -825,34 +825,53 @@ __global__ __launch_bounds__(BSUM_THREADS) void k_flag_block_sums(const uint8_t*
     for (int dd = 32; dd >= 1; dd >>= 1) { d += __shfl_down(d, dd, 64); s += __shfl_down(s, dd, 64); }
     if (lane == 0) { bs_distinct[blk] = d; bs_solid[blk] = s; }
 }
-// in-place exclusive scan of two u64 arrays of n entries (+ totals at [n]) by ONE workgroup, chunked with carry
-constexpr int SCAN2_ITEMS = 8;                  // consecutive elements per thread and round: one workgroup, n / 8192 rounds
-__global__ __launch_bounds__(1024) void k_scan2_u64(uint64_t* __restrict__ a, uint64_t* __restrict__ b, uint64_t n)
-{
-    __shared__ uint64_t s_a[16], s_b[16]; __shared__ uint64_t s_ca, s_cb;
+// in-place exclusive scan of two u64 arrays of n entries (+ totals at [n]) in three launches: every workgroup scans its own
+// chunk of 8192 entries and leaves the chunk totals, one workgroup scans the totals, a third pass adds them back
+constexpr int SCAN2_ITEMS = 8, SCAN2_CHUNK = 1024 * SCAN2_ITEMS;
+__device__ __forceinline__ void wg_scan2(uint64_t ta, uint64_t tb, uint64_t& ea, uint64_t& eb, uint64_t& tota, uint64_t& totb, uint64_t* s_a, uint64_t* s_b)
+{   // exclusive prefix of (ta, tb) over the 1024 threads of the workgroup + workgroup totals
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) { s_ca = 0; s_cb = 0; }
+    uint64_t xa = ta, xb = tb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t ya = __shfl_up((unsigned long long)xa, d, 64), yb = __shfl_up((unsigned long long)xb, d, 64); if (lane >= d) { xa += ya; xb += yb; } }
+    if (lane == 63) { s_a[wave] = xa; s_b[wave] = xb; }
     __syncthreads();
-    for (uint64_t c0 = 0; c0 < n; c0 += 1024 * SCAN2_ITEMS) {
-        const uint64_t i0 = c0 + (uint64_t)t * SCAN2_ITEMS;
-        uint64_t va[SCAN2_ITEMS], vb[SCAN2_ITEMS], ta = 0, tb = 0;
+    uint64_t pa = 0, pb = 0; tota = 0; totb = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) { pa += s_a[w]; pb += s_b[w]; } tota += s_a[w]; totb += s_b[w]; }
+    ea = pa + xa - ta; eb = pb + xb - tb;
+}
+__global__ __launch_bounds__(1024) void k_scan2_chunks(uint64_t* __restrict__ a, uint64_t* __restrict__ b, uint64_t n, uint64_t* __restrict__ ca, uint64_t* __restrict__ cb)
+{
+    __shared__ uint64_t s_a[16], s_b[16];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN2_CHUNK + (uint64_t)threadIdx.x * SCAN2_ITEMS;
+    uint64_t va[SCAN2_ITEMS], vb[SCAN2_ITEMS], ta = 0, tb = 0;
 #pragma unroll
-        for (int j = 0; j < SCAN2_ITEMS; j++) { va[j] = i0 + j < n ? a[i0 + j] : 0; vb[j] = i0 + j < n ? b[i0 + j] : 0; ta += va[j]; tb += vb[j]; }
-        uint64_t xa = ta, xb = tb;
+    for (int j = 0; j < SCAN2_ITEMS; j++) { va[j] = i0 + j < n ? a[i0 + j] : 0; vb[j] = i0 + j < n ? b[i0 + j] : 0; ta += va[j]; tb += vb[j]; }
+    uint64_t ra, rb, tota, totb;
+    wg_scan2(ta, tb, ra, rb, tota, totb, s_a, s_b);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint64_t ya = __shfl_up((unsigned long long)xa, d, 64), yb = __shfl_up((unsigned long long)xb, d, 64); if (lane >= d) { xa += ya; xb += yb; } }
-        if (lane == 63) { s_a[wave] = xa; s_b[wave] = xb; }
-        __syncthreads();
-        uint64_t pa = s_ca, pb = s_cb;
-        for (int w = 0; w < wave; w++) { pa += s_a[w]; pb += s_b[w]; }
-        uint64_t ra = pa + xa - ta, rb = pb + xb - tb;
+    for (int j = 0; j < SCAN2_ITEMS; j++) if (i0 + j < n) { a[i0 + j] = ra; b[i0 + j] = rb; ra += va[j]; rb += vb[j]; }
+    if (threadIdx.x == 0) { ca[blockIdx.x] = tota; cb[blockIdx.x] = totb; }
+}
+__global__ __launch_bounds__(1024) void k_scan2_totals(uint64_t* __restrict__ ca, uint64_t* __restrict__ cb, uint32_t n_chunks, uint64_t* __restrict__ a, uint64_t* __restrict__ b, uint64_t n)
+{   // n_chunks <= 1024 * SCAN2_ITEMS (n < 2^26 entries): one round
+    __shared__ uint64_t s_a[16], s_b[16];
+    const uint32_t i0 = threadIdx.x * SCAN2_ITEMS;
+    uint64_t va[SCAN2_ITEMS], vb[SCAN2_ITEMS], ta = 0, tb = 0;
 #pragma unroll
-        for (int j = 0; j < SCAN2_ITEMS; j++) if (i0 + j < n) { a[i0 + j] = ra; b[i0 + j] = rb; ra += va[j]; rb += vb[j]; }
-        __syncthreads();
-        if (t == 1023) { s_ca = pa + xa; s_cb = pb + xb; }
-        __syncthreads();
-    }
-    if (t == 0) { a[n] = s_ca; b[n] = s_cb; }
+    for (int j = 0; j < SCAN2_ITEMS; j++) { va[j] = i0 + j < n_chunks ? ca[i0 + j] : 0; vb[j] = i0 + j < n_chunks ? cb[i0 + j] : 0; ta += va[j]; tb += vb[j]; }
+    uint64_t ra, rb, tota, totb;
+    wg_scan2(ta, tb, ra, rb, tota, totb, s_a, s_b);
+#pragma unroll
+    for (int j = 0; j < SCAN2_ITEMS; j++) if (i0 + j < n_chunks) { ca[i0 + j] = ra; cb[i0 + j] = rb; ra += va[j]; rb += vb[j]; }
+    if (threadIdx.x == 0) { a[n] = tota; b[n] = totb; }
+}
+__global__ __launch_bounds__(1024) void k_scan2_add(uint64_t* __restrict__ a, uint64_t* __restrict__ b, uint64_t n, const uint64_t* __restrict__ ca, const uint64_t* __restrict__ cb)
+{
+    const uint64_t oa = ca[blockIdx.x], ob = cb[blockIdx.x];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN2_CHUNK + (uint64_t)threadIdx.x * SCAN2_ITEMS;
+#pragma unroll
+    for (int j = 0; j < SCAN2_ITEMS; j++) if (i0 + j < n) { a[i0 + j] += oa; b[i0 + j] += ob; }
 }
 // B5 dump: Count records {value, abundance} (Abundance.hpp:68-129), solid only, ascending
 template <int KW>
@@ -1148,7 +1167,14 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             hipLaunchKernelGGL(k_flag_block_sums, dim3((unsigned)((n_blocks + BSUM_THREADS / 64 - 1) / (BSUM_THREADS / 64))), dim3(BSUM_THREADS), 0, c->stream, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, n_blocks, c->amin, c->amax,
                                (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p);
         }
-        hipLaunchKernelGGL(k_scan2_u64, dim3(1), dim3(1024), 0, c->stream, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks);
+        {   const uint32_t n_chunks = (uint32_t)((n_blocks + SCAN2_CHUNK - 1) / SCAN2_CHUNK);
+            if (n_chunks > (uint32_t)SCAN2_CHUNK) { B.release(); GKC_FAIL(c, GKC_ERR_ARG, "batch too large for the block-sum scan"); }
+            CB_TRY(c->ensure(B.g_start, (size_t)std::max<uint32_t>(n_chunks, 1) * 16));          // chunk totals (scratch buffer, free at this point)
+            uint64_t* ca = (uint64_t*)B.g_start.p; uint64_t* cb = ca + std::max<uint32_t>(n_chunks, 1);
+            if (n_chunks) hipLaunchKernelGGL(k_scan2_chunks, dim3(n_chunks), dim3(1024), 0, c->stream, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks, ca, cb);
+            hipLaunchKernelGGL(k_scan2_totals, dim3(1), dim3(1024), 0, c->stream, ca, cb, n_chunks, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks);
+            if (n_chunks) hipLaunchKernelGGL(k_scan2_add, dim3(n_chunks), dim3(1024), 0, c->stream, (uint64_t*)B.bs_d.p, (uint64_t*)B.bs_s.p, n_blocks, (const uint64_t*)ca, (const uint64_t*)cb);
+        }
         hipLaunchKernelGGL(k_gather_u64, dim3((nb + 1 + 255) / 256), dim3(256), 0, c->stream, (const uint64_t*)B.bs_d.p, (const uint64_t*)B.bs_s.p,
                            (const uint64_t*)B.pidx.p, nb + 1, (uint64_t*)B.ptot.p);
         CB_HIP(hipGetLastError());

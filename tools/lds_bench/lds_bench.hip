@@ -13,7 +13,7 @@ __device__ __forceinline__ uint32_t rnd(uint32_t& s) { s = s * 1664525u + 101390
 // MODE 0 read64, 1 write64, 2 add32 no return, 3 add32 return, 4 cas64 return, 5 exch64 return, 6 read64 + cas64 dependent (the pair protocol),
 // 7 add32 return on a 32 KB table, 8 cas32 return
 template <int MODE, int ILP>
-__global__ __launch_bounds__(THREADS) void k_lds(uint64_t* out, int dep)
+__global__ __launch_bounds__(THREADS) void k_lds(uint64_t* out, int dep, int active = 64)
 {
     __shared__ unsigned long long tab[NSLOT];
     __shared__ uint32_t tab32[NSLOT];
@@ -22,11 +22,11 @@ __global__ __launch_bounds__(THREADS) void k_lds(uint64_t* out, int dep)
     uint32_t s = threadIdx.x * 2654435761u + blockIdx.x;
     unsigned long long acc = 0;
     for (int it = 0; it < ITER; it++) {
-        uint32_t q[ILP]; unsigned long long v[ILP];
+        uint32_t q[ILP]; unsigned long long v[ILP] = {};
 #pragma unroll
         for (int g = 0; g < ILP; g++) { q[g] = (rnd(s) + (dep ? (uint32_t)acc : 0u)) & (NSLOT - 1); }
 #pragma unroll
-        for (int g = 0; g < ILP; g++) {
+        for (int g = 0; g < ILP; g++) if ((int)(threadIdx.x & 63) < active) {
             if (MODE == 0) v[g] = *reinterpret_cast<volatile unsigned long long*>(&tab[q[g]]);
             else if (MODE == 1) { *reinterpret_cast<volatile unsigned long long*>(&tab[q[g]]) = s; v[g] = 0; }
             else if (MODE == 2) { atomicAdd(&tab32[q[g]], 1u); v[g] = 0; }
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(THREADS) void k_lds(uint64_t* out, int dep)
             else if (MODE == 8) v[g] = atomicCAS(&tab32[q[g]], 0u, 0u);
         }
 #pragma unroll
-        for (int g = 0; g < ILP; g++) acc += v[g];
+        for (int g = 0; g < ILP; g++) acc += ((int)(threadIdx.x & 63) < active) ? v[g] : 0;
     }
     out[blockIdx.x * THREADS + threadIdx.x] = acc + tab[threadIdx.x] + tab32[threadIdx.x];
 }
@@ -57,11 +57,24 @@ template <int MODE, int ILP> int run(const char* name, uint64_t* d_out, int dep)
            clk / ((double)THREADS / 64 * ITER * ILP) * 1.0);
     return 0;
 }
+template <int MODE> void sweep(const char* name, uint64_t* d_out)
+{
+    for (int a : {64, 32, 16, 8, 4, 1}) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL((k_lds<MODE, 1>), dim3(256), dim3(THREADS), 0, 0, d_out, 0, a);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k_lds<MODE, 1>), dim3(256), dim3(THREADS), 0, 0, d_out, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-16s active lanes %2d: %7.3f ms  %6.1f clk per wave-instr\n", name, a, ms, ms * 1e-3 * 2.4e9 / ((double)THREADS / 64 * ITER));
+    }
+}
 
 int main()
 {
     uint64_t* d_out; CHECK(hipMalloc(&d_out, 256 * THREADS * 8));
 #define RUN(M, name) run<M, 1>(name, d_out, 0); run<M, 4>(name, d_out, 0); run<M, 1>(name, d_out, 1);
     RUN(0, "read64"); RUN(1, "write64"); RUN(2, "add32 noret"); RUN(3, "add32 ret"); RUN(4, "cas64 ret"); RUN(5, "exch64 ret"); RUN(6, "read64+cas64"); RUN(8, "cas32 ret");
+    sweep<5>("exch64 ret", d_out); sweep<3>("add32 ret", d_out); sweep<2>("add32 noret", d_out); sweep<0>("read64", d_out);
     return 0;
 }
