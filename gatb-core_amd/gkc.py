@@ -22,6 +22,7 @@ SYMBOLS = [
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
     "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_synth_reads_device", "gkc_device_free",
+    "gkc_fastx_parse_device", "gkc_push_fastx",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
 ]
 
@@ -92,6 +93,8 @@ def lib():
         "gkc_synth_reads_device": (C.c_int, [vp, u64, u64, u64, u32, u64, u32, P(vp), P(vp)]),
         "gkc_device_free": (C.c_int, [vp, vp]),
         "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
+        "gkc_fastx_parse_device": (C.c_int, [vp, vp, u64, C.c_int, P(vp), P(vp), P(u64), P(u64), P(u64)]),
+        "gkc_push_fastx": (C.c_int, [vp, vp, u64, C.c_int, P(u64)]),
         "gkc_kmer_checksum_device": (C.c_int, [vp, vp, vp, u64, u64, P(u64), P(u64)]),
         "gkc_result_checksum": (C.c_int, [vp, P(u64), P(u64)]),
         "gkc_sample_minimizers": (C.c_int, [vp, vp, vp, u64, vp, vp]),
@@ -301,6 +304,27 @@ class Counter:
         self._chk(self.L.gkc_segments_clear(self.h))
 
     # ---- synthetic input + checksums
+    def push_fastx(self, text, final=True):
+        """FASTA / FASTQ text (bytes) parsed on the device and pushed; returns the number of bytes consumed"""
+        buf = np.frombuffer(bytes(text), dtype=np.uint8)
+        cons = C.c_uint64(0)
+        self._chk(self.L.gkc_push_fastx(self.h, _p(buf) if len(buf) else None, len(buf), 1 if final else 0, C.byref(cons)))
+        return cons.value
+
+    def fastx_parse(self, text, final=True):
+        """device parse of FASTA / FASTQ text -> (bases uint8[], offsets uint64[n+1], consumed); copies text in and results out (tests)"""
+        import torch
+        buf = np.frombuffer(bytes(text), dtype=np.uint8)
+        t = torch.from_numpy(buf.copy()).cuda() if len(buf) else torch.empty(0, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        b = C.c_void_p(); o = C.c_void_p(); nr = C.c_uint64(0); nb = C.c_uint64(0); cons = C.c_uint64(0)
+        self._chk(self.L.gkc_fastx_parse_device(self.h, t.data_ptr() if len(buf) else None, len(buf), 1 if final else 0,
+                                                C.byref(b), C.byref(o), C.byref(nr), C.byref(nb), C.byref(cons)))
+        bases = self.device_to_host(b.value, nb.value) if nb.value else np.zeros(0, np.uint8)
+        offs = self.device_to_host(o.value, (nr.value + 1) * 8).view(np.uint64)
+        self.device_free(b.value); self.device_free(o.value)
+        return bases, offs, cons.value
+
     def synth_reads_device(self, seed, n_reads, read_len, genome_len, sub_ppm, first_read=0):
         b = C.c_void_p(); o = C.c_void_p()
         self._chk(self.L.gkc_synth_reads_device(self.h, seed, first_read, n_reads, read_len, genome_len, sub_ppm, C.byref(b), C.byref(o)))

@@ -30,6 +30,7 @@ extern "C" {
 #define GKC_ERR_NOMEM     3   /* device or host allocation failed                */
 #define GKC_ERR_CAPACITY  4   /* caller buffer too small                         */
 #define GKC_ERR_NODEVICE  5   /* no usable gfx950 device                         */
+#define GKC_ERR_FORMAT    6   /* input text the device parser refuses (see gkc_fastx_parse_device) */
 
 #define GKC_MINIMIZER_LEXI 0  /* -minimizer-type 0: lexicographic + KMC2 "no inner AA" rule (Model.hpp:1220-1251) */
 #define GKC_MINIMIZER_FREQ 1  /* -minimizer-type 1: (freq_order[c], c) order (Model.hpp:957-973)                  */
@@ -176,6 +177,23 @@ int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes);     
  * ------------------------------------------------------------------------------------------------------------- */
 int gkc_synth_reads_device(gkc_ctx* ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                            uint64_t genome_len, uint32_t sub_rate_ppm, char** d_bases, uint64_t** d_offsets);
+/* ---- input: FASTA / FASTQ text -> flat bases + offsets ON THE DEVICE ------------------------------------
+ * Replaces BankFasta::Iterator::get_next_seq_from_file (bank/impl/BankFasta.cpp:488-571, buffered_gets :425-483) and the
+ * per-sequence copy into the flat buffer that gkc_push_reads takes. Same result as the reference reader for well-formed text:
+ *   FASTA : a line starting with '>' or '@' is a header, all other lines are sequence data (multi-line, CRLF: one trailing '\r' per
+ *           line dropped exactly like BankFasta.cpp:479; empty lines ignored);
+ *   FASTQ : four lines per record, quality at least as long as the sequence.
+ * Anything whose result under the reference's character state machine is NOT expressible per line (multi-line FASTQ, quality shorter
+ * than the sequence, a sequence line starting with '+', '>' / '@' before the first header line) returns GKC_ERR_FORMAT — there is no
+ * host fallback inside the library.
+ * d_text: n_bytes of text in device memory. final_chunk = 0: only complete records are parsed and *consumed tells how many bytes
+ * they covered (feed the rest again in front of the next chunk); 1: the text ends here. Outputs are allocated by the library
+ * (gkc_device_free): d_bases[n_bases], d_offsets[n_reads + 1] — exactly the arguments of gkc_push_reads_device. */
+int gkc_fastx_parse_device(gkc_ctx* ctx, const char* d_text, uint64_t n_bytes, int final_chunk,
+                           char** d_bases, uint64_t** d_offsets, uint64_t* n_reads, uint64_t* n_bases, uint64_t* consumed);
+/* host text -> H2D -> gkc_fastx_parse_device -> gkc_push_reads_device, inside a pass */
+int gkc_push_fastx(gkc_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, uint64_t* consumed);
+
 int gkc_device_free(gkc_ctx* ctx, void* d_ptr);
 int gkc_device_to_host(gkc_ctx* ctx, void* dst, const void* d_src, uint64_t n_bytes);
 /* order-independent checksum of the canonical k-mer multiset of device-resident reads, computed by an independent

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <ctype.h>
 
 static const uint64_t RANDOM_VALUES[256] = {
 #include "../include/gkc_random_values.inc"
@@ -737,4 +738,67 @@ void gko_bloom_contains8(const gko_bloom* b, const uint64_t* lo, const uint64_t*
         }
         out[i] = r;
     }
+}
+
+/* =====================================================================================================================
+ * bank: FASTA / FASTQ reader (bank/impl/BankFasta.cpp:391-571), restated over a memory buffer.
+ * ===================================================================================================================== */
+typedef struct { const char* p; uint64_t n, pos; } fx_in;
+static int fx_getc(fx_in* f) { return f->pos < f->n ? (int)(signed char)f->p[f->pos++] : -1; }           /* buffered_getc :413 */
+/* buffered_gets (:425-483) with allow_spaces: appends up to (not including) the next '\n' to dst; afterwards drops one trailing '\r'
+ * if the whole accumulated string is longer than 1. Returns -1 at end of input (nothing left), else the accumulated length. */
+static int64_t fx_gets_line(fx_in* f, char* dst, uint64_t* len, uint64_t cap, int* overflow)
+{
+    if (f->pos >= f->n) return -1;
+    uint64_t i = f->pos;
+    while (i < f->n && f->p[i] != '\n') i++;
+    uint64_t add = i - f->pos;
+    if (dst) { if (*len + add > cap) { *overflow = 1; add = cap - *len; } memcpy(dst + *len, f->p + f->pos, add); }
+    *len += add;
+    f->pos = (i < f->n) ? i + 1 : i;
+    if (*len > 1 && dst && dst[*len - 1] == '\r') (*len)--;
+    return (int64_t)*len;
+}
+int64_t gko_fastx_parse(const char* text, uint64_t n, char* out_data, uint64_t cap_data, uint64_t* out_offsets, uint64_t cap_seq)
+{
+    fx_in f = { text, n, 0 };
+    int last_char = 0, c, overflow = 0;
+    uint64_t n_seq = 0, total = 0;
+    char* qual = (char*)malloc(n + 2);
+    if (!qual) return -1;
+    for (;;) {                                                                     /* one iteration = one get_next_seq_from_file call */
+        if (last_char == 0) {                                                     /* :496-502 go to next header */
+            while ((c = fx_getc(&f)) != -1 && c != '>' && c != '@') ;
+            if (c == -1) break;                                                    /* return false */
+            last_char = c;
+        }
+        if (f.pos >= f.n) break;                                                   /* buffered_gets(header) < 0 -> return false (:505) */
+        {   /* header: first token up to a whitespace (:505), then the rest of the line (:508-525); not part of the output here */
+            uint64_t i = f.pos; while (i < f.n && !isspace((unsigned char)f.p[i])) i++;
+            const int dret = i < f.n ? f.p[i] : 0;
+            f.pos = i < f.n ? i + 1 : i;
+            if (dret != '\n') { uint64_t dummy = 0; (void)fx_gets_line(&f, NULL, &dummy, 0, &overflow); }
+        }
+        if (n_seq + 1 > cap_seq) { free(qual); return -1; }
+        out_offsets[n_seq] = total;
+        char* rd = out_data + total; uint64_t rlen = 0; const uint64_t rcap = cap_data - total;
+        while ((c = fx_getc(&f)) != -1 && c != '>' && c != '+' && c != '@') {    /* :532-537 */
+            if (c == '\n') continue;                                               /* empty line */
+            if (rlen + 1 > rcap) { overflow = 1; break; }
+            rd[rlen++] = (char)c;
+            (void)fx_gets_line(&f, rd, &rlen, rcap, &overflow);
+        }
+        if (overflow) { free(qual); return -1; }
+        if (c == '>' || c == '@') last_char = c;                                   /* :538 */
+        if (c == '+') {                                                            /* :546-560 fastq */
+            while ((c = fx_getc(&f)) != -1 && c != '\n') ;                         /* rest of the '+' line */
+            uint64_t qlen = 0; int ov2 = 0;
+            while (fx_gets_line(&f, qual, &qlen, n + 1, &ov2) >= 0 && qlen < rlen) ;   /* quality, consumed by length */
+            last_char = 0;
+        }
+        total += rlen; n_seq++;                                                    /* return true */
+    }
+    free(qual);
+    out_offsets[n_seq] = total;
+    return (int64_t)n_seq;
 }

@@ -113,3 +113,10 @@ void       gko_bloom_contains8(const gko_bloom*, const uint64_t* lo, const uint6
 }
 #endif
 #endif
+
+/* ---- bank: FASTA / FASTQ text -> sequences (BankFasta::Iterator::get_next_seq_from_file, bank/impl/BankFasta.cpp:488-571;
+ *      buffered_gets :425-483). Restated on an in-memory text: same character-level state machine (header = first token + rest of
+ *      line, sequence lines appended verbatim up to '\n' with ONE trailing '\r' dropped when the accumulated read is longer than 1,
+ *      a line starting with '>' '@' ends the sequence, '+' starts the quality which is consumed BY LENGTH, then everything up to the
+ *      next '>' / '@' character is skipped). Output: flat data + n_seq+1 offsets; returns n_seq, or -1 if a capacity is too small. */
+int64_t gko_fastx_parse(const char* text, uint64_t n, char* out_data, uint64_t cap_data, uint64_t* out_offsets, uint64_t cap_seq);

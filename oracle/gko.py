@@ -86,6 +86,22 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def fastx_parse(text):
+    """FASTA/FASTQ text (bytes) -> (flat uint8 data, offsets uint64[n_seq+1]) with the reference reader's rules"""
+    L = lib()
+    buf = np.frombuffer(bytes(text), dtype=np.uint8)
+    n = len(buf)
+    data = np.zeros(max(n, 1), dtype=np.uint8)
+    cap_seq = n // 2 + 2
+    offs = np.zeros(cap_seq + 1, dtype=np.uint64)
+    L.gko_fastx_parse.restype = C.c_int64
+    L.gko_fastx_parse.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    r = L.gko_fastx_parse(_ptr(buf) if n else None, n, _ptr(data), len(data), _ptr(offs), cap_seq)
+    if r < 0:
+        raise RuntimeError("gko_fastx_parse: capacity")
+    return data[:int(offs[r])].copy(), offs[:r + 1].copy()
+
+
 def pack_reads(reads):
     """list of bytes/str -> (flat uint8 array, offsets uint64[n+1])"""
     bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
