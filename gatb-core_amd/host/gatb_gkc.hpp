@@ -22,6 +22,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <ctype.h>
+#include <zlib.h>
 #include <algorithm>
 #include <cmath>
 #include <fstream>
@@ -116,23 +118,58 @@ public:
 protected:
     std::vector<char> _bases; std::vector<uint64_t> _off;
 };
-/** plain FASTA / FASTQ reader (uncompressed); multi-line FASTA records are concatenated */
-class BankFasta : public BankStrings {
+/** BankFasta (bank/impl/BankFasta.hpp): FASTA / FASTQ file, plain or gzip (gzread reads both, BankFasta.cpp:396).
+ *  The file text is kept as read; the hot path hands it to the device parser (gkc_push_fastx) in chunks. bases()/offsets() — what
+ *  the Repartitor sampling and estimate() use — come from a host walk of the text with the reader's rules
+ *  (BankFasta::Iterator::get_next_seq_from_file, BankFasta.cpp:488-571): header = rest of the line after '>' / '@'; sequence lines
+ *  appended up to '\n', one trailing '\r' dropped when the read is longer than 1; '+' starts a quality consumed by length. */
+class BankFasta : public IBank {
 public:
-    explicit BankFasta(const std::string& path) {
-        std::ifstream in(path);
-        if (!in) throw system::Exception("Unable to open file '%s'", path.c_str());
-        std::string line, cur; bool fastq = false, have = false; int fq = 0;
-        while (std::getline(in, line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            if (!have && line.empty()) continue;
-            if (!have) { fastq = line[0] == '@'; have = true; }
-            if (fastq) { if (fq == 1) add(line.c_str()); fq = (fq + 1) & 3; }
-            else if (!line.empty() && line[0] == '>') { if (!cur.empty()) { add(cur.c_str()); cur.clear(); } }
-            else cur += line;
-        }
-        if (!fastq && !cur.empty()) add(cur.c_str());
+    explicit BankFasta(const std::string& path) : _parsed(false) {
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) throw system::Exception("Unable to open file '%s'", path.c_str());
+        std::vector<char> buf(1 << 22);
+        for (;;) { const int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n < 0) { gzclose(f); throw system::Exception("read error in '%s'", path.c_str()); }
+                   if (n == 0) break; _text.append(buf.data(), (size_t)n); }
+        gzclose(f);
     }
+    const std::string& text() const { return _text; }
+    const std::vector<char>& bases() const { parse(); return _bases; }
+    const std::vector<uint64_t>& offsets() const { parse(); return _off; }
+private:
+    void parse() const {
+        if (_parsed) return;
+        _parsed = true; _off.assign(1, 0);
+        const char* p = _text.data(); const size_t n = _text.size(); size_t pos = 0; int last = 0;
+        auto getc = [&]() -> int { return pos < n ? (int)(signed char)p[pos++] : -1; };
+        auto line = [&](std::vector<char>* dst, size_t start) -> bool {        // rest of the current line; false at end of text
+            if (pos >= n) return false;
+            size_t i = pos; while (i < n && p[i] != '\n') i++;
+            if (dst) dst->insert(dst->end(), p + pos, p + i);
+            pos = i < n ? i + 1 : i;
+            if (dst && dst->size() - start > 1 && dst->back() == '\r') dst->pop_back();
+            return true;
+        };
+        std::vector<char> qual;
+        for (;;) {
+            int c;
+            if (last == 0) { while ((c = getc()) != -1 && c != '>' && c != '@') ; if (c == -1) break; last = c; }
+            if (pos >= n) break;
+            { size_t i = pos; while (i < n && !isspace((unsigned char)p[i])) i++; const int d = i < n ? p[i] : 0; pos = i < n ? i + 1 : i; if (d != '\n') line(nullptr, 0); }
+            const size_t start = _bases.size();
+            while ((c = getc()) != -1 && c != '>' && c != '+' && c != '@') { if (c == '\n') continue; _bases.push_back((char)c); line(&_bases, start); }
+            if (c == '>' || c == '@') last = c;
+            if (c == '+') {
+                while ((c = getc()) != -1 && c != '\n') ;
+                qual.clear();
+                while (line(&qual, 0) && qual.size() < _bases.size() - start) ;
+                last = 0;
+            }
+            _off.push_back(_bases.size());
+        }
+    }
+    std::string _text;
+    mutable bool _parsed; mutable std::vector<char> _bases; mutable std::vector<uint64_t> _off;
 };
 }  // namespace bank
 
@@ -420,9 +457,9 @@ public:
         return p;
     }
     SortingCountAlgorithm(bank::IBank* bank, tools::misc::IProperties* params)
-        : _bank(bank), _params(*params), _repartitor(nullptr), _ctx(nullptr) { _bank->use(); }
+        : _bank(bank), _params(*params), _repartitor(nullptr), _ctx(nullptr), _textRefused(false) { _bank->use(); }
     SortingCountAlgorithm(bank::IBank* bank, const Configuration& config, Repartitor* repartitor, std::vector<CountProcessor*> processors, tools::misc::IProperties* params)
-        : _bank(bank), _params(*params), _config(config), _repartitor(repartitor), _processors(processors), _ctx(nullptr) {
+        : _bank(bank), _params(*params), _config(config), _repartitor(repartitor), _processors(processors), _ctx(nullptr), _textRefused(false) {
         _bank->use(); if (_repartitor) _repartitor->use(); for (auto* p : _processors) p->use();
     }
     ~SortingCountAlgorithm() {
@@ -443,15 +480,38 @@ public:
     }
     gkc_ctx* context() { return _ctx; }
 
+    /** file banks: the text goes to the device parser in chunks (gkc_push_fastx). Text the device parser refuses (GKC_ERR_FORMAT:
+     *  e.g. multi-line FASTQ) is read by the host walk instead, like every bank of the reference; returns false in that case. */
+    bool pushText(uint32_t pass) {
+        auto* bf = dynamic_cast<bank::BankFasta*>(_bank);
+        if (!bf || _textRefused) return false;
+        const std::string& t = bf->text();
+        const size_t CHUNK = (size_t)1 << 30;
+        size_t pos = 0;
+        while (pos < t.size()) {
+            const size_t len = std::min(CHUNK, t.size() - pos); const int final_chunk = pos + len >= t.size();
+            uint64_t consumed = 0;
+            const int rc = gkc_push_fastx(_ctx, t.data() + pos, len, final_chunk, &consumed);
+            if (rc == GKC_ERR_FORMAT && pos == 0) {                // nothing pushed yet: restart the pass with the host reader
+                _textRefused = true; check(gkc_begin_pass(_ctx, pass)); return false;
+            }
+            check(rc);
+            if (!final_chunk && consumed == 0) throw system::Exception("a record of the bank is larger than %zu bytes", CHUNK);
+            pos += final_chunk ? len : (size_t)consumed;
+        }
+        return true;
+    }
+
     void execute() {
         configure();
         const uint32_t P = _config._nb_partitions;
         for (auto* p : _processors) p->begin(_config);
-        const auto& bases = _bank->bases(); const auto& offs = _bank->offsets();
+        auto bases = [&]() -> const std::vector<char>& { return _bank->bases(); };
+        auto offs = [&]() -> const std::vector<uint64_t>& { return _bank->offsets(); };
         std::vector<Count> buf; std::vector<typename Kmer<32>::Count> narrow;
         for (uint32_t pass = 0; pass < _config._nb_passes; pass++) {
             check(gkc_begin_pass(_ctx, pass));
-            check(gkc_push_reads(_ctx, bases.data(), offs.data(), offs.size() - 1));                 // fillPartitions
+            if (!pushText(pass)) check(gkc_push_reads(_ctx, bases().data(), offs().data(), offs().size() - 1));   // fillPartitions
             check(gkc_finish_pass(_ctx));                                                             // fillSolidKmers (device part)
             for (auto* proc : _processors) {
                 proc->beginPass(pass);
@@ -571,7 +631,7 @@ private:
     }
 
     bank::IBank* _bank; tools::misc::Properties _params; Configuration _config; Repartitor* _repartitor;
-    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx;
+    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx; bool _textRefused;
 };
 
 }}  // namespace kmer::impl

@@ -37,11 +37,24 @@ def test_reference_dsk_tests_through_cpp_classes(built, ref_vectors, tmp_path):
     assert "check1=33 check2=1 failures=0" in r.stdout
 
 
-@pytest.mark.parametrize("k,mtype", [(31, 0), (21, 1), (45, 0)])
-def test_cli_dump_matches_oracle(built, tmp_path, k, mtype):
+@pytest.mark.parametrize("k,mtype,fmt", [(31, 0, "fa"), (21, 1, "fq"), (45, 0, "fa.gz"), (31, 0, "fq-multiline")])
+def test_cli_dump_matches_oracle(built, tmp_path, k, mtype, fmt):
+    """file bank -> device text parser (gkc_push_fastx) -> count; "fq-multiline" is refused by the device parser and read by the host walk"""
+    import gzip
     reads = synth_reads(3000, 20000, 150, seed=3, n_rate=0.001, ragged=True)
-    fa = tmp_path / "reads.fa"
-    fa.write_text("".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads)))
+    fa = tmp_path / ("reads." + fmt)
+    if fmt == "fq":
+        text = "".join("@r%d\n%s\n+\n%s\n" % (i, r.decode(), "I" * len(r)) for i, r in enumerate(reads))
+    elif fmt == "fq-multiline":
+        text = "".join("@r%d\n%s\n%s\n+\n%s\n" % (i, r.decode()[:70], r.decode()[70:], "I" * len(r)) if len(r) > 70 else
+                       "@r%d\n%s\n+\n%s\n" % (i, r.decode(), "I" * len(r)) for i, r in enumerate(reads))
+    else:
+        text = "".join(">r%d\n%s\n" % (i, "\n".join(r.decode()[j:j + 60] for j in range(0, len(r), 60))) for i, r in enumerate(reads))
+    if fmt.endswith(".gz"):
+        with gzip.open(fa, "wb") as f:
+            f.write(text.encode())
+    else:
+        fa.write_text(text)
     out = str(tmp_path / "out")
     r = subprocess.run([os.path.join(built, "gkc_dsk"), "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2", "-minimizer-type", str(mtype),
                         "-nb-partitions", "8", "-out", out], capture_output=True, text=True, timeout=600)
@@ -56,7 +69,7 @@ def test_cli_dump_matches_oracle(built, tmp_path, k, mtype):
     freq = None
     if raw[12 + 2 * nmin]:
         freq = np.fromfile(out + ".minimRepart.minimFrequency", dtype=np.uint32)[:nmin].copy()
-    bases, offs = gko.pack_reads([x for x in reads if len(x) > 0])      # the FASTA reader drops empty records like BankFasta
+    bases, offs = gko.pack_reads(reads)
     ref = gko.Dsk(bases, offs, k, m, 8, table, freq_order=freq, abundance_min=2)
     rec = 16 if k <= 31 else 32
     for p in range(8):
