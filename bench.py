@@ -65,6 +65,34 @@ def cpu_baseline(k, m, parts, rep, seconds_target=15.0):
                       "%.3g valid k-mers/s" % (n, dt, d.stats["kmers_nb_valid"] / dt)}
 
 
+def fastq_parse_leg(c, n_reads=1_000_000, L=150):
+    """input side, reported beside the metric (never inside it): a 4-line FASTQ text of n_reads reads already resident in HBM ->
+    flat bases + offsets on the device (gkc_fastx_parse_device). Returns text GB/s and bases/s."""
+    import torch
+    rng = np.random.default_rng(1)
+    hdr = 12
+    rec = np.empty((n_reads, hdr + L + 3 + L + 1), dtype=np.uint8)
+    ids = np.char.zfill(np.arange(n_reads).astype("U10"), 10)
+    rec[:, 0] = ord("@"); rec[:, 1:11] = np.frombuffer("".join(ids).encode(), dtype=np.uint8).reshape(n_reads, 10); rec[:, 11] = 10
+    rec[:, hdr:hdr + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n_reads, L))]
+    rec[:, hdr + L:hdr + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+    rec[:, hdr + L + 3:hdr + 2 * L + 3] = rng.integers(33, 74, size=(n_reads, L), dtype=np.uint8)
+    rec[:, -1] = 10
+    t = torch.from_numpy(rec.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    b = C.c_void_p(); o = C.c_void_p(); nr = C.c_uint64(0); nb = C.c_uint64(0); cons = C.c_uint64(0)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        c._chk(c.L.gkc_fastx_parse_device(c.h, t.data_ptr(), t.numel(), 1, C.byref(b), C.byref(o), C.byref(nr), C.byref(nb), C.byref(cons)))
+        dt = time.perf_counter() - t0                      # the call returns after its last kernel has finished
+        c.device_free(b.value); c.device_free(o.value)
+        best = dt if best is None else min(best, dt)
+    assert nr.value == n_reads and nb.value == n_reads * L
+    return {"sample": "%d reads of %d bp, 4-line FASTQ, %d bytes of text resident in HBM" % (n_reads, L, t.numel()),
+            "text_GBps": t.numel() / best / 1e9, "gbases_per_s": n_reads * L / best / 1e9, "ms": best * 1e3}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,7 +199,7 @@ def main():
         workload = ("k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions" % (k, n_reads, m, parts))
         traffic = None
         kname = {"scan_count": "k_scan_tile<false, 2, true>", "scan_emit": "k_emit_desc<2>", "expand_count": "k_expand_count<1, 2>",
-                 "expand_scatter": "k_expand_scatter_pair", "bucket_sort": "k_wave_sort<1>", "bucket_sort_lds": "k_lds_sort<1>", "compact": "k_compact_flags<1>"}
+                 "expand_scatter": "k_expand_scatter_pair", "bucket_sort": "k_wave_sort<1, true>", "compact": "k_compact_flags<1>"}
         try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), only if they were taken on this exact workload
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload and kname.get(dom) in pt["kernels"]:
@@ -197,6 +225,8 @@ def main():
                          "launches_per_step": int(launches_per_step), "launch_ms": dom_ms / launches_per_step,
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step},
         }
+        if world == 1 and k == 31 and not args.no_cpu_baseline:
+            out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(k, m, min(parts, 256), repart_for_bench(m, min(parts, 256)))
         elif world == 1:
