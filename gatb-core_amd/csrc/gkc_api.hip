@@ -104,7 +104,7 @@ void gkc_destroy(gkc_ctx* c)
     clear_segments(c);
     std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first);
     for (uint32_t p : passes) free_pass_outputs(c, p);
-    c->d_mkey_lut.release(); c->d_key2val.release(); c->d_repart.release(); c->d_histo.release();
+    c->d_mkey_lut.release(); c->d_key2val.release(); c->d_repart.release(); c->d_repart_coarse.release(); c->d_histo.release();
     c->d_scan_counters.release(); c->d_rsbits.release(); c->d_scan_matrix.release(); c->d_desc.release(); c->d_desc_tile.release();
     c->pool.destroy();
     (void)hipStreamDestroy(c->stream);
@@ -141,6 +141,17 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
 
     GKC_TRY(c->ensure(c->d_repart, nm * 2));
     GKC_HIP(c, hipMemcpy(c->d_repart.p, repart, nm * 2, hipMemcpyHostToDevice));
+    {   // two-level Stage A above SCAN_COARSE_MAX partitions: groups of 2^coarse_shift consecutive partitions
+        const uint32_t cmax = getenv("GKC_SCAN_COARSE_MAX") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCAN_COARSE_MAX"))) : SCAN_COARSE_MAX;
+        c->coarse_shift = 0;
+        while (((nb_partitions - 1) >> c->coarse_shift) + 1 > cmax) c->coarse_shift++;
+        if (c->coarse_shift) {
+            std::vector<uint16_t> coarse(nm);
+            for (uint64_t i = 0; i < nm; i++) coarse[i] = (uint16_t)(repart[i] >> c->coarse_shift);
+            GKC_TRY(c->ensure(c->d_repart_coarse, nm * 2));
+            GKC_HIP(c, hipMemcpy(c->d_repart_coarse.p, coarse.data(), nm * 2, hipMemcpyHostToDevice));
+        }
+    }
     if (minimizer_type == GKC_MINIMIZER_FREQ) {
         // order keys: dense rank of canonical m-mers (and of the default 4^m-1) under (freq_order[c], c)   (Model.hpp:957-973)
         auto revm = [&](uint32_t x) { uint32_t r = 0; for (uint32_t i = 0; i < m; i++) { r = (r << 2) | ((x & 3) ^ 2); x >>= 2; } return r; };

@@ -30,6 +30,9 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;      // 8192 positions
 constexpr int DESC_START_BITS = 13, DESC_NBK_BITS = 6;         // record descriptor: [partition : 13][nbK-1 : 6][start in tile : 13]
 static_assert(SCAN_TILE == (1 << DESC_START_BITS), "descriptor start field");
 constexpr uint32_t DESC_PARTS_MAX = 1u << (32 - DESC_START_BITS - DESC_NBK_BITS);
+// Stage A buckets at most this many ways in one pass (LDS counters / cursors per workgroup); more partitions are reached in two levels:
+// scan into groups of 2^coarse_shift consecutive partitions, then split every group by recomputing each record's minimizer (k_refine_*)
+constexpr uint32_t SCAN_COARSE_MAX = 4096;
 constexpr int SCAN_HALO_WORDS = 4;                             // 64 bases of look-ahead (k<=63)
 constexpr int SCAN_WORDS = SCAN_TILE / 16 + SCAN_HALO_WORDS;   // 16-base words per tile
 
@@ -121,6 +124,8 @@ struct gkc_ctx {
     DevBuf d_mkey_lut;      // u32[4^m] : m-mer (forward strand) -> order key (freq mode only)
     DevBuf d_key2val;       // u32[4^m] : order key -> minimizer value (freq mode only)
     DevBuf d_repart;        // u16[4^m] : minimizer value -> partition
+    DevBuf d_repart_coarse; // u16[4^m] : minimizer value -> partition >> coarse_shift (only when nb_partitions > SCAN_COARSE_MAX)
+    uint32_t coarse_shift = 0;
     uint32_t default_key = 0;   // order key of the default minimizer 4^m-1
     // pass state
     bool in_pass = false; uint32_t pass = 0;

@@ -207,7 +207,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
     const int p0 = 16 * t;
     const uint32_t Wn = P.nb_mm;
     uint32_t mz[16];
+#ifdef GKC_EXP_SCAN_NOMIN
+    if (Wn == 12345) {
+#else
     if (Wn >= 16) {
+#endif
         uint32_t core = P.default_key;                        // the default minimizer 4^m-1 takes part (Model.hpp:1260)
         for (uint32_t i = 15; i < Wn; i++) { uint32_t v = s_mk[MKI(p0 + i)]; core = v < core ? v : core; }
         uint32_t suf = 0xFFFFFFFFu;
@@ -226,7 +230,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             uint32_t best = P.default_key;
-            for (uint32_t i = 0; i < Wn; i++) { uint32_t v = s_mk[MKI(p0 + j + i)]; best = v < best ? v : best; }
+#ifdef GKC_EXP_SCAN_NOMIN
+            for (uint32_t i = 0; i < 1; i++) {
+#else
+            for (uint32_t i = 0; i < Wn; i++) {
+#endif
+                uint32_t v = s_mk[MKI(p0 + j + i)]; best = v < best ? v : best; }
             mz[j] = best;
         }
     }
@@ -334,6 +343,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             dstore = dbase + (uint32_t)n_end <= P.desc_cap_wg;
             if (!dstore) *P.desc_overflow = 1u;
         }
+#ifdef GKC_EXP_SCAN_NOEMIT
+        n_end = n_end > 1000 ? n_end : 0;
+#endif
 #pragma unroll 1
         for (int e = 0; e < n_end; e++) {
             if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = 0xFFFFFFFFu;
@@ -473,18 +485,95 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
     return GKC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ two-level Stage A: refine
+// partition of a record = repart[minimizer of its first k-mer] (every k-mer of a super-k-mer has the same minimizer): the window minimum
+// of step 2 of k_scan_tile recomputed for ONE window, from the record's own bit string
+template <int RW>
+__device__ __forceinline__ uint32_t record_partition(const uint64_t (&R)[RW], const ScanParams& P)
+{
+    uint32_t best = P.default_key;
+    const uint64_t S0 = (R[0] << 8) | (R[1] >> 56);
+    uint64_t S1 = 0;
+    if (RW == 4) S1 = (R[1] << 8) | (R[RW > 2 ? 2 : 1] >> 56);
+    for (uint32_t j = 0; j < P.nb_mm; j++) {
+        const uint32_t e = 2 * (j + P.m);                              // bits of the string up to the end of m-mer j (<= 2k <= 126)
+        uint32_t fw;
+        if (RW == 2 || e <= 64) fw = (uint32_t)(S0 >> (64 - e)) & P.mmask;
+        else fw = (uint32_t)(((((u128)S0) << 64) | S1) >> (128 - e)) & P.mmask;
+        uint32_t key;
+        if (P.freq_mode) key = P.mkey_lut[fw];
+        else {
+            const uint32_t rc = (uint32_t)revcomp64(fw, P.m);
+            const uint32_t cn = fw < rc ? fw : rc;
+            uint32_t a = ~(cn | (cn >> 2));
+            a = (a >> 1) & a & P.mask_ma1;
+            key = a ? P.mmask : cn;
+        }
+        best = key < best ? key : best;
+    }
+    const uint32_t value = P.freq_mode ? P.key2val[best] : best;
+    return P.repart[value];
+}
+constexpr int REFINE_THREADS = 256, REFINE_MAX_FINE = 64;
+// one workgroup per coarse group: records -> fine partition; counts per fine partition + the fine id of every record
+template <int RW>
+__global__ __launch_bounds__(REFINE_THREADS) void k_refine_count(ScanParams P, const uint64_t* __restrict__ arena, const unsigned long long* __restrict__ coarse_off,
+                                                                  uint32_t shift, uint8_t* __restrict__ fine_id, unsigned long long* __restrict__ cnt_rec,
+                                                                  unsigned long long* __restrict__ cnt_km, uint32_t* __restrict__ bad)
+{
+    __shared__ uint32_t s_rec[REFINE_MAX_FINE]; __shared__ unsigned long long s_km[REFINE_MAX_FINE];
+    const uint32_t g = blockIdx.x, nf = 1u << shift;
+    if (threadIdx.x < nf) { s_rec[threadIdx.x] = 0; s_km[threadIdx.x] = 0; }
+    __syncthreads();
+    const unsigned long long r0 = coarse_off[g], r1 = coarse_off[g + 1];
+    for (unsigned long long r = r0 + threadIdx.x; r < r1; r += REFINE_THREADS) {
+        uint64_t R[RW];
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + r * RW);
+#pragma unroll
+        for (int i = 0; i < RW; i += 2) { const ulonglong2 v = src[i / 2]; R[i] = v.x; R[i + 1] = v.y; }
+        const uint32_t part = record_partition<RW>(R, P);
+        const uint32_t b = part - (g << shift);
+        if (b >= nf) { *bad = 1u; continue; }                          // cannot happen: the coarse group of a record is its partition >> shift
+        fine_id[r] = (uint8_t)b;
+        atomicAdd(&s_rec[b], 1u); atomicAdd(&s_km[b], (unsigned long long)(R[0] >> 56));
+    }
+    __syncthreads();
+    if (threadIdx.x < nf && ((g << shift) + threadIdx.x) < P.n_parts) { cnt_rec[(g << shift) + threadIdx.x] = s_rec[threadIdx.x]; cnt_km[(g << shift) + threadIdx.x] = s_km[threadIdx.x]; }
+}
+template <int RW>
+__global__ __launch_bounds__(REFINE_THREADS) void k_refine_scatter(const uint64_t* __restrict__ arena, const unsigned long long* __restrict__ coarse_off, uint32_t shift,
+                                                                    const uint8_t* __restrict__ fine_id, const unsigned long long* __restrict__ fine_off,
+                                                                    uint32_t n_parts, uint64_t* __restrict__ out)
+{
+    __shared__ unsigned long long s_cur[REFINE_MAX_FINE];
+    const uint32_t g = blockIdx.x, nf = 1u << shift;
+    if (threadIdx.x < nf) s_cur[threadIdx.x] = ((g << shift) + threadIdx.x) < n_parts ? fine_off[(g << shift) + threadIdx.x] : 0;
+    __syncthreads();
+    const unsigned long long r0 = coarse_off[g], r1 = coarse_off[g + 1];
+    for (unsigned long long r = r0 + threadIdx.x; r < r1; r += REFINE_THREADS) {
+        const unsigned long long slot = atomicAdd(&s_cur[fine_id[r]], 1ULL);
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + r * RW);
+        ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + slot * RW);
+#pragma unroll
+        for (int i = 0; i < RW / 2; i++) dst[i] = src[i];
+    }
+}
+
 constexpr uint32_t SCAN_LDS_PARTS_MAX = 16384;     // 64 KB of LDS counters at most
 constexpr size_t SCAN_STATIC_LDS = 64 * 1024;      // static LDS of k_scan_tile (upper bound used for residency)
 
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
 {
-    const uint32_t Pn = c->nb_partitions;
+    // above SCAN_COARSE_MAX partitions the scan buckets into groups of 2^coarse_shift partitions (Pn groups) and the groups are split at the end
+    const uint32_t Pfine = c->nb_partitions, cshift = c->coarse_shift;
+    const uint32_t Pn = cshift ? ((Pfine - 1) >> cshift) + 1 : Pfine;
+    if (cshift && (1u << cshift) > (uint32_t)REFINE_MAX_FINE) GKC_FAIL(c, GKC_ERR_ARG, "too many partitions for the two-level scan");
     if (n_bases >= (1ULL << 40)) GKC_FAIL(c, GKC_ERR_ARG, "a single push is limited to 2^40 bases");
     const uint64_t n_tiles = (n_bases + SCAN_TILE - 1) / SCAN_TILE;
     if (n_tiles >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "too many tiles in one push; split the batch");
 
     Segment seg; seg.rec_off.assign(Pn + 1, 0); seg.nkmers.assign(Pn, 0); seg.owned = true;
-    if (n_tiles == 0) { c->segments.push_back(seg); c->stats_now().nb_sequences += n_reads; return GKC_OK; }
+    if (n_tiles == 0) { seg.rec_off.assign(Pfine + 1, 0); seg.nkmers.assign(Pfine, 0); c->segments.push_back(seg); c->stats_now().nb_sequences += n_reads; return GKC_OK; }
 
     // read-start bitmask (+ slack so every tile can read its halo words)
     const size_t rs_words = (size_t)(n_tiles * SCAN_TILE / 32 + 64);
@@ -521,7 +610,7 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
     P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
     P.mkey_lut = (const uint32_t*)c->d_mkey_lut.p; P.key2val = (const uint32_t*)c->d_key2val.p; P.default_key = c->default_key;
-    P.repart = (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
+    P.repart = cshift ? (const uint16_t*)c->d_repart_coarse.p : (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
     P.cnt_rec = cnt; P.cnt_kmers = cnt + Pn; P.cursor = cnt + 2 * (size_t)Pn; P.gstats = cnt + 3 * (size_t)Pn;
     P.arena = nullptr;
     P.dbg_noatomic = getenv("GKC_DEBUG_NOATOMIC") != nullptr;
@@ -598,9 +687,49 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
             }
         }
     }
+    c->d_desc.release(); c->d_desc_tile.release();             // back to the pool: Stage B / the refine level may reuse the space
+    if (cshift) {
+        // second level: every group -> its 2^cshift partitions (minimizer of the record recomputed from its first k-mer)
+        ScopedTimer tm(c, "scan_refine");
+        Segment fine; fine.rec_off.assign(Pfine + 1, 0); fine.nkmers.assign(Pfine, 0); fine.owned = true;
+        if (total) {
+            DevBuf d_fid, d_cnt, d_coff;
+            struct Guard { DevBuf *a, *b, *cc; ~Guard() { a->release(); b->release(); cc->release(); } } guard{&d_fid, &d_cnt, &d_coff};
+            GKC_TRY(c->ensure(d_fid, (size_t)total)); GKC_TRY(c->ensure(d_cnt, ((size_t)2 * Pfine + 2) * 8)); GKC_TRY(c->ensure(d_coff, ((size_t)Pn + 1) * 8));
+            GKC_HIP(c, hipMemsetAsync(d_cnt.p, 0, ((size_t)2 * Pfine + 2) * 8, c->stream));
+            GKC_HIP(c, hipMemcpyAsync(d_coff.p, seg.rec_off.data(), ((size_t)Pn + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            ScanParams Q = P; Q.repart = (const uint16_t*)c->d_repart.p; Q.n_parts = Pfine;
+            unsigned long long* fc = (unsigned long long*)d_cnt.p;
+            if (c->record_bytes == 16) hipLaunchKernelGGL((k_refine_count<2>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, Q, (const uint64_t*)arena, (const unsigned long long*)d_coff.p,
+                                                          cshift, (uint8_t*)d_fid.p, fc, fc + Pfine, (uint32_t*)(fc + 2 * (size_t)Pfine));
+            else                       hipLaunchKernelGGL((k_refine_count<4>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, Q, (const uint64_t*)arena, (const unsigned long long*)d_coff.p,
+                                                          cshift, (uint8_t*)d_fid.p, fc, fc + Pfine, (uint32_t*)(fc + 2 * (size_t)Pfine));
+            GKC_HIP(c, hipGetLastError());
+            std::vector<unsigned long long> hc((size_t)2 * Pfine + 1);
+            GKC_HIP(c, hipMemcpyAsync(hc.data(), fc, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
+            GKC_HIP(c, hipStreamSynchronize(c->stream));
+            if (hc[2 * (size_t)Pfine]) GKC_FAIL(c, GKC_ERR_HIP, "internal error: a record left its partition group in the refine level");
+            uint64_t run = 0;
+            for (uint32_t p = 0; p < Pfine; p++) { fine.rec_off[p] = run; run += hc[p]; fine.nkmers[p] = hc[Pfine + p]; }
+            fine.rec_off[Pfine] = run;
+            if (run != total) GKC_FAIL(c, GKC_ERR_HIP, "internal error: refine level lost records");
+            void* arena2 = c->dalloc((size_t)total * c->record_bytes);
+            if (!arena2) return GKC_ERR_NOMEM;
+            GKC_HIP(c, hipMemcpyAsync(fc, fine.rec_off.data(), (size_t)Pfine * 8, hipMemcpyHostToDevice, c->stream));
+            if (c->record_bytes == 16) hipLaunchKernelGGL((k_refine_scatter<2>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, (const uint64_t*)arena, (const unsigned long long*)d_coff.p, cshift,
+                                                          (const uint8_t*)d_fid.p, (const unsigned long long*)fc, Pfine, (uint64_t*)arena2);
+            else                       hipLaunchKernelGGL((k_refine_scatter<4>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, (const uint64_t*)arena, (const unsigned long long*)d_coff.p, cshift,
+                                                          (const uint8_t*)d_fid.p, (const unsigned long long*)fc, Pfine, (uint64_t*)arena2);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->dfree(arena2); GKC_FAIL(c, GKC_ERR_HIP, "refine scatter failed: %s", hipGetErrorString(e)); }
+            for (auto& a : c->owned_arenas) if (a == arena) a = arena2;
+            c->dfree(arena); arena = arena2;
+        }
+        seg = std::move(fine);
+    }
     seg.d_records = arena;
     c->segments.push_back(std::move(seg));
-    c->d_desc.release(); c->d_desc_tile.release();             // back to the pool: Stage B may reuse the space
     return GKC_OK;
 }
 

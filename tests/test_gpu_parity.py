@@ -93,6 +93,26 @@ def test_frequency_order_minimizers(gkc):
     device_vs_oracle(gkc, reads[:1000], 63, m, parts, freq=freq)
 
 
+@pytest.mark.parametrize("cmax", [4, 7])
+def test_two_level_scan_many_partitions(gkc, monkeypatch, cmax):
+    """above SCAN_COARSE_MAX partitions Stage A scans into partition groups and splits the groups by recomputing each record's
+    minimizer (k_refine_*); forced here with a tiny group limit: lexicographic and frequency order, 8- and 16-byte keys, 2 passes"""
+    monkeypatch.setenv("GKC_SCAN_COARSE_MAX", str(cmax))
+    reads = synth_reads(3000, 15000, 150, seed=16, n_rate=0.002, ragged=True)
+    device_vs_oracle(gkc, reads, 31, 10, 64)
+    device_vs_oracle(gkc, reads[:1500], 63, 9, 37, batches=2)
+    device_vs_oracle(gkc, reads[:1500], 21, 8, 30, passes=2)
+    m = 8
+    L = gko.lib()
+    counts = np.zeros(4 ** m, np.uint32)
+    for r in reads[:300]:
+        L.gko_count_mmers(r, len(r), m, counts)
+    freq = np.zeros(4 ** m, np.uint32)
+    L.gko_freq_order_from_counts(m, counts, freq)
+    device_vs_oracle(gkc, reads[:1500], 31, m, 50, freq=freq)
+    device_vs_oracle(gkc, reads[:800], 45, m, 50, freq=freq)
+
+
 def test_reference_known_answers_through_the_device(gkc, ref_vectors):
     """TestDSK.cpp:147-305 run through the HIP path"""
     v = ref_vectors["dsk_check1"]
