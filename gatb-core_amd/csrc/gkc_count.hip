@@ -101,24 +101,32 @@ __device__ __forceinline__ void for_each_kmer16(const uint64_t (&R)[2], uint32_t
     }
 }
 
-// 32 <= k <= 63, 32-byte records (248-bit string, 124 nt): the same with a 128-bit window
+// 32 <= k <= 63, 32-byte records (248-bit string, 124 nt): the same with a 128-bit window, written on 64-bit halves (the compiler's
+// variable 128-bit shifts cost several times the few funnel shifts that are needed: `down` is in [2, 64], `sh` in [62, 124])
 template <class F>
 __device__ __forceinline__ void for_each_kmer32(const uint64_t (&R)[4], uint32_t k, F f)
 {
     const uint64_t S0 = (R[0] << 8) | (R[1] >> 56), S1 = (R[1] << 8) | (R[2] >> 56), S2 = (R[2] << 8) | (R[3] >> 56), S3 = R[3] << 8;
     const uint32_t nbk = (uint32_t)(R[0] >> 56), down = 128 - 2 * k, sh = 2 * (k - 1);
-    auto window = [&](uint32_t i) -> u128 {                       // bits [2i, 2i+128) of the string; 2i <= 118
+    uint64_t fh, fl;                                              // forward k-mer (2k bits) = window >> down
+    auto window = [&](uint32_t i) {                               // bits [2i, 2i+128) of the string (2i <= 118), shifted right by `down`
         const uint32_t s = 2 * i, t = s & 63;
         const bool j = s >= 64;
         const uint64_t A = j ? S1 : S0, B = j ? S2 : S1, C = j ? S3 : S2;
         const uint64_t hi = (A << t) | ((B >> 1) >> (63 - t)), lo = (B << t) | ((C >> 1) >> (63 - t));
-        return ((u128)hi << 64) | lo;
+        if (down == 64) { fh = 0; fl = hi; }
+        else { fh = hi >> down; fl = (lo >> down) | (hi << (64 - down)); }
     };
-    u128 fw = window(0) >> down, rv = revcomp128(fw, k);
+    window(0);
+    const u128 rv0 = revcomp128(((u128)fh << 64) | fl, k);
+    uint64_t rh = (uint64_t)(rv0 >> 64), rl = (uint64_t)rv0;
     for (uint32_t i = 0; i < nbk; i++) {
-        f(fw < rv ? fw : rv);
-        fw = window(i + 1) >> down;
-        rv = (rv >> 2) | ((u128)(((uint32_t)fw & 3u) ^ 2u) << sh);
+        const bool fwd = fh < rh || (fh == rh && fl < rl);
+        f(fwd ? (((u128)fh << 64) | fl) : (((u128)rh << 64) | rl));
+        window(i + 1);
+        const uint64_t c = (uint64_t)(((uint32_t)fl & 3u) ^ 2u);
+        rl = (rl >> 2) | (rh << 62); rh >>= 2;
+        if (sh >= 64) rh |= c << (sh - 64); else rl |= c << sh;
     }
 }
 // record width -> fastest k-mer walk (the generic per-nucleotide for_each_kmer stays as the reference restatement for other widths)
@@ -1250,6 +1258,11 @@ int gkc_count_pass(gkc_ctx* c)
         batch.clear(); acc = 0; budget = budget_now(); return r;
     };
     for (uint32_t p = 0; p < Pn && rc == GKC_OK; p++) {
+        if (part_keys[p] == 0) {                               // nothing to count (e.g. a partition another rank owns): an empty, finished dataset
+            Dataset& D = c->datasets[(size_t)c->pass * Pn + p];
+            D.d_counts = nullptr; D.n_solid = 0; D.n_distinct = 0; D.n_kmers = 0; D.done = true;
+            continue;
+        }
         if (!batch.empty() && acc + part_keys[p] > budget) rc = flush();
         if (rc != GKC_OK) break;
         batch.push_back(p); acc += part_keys[p];
