@@ -361,8 +361,45 @@ public:
     bool process(size_t, const Type&, const CountVector&, CountNumber sum) { (*_shared)[(size_t)sum >= _length ? _length : (size_t)sum]++; return true; }
     std::string getName() const { return "histogram"; }
     const std::vector<uint64_t>& getHistogram() const { return *_shared; }
+
+    /** Histogram::compute_threshold (tools/misc/impl/Histogram.cpp:61-190): smoothed histogram, first increase, first peak after it, cutoff =
+     *  the minimum between them, capped where 25 % of the k-mer volume would be eliminated, floored by min_auto_threshold */
+    void compute_threshold(int min_auto_threshold = 3) {
+        const std::vector<uint64_t>& h = *_shared; const size_t L = _length;
+        std::vector<uint64_t> sm(L + 1, 0);
+        uint64_t sum_allk = 0;
+        _cutoff = 0; _nbsolids = 0; _firstPeak = 0; _ratio_weak_volume = 0;
+        if (L >= 2) { sm[1] = (uint64_t)(0.6 * (double)h[1] + 0.4 * (double)h[2]); sum_allk += h[1] * 1; }
+        int first_inc = -1, idx_max = -1; uint64_t max_val = 0;
+        for (size_t i = 2; i < L; i++) {
+            sum_allk += h[i] * i;
+            sm[i] = (uint64_t)(0.2 * (double)h[i - 1] + 0.6 * (double)h[i] + 0.2 * (double)h[i + 1]);
+            if (first_inc == -1 && sm[i - 1] < sm[i]) first_inc = (int)i - 1;
+            if (first_inc > 0 && sm[i] > max_val) { max_val = sm[i]; idx_max = (int)i; }
+        }
+        sum_allk += h[L] * L;
+        if (first_inc == -1) { _cutoff = (size_t)min_auto_threshold; return; }
+        _firstPeak = (size_t)idx_max;
+        uint64_t min_val = 10000000000ULL; int idx_min = -1;
+        for (int i = first_inc; i <= idx_max; i++) if (sm[i] < min_val) { min_val = sm[i]; idx_min = i; }
+        if (idx_min != -1) _cutoff = (size_t)idx_min;
+        uint64_t sum_elim = 0; size_t max_cutoff = 0;
+        for (size_t i = 0; i < L + 1; i++) { sum_elim += h[i] * i; if ((double)sum_elim / sum_allk >= 0.25) { max_cutoff = i + 1; break; } }
+        if (_cutoff > max_cutoff) _cutoff = max_cutoff;
+        if (_cutoff < (size_t)min_auto_threshold) _cutoff = (size_t)min_auto_threshold;
+        for (size_t i = _cutoff; i < L + 1; i++) _nbsolids += h[i];
+        uint64_t vol_weak = 0, vol_total = 0;
+        for (size_t i = 0; i < _cutoff; i++) vol_weak += h[i] * i;
+        for (size_t i = 0; i < L + 1; i++) vol_total += h[i] * i;
+        _ratio_weak_volume = (float)vol_weak / (float)vol_total;
+    }
+    size_t get_solid_cutoff() const { return _cutoff; }
+    uint64_t get_nbsolids_auto() const { return _nbsolids; }
+    size_t get_first_peak() const { return _firstPeak; }
+    float get_ratio_weak() const { return _ratio_weak_volume; }
 private:
     size_t _length; std::vector<uint64_t> _own; std::vector<uint64_t>* _shared;
+    size_t _cutoff = 0; uint64_t _nbsolids = 0; size_t _firstPeak = 0; float _ratio_weak_volume = 0;
 };
 
 /** CountProcessorSoliditySum (kmer/impl/CountProcessorSolidity.hpp:60-190): closed interval test on the sum */

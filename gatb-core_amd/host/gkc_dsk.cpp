@@ -15,8 +15,11 @@ template <size_t span> static int run(tools::misc::IProperties* params, const st
         auto* chain = dynamic_cast<CountProcessorChain<span>*>(dsk.getProcessor(0));
         if (chain) {
             chain->template get<CountProcessorDump<span>>()->saveRaw(out);
-            std::ofstream h(out + ".histo"); const auto& hv = chain->template get<CountProcessorHistogram<span>>()->getHistogram();
+            auto* hp = chain->template get<CountProcessorHistogram<span>>();
+            std::ofstream h(out + ".histo"); const auto& hv = hp->getHistogram();
             for (size_t i = 1; i < hv.size(); i++) if (hv[i]) h << i << "\t" << hv[i] << "\n";
+            hp->compute_threshold(3);                                              // histogram/cutoff, nbsolidsforcutoff (SortingCountAlgorithm.cpp:700-726)
+            std::ofstream cu(out + ".cutoff"); cu << hp->get_solid_cutoff() << "\t" << hp->get_nbsolids_auto() << "\t" << hp->get_first_peak() << "\n";
         }
         dsk.getRepartitor()->save(out + ".minimRepart");
         std::ofstream info(out + ".info"); for (auto& kv : dsk.getInfo()->map()) info << kv.first << "\t" << kv.second << "\n";

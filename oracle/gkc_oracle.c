@@ -802,3 +802,36 @@ int64_t gko_fastx_parse(const char* text, uint64_t n, char* out_data, uint64_t c
     out_offsets[n_seq] = total;
     return (int64_t)n_seq;
 }
+
+/* =====================================================================================================================
+ * Histogram::compute_threshold (tools/misc/impl/Histogram.cpp:61-190)
+ * ===================================================================================================================== */
+void gko_histogram_cutoff(const uint64_t* h, uint64_t L, int min_auto_threshold, uint64_t out[3])
+{
+    uint64_t* sm = (uint64_t*)calloc(L + 2, 8);
+    uint64_t sum_allk = 0, cutoff = 0, nbsolids = 0, first_peak = 0;
+    if (L >= 2) { sm[1] = (uint64_t)(0.6 * (double)h[1] + 0.4 * (double)h[2]); sum_allk += h[1]; }                 /* :66-71 */
+    int64_t first_inc = -1, idx_max = -1; uint64_t max_val = 0;
+    for (uint64_t i = 2; i < L; i++) {                                                                              /* :78-98 */
+        sum_allk += h[i] * i;
+        sm[i] = (uint64_t)(0.2 * (double)h[i - 1] + 0.6 * (double)h[i] + 0.2 * (double)h[i + 1]);
+        if (first_inc == -1 && sm[i - 1] < sm[i]) first_inc = (int64_t)i - 1;
+        if (first_inc > 0 && sm[i] > max_val) { max_val = sm[i]; idx_max = (int64_t)i; }
+    }
+    sum_allk += h[L] * L;                                                                                           /* :100 */
+    if (first_inc == -1) { out[0] = (uint64_t)min_auto_threshold; out[1] = 0; out[2] = 0; free(sm); return; }       /* :102-106 */
+    first_peak = (uint64_t)idx_max;
+    uint64_t min_val = 10000000000ULL; int64_t idx_min = -1;
+    for (int64_t i = first_inc; i <= idx_max; i++) if (sm[i] < min_val) { min_val = sm[i]; idx_min = i; }           /* :116-123 */
+    if (idx_min != -1) cutoff = (uint64_t)idx_min;
+    uint64_t sum_elim = 0, max_cutoff = 0;
+    for (uint64_t i = 0; i < L + 1; i++) {                                                                          /* :131-143 */
+        sum_elim += h[i] * i;
+        if ((double)sum_elim / sum_allk >= 0.25) { max_cutoff = i + 1; break; }
+    }
+    if (cutoff > max_cutoff) cutoff = max_cutoff;
+    if (cutoff < (uint64_t)min_auto_threshold) cutoff = (uint64_t)min_auto_threshold;
+    for (uint64_t i = cutoff; i < L + 1; i++) nbsolids += h[i];                                                     /* :168-172 */
+    out[0] = cutoff; out[1] = nbsolids; out[2] = first_peak;
+    free(sm);
+}

@@ -120,3 +120,6 @@ void       gko_bloom_contains8(const gko_bloom*, const uint64_t* lo, const uint6
  *      a line starting with '>' '@' ends the sequence, '+' starts the quality which is consumed BY LENGTH, then everything up to the
  *      next '>' / '@' character is skipped). Output: flat data + n_seq+1 offsets; returns n_seq, or -1 if a capacity is too small. */
 int64_t gko_fastx_parse(const char* text, uint64_t n, char* out_data, uint64_t cap_data, uint64_t* out_offsets, uint64_t cap_seq);
+
+/* ---- Histogram::compute_threshold (tools/misc/impl/Histogram.cpp:61-190): histo[0..length] -> out = {cutoff, nbsolids, first_peak} */
+void gko_histogram_cutoff(const uint64_t* histo, uint64_t length, int min_auto_threshold, uint64_t out[3]);

@@ -102,6 +102,17 @@ def fastx_parse(text):
     return data[:int(offs[r])].copy(), offs[:r + 1].copy()
 
 
+def histogram_cutoff(histo, min_auto_threshold=3):
+    """(cutoff, nb_solids, first_peak) of Histogram::compute_threshold on histo[0..length]"""
+    L = lib()
+    h = np.ascontiguousarray(histo, dtype=np.uint64)
+    out = np.zeros(3, dtype=np.uint64)
+    L.gko_histogram_cutoff.restype = None
+    L.gko_histogram_cutoff.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    L.gko_histogram_cutoff(_ptr(h), len(h) - 1, min_auto_threshold, _ptr(out))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def pack_reads(reads):
     """list of bytes/str -> (flat uint8 array, offsets uint64[n+1])"""
     bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]

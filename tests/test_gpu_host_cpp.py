@@ -82,3 +82,6 @@ def test_cli_dump_matches_oracle(built, tmp_path, k, mtype, fmt):
     hist = {int(a): int(b) for a, b in (l.split("\t") for l in open(out + ".histo").read().splitlines())}
     rh = ref.histogram()
     assert hist == {i: int(c) for i, c in enumerate(rh) if c and i > 0}
+    # histogram/cutoff, nbsolidsforcutoff (Histogram::compute_threshold) computed by the C++ layer from the device histogram
+    cut = [int(x) for x in open(out + ".cutoff").read().split()]
+    assert tuple(cut) == gko.histogram_cutoff(rh, 3)

@@ -257,3 +257,17 @@ def test_bloom_seeds_documented_values():
     s = np.zeros(10, np.uint64)
     gko.lib().gko_bloom_seeds(0, s)
     assert int(s[0]) == 0xffaa54ffe6e6e6e7 and int(s[1]) == 0x1140aada557088a4      # SURVEY §8c' (oracle-verified)
+
+
+def test_histogram_cutoff_properties():
+    """Histogram::compute_threshold restated (Histogram.cpp:61-190). The reference's unit tests hold no known answer for it (parity
+    unpinned for this function): what is checked here are the properties its code guarantees."""
+    x = np.arange(10001)
+    h = np.zeros(10001, np.uint64)
+    h[1:] = (1e6 * np.exp(-(x[1:] - 1) / 0.8) + 2e4 * np.exp(-0.5 * ((x[1:] - 30) / 5.5) ** 2)).astype(np.uint64)
+    cut, nbs, peak = gko.histogram_cutoff(h, 3)
+    assert peak == 30 and 3 <= cut < peak                          # valley between the error k-mers and the coverage peak
+    assert nbs == int(h[cut:].sum())
+    mono = np.zeros(10001, np.uint64); mono[1:200] = np.arange(199, 0, -1, dtype=np.uint64) * 1000   # never increases: default threshold
+    assert gko.histogram_cutoff(mono, 3)[0] == 3
+    assert gko.histogram_cutoff(mono, 7)[0] == 7
