@@ -133,6 +133,109 @@ __global__ void k_bloom_contains8(BloomParams B, const uint8_t* __restrict__ key
     }
 }
 
+// ------------------------------------------------------------------------------------------------ region build (cache / neighbor kinds)
+// The atomic kernel above is bound by the device's global-atomic rate (~2e10 /s: 7 bits x 5.8e8 k-mers = 190 ms). In the two
+// block-coherent kinds every bit of an item lies in [h0, h0 + 4096) — so the items are first bucketed by REGION of h0 (2^20 bits of the
+// array = 128 KB), then one workgroup per region builds its piece of the array in LDS (LDS atomics) and ORs it into HBM once:
+// plain read-modify-write for the words only this region can touch, atomic OR for the two 4 KB-bit fringes it shares with its
+// neighbours. Same bits, any order: the array stays byte-identical to the reference's.
+constexpr uint32_t BR_BITS = 20, BR_WORDS = 1u << (BR_BITS - 5), BR_FRINGE_WORDS = (4096 + 64) / 32 + 1;      // 131 words may spill over
+constexpr uint32_t BR_MAX_REGIONS = 16384, BR_WGS = 1024, BR_THREADS = 1024;
+struct BloomItem { uint64_t key64; uint32_t rel; uint32_t pad; };                 // what the build needs: hash input of the offsets + h0 inside the region
+struct BSeg { const uint8_t* p; uint64_t n, first; };
+struct BSegTable { BSeg s[16]; uint32_t n; uint32_t stride; uint64_t total; };
+
+__device__ __forceinline__ void bloom_root(const BloomParams& B, u128 x, uint64_t& h0, uint64_t& key64)
+{
+    if (B.kind == 1) { h0 = hash1_dev(x, B.seeds[0], B.wide) % B.reduced_tai; key64 = (uint64_t)x; }
+    else {
+        const uint32_t k = B.k;
+        const uint32_t suffix = (uint32_t)x & 3u, prefix = ((uint32_t)(x >> (2 * (k - 1))) & 3u) << 2;
+        u128 core; uint64_t racine;
+        neighbor_root(B, x, core, racine);
+        h0 = racine + d_cano2[(prefix + suffix) & 15]; key64 = (uint64_t)core;
+    }
+}
+__device__ __forceinline__ const uint8_t* bseg_item(const BSegTable& T, uint64_t g)
+{
+    uint32_t i = 0;
+    while (i + 1 < T.n && g >= T.s[i + 1].first) i++;
+    return T.s[i].p + (g - T.s[i].first) * T.stride;
+}
+// pass 1 / 2 over the items with a STATIC item -> workgroup assignment (identical in both launches): LDS histogram of regions, then LDS cursors
+template <bool SCATTER>
+__global__ __launch_bounds__(BR_THREADS) void k_bloom_regions(BloomParams B, BSegTable T, uint64_t chunk, uint32_t n_regions, uint32_t* __restrict__ wg_cnt,
+                                                               const uint32_t* __restrict__ region_off, BloomItem* __restrict__ items)
+{
+    extern __shared__ uint32_t s_r[];                              // [n_regions] count / cursor
+    for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS)
+        s_r[r] = SCATTER ? region_off[r] + wg_cnt[(uint64_t)blockIdx.x * n_regions + r] : 0u;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(T.total, i0 + chunk);
+    for (uint64_t g = i0 + threadIdx.x; g < i1; g += BR_THREADS) {
+        const u128 x = load_key(bseg_item(T, g), B.wide);
+        uint64_t h0, key64; bloom_root(B, x, h0, key64);
+        const uint32_t slot = atomicAdd(&s_r[(uint32_t)(h0 >> BR_BITS)], 1u);
+        if (SCATTER) { BloomItem it; it.key64 = key64; it.rel = (uint32_t)(h0 & ((1u << BR_BITS) - 1)); it.pad = 0; items[slot] = it; }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS) wg_cnt[(uint64_t)blockIdx.x * n_regions + r] = s_r[r];
+    }
+}
+// per region: exclusive prefix of the workgroup counts (in place) and the region total
+__global__ void k_bloom_wg_prefix(uint32_t* __restrict__ wg_cnt, uint32_t n_wgs, uint32_t n_regions, uint32_t* __restrict__ region_tot)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < n_wgs; w++) { const uint32_t t = wg_cnt[(uint64_t)w * n_regions + r]; wg_cnt[(uint64_t)w * n_regions + r] = run; run += t; }
+    region_tot[r] = run;
+}
+__global__ __launch_bounds__(1024) void k_bloom_region_scan(const uint32_t* __restrict__ tot, uint32_t n_regions, uint32_t* __restrict__ off)
+{   // exclusive scan of <= 16384 totals by one workgroup (16 per thread); off[n_regions] = sum
+    __shared__ uint32_t s_w[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t v[16], tv = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const uint32_t i = t * 16 + j; v[j] = i < n_regions ? tot[i] : 0; tv += v[j]; }
+    uint32_t x = tv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t p = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) p += s_w[w]; total += s_w[w]; }
+    uint32_t r = p + x - tv;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const uint32_t i = t * 16 + j; if (i < n_regions) off[i] = r; r += v[j]; }
+    if (t == 0) off[n_regions] = total;
+}
+__global__ __launch_bounds__(BR_THREADS) void k_bloom_region_build(BloomParams B, const BloomItem* __restrict__ items, const uint32_t* __restrict__ region_off)
+{
+    extern __shared__ uint32_t s_img[];                            // [BR_WORDS + BR_FRINGE_WORDS] this region's bits + what spills into the next one
+    constexpr uint32_t NW = BR_WORDS + BR_FRINGE_WORDS;
+    for (uint32_t i = threadIdx.x; i < NW; i += BR_THREADS) s_img[i] = 0;
+    __syncthreads();
+    const uint32_t r = blockIdx.x, i0 = region_off[r], i1 = region_off[r + 1];
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += BR_THREADS) {
+        const BloomItem it = items[i];
+        atomicOr(&s_img[it.rel >> 5], 1u << (it.rel & 31));
+        for (uint32_t j = 1; j < B.nb_hash; j++) {
+            const uint32_t h = it.rel + (uint32_t)(simplehash16_dev(it.key64, (int)j, B.wide) & 4095);
+            atomicOr(&s_img[h >> 5], 1u << (h & 31));
+        }
+    }
+    __syncthreads();
+    uint32_t* g = B.words + (uint64_t)r * BR_WORDS;
+    for (uint32_t i = threadIdx.x; i < NW; i += BR_THREADS) {
+        const uint32_t v = s_img[i];
+        if (!v) continue;
+        if (i < BR_FRINGE_WORDS || i >= BR_WORDS) atomicOr(&g[i], v);            // words the neighbouring regions' workgroups may touch too
+        else g[i] |= v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 static BloomParams params_of(const gkc_bloom* b)
 {
@@ -183,17 +286,57 @@ static int check_stride(gkc_bloom* b, uint32_t stride)
     return GKC_OK;
 }
 
+// inserts the items of up to 16 device arrays; block-coherent kinds go through the region build when the array has <= BR_MAX_REGIONS regions
+static int bloom_insert_arrays(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, uint32_t stride)
+{
+    gkc_ctx* c = b->ctx;
+    uint64_t total = 0; for (uint32_t i = 0; i < n_segs; i++) total += segs[i].n;
+    if (!total) return GKC_OK;
+    ScopedTimer tm(c, "bloom_insert");
+    const uint64_t n_bits = b->tai + 1;
+    const uint32_t n_regions = (uint32_t)std::min<uint64_t>((n_bits + (1u << BR_BITS) - 1) >> BR_BITS, 0xffffffffu);
+    const bool regions = b->kind != 0 && n_regions <= BR_MAX_REGIONS && total < (1ULL << 32) && n_segs <= 16 && getenv("GKC_BLOOM_ATOMIC") == nullptr;
+    if (!regions) {
+        for (uint32_t i = 0; i < n_segs; i++) if (segs[i].n) {
+            const unsigned grid = (unsigned)std::min<uint64_t>((segs[i].n + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(k_bloom_insert, dim3(grid), dim3(256), 0, c->stream, params_of(b), segs[i].p, segs[i].n, stride);
+        }
+        GKC_HIP(c, hipGetLastError());
+        return GKC_OK;
+    }
+    BSegTable T{}; T.n = n_segs; T.stride = stride; T.total = total;
+    { uint64_t first = 0; for (uint32_t i = 0; i < n_segs; i++) { T.s[i] = segs[i]; T.s[i].first = first; first += segs[i].n; } }
+    const uint32_t n_wgs = (uint32_t)std::min<uint64_t>(BR_WGS, (total + BR_THREADS - 1) / BR_THREADS);
+    const uint64_t chunk = (total + n_wgs - 1) / n_wgs;
+    DevBuf d_wg, d_tot, d_off, d_items;
+    struct Guard { DevBuf *a, *b2, *c2, *d; ~Guard() { a->release(); b2->release(); c2->release(); d->release(); } } guard{&d_wg, &d_tot, &d_off, &d_items};
+    GKC_TRY(c->ensure(d_wg, (size_t)n_wgs * n_regions * 4)); GKC_TRY(c->ensure(d_tot, (size_t)n_regions * 4)); GKC_TRY(c->ensure(d_off, ((size_t)n_regions + 1) * 4));
+    GKC_TRY(c->ensure(d_items, (size_t)total * sizeof(BloomItem)));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_regions<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_regions<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_region_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BR_WORDS + BR_FRINGE_WORDS) * 4));
+        attr_set = true;
+    }
+    const BloomParams P = params_of(b);
+    hipLaunchKernelGGL((k_bloom_regions<false>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)nullptr, (BloomItem*)nullptr);
+    hipLaunchKernelGGL(k_bloom_wg_prefix, dim3((n_regions + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d_wg.p, n_wgs, n_regions, (uint32_t*)d_tot.p);
+    hipLaunchKernelGGL(k_bloom_region_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)d_tot.p, n_regions, (uint32_t*)d_off.p);
+    hipLaunchKernelGGL((k_bloom_regions<true>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)d_off.p, (BloomItem*)d_items.p);
+    hipLaunchKernelGGL(k_bloom_region_build, dim3(n_regions), dim3(BR_THREADS), (size_t)(BR_WORDS + BR_FRINGE_WORDS) * 4, c->stream, P, (const BloomItem*)d_items.p, (const uint32_t*)d_off.p);
+    GKC_HIP(c, hipGetLastError());
+    GKC_HIP(c, hipStreamSynchronize(c->stream));                   // the scratch buffers go back to the pool
+    return GKC_OK;
+}
+
 int gkc_bloom_insert_device(gkc_bloom* b, const void* d_keys, uint64_t n, uint32_t stride)
 {
     if (!b) return GKC_ERR_ARG;
-    gkc_ctx* c = b->ctx;
     GKC_TRY(check_stride(b, stride));
     if (!n) return GKC_OK;
-    ScopedTimer tm(c, "bloom_insert");
-    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(k_bloom_insert, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d_keys, n, stride);
-    GKC_HIP(c, hipGetLastError());
-    return GKC_OK;
+    BSeg sg{ (const uint8_t*)d_keys, n, 0 };
+    return bloom_insert_arrays(b, &sg, 1, stride);
 }
 int gkc_bloom_insert(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride)
 {
@@ -213,8 +356,15 @@ int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* c)
 {
     if (!b || !c) return GKC_ERR_ARG;
     if (c->k != b->k) GKC_FAIL(c, GKC_ERR_ARG, "bloom k (%u) differs from the context's k (%u)", b->k, c->k);
-    for (const Dataset& D : c->datasets)
-        if (D.done && D.n_solid) GKC_TRY(gkc_bloom_insert_device(b, D.d_counts, D.n_solid, c->key_words == 1 ? 16 : 32));
+    // datasets of one Stage-B batch are consecutive in one output buffer: a handful of arrays in all
+    const uint32_t stride = c->key_words == 1 ? 16 : 32;
+    std::vector<BSeg> segs;
+    for (const Dataset& D : c->datasets) {
+        if (!D.done || !D.n_solid) continue;
+        if (!segs.empty() && (const uint8_t*)D.d_counts == segs.back().p + segs.back().n * stride) { segs.back().n += D.n_solid; continue; }
+        segs.push_back(BSeg{ (const uint8_t*)D.d_counts, D.n_solid, 0 });
+    }
+    for (size_t i = 0; i < segs.size(); i += 16) GKC_TRY(bloom_insert_arrays(b, segs.data() + i, (uint32_t)std::min<size_t>(16, segs.size() - i), stride));
     GKC_HIP(c, hipStreamSynchronize(c->stream));
     return GKC_OK;
 }

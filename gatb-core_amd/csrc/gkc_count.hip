@@ -513,10 +513,17 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
         if ((headm >> r) & 1) cur = e;
         if ((tailm >> r) & 1) {
             const uint32_t c = (uint32_t)(e - cur + 1);
+#ifndef GKC_EXP_NORLESTORE
             if constexpr (F && KW == 1) outk[start + idx] = (v[r] & TAG64_MANT) | top; else outk[start + idx] = v[r];
-            put_count(O, start + idx, c); idx++;
+            put_count(O, start + idx, c);
+#else
+            if (c == 0x7fffffffu) outk[start + idx] = v[r];
+#endif
+            idx++;
+#ifndef GKC_EXP_NOHIST
             const uint32_t hb = c >= O.histo_max ? O.histo_max : c;              // Histogram::inc (Histogram.hpp:92)
             if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
+#endif
         }
     }
 }

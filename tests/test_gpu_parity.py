@@ -197,6 +197,21 @@ def test_bloom_bit_identical(gkc, k):
             db.close()
 
 
+@pytest.mark.parametrize("k", [31, 63])
+def test_bloom_region_build_bit_identical(gkc, k):
+    """cache / neighbor kinds are built region by region in LDS (2^20 bits per region, shared fringes ORed atomically): several regions,
+    two insert calls into the same filter"""
+    rng = np.random.default_rng(100 + k)
+    keys = [int.from_bytes(rng.bytes(16), "little") & (4 ** k - 1) for _ in range(120000)]
+    c = gkc.Counter(0)
+    for kind in ("cache", "neighbor"):
+        bits = 5_000_000 + 12345
+        ob = gko.Bloom(kind, bits, 7, k); ob.insert(keys)
+        db = gkc.Bloom(c, kind, bits, 7, k); db.insert(keys[:70000]); db.insert(keys[70000:])
+        assert np.array_equal(db.array(), ob.array()), kind
+        db.close()
+
+
 def test_bloom_of_solid_kmers_and_cfp_known_answer(gkc, ref_vectors):
     """BloomAlgorithm::execute sizing + TestDebloom.cpp:133-137's 20 critical false positives, with the device filter"""
     v = ref_vectors["debloom_k11"]; k = v["k"]
