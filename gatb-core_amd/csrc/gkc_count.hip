@@ -544,16 +544,45 @@ __device__ __forceinline__ void wave_sort_dispatch(const typename KeyT<KW>::type
 }
 
 // one WAVE per small bucket, straight from HBM (no LDS, no barrier)
+// Appending to a device-wide list through ONE counter word saturates at ~9e7 appends/s (MI355X_MICROARCH.md, "dequeue"): the sort
+// kernels therefore collect the buckets they pass on in an LDS list per workgroup and reserve list space once per flush.
+constexpr int WGLIST_CAP = 128;
+struct WgList { uint32_t n; uint32_t base; uint32_t item[WGLIST_CAP]; };
+__device__ __forceinline__ void wglist_flush(WgList* L, uint32_t* count, uint32_t* list)     // all threads of the workgroup
+{
+    __syncthreads();
+    const uint32_t n = min(L->n, (uint32_t)WGLIST_CAP);
+    if (threadIdx.x == 0 && n) L->base = atomicAdd(count, n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) list[L->base + i] = L->item[i];
+    __syncthreads();
+    if (threadIdx.x == 0) L->n = 0;
+    __syncthreads();
+}
+// one lane: keep g for the next flush; a full LDS list falls back to the direct append (rare)
+__device__ __forceinline__ void wglist_push(WgList* L, uint32_t g, uint32_t* count, uint32_t* list)
+{
+    const uint32_t i = atomicAdd(&L->n, 1u);
+    if (i < (uint32_t)WGLIST_CAP) L->item[i] = g;
+    else { const uint32_t slot = atomicAdd(count, 1u); list[slot] = g; }
+}
+
 #ifndef GKC_WS_WAVES
 #define GKC_WS_WAVES 5      // waves per SIMD the register budget is cut for: 3 (151 VGPRs) 98 ms, 4: 87 ms, 5: 84 ms, 6: 85 ms per 1.2e10 keys
 #endif
+#ifndef GKC_T1_MID
+#define GKC_T1_MID 0          // 1: first tier stops at 512 / 256 keys (8 / 4 per lane), a KPL-16 / 8 instance of k_wave_sort_big takes the next class
+#endif
+template <int KW> struct WaveCapT1 { static constexpr int KPL_MAX = GKC_T1_MID ? WaveCap<KW>::KPL_MAX : WaveCapBig<KW>::KPL_MAX; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 template <int KW, bool F>
 __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                              const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O)
 {
     __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ WgList s_over;
     const int t = threadIdx.x, lane = t & 63;
     if (t < HIST_LDS) s_hc[t] = 0;
+    if (t == 0) s_over.n = 0;
     __syncthreads();
     const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
     uint32_t nb_done = 0; unsigned long long nk_done = 0;
@@ -562,11 +591,11 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const 
         const uint32_t n = n_next; const uint64_t start = start_next;
         if (g + n_waves < n_buckets) { n_next = b_n[g + n_waves]; start_next = b_start[g + n_waves]; }     // next bucket's descriptor in flight during this sort
         if (n == 0) continue;
-        if (n > WaveCapBig<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over_count, 1u); O.over_list[slot] = g; } continue; }
+        if (n > WaveCapT1<KW>::CAP) { if (lane == 0) wglist_push(&s_over, g, O.over_count, O.over_list); continue; }
         nb_done++; nk_done += n;
-        wave_sort_dispatch<KW, WaveCapBig<KW>::KPL_MAX, F>(src + start, outk, start, n, O, s_hc, lane);
+        wave_sort_dispatch<KW, WaveCapT1<KW>::KPL_MAX, F>(src + start, outk, start, n, O, s_hc, lane);
     }
-    __syncthreads();
+    wglist_flush(&s_over, O.over_count, O.over_list);
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
     if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
 }
@@ -577,24 +606,27 @@ template <int KW> struct WaveCapHuge { static constexpr int KPL = (KW == 1) ? 32
 #ifndef GKC_WSB_WAVES
 #define GKC_WSB_WAVES 3     // 2 (214 VGPRs): 16.3 ms, 3: 13.4 ms, 4: 13.2 ms
 #endif
-template <int KW, bool F>
+template <int KW, bool F, int KPL>
 __global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
                                                                  const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
-                                                                 const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
+                                                                 const uint32_t* __restrict__ list, uint32_t n_list, uint32_t n_min, uint32_t n_report /* buckets beyond go to the next list */, SortOut O)
 {
     __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ WgList s_over;
     const int t = threadIdx.x, lane = t & 63;
     if (t < HIST_LDS) s_hc[t] = 0;
+    if (t == 0) s_over.n = 0;
     __syncthreads();
     const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
     for (uint32_t li = wave; li < n_list; li += n_waves) {
         const uint32_t g = list[li];
         const uint32_t n = b_n[g];
         const uint64_t start = b_start[g];
-        if (n > WaveCapHuge<KW>::CAP) { if (lane == 0) { const uint32_t slot = atomicAdd(O.over3_count, 1u); O.over3_list[slot] = g; } continue; }
-        wave_sort_bucket<KW, WaveCapHuge<KW>::KPL, F>(src + start, outk, start, n, O, s_hc, lane);
+        if (n_report && n > n_report) { if (lane == 0) wglist_push(&s_over, g, O.over3_count, O.over3_list); continue; }
+        if (n <= n_min || n > 64u * KPL) continue;                 // another instance's class
+        wave_sort_bucket<KW, KPL, F>(src + start, outk, start, n, O, s_hc, lane);
     }
-    __syncthreads();
+    wglist_flush(&s_over, O.over3_count, O.over3_list);
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
 }
 
@@ -1073,10 +1105,18 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         uint32_t n_mid2 = 0;
         {   ScopedTimer tm(c, "bucket_sort_big");                 // up to 2x the first tier: double-size wave network
             const unsigned grid = (unsigned)std::min<uint64_t>((n_mid + 3) / 4, 256 * 16);
-            if (tag) hipLaunchKernelGGL((k_wave_sort_big<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
-                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, O);
-            else hipLaunchKernelGGL((k_wave_sort_big<KW, false>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
-                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, O);
+            constexpr int KB = WaveCapHuge<KW>::KPL;
+            if (GKC_T1_MID) {
+                if (tag) hipLaunchKernelGGL((k_wave_sort_big<KW, FT, KB / 2>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, 0u, 0u, O);
+                else hipLaunchKernelGGL((k_wave_sort_big<KW, false, KB / 2>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, 0u, 0u, O);
+            }
+            const uint32_t big_min = GKC_T1_MID ? 64u * (KB / 2) : 0u;
+            if (tag) hipLaunchKernelGGL((k_wave_sort_big<KW, FT, KB>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, big_min, 64u * KB, O);
+            else hipLaunchKernelGGL((k_wave_sort_big<KW, false, KB>), dim3(grid), dim3(SORT_THREADS), 0, c->stream, (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint32_t*)O.over_list, n_mid, big_min, 64u * KB, O);
             CB_HIP(hipGetLastError());
             CB_HIP(hipMemcpyAsync(&n_mid2, B.over3.p, 4, hipMemcpyDeviceToHost, c->stream));
             CB_HIP(hipStreamSynchronize(c->stream));
