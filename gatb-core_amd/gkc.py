@@ -22,7 +22,8 @@ SYMBOLS = [
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
     "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_synth_reads_device", "gkc_device_free",
-    "gkc_fastx_parse_device", "gkc_push_fastx",
+    "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
+    "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
 ]
 
@@ -95,6 +96,10 @@ def lib():
         "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
         "gkc_fastx_parse_device": (C.c_int, [vp, vp, u64, C.c_int, P(vp), P(vp), P(u64), P(u64), P(u64)]),
         "gkc_push_fastx": (C.c_int, [vp, vp, u64, C.c_int, P(u64)]),
+        "gkc_mphf_build": (C.c_int, [vp, vp, u64, u32, u32, P(vp)]), "gkc_mphf_build_solid": (C.c_int, [vp, P(vp)]),
+        "gkc_mphf_destroy": (None, [vp]), "gkc_mphf_size": (u64, [vp]), "gkc_mphf_lookup": (C.c_int, [vp, vp, u64, u32, vp]),
+        "gkc_mphf_save_size": (u64, [vp]), "gkc_mphf_save": (C.c_int, [vp, vp, u64]),
+        "gkc_mphf_abundance_map": (C.c_int, [vp, vp, vp, u64, P(u64)]),
         "gkc_kmer_checksum_device": (C.c_int, [vp, vp, vp, u64, u64, P(u64), P(u64)]),
         "gkc_result_checksum": (C.c_int, [vp, P(u64), P(u64)]),
         "gkc_sample_minimizers": (C.c_int, [vp, vp, vp, u64, vp, vp]),
@@ -347,6 +352,56 @@ class Counter:
         a = C.c_uint64(); b = C.c_uint64()
         self._chk(self.L.gkc_result_checksum(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+class Mphf:
+    """BooPHF minimal perfect hash built on the device (include/gkc.h gkc_mphf_*)"""
+
+    def __init__(self, counter, keys=None, k=None):
+        """keys=None: the solid k-mers of the counter; else a list of ints / uint64 array (k <= 31) or list of ints (k <= 63)"""
+        self.c = counter; self.L = counter.L
+        h = C.c_void_p()
+        if keys is None:
+            counter._chk(self.L.gkc_mphf_build_solid(counter.h, C.byref(h))); self.k = counter.k
+        else:
+            self.k = k
+            a = self._keys(keys)
+            counter._chk(self.L.gkc_mphf_build(counter.h, _p(a), len(a), a.strides[0], k, C.byref(h)))
+        self.h = h
+
+    def _keys(self, keys):
+        if self.k <= 31:
+            return np.ascontiguousarray(np.array([int(x) for x in keys], dtype=np.uint64))
+        a = np.zeros((len(keys), 2), dtype=np.uint64)
+        for i, x in enumerate(keys):
+            a[i, 0] = int(x) & 0xFFFFFFFFFFFFFFFF; a[i, 1] = int(x) >> 64
+        return a
+
+    @property
+    def size(self):
+        return self.L.gkc_mphf_size(self.h)
+
+    def lookup(self, keys):
+        a = self._keys(keys); out = np.zeros(len(a), np.uint64)
+        self.c._chk(self.L.gkc_mphf_lookup(self.h, _p(a), len(a), a.strides[0], _p(out))); return out
+
+    def save(self):
+        n = self.L.gkc_mphf_save_size(self.h); out = np.zeros(n, np.uint8)
+        self.c._chk(self.L.gkc_mphf_save(self.h, _p(out), n)); return out
+
+    def abundance_map(self):
+        out = np.zeros(self.size, np.uint8); above = C.c_uint64(0)
+        self.c._chk(self.L.gkc_mphf_abundance_map(self.h, self.c.h, _p(out), len(out), C.byref(above))); return out, above.value
+
+    def close(self):
+        if self.h:
+            self.L.gkc_mphf_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Bloom:

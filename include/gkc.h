@@ -177,6 +177,25 @@ int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes);     
  * ------------------------------------------------------------------------------------------------------------- */
 int gkc_synth_reads_device(gkc_ctx* ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                            uint64_t genome_len, uint32_t sub_rate_ppm, char** d_bases, uint64_t** d_offsets);
+/* ---- MPHF + abundance map ------------------------------------------------------------------------------
+ * Replaces MPHFAlgorithm::execute / populate (kmer/impl/MPHFAlgorithm.cpp:150-275) and the BooPHF build behind it
+ * (thirdparty/BooPHF/BooPHF.h:734-1108 as instantiated by tools/collections/impl/BooPHF.hpp:236-300: jenkins64 hasher seeded by
+ * std::mt19937_64(37), gamma 3, 25 levels). The level bit arrays and rank samples are the ones BooPHF builds for the same keys, so
+ * gkc_mphf_save writes the byte stream of boomphf::mphf::save (what MPHF<>::save puts into the "dsk/mphf" collection, loadable by
+ * BooPHF::load) and gkc_mphf_lookup returns BooPHF::lookup's codes. Keys: `stride` bytes per item, the k-mer in the first 8 (k <= 31)
+ * or 16 (k <= 63) bytes — a Count array works as it is. */
+typedef struct gkc_mphf gkc_mphf;
+int      gkc_mphf_build(gkc_ctx* ctx, const void* keys /* host */, uint64_t n, uint32_t stride, uint32_t k, gkc_mphf** out);
+int      gkc_mphf_build_solid(gkc_ctx* ctx, gkc_mphf** out);          /* keys = the solid k-mers of every finished dataset (getSolidKmers() order) */
+void     gkc_mphf_destroy(gkc_mphf* m);
+uint64_t gkc_mphf_size(const gkc_mphf* m);                             /* number of keys (BooPHF::size) */
+int      gkc_mphf_lookup(gkc_mphf* m, const void* keys /* host */, uint64_t n, uint32_t stride, uint64_t* codes);   /* ~0: not a key (final level miss) */
+uint64_t gkc_mphf_save_size(const gkc_mphf* m);
+int      gkc_mphf_save(gkc_mphf* m, uint8_t* out, uint64_t cap);
+/* MPHFAlgorithm::populate: out[code(kmer)] = index of the k-mer's abundance in MapMPHF's discretization table (MapMPHF.hpp:96-145),
+ * for every solid k-mer of the context; *nb_above_precision = abundances beyond the table (MPHFAlgorithm.cpp:254-258) */
+int      gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* ctx, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision);
+
 /* ---- input: FASTA / FASTQ text -> flat bases + offsets ON THE DEVICE ------------------------------------
  * Replaces BankFasta::Iterator::get_next_seq_from_file (bank/impl/BankFasta.cpp:488-571, buffered_gets :425-483) and the
  * per-sequence copy into the flat buffer that gkc_push_reads takes. Same result as the reference reader for well-formed text:

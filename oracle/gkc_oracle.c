@@ -835,3 +835,157 @@ void gko_histogram_cutoff(const uint64_t* h, uint64_t L, int min_auto_threshold,
     out[0] = cutoff; out[1] = nbsolids; out[2] = first_peak;
     free(sm);
 }
+
+/* =====================================================================================================================
+ * MPHF (BooPHF) — thirdparty/BooPHF/BooPHF.h, tools/collections/impl/BooPHF.hpp
+ * ===================================================================================================================== */
+#include <math.h>
+#define MPHF_NB_LEVELS 25                                         /* BooPHF.h:1029 */
+#define MPHF_SEED 18006821046139946489ULL                         /* std::mt19937_64 rng(37); rng()  (BooPHF.hpp:246-249) */
+struct gko_mphf {
+    double gamma; uint64_t nelem, lastbitsetrank; int wide;
+    uint64_t domain[MPHF_NB_LEVELS]; uint64_t nchar[MPHF_NB_LEVELS]; uint64_t* bits[MPHF_NB_LEVELS];
+    uint64_t nranks[MPHF_NB_LEVELS]; uint64_t* ranks[MPHF_NB_LEVELS];
+    uint64_t nfinal; uint64_t* final_lo; uint64_t* final_hi; uint64_t* final_val;
+};
+static void jenkins_mix(uint64_t* a, uint64_t* b, uint64_t* c)     /* BooPHF.hpp:186-201 */
+{
+    *a -= *b; *a -= *c; *a ^= (*c >> 43);  *b -= *c; *b -= *a; *b ^= (*a << 9);   *c -= *a; *c -= *b; *c ^= (*b >> 8);
+    *a -= *b; *a -= *c; *a ^= (*c >> 38);  *b -= *c; *b -= *a; *b ^= (*a << 23);  *c -= *a; *c -= *b; *c ^= (*b >> 5);
+    *a -= *b; *a -= *c; *a ^= (*c >> 35);  *b -= *c; *b -= *a; *b ^= (*a << 49);  *c -= *a; *c -= *b; *c ^= (*b >> 11);
+    *a -= *b; *a -= *c; *a ^= (*c >> 12);  *b -= *c; *b -= *a; *b ^= (*a << 18);  *c -= *a; *c -= *b; *c ^= (*b >> 22);
+}
+/* jenkins64_hasher::operator()(byte_range) on the 8 / 16 key bytes (BooPHF.hpp:93-146): the two hashes BooPHF asks for are get<0> and get<2> (:254-258) */
+static void mphf_hash_pair(uint64_t lo, uint64_t hi, int wide, uint64_t* h0, uint64_t* h1)
+{
+    uint64_t a = MPHF_SEED, b = MPHF_SEED, c = 0x9e3779b97f4a7c13ULL;
+    c += wide ? 16 : 8;
+    if (wide) b += hi;
+    a += lo;
+    jenkins_mix(&a, &b, &c);
+    *h0 = a; *h1 = c;
+}
+static uint64_t xs_next(uint64_t* s)                                /* BooPHF.h:350-358 */
+{
+    uint64_t s1 = s[0]; const uint64_t s0 = s[1];
+    s[0] = s0; s1 ^= s1 << 23;
+    return (s[1] = (s1 ^ s0 ^ (s1 >> 17) ^ (s0 >> 26))) + s0;
+}
+/* getLevel (BooPHF.h:1062-1095): first level < maxlevel whose bit is set at the key's slot; returns the hash of the last level looked at */
+static uint64_t mphf_get_level(const gko_mphf* m, uint64_t lo, uint64_t hi, int maxlevel, int* res_level, uint64_t s[2])
+{
+    int level = 0; uint64_t hash_raw = 0, h0, h1;
+    mphf_hash_pair(lo, hi, m->wide, &h0, &h1);
+    for (int ii = 0; ii < MPHF_NB_LEVELS - 1 && ii < maxlevel; ii++) {
+        if (ii == 0) { s[0] = h0; hash_raw = h0; } else if (ii == 1) { s[1] = h1; hash_raw = h1; } else hash_raw = xs_next(s);
+        const uint64_t pos = hash_raw % m->domain[ii];
+        if ((m->bits[ii][pos >> 6] >> (pos & 63)) & 1ULL) break;
+        level++;
+    }
+    *res_level = level;
+    return hash_raw;
+}
+gko_mphf* gko_mphf_build(const void* keys, uint64_t n, uint32_t stride, int wide)
+{
+    if (n == 0) return NULL;
+    gko_mphf* m = (gko_mphf*)calloc(1, sizeof(gko_mphf));
+    m->gamma = 3.0; m->nelem = n; m->wide = wide;
+    const uint64_t hash_domain = (uint64_t)ceil((double)n * m->gamma);                                            /* :735 */
+    const double proba = 1.0 - pow(((m->gamma * (double)n - 1) / (m->gamma * (double)n)), (double)(n - 1));      /* :1024 */
+    for (int ii = 0; ii < MPHF_NB_LEVELS; ii++) {                                                                /* :1034-1046 */
+        m->domain[ii] = (((uint64_t)(hash_domain * pow(proba, ii)) + 63) / 64) * 64;
+        if (m->domain[ii] == 0) m->domain[ii] = 64;
+    }
+    const uint8_t* kp = (const uint8_t*)keys;
+    uint64_t offset = 0; uint64_t cap_final = 16; m->final_lo = malloc(cap_final * 8); m->final_hi = malloc(cap_final * 8); m->final_val = malloc(cap_final * 8);
+    for (int i = 0; i < MPHF_NB_LEVELS; i++) {
+        m->nchar[i] = 1ULL + m->domain[i] / 64ULL;                                                               /* bitVector ctor :427-431 */
+        m->bits[i] = (uint64_t*)calloc(m->nchar[i], 8);
+        uint64_t* coll = (uint64_t*)calloc(m->nchar[i], 8);
+        uint64_t hashidx = 0;
+        for (uint64_t q = 0; q < n; q++) {                                                                       /* processLevel :849-927 */
+            uint64_t lo, hi = 0; memcpy(&lo, kp + q * stride, 8); if (wide) memcpy(&hi, kp + q * stride + 8, 8);
+            int level; uint64_t s[2] = {0, 0};
+            (void)mphf_get_level(m, lo, hi, i, &level, s);
+            if (level != i) continue;
+            if (i == MPHF_NB_LEVELS - 1) {                                                                       /* exact hash for what is left */
+                if (hashidx == cap_final) { cap_final *= 2; m->final_lo = realloc(m->final_lo, cap_final * 8); m->final_hi = realloc(m->final_hi, cap_final * 8); m->final_val = realloc(m->final_val, cap_final * 8); }
+                m->final_lo[hashidx] = lo; m->final_hi[hashidx] = hi; m->final_val[hashidx] = hashidx; hashidx++;
+            } else {
+                uint64_t h0, h1, lh; mphf_hash_pair(lo, hi, wide, &h0, &h1);
+                if (level == 0) lh = h0; else if (level == 1) lh = h1; else lh = xs_next(s);                     /* :905-914; s holds the state after level-1 looks */
+                const uint64_t pos = lh % m->domain[i];                                                          /* insertIntoLevel :1098-1108 */
+                const uint64_t bit = 1ULL << (pos & 63);
+                if (m->bits[i][pos >> 6] & bit) coll[pos >> 6] |= bit; else m->bits[i][pos >> 6] |= bit;
+            }
+        }
+        if (i == MPHF_NB_LEVELS - 1) m->nfinal = hashidx;
+        for (uint64_t w = 0; w < m->domain[i] / 64; w++) m->bits[i][w] &= ~coll[w];                               /* clearCollisions :511-523 */
+        free(coll);
+        m->nranks[i] = 0; m->ranks[i] = (uint64_t*)malloc((m->nchar[i] / 8 + 2) * 8);                            /* build_ranks :596-609 */
+        uint64_t cur = offset;
+        for (uint64_t w = 0; w < m->nchar[i]; w++) {
+            if (((w * 64) % 512) == 0) m->ranks[i][m->nranks[i]++] = cur;
+            cur += (uint64_t)__builtin_popcountll(m->bits[i][w]);
+        }
+        offset = cur;
+    }
+    m->lastbitsetrank = offset;
+    return m;
+}
+void gko_mphf_free(gko_mphf* m)
+{
+    if (!m) return;
+    for (int i = 0; i < MPHF_NB_LEVELS; i++) { free(m->bits[i]); free(m->ranks[i]); }
+    free(m->final_lo); free(m->final_hi); free(m->final_val); free(m);
+}
+uint64_t gko_mphf_lookup(const gko_mphf* m, uint64_t lo, uint64_t hi)                                            /* lookup :787-822 */
+{
+    int level; uint64_t s[2] = {0, 0};
+    const uint64_t level_hash = mphf_get_level(m, lo, hi, 100, &level, s);
+    if (level == MPHF_NB_LEVELS - 1) {
+        for (uint64_t i = 0; i < m->nfinal; i++) if (m->final_lo[i] == lo && m->final_hi[i] == hi) return m->final_val[i] + m->lastbitsetrank;
+        return ~0ULL;
+    }
+    const uint64_t pos = level_hash % m->domain[level];
+    const uint64_t word = pos / 64, block = pos / 512;                                                           /* bitVector::rank :611-624 */
+    uint64_t r = m->ranks[level][block];
+    for (uint64_t w = block * 512 / 64; w < word; w++) r += (uint64_t)__builtin_popcountll(m->bits[level][w]);
+    r += (uint64_t)__builtin_popcountll(m->bits[level][word] & ((1ULL << (pos % 64)) - 1));
+    return r;
+}
+uint64_t gko_mphf_save(const gko_mphf* m, uint8_t* out, uint64_t cap)                                            /* mphf::save :933-958, bitVector::save :627-635 */
+{
+    uint64_t pos = 0;
+#define PUT(ptr, nbytes) do { if (out && pos + (nbytes) <= cap) memcpy(out + pos, (ptr), (nbytes)); pos += (nbytes); } while (0)
+    const int nbl = MPHF_NB_LEVELS;
+    PUT(&m->gamma, 8); PUT(&nbl, 4); PUT(&m->lastbitsetrank, 8); PUT(&m->nelem, 8);
+    for (int i = 0; i < MPHF_NB_LEVELS; i++) {
+        PUT(&m->domain[i], 8); PUT(&m->nchar[i], 8); PUT(m->bits[i], m->nchar[i] * 8);
+        PUT(&m->nranks[i], 8); PUT(m->ranks[i], m->nranks[i] * 8);
+    }
+    PUT(&m->nfinal, 8);
+    for (uint64_t i = 0; i < m->nfinal; i++) { PUT(&m->final_lo[i], 8); if (m->wide) PUT(&m->final_hi[i], 8); PUT(&m->final_val[i], 8); }
+#undef PUT
+    return pos;
+}
+int gko_abundance_index(int abundance)                                                                           /* MapMPHF.hpp:96-145 + MPHFAlgorithm.cpp:253-266 */
+{
+    static int disc[257]; static int init = 0;
+    if (!init) {
+        int total = 0, idx = 1; disc[0] = 0;
+        for (int i = 1; i <= 70; i++, idx++) { total += 1; disc[idx] = total; }
+        for (int i = 1; i <= 15; i++, idx++) { total += 2; disc[idx] = total; }
+        for (int i = 1; i <= 40; i++, idx++) { total += 10; disc[idx] = total; }
+        for (int i = 1; i <= 25; i++, idx++) { total += 20; disc[idx] = total; }
+        for (int i = 1; i <= 40; i++, idx++) { total += 100; disc[idx] = total; }
+        for (int i = 1; i <= 25; i++, idx++) { total += 200; disc[idx] = total; }
+        for (int i = 1; i <= 40; i++, idx++) { total += 1000; disc[idx] = total; }
+        disc[256] = total; init = 1;
+    }
+    const int max_discrete = disc[257 - 2];
+    if (abundance >= max_discrete) return 257 - 2;
+    int lo = 0, hi = 257;                                        /* std::upper_bound: first cell strictly greater than abundance, then the previous one */
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (disc[mid] <= abundance) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}

@@ -123,3 +123,14 @@ int64_t gko_fastx_parse(const char* text, uint64_t n, char* out_data, uint64_t c
 
 /* ---- Histogram::compute_threshold (tools/misc/impl/Histogram.cpp:61-190): histo[0..length] -> out = {cutoff, nbsolids, first_peak} */
 void gko_histogram_cutoff(const uint64_t* histo, uint64_t length, int min_auto_threshold, uint64_t out[3]);
+
+/* ---- MPHF: BooPHF (thirdparty/BooPHF/BooPHF.h:714-1200) as GATB instantiates it (tools/collections/impl/BooPHF.hpp:236-300:
+ *      jenkins64 hasher seeded by std::mt19937_64(37), gamma = 3, 25 levels) + the abundance map of MPHFAlgorithm::populate
+ *      (kmer/impl/MPHFAlgorithm.cpp:222-275) with MapMPHF's discretization table (tools/collections/impl/MapMPHF.hpp:96-145).
+ *      Keys: n items of `stride` bytes whose first 8 (wide = 0) or 16 (wide = 1) bytes are the k-mer, little-endian. */
+typedef struct gko_mphf gko_mphf;
+gko_mphf* gko_mphf_build(const void* keys, uint64_t n, uint32_t stride, int wide);
+void      gko_mphf_free(gko_mphf*);
+uint64_t  gko_mphf_lookup(const gko_mphf*, uint64_t lo, uint64_t hi);        /* ULLONG_MAX: not in the set (final level miss) */
+uint64_t  gko_mphf_save(const gko_mphf*, uint8_t* out, uint64_t cap);         /* mphf::save byte stream; returns its size (out may be NULL) */
+int       gko_abundance_index(int abundance);                                 /* MPHFAlgorithm.cpp:253-266 */

@@ -113,6 +113,42 @@ def histogram_cutoff(histo, min_auto_threshold=3):
     return int(out[0]), int(out[1]), int(out[2])
 
 
+class Mphf:
+    """BooPHF restated (oracle/gkc_oracle.c gko_mphf_*)"""
+
+    def __init__(self, keys, k):
+        L = lib()
+        L.gko_mphf_build.restype = C.c_void_p; L.gko_mphf_build.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int]
+        L.gko_mphf_lookup.restype = C.c_uint64; L.gko_mphf_lookup.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.gko_mphf_save.restype = C.c_uint64; L.gko_mphf_save.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.gko_mphf_free.restype = None; L.gko_mphf_free.argtypes = [C.c_void_p]
+        self.L = L; self.wide = k > 31
+        a = np.zeros((len(keys), 2), dtype=np.uint64)
+        for i, x in enumerate(keys):
+            a[i, 0] = int(x) & 0xFFFFFFFFFFFFFFFF; a[i, 1] = int(x) >> 64
+        self.n = len(keys)
+        self.h = L.gko_mphf_build(_ptr(a), len(keys), 16, 1 if self.wide else 0)
+
+    def lookup(self, keys):
+        return np.array([self.L.gko_mphf_lookup(self.h, int(x) & 0xFFFFFFFFFFFFFFFF, int(x) >> 64) for x in keys], dtype=np.uint64)
+
+    def save(self):
+        n = self.L.gko_mphf_save(self.h, None, 0)
+        out = np.zeros(n, np.uint8); self.L.gko_mphf_save(self.h, _ptr(out), n); return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.gko_mphf_free(self.h); self.h = None
+        except Exception:
+            pass
+
+
+def abundance_index(a):
+    L = lib(); L.gko_abundance_index.restype = C.c_int; L.gko_abundance_index.argtypes = [C.c_int]
+    return L.gko_abundance_index(int(a))
+
+
 def pack_reads(reads):
     """list of bytes/str -> (flat uint8 array, offsets uint64[n+1])"""
     bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]

@@ -271,3 +271,28 @@ def test_histogram_cutoff_properties():
     mono = np.zeros(10001, np.uint64); mono[1:200] = np.arange(199, 0, -1, dtype=np.uint64) * 1000   # never increases: default threshold
     assert gko.histogram_cutoff(mono, 3)[0] == 3
     assert gko.histogram_cutoff(mono, 7)[0] == 7
+
+
+def test_mphf_check1_known_answers():
+    """TestMPHF.cpp:95-161 MPHF_check1: k=11 on a 140-nt sequence -> 130 solid k-mers, the MPHF is a bijection onto [0,130)
+    (TestMPHF.cpp:209-246 checks exactly that), the abundance map has 130 cells"""
+    seq = ("CGCTACAGCAGCTAGTTCATCATTGTTTATCAATGATAAAATATAATAAGCTAAAAGGAAACTATAAATA"
+           "ACCATGTATAATTATAAGTAGGTACCTATTTTTTTATTTTAAACTGAAATTCAATATTATATAGGCAAAG")
+    k = 11
+    bases, offs = gko.pack_reads([seq])
+    d = gko.Dsk(bases, offs, k, 8, 4, simple_repart(8, 4))
+    keys = sorted(d.all_counts().keys())
+    assert len(keys) == len(seq) - k + 1 == 130
+    m = gko.Mphf(keys, k)
+    codes = m.lookup(keys)
+    assert sorted(codes.tolist()) == list(range(130))
+    # stream layout of mphf::save (BooPHF.h:933-958): gamma, nb_levels, lastbitsetrank, nelem
+    s = m.save()
+    assert s[:8].view(np.float64)[0] == 3.0 and s[8:12].view(np.int32)[0] == 25
+    assert s[12:20].view(np.uint64)[0] == 130 and s[20:28].view(np.uint64)[0] == 130
+
+
+def test_abundance_discretization():
+    # MapMPHF.hpp:96-145: steps 1 (x70), 2 (x15), 10 (x40), 20 (x25), 100 (x40), 200 (x25), 1000 (x40); MPHFAlgorithm.cpp:253-266
+    assert [gko.abundance_index(a) for a in (0, 1, 70, 71, 72, 100, 500, 501)] == [0, 1, 70, 70, 71, 85, 125, 125]
+    assert gko.abundance_index(50000) == 255 and gko.abundance_index(49999) == 254

@@ -19,3 +19,11 @@ for kind in ("basic", "cache", "neighbor"):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(kind, "solid", ns, "bits", bits, "insert ms", round(dt * 1e3, 1), "G kmers/s", round(ns / dt / 1e9, 2))
     del b
+# MPHF of the same solid k-mers + abundance map
+torch.cuda.synchronize(); t0 = time.perf_counter()
+mp = gkc.Mphf(c)
+torch.cuda.synchronize(); t1 = time.perf_counter()
+amap, above = mp.abundance_map()
+torch.cuda.synchronize(); t2 = time.perf_counter()
+print("mphf keys", mp.size, "build ms", round((t1 - t0) * 1e3, 1), "G keys/s", round(mp.size / (t1 - t0) / 1e9, 2), "stream bytes", mp.L.gkc_mphf_save_size(mp.h),
+      "bits/key", round(mp.L.gkc_mphf_save_size(mp.h) * 8 / mp.size, 2), "| abundance map ms (incl. D2H of %d MB)" % (mp.size >> 20), round((t2 - t1) * 1e3, 1), "above", above)
