@@ -217,14 +217,15 @@ __global__ __launch_bounds__(1024) void k_ms_add(uint64_t* __restrict__ a, uint6
 #pragma unroll
     for (int j = 0; j < MS_ITEMS; j++) if (i0 + j < n) a[i0 + j] += o;
 }
+// in-place exclusive scan of a[0..n), *d_total = sum: chunks of 8192, the chunk totals scanned the same way (two levels reach 5.5e11 items)
 int ms_scan(gkc_ctx* c, uint64_t* a, uint64_t n, uint64_t* d_total, DevBuf& scratch)
 {
-    const uint32_t n_chunks = (uint32_t)((n + MS_CHUNK - 1) / MS_CHUNK);
-    if (n_chunks > (uint32_t)MS_CHUNK) GKC_FAIL(c, GKC_ERR_ARG, "too many items for one scan");
-    GKC_TRY(c->ensure(scratch, (size_t)std::max<uint32_t>(n_chunks, 1) * 8));
-    if (n_chunks) hipLaunchKernelGGL(k_ms_chunks, dim3(n_chunks), dim3(1024), 0, c->stream, a, n, (uint64_t*)scratch.p);
-    hipLaunchKernelGGL(k_ms_totals, dim3(1), dim3(1024), 0, c->stream, (uint64_t*)scratch.p, n_chunks, d_total);
-    if (n_chunks) hipLaunchKernelGGL(k_ms_add, dim3(n_chunks), dim3(1024), 0, c->stream, a, n, (const uint64_t*)scratch.p);
+    const uint64_t n_chunks = (n + MS_CHUNK - 1) / MS_CHUNK;
+    GKC_TRY(c->ensure(scratch, (size_t)std::max<uint64_t>(n_chunks, 1) * 8));
+    if (n_chunks) hipLaunchKernelGGL(k_ms_chunks, dim3((unsigned)n_chunks), dim3(1024), 0, c->stream, a, n, (uint64_t*)scratch.p);
+    if (n_chunks <= (uint64_t)MS_CHUNK) hipLaunchKernelGGL(k_ms_totals, dim3(1), dim3(1024), 0, c->stream, (uint64_t*)scratch.p, (uint32_t)n_chunks, d_total);
+    else { DevBuf deeper; int rc = ms_scan(c, (uint64_t*)scratch.p, n_chunks, d_total, deeper); (void)hipStreamSynchronize(c->stream); deeper.release(); if (rc != GKC_OK) return rc; }
+    if (n_chunks) hipLaunchKernelGGL(k_ms_add, dim3((unsigned)n_chunks), dim3(1024), 0, c->stream, a, n, (const uint64_t*)scratch.p);
     GKC_HIP(c, hipGetLastError());
     return GKC_OK;
 }
@@ -440,11 +441,17 @@ int gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* c, uint8_t* out, uint64_t cap, 
     if (e == hipSuccess) e = hipMemsetAsync(dst.p, 0, 16, c->stream);
     const uint32_t stride = c->key_words == 1 ? 16 : 32;
     {   ScopedTimer tm(c, "mphf_populate");
+        std::vector<std::pair<const uint8_t*, uint64_t>> segs;        // datasets of one Stage-B batch are one array
         for (const Dataset& D : c->datasets) {
-            if (e != hipSuccess || !D.done || !D.n_solid) continue;
-            const unsigned grid = (unsigned)std::min<uint64_t>((D.n_solid + 255) / 256, 256 * 32);
+            if (!D.done || !D.n_solid) continue;
+            if (!segs.empty() && (const uint8_t*)D.d_counts == segs.back().first + segs.back().second * stride) { segs.back().second += D.n_solid; continue; }
+            segs.push_back({ (const uint8_t*)D.d_counts, D.n_solid });
+        }
+        for (auto& sg : segs) {
+            if (e != hipSuccess) break;
+            const unsigned grid = (unsigned)std::min<uint64_t>((sg.second + 255) / 256, 256 * 32);
             hipLaunchKernelGGL(k_mphf_populate, dim3(grid), dim3(256), 0, c->stream, m->L, (const uint64_t*)m->bits.p, (const uint64_t*)m->ranks.p, m->wide, (const uint64_t*)m->final_keys.p,
-                               m->n_final, m->lastbitsetrank, (const uint8_t*)D.d_counts, D.n_solid, stride, m->nelem, (uint8_t*)dmap.p, (unsigned long long*)dst.p);
+                               m->n_final, m->lastbitsetrank, sg.first, sg.second, stride, m->nelem, (uint8_t*)dmap.p, (unsigned long long*)dst.p);
             e = hipGetLastError();
         }
     }

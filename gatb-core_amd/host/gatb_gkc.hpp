@@ -772,6 +772,76 @@ private:
     gkc_ctx* _ctx; size_t _kmerSize; float _nbitsPerKmer; tools::collections::impl::BloomKind _kind;
     tools::collections::impl::IBloom<Type>* _bloom; tools::misc::Properties _info;
 };
+
+/** MPHFAlgorithm (kmer/impl/MPHFAlgorithm.hpp:79-170, .cpp:150-275): BooPHF of the solid k-mers + abundance map, both built on the
+ *  device from the counting context's result buffers. AbundanceMap = MapMPHF<Type, uint8_t>: size(), at(kmer), getCode(kmer)
+ *  (tools/collections/impl/MapMPHF.hpp:60-260); the saved hash is the byte stream MPHF<>::save writes into "dsk/mphf". */
+template <size_t span = KMER_DEFAULT_SPAN>
+class MPHFAlgorithm {
+public:
+    typedef typename Kmer<span>::Type Type;
+    class AbundanceMap {
+    public:
+        AbundanceMap(gkc_mphf* h, size_t kmerBytes) : _h(h), _kb(kmerBytes), _data(gkc_mphf_size(h), 0) {}
+        size_t size() const { return _data.size(); }
+        uint64_t getCode(const Type& kmer) const {
+            uint64_t code = 0, raw[2] = { 0, 0 };
+            memcpy(raw, &kmer, _kb);                                   // LargeInt<1|2> is its little-endian value (8 / 16 bytes)
+            if (gkc_mphf_lookup(_h, raw, 1, (uint32_t)_kb, &code) != GKC_OK) throw system::Exception("MPHF lookup failed");
+            return code;
+        }
+        uint8_t& at(const Type& kmer) { const uint64_t c = getCode(kmer); if (c >= _data.size()) throw system::Exception("MPHF check: value out of bounds"); return _data[c]; }
+        uint8_t& at(uint64_t code) { return _data[code]; }
+        std::vector<uint8_t>& data() { return _data; }
+    private:
+        gkc_mphf* _h; size_t _kb; std::vector<uint8_t> _data;
+    };
+    typedef std::vector<std::vector<typename Kmer<span>::Count>> Store;
+    /** solidCounts = the dump processor's datasets (getSolidCounts()): keys and abundances come from there, as in the reference.
+     *  Without it the device result buffers are used directly (valid when the device applied the solidity window itself). */
+    explicit MPHFAlgorithm(gkc_ctx* countedCtx, size_t kmerSize, const Store* solidCounts = nullptr)
+        : _ctx(countedCtx), _k(kmerSize), _store(solidCounts), _h(nullptr), _map(nullptr), _dataSize(0) {}
+    ~MPHFAlgorithm() { delete _map; if (_h) gkc_mphf_destroy(_h); }
+    /** index of an abundance in MapMPHF's discretization table (MapMPHF.hpp:96-145, MPHFAlgorithm.cpp:253-266) */
+    static int abundanceIndex(int abundance) {
+        static std::vector<int> disc;
+        if (disc.empty()) { disc.resize(257); int total = 0, idx = 1; disc[0] = 0;
+            auto run = [&](int cnt, int step) { for (int i = 1; i <= cnt; i++, idx++) { total += step; disc[idx] = total; } };
+            run(70, 1); run(15, 2); run(40, 10); run(25, 20); run(40, 100); run(25, 200); run(40, 1000); disc[256] = total; }
+        if (abundance >= disc[disc.size() - 2]) return (int)disc.size() - 2;
+        return (int)(std::upper_bound(disc.begin(), disc.end(), abundance) - disc.begin()) - 1;
+    }
+    void execute() {
+        const size_t kb = _k <= 31 ? 8 : 16;
+        uint64_t above = 0;
+        if (_store) {
+            typedef typename Kmer<span>::Count Count;
+            std::vector<Count> all; for (auto& d : *_store) all.insert(all.end(), d.begin(), d.end());
+            if (gkc_mphf_build(_ctx, all.data(), all.size(), (uint32_t)sizeof(Count), (uint32_t)_k, &_h) != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx));   // build
+            _map = new AbundanceMap(_h, kb);
+            std::vector<uint64_t> codes(all.size());
+            if (gkc_mphf_lookup(_h, all.data(), all.size(), (uint32_t)sizeof(Count), codes.data()) != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx));
+            for (size_t i = 0; i < all.size(); i++) {                                                                  // populate
+                if (codes[i] >= all.size()) throw system::Exception("MPHF check: value out of bounds");
+                const int idx = abundanceIndex((int)all[i].abundance); if (idx == 255) above++;
+                _map->at(codes[i]) = (uint8_t)idx;
+            }
+        } else {
+            if (gkc_mphf_build_solid(_ctx, &_h) != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx));
+            _map = new AbundanceMap(_h, kb);
+            if (gkc_mphf_abundance_map(_h, _ctx, _map->data().data(), _map->data().size(), &above) != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx));
+        }
+        _dataSize = gkc_mphf_save_size(_h);                                                                           // save
+        _info.add("nb_keys", "%llu", (unsigned long long)_map->size()); _info.add("data_size", "%llu", (unsigned long long)_dataSize);
+        _info.add("bits_per_key", "%.3f", (float)(_dataSize * 8) / (float)_map->size()); _info.add("nb_abund_above_prec", "%llu", (unsigned long long)above);
+    }
+    AbundanceMap* getAbundanceMap() { return _map; }
+    /** the stream MPHF<>::save puts into the storage group (tools/collections/impl/BooPHF.hpp:313-322) */
+    std::vector<uint8_t> savedHash() const { std::vector<uint8_t> v(_dataSize); if (gkc_mphf_save(_h, v.data(), v.size()) != GKC_OK) throw system::Exception("MPHF save failed"); return v; }
+    const tools::misc::Properties* getInfo() const { return &_info; }
+private:
+    gkc_ctx* _ctx; size_t _k; const Store* _store; gkc_mphf* _h; AbundanceMap* _map; uint64_t _dataSize; tools::misc::Properties _info;
+};
 }}  // namespace kmer::impl
 
 }}  // namespace gatb::core

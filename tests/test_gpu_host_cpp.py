@@ -57,7 +57,7 @@ def test_cli_dump_matches_oracle(built, tmp_path, k, mtype, fmt):
         fa.write_text(text)
     out = str(tmp_path / "out")
     r = subprocess.run([os.path.join(built, "gkc_dsk"), "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2", "-minimizer-type", str(mtype),
-                        "-nb-partitions", "8", "-out", out], capture_output=True, text=True, timeout=600)
+                        "-nb-partitions", "8", "-mphf", "1", "-out", out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     info = dict(l.split("\t") for l in open(out + ".info").read().splitlines())
     # the repartition table the C++ layer built (device statistics -> host table) drives the oracle too
@@ -82,6 +82,19 @@ def test_cli_dump_matches_oracle(built, tmp_path, k, mtype, fmt):
     hist = {int(a): int(b) for a, b in (l.split("\t") for l in open(out + ".histo").read().splitlines())}
     rh = ref.histogram()
     assert hist == {i: int(c) for i, c in enumerate(rh) if c and i > 0}
+    # MPHFAlgorithm through the C++ layer: saved hash = BooPHF's stream for the solid k-mers in getSolidKmers() order, abundance map
+    order, ab = [], {}
+    for p in range(8):
+        lo, hi, a = ref.part(p)
+        for x, y, z in zip(lo, hi, a):
+            key = int(x) | (int(y) << 64); order.append(key); ab[key] = int(z)
+    om = gko.Mphf(order, k)
+    assert np.array_equal(np.fromfile(out + ".mphf", dtype=np.uint8), om.save())
+    amap = np.fromfile(out + ".abundancemap", dtype=np.uint8)
+    want = np.zeros(len(order), np.uint8)
+    for key, cd in zip(order, om.lookup(order)):
+        want[int(cd)] = gko.abundance_index(ab[key])
+    assert np.array_equal(amap, want)
     # histogram/cutoff, nbsolidsforcutoff (Histogram::compute_threshold) computed by the C++ layer from the device histogram
     cut = [int(x) for x in open(out + ".cutoff").read().split()]
     assert tuple(cut) == gko.histogram_cutoff(rh, 3)

@@ -19,7 +19,8 @@ for kind in ("basic", "cache", "neighbor"):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(kind, "solid", ns, "bits", bits, "insert ms", round(dt * 1e3, 1), "G kmers/s", round(ns / dt / 1e9, 2))
     del b
-# MPHF of the same solid k-mers + abundance map
+# MPHF of the same solid k-mers + abundance map (second build: the device pool is warm)
+mp = gkc.Mphf(c); mp.close()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 mp = gkc.Mphf(c)
 torch.cuda.synchronize(); t1 = time.perf_counter()
