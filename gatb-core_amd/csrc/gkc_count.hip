@@ -1173,7 +1173,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             // deeper levels see clustered keys (that is why the bucket was oversize): split 8x finer than the mean asks for
             uint32_t bits = 1;
             while (bits < (uint32_t)MAX_SUB_BITS && bits < left && (d.n >> bits) > target) bits++;
-            bits = std::min<uint32_t>(std::min<uint32_t>(bits + 2, (uint32_t)MAX_SUB_BITS), left);
+            static const int extra_env = getenv("GKC_SPLIT_EXTRA") ? atoi(getenv("GKC_SPLIT_EXTRA")) : 2;
+            bits = std::min<uint32_t>(std::min<uint32_t>(bits + (uint32_t)extra_env, (uint32_t)MAX_SUB_BITS), left);
             d.bits = bits; d.left = left; d.child_base = n_child; n_child += (1ull << bits);
             split.push_back(d);
         }

@@ -31,6 +31,7 @@
 #include <string>
 #include <vector>
 #include "../../include/gkc.h"
+#include "gkc_h5.hpp"
 
 namespace gatb { namespace core {
 
@@ -289,6 +290,19 @@ public:
         }
     }
     /** byte stream of Repartitor::save: u16 nbpart; u64 nb_minims; u16 nbPass; u16 table[]; u8 hasFreq; u32 magic (+ freq file) */
+    /** the stream the reference stores as the u8 dataset minimizers/minimRepart (PartiInfo.cpp:271-295) */
+    std::vector<uint8_t> stream() const {
+        std::vector<uint8_t> v; const uint32_t magic = 0x12345678; const uint8_t hasf = !_freq_order.empty();
+        auto put = [&](const void* p, size_t n) { v.insert(v.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
+        put(&_nbpart, 2); put(&_nb_minims, 8); put(&_nbPass, 2); put(_repart_table.data(), 2 * _nb_minims); put(&hasf, 1); put(&magic, 4);
+        return v;
+    }
+    std::vector<uint8_t> frequencyStream() const {
+        std::vector<uint8_t> v; const uint32_t magic = 0x12345678;
+        if (_freq_order.empty()) return v;
+        v.insert(v.end(), (const uint8_t*)_freq_order.data(), (const uint8_t*)_freq_order.data() + 4 * _nb_minims);
+        v.insert(v.end(), (const uint8_t*)&magic, (const uint8_t*)&magic + 4); return v;
+    }
     void save(const std::string& path) const {
         std::ofstream os(path, std::ios::binary);
         const uint32_t magic = 0x12345678; const uint8_t hasf = !_freq_order.empty();
@@ -364,7 +378,7 @@ public:
 
     /** Histogram::compute_threshold (tools/misc/impl/Histogram.cpp:61-190): smoothed histogram, first increase, first peak after it, cutoff =
      *  the minimum between them, capped where 25 % of the k-mer volume would be eliminated, floored by min_auto_threshold */
-    void compute_threshold(int min_auto_threshold = 3) {
+    void compute_threshold(int min_auto_threshold = 2 /* -abundance-min-threshold default, SortingCountAlgorithm.cpp:212 */) {
         const std::vector<uint64_t>& h = *_shared; const size_t L = _length;
         std::vector<uint64_t> sm(L + 1, 0);
         uint64_t sum_allk = 0;
@@ -516,6 +530,56 @@ public:
         throw system::Exception("no dump processor");
     }
     gkc_ctx* context() { return _ctx; }
+
+    /** the .h5 the DSK step of dbgh5 leaves (tools/storage/impl/StorageHDF5.hpp, CountProcessorDump.hpp:85-131, Histogram::save, Repartitor::save):
+     *  /dsk/solid/<dataset> Count datasets, /histogram/{histogram,cutoff,nbsolidsforcutoff}, /minimizers/minimRepart(+minimFrequency),
+     *  /configuration, string attributes. Written by the native writer gkc_h5.hpp (contiguous datasets; same names, types and values). */
+    void saveH5(const std::string& path) {
+        auto* chain = dynamic_cast<CountProcessorChain<span>*>(_processors.empty() ? nullptr : _processors[0]);
+        auto* dump = chain ? chain->template get<CountProcessorDump<span>>() : nullptr;
+        auto* histo = chain ? chain->template get<CountProcessorHistogram<span>>() : nullptr;
+        if (!dump || !histo) throw system::Exception("saveH5 needs the default processor chain");
+        const auto& store = dump->getSolidCounts();
+        gkc_h5::File f(std::max<size_t>(store.size(), 16));
+        auto xml = [](const std::string& root, const std::map<std::string, std::string>& kv) {
+            std::string x = "\n<" + root + ">\n"; for (auto& p : kv) x += "   <" + p.first + ">" + p.second + "</" + p.first + ">\n"; return x + "</" + root + ">"; };
+        uint64_t nb_solid = 0; for (auto& d : store) nb_solid += d.size();
+        f.set_attribute("/", "kmer_size", std::to_string(_config._kmerSize));
+        f.set_attribute("/", "nb_solid_kmers", std::to_string(nb_solid));
+        f.set_attribute("/", "state", "7");                                   // Graph.cpp: init | bank converter | sorting count done
+        f.set_attribute("/", "xml", xml("gatb-core-library", { {"version", "gkc-" + std::string(gkc_version())}, {"build_kmer_size", "32 64"} }));
+        f.set_attribute("/configuration", "xml", xml("configuration", {
+            {"kmer_size", std::to_string(_config._kmerSize)}, {"mini_size", std::to_string(_config._minim_size)}, {"solidity_kind", "sum"},
+            {"abundance_min", std::to_string(_config._abundance_min)}, {"abundance_max", std::to_string(_config._abundance_max)},
+            {"estimated_sequence_number", std::to_string(_config._estimateSeqNb)}, {"estimated_kmers_number", std::to_string(_config._kmersNb)},
+            {"max_memory", std::to_string(_config._max_memory)}, {"nb_passes", std::to_string(_config._nb_passes)}, {"nb_partitions", std::to_string(_config._nb_partitions)},
+            {"nb_bits_per_kmer", std::to_string(span <= 32 ? 64 : 128)}, {"minimizer_type", std::to_string(_config._minimizerType)},
+            {"repartition_type", std::to_string(_config._repartitionType)}, {"nb_banks", std::to_string(_config._nb_banks)} }));
+        f.set_attribute("/dsk", "kmer_size", std::to_string(_config._kmerSize));
+        f.set_attribute("/dsk", "xml", xml("dsk", _info.map()));
+        f.set_attribute("/dsk/solid", "nb_partitions", std::to_string(store.size()));
+        // Count = {value, abundance} (Abundance.hpp:108-125); value: u64, or the 128-bit integer of LargeInt<2>::hdf5 (LargeInt2.pri:137-142)
+        const gkc_h5::Type vt = span <= 32 ? gkc_h5::Type::integer(8, false) : gkc_h5::Type::integer(16, true, 128);
+        const gkc_h5::Type ct = gkc_h5::Type::compound((uint32_t)sizeof(Count), { {"value", {0, vt}}, {"abundance", {(uint32_t)(span <= 32 ? 8 : 16), gkc_h5::Type::integer(4, false)}} });
+        for (size_t i = 0; i < store.size(); i++) f.add_dataset("/dsk/solid/" + std::to_string(i), ct, store[i].data(), store[i].size());
+        // Histogram::save: entries 1..length as {u16 index (stored on 4 bytes), u64 abundance}, then cutoff and nbsolids (Histogram.cpp:192-240)
+        struct HEntry { uint32_t index; uint32_t pad; uint64_t abundance; };
+        const auto& hv = histo->getHistogram();
+        std::vector<HEntry> he; for (size_t i = 1; i < hv.size(); i++) he.push_back(HEntry{ (uint32_t)i, 0, hv[i] });
+        const gkc_h5::Type ht = gkc_h5::Type::compound(16, { {"index", {0, gkc_h5::Type::integer(4, false)}}, {"abundance", {8, gkc_h5::Type::integer(8, false)}} });
+        f.add_dataset("/histogram/histogram", ht, he.data(), he.size());
+        histo->compute_threshold(_params.has("-abundance-min-threshold") ? (int)_params.getInt("-abundance-min-threshold") : 2);
+        const uint64_t cutoff = histo->get_solid_cutoff(), nbs = histo->get_nbsolids_auto();
+        f.add_dataset("/histogram/cutoff", gkc_h5::Type::integer(8, false), &cutoff, 1);
+        f.add_dataset("/histogram/nbsolidsforcutoff", gkc_h5::Type::integer(8, false), &nbs, 1);
+        const std::vector<uint8_t> rs = _repartitor->stream(), fs = _repartitor->frequencyStream();
+        f.add_dataset("/minimizers/minimRepart", gkc_h5::Type::integer(1, false), rs.data(), rs.size());
+        if (!fs.empty()) f.add_dataset("/minimizers/minimFrequency", gkc_h5::Type::integer(1, false), fs.data(), fs.size());
+        const auto& img = f.finish();
+        std::ofstream os(path, std::ios::binary);
+        if (!os) throw system::Exception("Unable to create '%s'", path.c_str());
+        os.write((const char*)img.data(), (std::streamsize)img.size());
+    }
 
     /** file banks: the text goes to the device parser in chunks (gkc_push_fastx). Text the device parser refuses (GKC_ERR_FORMAT:
      *  e.g. multi-line FASTQ) is read by the host walk instead, like every bank of the reference; returns false in that case. */

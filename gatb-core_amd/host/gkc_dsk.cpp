@@ -18,7 +18,7 @@ template <size_t span> static int run(tools::misc::IProperties* params, const st
             auto* hp = chain->template get<CountProcessorHistogram<span>>();
             std::ofstream h(out + ".histo"); const auto& hv = hp->getHistogram();
             for (size_t i = 1; i < hv.size(); i++) if (hv[i]) h << i << "\t" << hv[i] << "\n";
-            hp->compute_threshold(3);                                              // histogram/cutoff, nbsolidsforcutoff (SortingCountAlgorithm.cpp:700-726)
+            hp->compute_threshold(2);                                              // histogram/cutoff, nbsolidsforcutoff (SortingCountAlgorithm.cpp:700-726)
             std::ofstream cu(out + ".cutoff"); cu << hp->get_solid_cutoff() << "\t" << hp->get_nbsolids_auto() << "\t" << hp->get_first_peak() << "\n";
         }
         if (chain && params->has("-mphf") && params->getInt("-mphf")) {                         // dbgh5's mphf step on the counted k-mers (-mphf 1)
@@ -27,6 +27,7 @@ template <size_t span> static int run(tools::misc::IProperties* params, const st
             const auto h = mphf.savedHash(); std::ofstream mo(out + ".mphf", std::ios::binary); mo.write((const char*)h.data(), (std::streamsize)h.size());
             auto& d = mphf.getAbundanceMap()->data(); std::ofstream ao(out + ".abundancemap", std::ios::binary); ao.write((const char*)d.data(), (std::streamsize)d.size());
         }
+        dsk.saveH5(out + ".h5");
         dsk.getRepartitor()->save(out + ".minimRepart");
         std::ofstream info(out + ".info"); for (auto& kv : dsk.getInfo()->map()) info << kv.first << "\t" << kv.second << "\n";
     }

@@ -97,4 +97,4 @@ def test_cli_dump_matches_oracle(built, tmp_path, k, mtype, fmt):
     assert np.array_equal(amap, want)
     # histogram/cutoff, nbsolidsforcutoff (Histogram::compute_threshold) computed by the C++ layer from the device histogram
     cut = [int(x) for x in open(out + ".cutoff").read().split()]
-    assert tuple(cut) == gko.histogram_cutoff(rh, 3)
+    assert tuple(cut) == gko.histogram_cutoff(rh, 2)

@@ -260,8 +260,8 @@ def test_bloom_seeds_documented_values():
 
 
 def test_histogram_cutoff_properties():
-    """Histogram::compute_threshold restated (Histogram.cpp:61-190). The reference's unit tests hold no known answer for it (parity
-    unpinned for this function): what is checked here are the properties its code guarantees."""
+    """Histogram::compute_threshold restated (Histogram.cpp:61-190): properties its code guarantees. The known answers (cutoff and
+    nbsolidsforcutoff written by the reference itself) are in tests/test_reference_run.py."""
     x = np.arange(10001)
     h = np.zeros(10001, np.uint64)
     h[1:] = (1e6 * np.exp(-(x[1:] - 1) / 0.8) + 2e4 * np.exp(-0.5 * ((x[1:] - 30) / 5.5) ** 2)).astype(np.uint64)

@@ -1,0 +1,60 @@
+"""The oracle against outputs of the reference ITSELF (tests/golden/reference_run/*.npz, written by tools/make_reference_run_vectors.py
+from runs of the reference's own dbgh5): solid k-mer sets per dataset, histogram, cutoff, Bloom arrays of the three kinds, MPHF stream."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import gko
+
+DIR = os.path.join(os.path.dirname(__file__), "golden", "reference_run")
+FIX = sorted(glob.glob(os.path.join(DIR, "*.npz")))
+
+
+def load(path):
+    z = np.load(path)
+    k = int(z["k"])
+    vb = z["solid_value_bytes"]
+    vals = [int.from_bytes(bytes(r), "little") for r in vb]
+    sizes = z["solid_sizes"].tolist()
+    parts, pos = [], 0
+    for n in sizes:
+        parts.append(list(zip(vals[pos:pos + n], z["solid_abundance"][pos:pos + n].tolist()))); pos += n
+    rep = z["minimRepart"]
+    nbpart = int(rep[:2].view("<u2")[0]); nmin = int(rep[2:10].view("<u8")[0])
+    table = rep[12:12 + 2 * nmin].view("<u2").copy()
+    m = int(round(np.log2(nmin) / 2))
+    return z, k, m, nbpart, table, parts
+
+
+def oracle_run(z, k, m, nbpart, table):
+    bases, offs = gko.fastx_parse(bytes(z["fasta"]))
+    # partition membership only depends on the table in lexicographic mode; in frequency mode (one partition here) every minimizer maps to 0
+    return gko.Dsk(bases, offs, k, m, nbpart, table, abundance_min=2)
+
+
+@pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[:-4] for p in FIX])
+def test_oracle_equals_reference_run(path):
+    z, k, m, nbpart, table, parts = load(path)
+    if "freq" in path:
+        assert nbpart == 1
+    d = oracle_run(z, k, m, nbpart, table)
+    assert d.stats["kmers_nb_solid"] == int(z["nb_solid_kmers"]) == sum(len(p) for p in parts)
+    for p in range(nbpart):
+        lo, hi, ab = d.part(p)
+        got = [(int(a) | (int(b) << 64), int(c)) for a, b, c in zip(lo, hi, ab)]
+        assert got == parts[p], (p, len(got), len(parts[p]))                        # same k-mers, same counts, same (ascending) order
+    h = d.histogram()
+    assert z["histogram_index"].tolist() == list(range(1, len(z["histogram_index"]) + 1))
+    assert np.array_equal(h[1:len(z["histogram_abundance"]) + 1], z["histogram_abundance"])
+    cut, nbs, _ = gko.histogram_cutoff(h, 2)                                          # Histogram::compute_threshold, -abundance-min-threshold default 2
+                                                                                      # (SortingCountAlgorithm.cpp:212)
+    assert (cut, nbs) == (int(z["cutoff"]), int(z["nbsolidsforcutoff"]))
+    order = [x for p in parts for x, _ in p]
+    if "bloom" in z:
+        kind = bytes(z["bloom_type"]).decode(); size = int(bytes(z["bloom_size"]).decode()); nh = int(bytes(z["bloom_nb_hash"]).decode())
+        ob = gko.Bloom(kind, size, nh, k); ob.insert(order)
+        assert np.array_equal(ob.array(), z["bloom"]), kind
+    if "mphf" in z:
+        assert np.array_equal(gko.Mphf(order, k).save(), z["mphf"])

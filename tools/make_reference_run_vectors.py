@@ -1,0 +1,86 @@
+"""Golden vectors from the reference ITSELF: runs the reference's dbgh5 / gatb-h5dump binaries that the survey phase of this project had
+built in this container (/tmp/gatb_build, the reference's own cmake build — not rebuilt or modified here) on small generated inputs and
+stores what they wrote as fixtures under tests/golden/reference_run/. The tests only read the committed fixtures.
+
+    python tools/make_reference_run_vectors.py [/tmp/gatb_build/bin/Release]
+
+What is kept per run: the input FASTA, the (k-mer, abundance) records of every /dsk/solid/<p> dataset in dataset order, the histogram
+datasets, and — where the run produced them — the byte arrays /bloom/bloom (with its size / nb_hash / type attributes) and /dsk/mphf."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.util import synth_reads  # noqa: E402
+
+BIN = sys.argv[1] if len(sys.argv) > 1 else "/tmp/gatb_build/bin/Release"
+OUT = os.path.join(ROOT, "tests", "golden", "reference_run")
+
+
+def h5dump(args):
+    return subprocess.run([os.path.join(BIN, "gatb-h5dump")] + args, capture_output=True, text=True).stdout
+
+
+def dataset_bytes(h5, path, mode):
+    with tempfile.NamedTemporaryFile() as t:
+        subprocess.run([os.path.join(BIN, "gatb-h5dump"), "-d", path, "-b", mode, "-o", t.name, h5], capture_output=True)
+        return np.fromfile(t.name, dtype=np.uint8)
+
+
+def attr(h5, path):
+    m = re.search(r'\(0\): "(.*?)"\s*\}', h5dump(["-a", path, h5]), re.S)
+    return m.group(1) if m else None
+
+
+def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1):
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "in.fa")
+        text = "".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads))
+        open(fa, "w").write(text)
+        out = os.path.join(td, "ref")
+        cmd = [os.path.join(BIN, "dbgh5"), "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", td, "-nb-cores", str(cores),
+               "-max-memory", "2000", "-verbose", "0"] + extra
+        subprocess.run(cmd, check=True, capture_output=True)
+        h5 = out + ".h5"
+        nparts = int(attr(h5, "/dsk/solid/nb_partitions"))
+        rec = 12 if k <= 31 else 20                                # packed file records: value (8 / 16 bytes) + u32 abundance
+        vals, abs_, sizes = [], [], []
+        for p in range(nparts):
+            raw = dataset_bytes(h5, "/dsk/solid/%d" % p, "FILE")
+            n = len(raw) // rec
+            raw = raw[:n * rec].reshape(n, rec)
+            vals.append(raw[:, :rec - 4].copy()); abs_.append(raw[:, rec - 4:].copy().view("<u4")[:, 0]); sizes.append(n)
+        hist = dataset_bytes(h5, "/histogram/histogram", "FILE")
+        hist = hist[:len(hist) // 12 * 12].reshape(-1, 12)
+        fx = {"fasta": np.frombuffer(text.encode(), dtype=np.uint8), "k": np.int64(k),
+              "solid_value_bytes": np.concatenate(vals) if vals else np.zeros((0, rec - 4), np.uint8), "solid_abundance": np.concatenate(abs_),
+              "solid_sizes": np.array(sizes, dtype=np.int64),
+              "histogram_index": hist[:, :4].copy().view("<u4")[:, 0], "histogram_abundance": hist[:, 4:].copy().view("<u8")[:, 0],
+              "cutoff": dataset_bytes(h5, "/histogram/cutoff", "LE").view("<u8")[0], "nbsolidsforcutoff": dataset_bytes(h5, "/histogram/nbsolidsforcutoff", "LE").view("<u8")[0],
+              "minimRepart": dataset_bytes(h5, "/minimizers/minimRepart", "LE"), "nb_solid_kmers": np.int64(int(attr(h5, "/nb_solid_kmers")))}
+        if want_bloom:
+            fx["bloom"] = dataset_bytes(h5, "/bloom/bloom", "LE")
+            for a in ("size", "nb_hash", "type", "kmer_size"):
+                v = attr(h5, "/bloom/bloom/" + a)
+                fx["bloom_" + a] = np.frombuffer((v or "").encode(), dtype=np.uint8)
+        if want_mphf:
+            fx["mphf"] = dataset_bytes(h5, "/dsk/mphf", "LE")
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
+        print(tag, "partitions", nparts, "solid", int(fx["nb_solid_kmers"]), {k_: (v.shape if hasattr(v, "shape") else v) for k_, v in fx.items() if k_ in ("bloom", "mphf")})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    reads = synth_reads(600, 3000, 150, seed=41, n_rate=0.002)
+    count_only = ["-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"]
+    run("k31_neighbor_mphf", reads, 31, ["-bloom", "neighbor", "-debloom", "none", "-branching-nodes", "none"], want_bloom=True, want_mphf=True)
+    run("k31_basic", reads, 31, ["-bloom", "basic", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"], want_bloom=True)
+    run("k31_cache", reads, 31, ["-bloom", "cache", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"], want_bloom=True)
+    run("k21_freq", reads, 21, count_only + ["-minimizer-type", "1", "-repartition-type", "1"])
+    run("k31_2parts_mphf", synth_reads(2000, 10000, 150, seed=3), 31, ["-bloom", "none", "-debloom", "none", "-branching-nodes", "none"], want_mphf=True, cores=2)
+    run("k63_neighbor_mphf", reads[:300], 63, ["-bloom", "neighbor", "-debloom", "none", "-branching-nodes", "none"], want_bloom=True, want_mphf=True)
