@@ -176,6 +176,20 @@ def main():
     if world > 1:
         t = torch.tensor([distinct, valid], device="cuda", dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
     ktime = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
+    # Stage B runs two lanes (two streams): inside the timed region a kernel's event duration includes the time it shares the chip with the
+    # other lane's kernels. One extra UNTIMED step with a single lane gives the same kernels' durations in isolation (reported beside, never
+    # instead of, the timed-region figures).
+    iso = None
+    if world == 1 and os.environ.get("GKC_STAGEB_LANES", "2") != "1":
+        prev = os.environ.get("GKC_STAGEB_LANES")
+        os.environ["GKC_STAGEB_LANES"] = "1"
+        b1 = {nme: c.timing(nme) for nme in names}
+        step(); sync()
+        iso = {nme: ((c.timing(nme)[0] - b1[nme][0]), (c.timing(nme)[1] - b1[nme][1])) for nme in names}
+        if prev is None:
+            os.environ.pop("GKC_STAGEB_LANES")
+        else:
+            os.environ["GKC_STAGEB_LANES"] = prev
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -223,8 +237,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch)" if traffic else None,
                          "launches_per_step": int(launches_per_step), "launch_ms": dom_ms / launches_per_step,
-                         "algorithmic_bytes_per_launch": alg[dom] / launches_per_step},
+                         "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
+                         "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))},
         }
+        if iso is not None and iso[dom][0] > 0:
+            il = max(1, iso[dom][1])
+            out["roofline"]["single_lane"] = {"note": "same kernel in one extra untimed step with one Stage-B lane (no other kernel on the chip)",
+                                              "launch_ms": iso[dom][0] / il, "achieved": alg[dom] / (iso[dom][0] * 1e-3) / 1e9,
+                                              "frac": alg[dom] / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "kernel_ms_per_step": {n_: round(iso[n_][0], 3) for n_ in names}}
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
         if not args.no_cpu_baseline and world == 1:

@@ -108,6 +108,7 @@ void gkc_destroy(gkc_ctx* c)
     c->d_scan_counters.release(); c->d_rsbits.release(); c->d_scan_matrix.release(); c->d_desc.release(); c->d_desc_tile.release();
     c->pool.destroy();
     (void)hipStreamDestroy(c->stream);
+    for (hipStream_t st : c->lane_streams) if (st) (void)hipStreamDestroy(st);
     delete c;
 }
 

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <mutex>
 #include "../../include/gkc.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -42,10 +43,15 @@ constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram 
 constexpr int SUB_TARGET = 512;                                // mean keys per level-1 bucket: a wave sorts <= 1024 / 512 straight from HBM;
                                                                // denser buckets (<= 6144 / 3072) are split + sorted inside LDS, larger ones in HBM
 
+// Stage B runs batches on two host threads, each with its own stream: the thread-local override routes every launch / copy / timer of
+// that thread to its lane's stream (cur_stream() below)
+inline thread_local hipStream_t gkc_tl_stream = nullptr;
+
 // ------------------------------------------------------------------------------------------------ device buffer
 // Caching device allocator: hipMalloc/hipFree of multi-GB buffers cost tens of ms per GB on this platform (far more than
 // the kernels that use them), so freed blocks are kept and reused by later passes of the same shape.
 struct DevPool {
+    std::recursive_mutex mu;                  // Stage B drives two host threads (two streams) through one pool
     std::multimap<size_t, void*> cache;       // free blocks by size
     std::map<void*, size_t> live;             // blocks handed out
     size_t cached_bytes = 0;
@@ -59,6 +65,7 @@ struct DevPool {
         return (b + g - 1) / g * g;
     }
     void* alloc(size_t bytes, hipError_t* err) {
+        std::lock_guard<std::recursive_mutex> lk(mu);
         const size_t want = round(bytes ? bytes : 1);
         auto it = cache.lower_bound(want);
         if (it != cache.end() && it->first <= want + want / 4 + ((size_t)1 << 20)) {       // close enough: reuse
@@ -80,12 +87,15 @@ struct DevPool {
     }
     void free(void* p) {
         if (!p) return;
+        // a block freed by one lane may be handed to the other lane (another stream) at once: its last user must have finished
+        if (gkc_tl_stream) (void)hipStreamSynchronize(gkc_tl_stream);
+        std::lock_guard<std::recursive_mutex> lk(mu);
         auto it = live.find(p);
         if (it == live.end()) { (void)hipFree(p); return; }
         cache.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
     }
-    void trim() { for (auto& kv : cache) (void)hipFree(kv.second); cache.clear(); cached_bytes = 0; }
-    void destroy() { trim(); for (auto& kv : live) (void)hipFree(kv.first); live.clear(); }
+    void trim() { std::lock_guard<std::recursive_mutex> lk(mu); for (auto& kv : cache) (void)hipFree(kv.second); cache.clear(); cached_bytes = 0; }
+    void destroy() { std::lock_guard<std::recursive_mutex> lk(mu); trim(); for (auto& kv : live) (void)hipFree(kv.first); live.clear(); }
 };
 
 struct DevBuf {
@@ -137,6 +147,8 @@ struct gkc_ctx {
     DevBuf d_histo;                                  // u64[histo_max+1]
     std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them
     gkc_stats& stats_now() { return pass_stats[pass]; }
+    std::mutex mu;                         // shared bookkeeping (timing, stats, outputs, error text) when Stage B runs two lanes
+    hipStream_t lane_streams[3] = {nullptr, nullptr, nullptr};   // extra Stage-B lanes (created on first use)
     std::map<std::string, Timing> timing;
     // scratch reused across calls
     DevBuf d_scan_counters;    // u64[2P + 8]
@@ -147,8 +159,9 @@ struct gkc_ctx {
 
     void set_error(int code, const char* fmt, ...) {
         char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-        err.code = code; err.msg = buf;
+        std::lock_guard<std::mutex> lk(err_mu); err.code = code; err.msg = buf;
     }
+    std::mutex err_mu;
     DevPool pool;
     int ensure(DevBuf& b, size_t bytes) {
         if (b.bytes >= bytes && b.p) return GKC_OK;
@@ -163,18 +176,20 @@ struct gkc_ctx {
     void dfree(void* p) { pool.free(p); }
 };
 
+inline hipStream_t cur_stream(gkc_ctx* c) { return gkc_tl_stream ? gkc_tl_stream : c->stream; }
+
 // RAII event timer accumulating into ctx->timing[name]
 struct ScopedTimer {
     gkc_ctx* c; const char* name; hipEvent_t a, b; bool on;
     ScopedTimer(gkc_ctx* c_, const char* n) : c(c_), name(n), on(true) {
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, cur_stream(c));
     }
     ~ScopedTimer() {
         if (!on) return;
-        (void)hipEventRecord(b, c->stream); (void)hipEventSynchronize(b);
+        (void)hipEventRecord(b, cur_stream(c)); (void)hipEventSynchronize(b);
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-        Timing& t = c->timing[name]; t.ms += ms; t.launches += 1;
+        { std::lock_guard<std::mutex> lk(c->mu); Timing& t = c->timing[name]; t.ms += ms; t.launches += 1; }
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     }
 };
