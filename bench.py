@@ -217,7 +217,8 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), only if they were taken on this exact workload
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload and kname.get(dom) in pt["kernels"]:
-                traffic = pt["kernels"][kname[dom]]["hbm_bytes_per_launch"]
+                kt = pt["kernels"][kname[dom]]                     # per launch = per-step bytes / this run's launches per step (the batch split may differ)
+                traffic = kt["hbm_bytes_per_step"] / max(1, ktime[dom][1] // max(1, args.steps)) if "hbm_bytes_per_step" in kt else kt["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         launches_per_step = max(1, ktime[dom][1] // max(1, args.steps))
@@ -235,7 +236,7 @@ def main():
                        "kernel_ms_per_step": {n_: round(ktime[n_][0] / args.steps, 3) for n_ in names}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes per launch)" if traffic else None,
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate single-lane passes; bytes per step / launches per step)" if traffic else None,
                          "launches_per_step": int(launches_per_step), "launch_ms": dom_ms / launches_per_step,
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
                          "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))},

@@ -14,11 +14,12 @@ def per_kernel(dbfile, counter):
 
 
 f = per_kernel(sys.argv[1], "FETCH_SIZE"); w = per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"workload": sys.argv[3], "note": "read_bytes = 2*FETCH_SIZE*1024 (gfx950 half-count correction), write_bytes = WRITE_SIZE*1024; per launch = sum / dispatches",
+res = {"workload": sys.argv[3], "note": "read_bytes = 2*FETCH_SIZE*1024 (gfx950 half-count correction), write_bytes = WRITE_SIZE*1024; per launch = sum / dispatches; collected with GKC_STAGEB_LANES=1 (with two lanes the device-wide counters of a dispatch include the other lane's kernels)",
        "kernels": {}}
 for k in sorted(set(f) | set(w)):
     fv, fn = f.get(k, (0, 1)); wv, wn = w.get(k, (0, 1))
     res["kernels"][k] = {"dispatches": int(max(fn, wn)), "read_bytes_total": 2 * fv * 1024, "write_bytes_total": wv * 1024,
-                         "hbm_bytes_per_launch": (2 * fv * 1024 + wv * 1024) / max(fn, wn)}
+                         "hbm_bytes_per_launch": (2 * fv * 1024 + wv * 1024) / max(fn, wn),
+                         "hbm_bytes_per_step": 2 * fv * 1024 + wv * 1024}          # the PMC passes run exactly one step (--steps 1 --warmup 0)
 json.dump(res, open(sys.argv[4], "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in res["kernels"].items()}, indent=0))
