@@ -37,11 +37,11 @@ constexpr uint32_t SCAN_COARSE_MAX = 4096;
 constexpr int SCAN_HALO_WORDS = 4;                             // 64 bases of look-ahead (k<=63)
 constexpr int SCAN_WORDS = SCAN_TILE / 16 + SCAN_HALO_WORDS;   // 16-base words per tile
 
-// Stage B: a partition is split by key range into <= MAX_SUB sub-buckets, each sorted inside LDS.
+// Stage B: a partition is split by key range into <= MAX_SUB sub-buckets, each sorted in registers by one wave (or workgroup).
 constexpr int MAX_SUB_BITS = 13;
 constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram / cursors: 32 KB
-constexpr int SUB_TARGET = 512;                                // mean keys per level-1 bucket: a wave sorts <= 1024 / 512 straight from HBM;
-                                                               // denser buckets (<= 6144 / 3072) are split + sorted inside LDS, larger ones in HBM
+constexpr int SUB_TARGET = 512;                                // mean keys per level-1 bucket: a wave sorts <= 1024 / 512 straight from HBM (<= 2048 / 1024 in
+                                                               // the double-size tier), a workgroup <= 4096 / 2048, larger buckets are split in HBM
 
 // Stage B runs batches on two host threads, each with its own stream: the thread-local override routes every launch / copy / timer of
 // that thread to its lane's stream (cur_stream() below)

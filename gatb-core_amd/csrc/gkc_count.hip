@@ -8,19 +8,21 @@
 //   B4 PartitionsByHashCommand (fallback when a partition does not fit): here = the oversize path.
 //
 // MI355X design: a key never makes more than one round trip through HBM.
-//   expand_count   one workgroup per partition streams its 16/32-byte records (coalesced), regenerates the canonical
-//                  k-mers with a rolling forward/reverse pair and histograms their top bits in LDS (<=4096 key-range
-//                  sub-buckets per partition, sized so a sub-bucket fits one LDS sort); the same workgroup scans the
-//                  histogram into exact sub-bucket offsets.
-//   expand_scatter same stream again, LDS cursors (no global atomics), keys written once to their sub-bucket.
-//   bucket_sort    one WAVE per sub-bucket: keys in registers, bitonic network (register compare-exchanges + lane-xor
-//                  shuffles, no LDS, no barrier), run-length count, abundance histogram (LDS-aggregated); distinct keys
-//                  and abundances are written back at the head of the sub-bucket's own slot range.
-//   split levels   sub-buckets larger than a wave holds (k-mers that start with their minimizer share their top bits;
-//                  repeats; too few partitions) are split again on their next key bits, keys -> keys, and re-sorted;
+//   expand_count   one workgroup per partition streams its 16/32-byte records (coalesced), cuts the canonical k-mers out of the
+//                  record's bit string and histograms their top bits in LDS (<= 8192 key-range sub-buckets per partition, sized
+//                  so a sub-bucket fits one wave's registers); the same workgroup scans the histogram into exact sub-bucket offsets.
+//   expand_scatter same stream again; 8-byte keys leave in aligned 16-byte pairs (one parking slot per sub-bucket in LDS, exchange-only
+//                  protocol, no global atomics), 16-byte keys one by one.
+//   bucket_sort    one WAVE per sub-bucket: keys in registers, bitonic network (in-lane steps as v_min/max_f64 on double-tagged keys,
+//                  cross-lane steps as DPP / bpermute exchanges, no LDS, no barrier), run-length count, abundance histogram
+//                  (LDS-aggregated); distinct keys and abundances are written back at the head of the sub-bucket's own slot range.
+//                  Tiers: <= 1024 keys (k_wave_sort), <= 2048 (k_wave_sort_big), <= 4096 (k_wg_sort, 4 waves merged through LDS).
+//   split levels   sub-buckets larger than that (k-mers that start with their minimizer share their top bits; repeats; too few
+//                  partitions) are split again on their next informative key bits, keys -> keys, and go through the tiers again;
 //                  when no key bit is left all keys are one k-mer. Any skew terminates in <= ceil(2k/13)+1 levels.
 //   compact        slot flags (abundance != 0) -> block sums -> prefix -> records {value, abundance} in the reference's
 //                  Count layout, contiguous and ascending per partition (slot order is key order).
+//   Batches of partitions are taken from one queue by two host threads, each on its own stream (gkc_count_pass).
 #include "gkc_common.hpp"
 #include "gkc_device.hpp"
 #include <algorithm>
@@ -1080,7 +1082,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             std::vector<uint32_t> hn(n_buckets);
             CB_HIP(hipMemcpyAsync(hn.data(), B.b_n[cur].p, (size_t)n_buckets * 4, hipMemcpyDeviceToHost, cur_stream(c)));
             CB_HIP(hipStreamSynchronize(cur_stream(c)));
-            const uint32_t edges[] = {0, 64, 128, 256, 512, 1024, 2048, 6144, 0xffffffffu};
+            const uint32_t edges[] = {0, 64, 128, 256, 512, 1024, 2048, 4096, 0xffffffffu};
             uint64_t nb_[9] = {0}, nk_[9] = {0};
             for (uint32_t v : hn) { int e = 0; while (v > edges[e]) e++; nb_[e]++; nk_[e] += v; }
             fprintf(stderr, "[gkc] level %d sizes:", level);

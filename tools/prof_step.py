@@ -12,7 +12,7 @@ c = gkc.Counter(0)
 rep = bench.repart_for_bench(10, parts)
 c.configure(k, 10, parts, rep)
 db, do = c.synth_reads_device(2, n, 150, n * 5, 10000)
-names = ["scan_count", "scan_emit", "scan_refine", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_lds", "bucket_sort_wg", "bucket_sort_deep", "split_levels", "compact",
+names = ["scan_count", "scan_emit", "scan_refine", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "bucket_sort_deep", "split_levels", "compact",
          "total_stage_a", "total_stage_b"]
 for it in range(3):
     base = {x: c.timing(x) for x in names}
