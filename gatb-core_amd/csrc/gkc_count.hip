@@ -1296,22 +1296,25 @@ int gkc_count_pass(gkc_ctx* c)
     if (lanes < 1) lanes = 1;
     if (lanes > 4) lanes = 4;
     if (total_keys < 50000000ULL || c->key_budget) lanes = 1;               // small inputs (and the tests' tiny forced budgets): one lane
+    bool tight = false;                                                       // memory is running out: the extra lanes retire, one lane finishes the pass
     auto budget_now = [&]() -> size_t {                                      // keys of the next batch of ONE lane, from the memory free right now
         if (c->key_budget) return c->key_budget;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
         free_b += c->pool.cached_bytes;                      // blocks parked in the caching allocator are reusable
-        size_t b = (size_t)((double)free_b * 0.85) / per_key / (size_t)lanes;
-        b = std::max<size_t>(b, (size_t)1 << 20);
-        return std::min<size_t>(b, ((size_t)3 << 30) / (size_t)lanes);
+        const size_t all = (size_t)((double)free_b * 0.85) / per_key;
+        if (lanes > 1 && all < ((size_t)1 << 30)) tight = true;             // results of earlier batches stay resident: late batches see less
+        const size_t div = tight ? 1 : (size_t)lanes;
+        return std::min<size_t>(std::max<size_t>(all / div, (size_t)1 << 20), ((size_t)3 << 30) / div);
     };
     std::vector<void*>& outputs = c->pass_outputs[c->pass];
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
-    auto carve = [&](std::vector<uint32_t>& batch) -> bool {                 // next batch of consecutive partitions; false when nothing is left
+    auto carve = [&](std::vector<uint32_t>& batch, bool extra_lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
         batch.clear();
         if (first_rc != GKC_OK) return false;
         const size_t budget = budget_now();
+        if (tight && extra_lane) return false;
         uint64_t acc = 0;
         while (next_p < Pn) {
             const uint32_t p = next_p;
@@ -1329,7 +1332,7 @@ int gkc_count_pass(gkc_ctx* c)
         (void)hipSetDevice(c->device);
         gkc_tl_stream = st;
         std::vector<uint32_t> batch;
-        while (carve(batch)) {
+        while (carve(batch, st != c->stream)) {
             const int r = (c->key_words == 1) ? count_batch<1, 2>(c, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, batch, part_keys, segs, outputs);
             if (r != GKC_OK) { std::lock_guard<std::mutex> lk(plan_mu); if (first_rc == GKC_OK) first_rc = r; break; }
         }
