@@ -162,6 +162,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
     }
     uint32_t nv_acc = 0, ni_acc = 0, n_rec = 0;
 
+  // the tile's bases (16 per thread + the halo words) and read-start bits are fetched one tile AHEAD into registers: with two workgroups
+  // per CU and ~7 barriers per tile nothing else hides the global-load latency (measured: a third of the kernel)
+  static_assert(SCAN_WORDS <= 2 * SCAN_THREADS && SCAN_TILE / 32 + 8 <= SCAN_THREADS, "one or two words and one read-start word per thread");
+  uint32_t pfA[4] = {0, 0, 0, 0}, pfB[4] = {0, 0, 0, 0}, pfR = 0;
+  auto prefetch = [&](uint64_t tile_) {
+      const uint64_t t0_ = tile_ * SCAN_TILE; const int tt = threadIdx.x;
+      load16(P.bases, t0_ + 16ull * tt, P.n_bases, pfA);
+      if (tt + SCAN_THREADS < SCAN_WORDS) load16(P.bases, t0_ + 16ull * (tt + SCAN_THREADS), P.n_bases, pfB);
+      if (tt < SCAN_TILE / 32 + 8) pfR = P.rsbits[t0_ / 32 + tt];
+  };
+  if (blockIdx.x < P.n_tiles) prefetch(blockIdx.x);
   for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
     const uint64_t t0 = tile * SCAN_TILE;
     int t = threadIdx.x;
@@ -170,14 +181,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
     __syncthreads();                                           // LDS of the previous tile fully consumed
 
     // ---- step 0: ASCII -> bit planes (A1) ----
-    for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
-        uint32_t dw[4], le, bad;
-        load16(P.bases, t0 + 16ull * w, P.n_bases, dw);
-        encode16(dw, le, bad);
-        const uint32_t be = rev2bit(le);
-        s_be[w] = be; s_le[w] = le; s_bad[w] = (uint16_t)bad;
+    {
+        uint32_t le, bad;
+        encode16(pfA, le, bad);
+        s_be[t] = rev2bit(le); s_le[t] = le; s_bad[t] = (uint16_t)bad;
+        if (t + SCAN_THREADS < SCAN_WORDS) { encode16(pfB, le, bad); s_be[t + SCAN_THREADS] = rev2bit(le); s_le[t + SCAN_THREADS] = le; s_bad[t + SCAN_THREADS] = (uint16_t)bad; }
+        if (t < SCAN_TILE / 32 + 8) s_rs[t] = pfR;
     }
-    for (int i = t; i < SCAN_TILE / 32 + 8; i += SCAN_THREADS) s_rs[i] = P.rsbits[t0 / 32 + i];
+    if (tile + gridDim.x < P.n_tiles) prefetch(tile + gridDim.x);     // in flight during the rest of this tile
     __syncthreads();
 
     // ---- step 1: order key of the m-mer starting at every position (A3: LUT semantics) ----
@@ -197,6 +208,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                 a = (a >> 1) & a & P.mask_ma1;                // "AA" anywhere but as prefix (KMC2 rule)
                 key = a ? P.mmask : c;
             }
+#ifdef GKC_EXP_SCAN_NOSTEP1
+            key = (uint32_t)(w & 7);
+#endif
             s_mk[17 * w + j] = key;
         }
     }
@@ -271,6 +285,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         const uint32_t fits = lim >= 15 ? 0xFFFFu : (lim < 0 ? 0u : ((2u << (uint32_t)lim) - 1u));
         existsmask = ~rsany & fits;
         validmask = existsmask & ~badany;
+#ifdef GKC_EXP_SCAN_NOSTEP3
+        existsmask = fits; validmask = fits;
+#endif
     }
 
     // ---- step 4: natural super-k-mer starts and the workgroup-wide "last start" max-scan (A4) ----
