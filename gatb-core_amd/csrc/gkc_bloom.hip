@@ -183,6 +183,42 @@ __global__ __launch_bounds__(BR_THREADS) void k_bloom_regions(BloomParams B, BSe
         for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS) wg_cnt[(uint64_t)blockIdx.x * n_regions + r] = s_r[r];
     }
 }
+// basic kind: the nb_hash positions of an item are independent -> every POSITION is bucketed by region (4 bytes each)
+template <bool SCATTER>
+__global__ __launch_bounds__(BR_THREADS) void k_bloom_regions_basic(BloomParams B, BSegTable T, uint64_t chunk, uint32_t n_regions, uint32_t* __restrict__ wg_cnt,
+                                                                     const uint32_t* __restrict__ region_off, uint32_t* __restrict__ rels)
+{
+    extern __shared__ uint32_t s_r[];
+    for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS)
+        s_r[r] = SCATTER ? region_off[r] + wg_cnt[(uint64_t)blockIdx.x * n_regions + r] : 0u;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(T.total, i0 + chunk);
+    for (uint64_t g = i0 + threadIdx.x; g < i1; g += BR_THREADS) {
+        const u128 x = load_key(bseg_item(T, g), B.wide);
+        for (uint32_t j = 0; j < B.nb_hash; j++) {
+            const uint64_t h = hash1_dev(x, B.seeds[j], B.wide);
+            const uint64_t pos = B.pow2 ? (h & B.tai) : (h % B.tai);
+            const uint32_t slot = atomicAdd(&s_r[(uint32_t)(pos >> BR_BITS)], 1u);
+            if (SCATTER) rels[slot] = (uint32_t)(pos & ((1u << BR_BITS) - 1));
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS) wg_cnt[(uint64_t)blockIdx.x * n_regions + r] = s_r[r];
+    }
+}
+__global__ __launch_bounds__(BR_THREADS) void k_bloom_region_build_basic(BloomParams B, const uint32_t* __restrict__ rels, const uint32_t* __restrict__ region_off)
+{
+    extern __shared__ uint32_t s_img[];                            // [BR_WORDS]: positions never leave their region
+    for (uint32_t i = threadIdx.x; i < BR_WORDS; i += BR_THREADS) s_img[i] = 0;
+    __syncthreads();
+    const uint32_t r = blockIdx.x, i0 = region_off[r], i1 = region_off[r + 1];
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += BR_THREADS) { const uint32_t h = rels[i]; atomicOr(&s_img[h >> 5], 1u << (h & 31)); }
+    __syncthreads();
+    uint32_t* g = B.words + (uint64_t)r * BR_WORDS;
+    for (uint32_t i = threadIdx.x; i < BR_WORDS; i += BR_THREADS) { const uint32_t v = s_img[i]; if (v) g[i] |= v; }
+}
+
 // per region: exclusive prefix of the workgroup counts (in place) and the region total
 __global__ void k_bloom_wg_prefix(uint32_t* __restrict__ wg_cnt, uint32_t n_wgs, uint32_t n_regions, uint32_t* __restrict__ region_tot)
 {
@@ -295,7 +331,8 @@ static int bloom_insert_arrays(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, 
     ScopedTimer tm(c, "bloom_insert");
     const uint64_t n_bits = b->tai + 1;
     const uint32_t n_regions = (uint32_t)std::min<uint64_t>((n_bits + (1u << BR_BITS) - 1) >> BR_BITS, 0xffffffffu);
-    const bool regions = b->kind != 0 && n_regions <= BR_MAX_REGIONS && total < (1ULL << 32) && n_segs <= 16 && getenv("GKC_BLOOM_ATOMIC") == nullptr;
+    const uint64_t n_virtual = b->kind == 0 ? total * b->nb_hash : total;        // basic: one bucketed entry per position
+    const bool regions = n_regions <= BR_MAX_REGIONS && n_virtual < (1ULL << 32) && n_segs <= 16 && getenv("GKC_BLOOM_ATOMIC") == nullptr;
     if (!regions) {
         for (uint32_t i = 0; i < n_segs; i++) if (segs[i].n) {
             const unsigned grid = (unsigned)std::min<uint64_t>((segs[i].n + 255) / 256, 256 * 16);
@@ -311,7 +348,7 @@ static int bloom_insert_arrays(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, 
     DevBuf d_wg, d_tot, d_off, d_items;
     struct Guard { DevBuf *a, *b2, *c2, *d; ~Guard() { a->release(); b2->release(); c2->release(); d->release(); } } guard{&d_wg, &d_tot, &d_off, &d_items};
     GKC_TRY(c->ensure(d_wg, (size_t)n_wgs * n_regions * 4)); GKC_TRY(c->ensure(d_tot, (size_t)n_regions * 4)); GKC_TRY(c->ensure(d_off, ((size_t)n_regions + 1) * 4));
-    GKC_TRY(c->ensure(d_items, (size_t)total * sizeof(BloomItem)));
+    GKC_TRY(c->ensure(d_items, b->kind == 0 ? (size_t)n_virtual * 4 : (size_t)total * sizeof(BloomItem)));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_regions<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
@@ -320,11 +357,26 @@ static int bloom_insert_arrays(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, 
         attr_set = true;
     }
     const BloomParams P = params_of(b);
+    if (b->kind == 0) {
+        static bool attr_basic = false;
+        if (!attr_basic) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_regions_basic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_regions_basic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_region_build_basic), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_WORDS * 4));
+            attr_basic = true;
+        }
+        hipLaunchKernelGGL((k_bloom_regions_basic<false>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_bloom_wg_prefix, dim3((n_regions + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d_wg.p, n_wgs, n_regions, (uint32_t*)d_tot.p);
+        hipLaunchKernelGGL(k_bloom_region_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)d_tot.p, n_regions, (uint32_t*)d_off.p);
+        hipLaunchKernelGGL((k_bloom_regions_basic<true>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)d_off.p, (uint32_t*)d_items.p);
+        hipLaunchKernelGGL(k_bloom_region_build_basic, dim3(n_regions), dim3(BR_THREADS), (size_t)BR_WORDS * 4, c->stream, P, (const uint32_t*)d_items.p, (const uint32_t*)d_off.p);
+    } else {
     hipLaunchKernelGGL((k_bloom_regions<false>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)nullptr, (BloomItem*)nullptr);
-    hipLaunchKernelGGL(k_bloom_wg_prefix, dim3((n_regions + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d_wg.p, n_wgs, n_regions, (uint32_t*)d_tot.p);
-    hipLaunchKernelGGL(k_bloom_region_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)d_tot.p, n_regions, (uint32_t*)d_off.p);
-    hipLaunchKernelGGL((k_bloom_regions<true>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)d_off.p, (BloomItem*)d_items.p);
-    hipLaunchKernelGGL(k_bloom_region_build, dim3(n_regions), dim3(BR_THREADS), (size_t)(BR_WORDS + BR_FRINGE_WORDS) * 4, c->stream, P, (const BloomItem*)d_items.p, (const uint32_t*)d_off.p);
+        hipLaunchKernelGGL(k_bloom_wg_prefix, dim3((n_regions + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d_wg.p, n_wgs, n_regions, (uint32_t*)d_tot.p);
+        hipLaunchKernelGGL(k_bloom_region_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)d_tot.p, n_regions, (uint32_t*)d_off.p);
+        hipLaunchKernelGGL((k_bloom_regions<true>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)d_off.p, (BloomItem*)d_items.p);
+        hipLaunchKernelGGL(k_bloom_region_build, dim3(n_regions), dim3(BR_THREADS), (size_t)(BR_WORDS + BR_FRINGE_WORDS) * 4, c->stream, P, (const BloomItem*)d_items.p, (const uint32_t*)d_off.p);
+    }
     GKC_HIP(c, hipGetLastError());
     GKC_HIP(c, hipStreamSynchronize(c->stream));                   // the scratch buffers go back to the pool
     return GKC_OK;

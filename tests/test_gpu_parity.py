@@ -199,12 +199,12 @@ def test_bloom_bit_identical(gkc, k):
 
 @pytest.mark.parametrize("k", [31, 63])
 def test_bloom_region_build_bit_identical(gkc, k):
-    """cache / neighbor kinds are built region by region in LDS (2^20 bits per region, shared fringes ORed atomically): several regions,
-    two insert calls into the same filter"""
+    """the filters are built region by region in LDS (2^20 bits per region; block-coherent kinds: shared fringes ORed atomically; basic:
+    every position bucketed on its own): several regions, two insert calls into the same filter"""
     rng = np.random.default_rng(100 + k)
     keys = [int.from_bytes(rng.bytes(16), "little") & (4 ** k - 1) for _ in range(120000)]
     c = gkc.Counter(0)
-    for kind in ("cache", "neighbor"):
+    for kind in ("basic", "cache", "neighbor"):
         bits = 5_000_000 + 12345
         ob = gko.Bloom(kind, bits, 7, k); ob.insert(keys)
         db = gkc.Bloom(c, kind, bits, 7, k); db.insert(keys[:70000]); db.insert(keys[70000:])
