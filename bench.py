@@ -268,6 +268,21 @@ def main():
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
                          "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))},
         }
+        # the nominal 8 TB/s beside what a plain device copy reaches on this box (read + write bytes / time)
+        try:
+            a_ = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b_ = torch.empty_like(a_)
+            b_.copy_(a_); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                b_.copy_(a_)
+            e1.record(); torch.cuda.synchronize()
+            copy_gbs = 5 * 2 * a_.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            out["roofline"]["device_copy_GBps"] = copy_gbs
+            out["roofline"]["frac_of_device_copy"] = achieved / copy_gbs
+            del a_, b_
+        except Exception:
+            pass
         if iso is not None and iso[dom][0] > 0:
             il = max(1, iso[dom][1])
             out["roofline"]["single_lane"] = {"note": "same kernel in one extra untimed step with one Stage-B lane (no other kernel on the chip)",
