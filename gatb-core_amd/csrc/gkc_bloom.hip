@@ -456,6 +456,13 @@ int gkc_bloom_get_array(gkc_bloom* b, uint8_t* out, uint64_t cap)
     GKC_HIP(c, hipStreamSynchronize(c->stream));
     return GKC_OK;
 }
+int gkc_bloom_device_array(gkc_bloom* b, void** d_bits, uint64_t* n_bytes)
+{
+    if (!b || !d_bits || !n_bytes) return GKC_ERR_ARG;
+    (void)hipStreamSynchronize(b->ctx->stream);
+    *d_bits = b->bits.p; *n_bytes = (b->nchar + 3) / 4 * 4;
+    return GKC_OK;
+}
 int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes)
 {
     if (!b) return GKC_ERR_ARG;

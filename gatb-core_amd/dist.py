@@ -96,6 +96,36 @@ def exchange_buckets(send, rec_off, kmers, record_bytes, rank, world, group=None
     return recv, chunks
 
 
+def allreduce_or(t, group=None, slice_bytes=256 << 20):
+    """in-place bitwise-OR all-reduce of a uint8 tensor (Bloom bit arrays: every rank inserted the solid k-mers of the partitions it owns;
+    the OR of the partial filters is the filter of the whole set, bit for bit — SURVEY.md §8e). torch's NCCL/RCCL backend has no bitwise
+    reduce op, so every slice is all-gathered (world x slice_bytes of scratch) and ORed locally."""
+    world = dist.get_world_size(group)
+    flat = t.view(-1)
+    if world == 1:
+        return t
+    step = max(1, int(slice_bytes) // max(1, t.element_size()))
+    tmp = torch.empty((world, min(step, flat.numel())), dtype=flat.dtype, device=flat.device)
+    for i in range(0, flat.numel(), step):
+        part = flat[i:i + step]
+        buf = tmp[:, :part.numel()].contiguous() if part.numel() != tmp.shape[1] else tmp
+        dist.all_gather_into_tensor(buf.view(-1), part.contiguous(), group=group)
+        acc = buf[0]
+        for r in range(1, world):
+            acc = acc | buf[r]
+        part.copy_(acc)
+    return t
+
+
+def allreduce_or_bloom(bloom, group=None):
+    """OR-reduce a gkc.Bloom across the ranks, in place on the device"""
+    ptr, nbytes = bloom.device_array()
+    t = torch.as_tensor(DevArray(ptr, nbytes), device="cuda")
+    allreduce_or(t, group)
+    torch.cuda.synchronize()
+    return bloom
+
+
 class DistributedCounter:
     """Host-side driver of one rank. ``counter`` is a gkc.Counter already configured with the SAME model / repartition
     table on every rank. Call ``exchange()`` between the pushes and ``finish_pass()`` of every pass."""

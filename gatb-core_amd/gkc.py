@@ -21,7 +21,7 @@ SYMBOLS = [
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
-    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_synth_reads_device", "gkc_device_free",
+    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free",
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
@@ -91,6 +91,7 @@ def lib():
         "gkc_bloom_contains8": (C.c_int, [vp, vp, u64, u32, vp]),
         "gkc_bloom_get_array": (C.c_int, [vp, vp, u64]),
         "gkc_bloom_set_array": (C.c_int, [vp, vp, u64]),
+        "gkc_bloom_device_array": (C.c_int, [vp, P(vp), P(u64)]),
         "gkc_synth_reads_device": (C.c_int, [vp, u64, u64, u64, u32, u64, u32, P(vp), P(vp)]),
         "gkc_device_free": (C.c_int, [vp, vp]),
         "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
@@ -442,6 +443,11 @@ class Bloom:
     @property
     def bitsize(self):
         return self.L.gkc_bloom_bitsize(self.h)
+
+    def device_array(self):
+        """(device pointer, bytes) of the bit array: zero-copy view for torch.distributed (dist.allreduce_or_bloom)"""
+        p = C.c_void_p(); n = C.c_uint64(0)
+        self.c._chk(self.L.gkc_bloom_device_array(self.h, C.byref(p), C.byref(n))); return p.value, n.value
 
     def array(self):
         out = np.zeros(self.nbytes, np.uint8)

@@ -166,6 +166,9 @@ int gkc_bloom_contains(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stri
 int gkc_bloom_contains8(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out);  /* neighbor kind */
 int gkc_bloom_get_array(gkc_bloom* b, uint8_t* out, uint64_t cap_bytes);                               /* IBloom::getArray() */
 int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes);                            /* StorageTools::loadBloom */
+/* the bit array where it lives (device memory, n_bytes = gkc_bloom_nbytes rounded up to 4): multi-GPU runs insert their own
+ * partitions' solid k-mers and OR-reduce the arrays in place (all-reduce with bitwise OR over RCCL) */
+int gkc_bloom_device_array(gkc_bloom* b, void** d_bits, uint64_t* n_bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Synthetic reads generated in HBM (bench / parity at full size; SURVEY §8d generator): genome of genome_len uniform

@@ -91,3 +91,32 @@ def test_owner_ranges():
     assert gd.owner_ranges(4096, 8)[7] == (3584, 4096)
     with pytest.raises(ValueError):
         gd.owner_ranges(10, 4)
+
+
+def _or_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ge.load()
+    from gatb_core_amd import dist as gdist
+    rng = np.random.default_rng(100 + rank)
+    mine = rng.integers(0, 256, size=100_003, dtype=np.uint8) & rng.integers(0, 256, size=100_003, dtype=np.uint8)
+    t = torch.from_numpy(mine.copy())
+    gdist.allreduce_or(t)
+    q.put((rank, mine, t.numpy().copy()))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_bloom_or_reduce_gloo():
+    """partial Bloom filters of the ranks are combined with a bitwise-OR all-reduce (dist.allreduce_or)"""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    ps = [ctx.Process(target=_or_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=60) for p in ps]
+    want = got[0][1] | got[1][1]
+    for _, _, red in got:
+        assert np.array_equal(red, want)

@@ -375,6 +375,36 @@ def test_distributed_counter_world1_rccl(gkc):
         dist.destroy_process_group()
 
 
+def test_bloom_or_reduce_world1_rccl(gkc):
+    """two partial filters (the solid k-mers of two owner shards) ORed through torch.distributed (nccl = RCCL, world 1 here) equal the
+    filter of the whole set; exercises gkc_bloom_device_array + dist.allreduce_or_bloom on the device"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gatb_core_amd import dist as gdist
+    rng = np.random.default_rng(77)
+    k = 31
+    keys = [int.from_bytes(rng.bytes(16), "little") & (4 ** k - 1) for _ in range(40000)]
+    c = gkc.Counter(0)
+    whole = gkc.Bloom(c, "neighbor", 2_000_000, 7, k); whole.insert(keys)
+    a = gkc.Bloom(c, "neighbor", 2_000_000, 7, k); a.insert(keys[:25000])
+    b = gkc.Bloom(c, "neighbor", 2_000_000, 7, k); b.insert(keys[25000:])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        # world 1: the reduce is the identity; OR the second shard in by hand through the same zero-copy view, then reduce
+        pa, na = a.device_array(); pb, nb = b.device_array()
+        ta = torch.as_tensor(gdist.DevArray(pa, na), device="cuda"); tb = torch.as_tensor(gdist.DevArray(pb, nb), device="cuda")
+        ta |= tb
+        gdist.allreduce_or_bloom(a)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert np.array_equal(a.array(), whole.array())
+
+
 def test_repartitor_sampling_statistics(gkc):
     """gkc_sample_minimizers / gkc_count_mmers against the oracle's restatement of SampleRepart / MmersFrequency"""
     reads = synth_reads(800, 8000, 150, seed=31, n_rate=0.002, ragged=True)
