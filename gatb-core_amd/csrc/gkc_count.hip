@@ -142,6 +142,18 @@ __device__ __forceinline__ void for_each_kmer_fast(const uint64_t (&R)[RW], uint
     else for_each_kmer<KW, RW>(R, k, f);
 }
 
+// sub-bucket of a key = its top bits: key >> shift (the result fits 13 bits). For 16-byte keys a variable 128-bit shift is several times the
+// work of the one or two 64-bit shifts that are needed
+template <int KW> __device__ __forceinline__ uint32_t sub_index(typename KeyT<KW>::type c, uint32_t shift)
+{
+    if constexpr (KW == 1) return (uint32_t)(c >> shift);
+    else {
+        const uint64_t hi = (uint64_t)(c >> 64), lo = (uint64_t)c;
+        if (shift >= 64) return (uint32_t)(hi >> (shift - 64));
+        return (uint32_t)((hi << (64 - shift)) | (lo >> shift));            // shift in [1, 63] here (2k - 13 >= 51 for k >= 32)
+    }
+}
+
 constexpr int EXPAND_THREADS = 512;
 
 // ------------------------------------------------------------------------------------------------ B1 expand_count
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         const uint8_t* base = segs.rec[s];
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
-            for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
+            for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[sub_index<KW>(c, pd.shift)], 1u); });
         }
     }
     __syncthreads();
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_scatter(const PartDes
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
             for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) {
-                const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(c >> pd.shift)], 1u);
+                const uint32_t slot = atomicAdd(&s_cur[sub_index<KW>(c, pd.shift)], 1u);
                 out[slot] = c;
             });
         }
