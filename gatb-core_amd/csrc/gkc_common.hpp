@@ -8,6 +8,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include "../../include/gkc.h"
@@ -55,6 +56,8 @@ struct DevPool {
     std::multimap<size_t, void*> cache;       // free blocks by size
     std::map<void*, size_t> live;             // blocks handed out
     size_t cached_bytes = 0;
+    bool tight = false;                       // set by the Stage-B planner when it had to shrink its batches
+    uint64_t n_malloc = 0, n_fail = 0, n_trim = 0; double malloc_ms = 0;   // diagnostics (GKC_POOL_DEBUG)
     // size classes: 256 B granules below 2 MB, 2 MB granules up to 64 MB, then 16 classes per octave (<= 6.25 % slack) so that the
     // slightly different buffer sizes of successive Stage-B batches / passes land in the same class and are reused
     static size_t round(size_t b) {
@@ -68,18 +71,25 @@ struct DevPool {
         std::lock_guard<std::recursive_mutex> lk(mu);
         const size_t want = round(bytes ? bytes : 1);
         auto it = cache.lower_bound(want);
-        if (it != cache.end() && it->first <= want + want / 4 + ((size_t)1 << 20)) {       // close enough: reuse
+        if (it != cache.end() && (it->first <= want + want / 4 + ((size_t)1 << 20) || (tight && want >= ((size_t)64 << 20)))) {   // close enough (memory tight: any larger block): reuse
             void* p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess; return p;
         }
         void* p = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        n_malloc++;
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            n_fail++;
             if (it != cache.end()) {                                   // out of memory: any cached block that is large enough will do
-                p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess; return p;
+                p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess;
+                malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return p;
             }
+            n_trim++;
             trim(); e = hipMalloc(&p, want);                           // give cached blocks back and retry
         }
+        malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *err = e;
         if (e != hipSuccess) return nullptr;
         live[p] = want;

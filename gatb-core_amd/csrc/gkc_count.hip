@@ -1296,10 +1296,16 @@ int gkc_count_pass(gkc_ctx* c)
     if (e1 != hipSuccess || e2 != hipSuccess) { d_recptr.release(); d_recoff.release(); GKC_FAIL(c, GKC_ERR_HIP, "segment table upload failed"); }
     SegTable segs{ (const uint8_t* const*)d_recptr.p, (const uint64_t*)d_recoff.p, n_seg, Pn };
 
-    // batches of consecutive partitions bounded by a key budget that is re-derived from the free HBM before every batch
-    // (results of earlier batches stay resident). Per key slot: key (x2: a split level may need the ping-pong buffer), 5 B of
-    // abundance planes, and room for its Count record.
-    const size_t per_key = 2 * (c->key_words == 1 ? 8 : 16) + 5 + (c->key_words == 1 ? 16 : 32);
+    // Batches of consecutive partitions, each bounded by a key budget. The budget is FIXED for the pass (derived once from the memory free
+    // at its start): equal batches ask the caching allocator for the same block sizes again and again, so after the first batches no
+    // hipMalloc / hipFree happens at all (re-deriving it from the shrinking free memory made every batch a new size — at k=63, where
+    // the results take half the HBM, that cost seconds of hipMalloc / hipFree in a pass). Per key slot a batch needs the key twice (a
+    // split level uses the ping-pong buffer) and 5 B of abundance planes — its working set, returned to the pool afterwards — and leaves
+    // one Count record per SOLID distinct key resident. Working sets get at most half of the free memory; before every batch the planner
+    // checks that the working set plus the batch's results (at the distinct ratio seen so far, 1.0 before anything finished) still fit,
+    // and otherwise halves the budget (power-of-two ladder: the cached larger blocks stay usable) or retires the extra lanes.
+    const size_t key_bytes = c->key_words == 1 ? 8 : 16, rec_bytes = c->key_words == 1 ? 16 : 32;
+    const size_t work_per_key = 2 * key_bytes + 5;
     // Two LANES: Stage B's kernels are bound by different things (expand: store atoms and LDS, sorts: VALU, compaction: HBM), and a single
     // in-order stream leaves most of the chip waiting on whichever bound the current kernel has. Two host threads therefore take batches
     // from one queue, each on its own stream (thread-local stream override, cur_stream()): measured 264 -> 229 ms for the same work.
@@ -1309,24 +1315,44 @@ int gkc_count_pass(gkc_ctx* c)
     if (lanes > 4) lanes = 4;
     if (total_keys < 50000000ULL || c->key_budget) lanes = 1;               // small inputs (and the tests' tiny forced budgets): one lane
     bool tight = false;                                                       // memory is running out: the extra lanes retire, one lane finishes the pass
-    auto budget_now = [&]() -> size_t {                                      // keys of the next batch of ONE lane, from the memory free right now
-        if (c->key_budget) return c->key_budget;
+    const double avail0 = [&] {                                              // memory this pass may use: free now + blocks parked in the caching allocator
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-        free_b += c->pool.cached_bytes;                      // blocks parked in the caching allocator are reusable
-        const size_t all = (size_t)((double)free_b * 0.85) / per_key;
-        if (lanes > 1 && all < ((size_t)1 << 30)) tight = true;             // results of earlier batches stay resident: late batches see less
-        const size_t div = tight ? 1 : (size_t)lanes;
-        return std::min<size_t>(std::max<size_t>(all / div, (size_t)1 << 20), ((size_t)3 << 30) / div);
+        return (double)(free_b + c->pool.cached_bytes);
+    }();
+    static const size_t cap_env = getenv("GKC_BATCH_KEYS") ? (size_t)atoll(getenv("GKC_BATCH_KEYS")) : 0;
+    const size_t cap = cap_env ? cap_env : (c->key_words == 1 ? (size_t)1600000000ULL : (size_t)1200000000ULL);   // the same with one lane or two
+    const size_t fixed_budget = std::min<size_t>(std::max<size_t>((size_t)(0.5 * avail0) / work_per_key / (size_t)lanes, (size_t)1 << 20), cap);
+    uint64_t done_keys = 0, done_solid = 0;                                  // keys / resident records of this pass's finished batches (guarded by plan_mu)
+    double inflight[4] = { 0, 0, 0, 0 };                                     // bytes each lane's running batch may still claim (working set + its results)
+    c->pool.tight = false;
+    auto per_key_now = [&]() -> double {
+        const double d_est = done_keys ? std::min(1.0, 1.05 * (double)done_solid / (double)done_keys) : 1.0;
+        return (double)work_per_key + (double)rec_bytes * d_est;
+    };
+    auto budget_now = [&](int lane) -> size_t {                              // keys of the next batch of one lane (called under plan_mu)
+        if (c->key_budget) return c->key_budget;
+        double committed = 0; for (int l = 0; l < 4; l++) if (l != lane) committed += inflight[l];
+        const double left = 0.9 * avail0 - (double)done_solid * (double)rec_bytes - committed;
+        const size_t fits = left > 0 ? (size_t)(left / per_key_now()) : 0;
+        size_t b = fixed_budget;
+        if (b > fits) {
+            c->pool.tight = true;
+            if (lanes > 1) tight = true;                                     // first the extra lanes retire ...
+            if (lane != 0) return b;
+            while (b > fits && b > ((size_t)1 << 20)) b /= 2;                // ... then the main lane's batches shrink
+        }
+        return b;
     };
     std::vector<void*>& outputs = c->pass_outputs[c->pass];
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
-    auto carve = [&](std::vector<uint32_t>& batch, bool extra_lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
+    auto carve = [&](std::vector<uint32_t>& batch, int lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
         batch.clear();
         if (first_rc != GKC_OK) return false;
-        const size_t budget = budget_now();
-        if (tight && extra_lane) return false;
+        inflight[lane] = 0;
+        const size_t budget = budget_now(lane);
+        if (tight && lane != 0) return false;
         uint64_t acc = 0;
         while (next_p < Pn) {
             const uint32_t p = next_p;
@@ -1338,15 +1364,24 @@ int gkc_count_pass(gkc_ctx* c)
             if (!batch.empty() && acc + part_keys[p] > budget) break;
             batch.push_back(p); acc += part_keys[p]; next_p++;
         }
+        // the expand kernels run one workgroup per partition, one workgroup per CU: a batch of 545 partitions takes three rounds on 256 CUs
+        // with the last one 13 % full — whole multiples of the CU count leave no such tail
+        static const size_t align = getenv("GKC_BATCH_ALIGN") ? (size_t)atoll(getenv("GKC_BATCH_ALIGN")) : 0;
+        if (align && next_p < Pn && batch.size() > align)
+            for (const size_t keep = batch.size() / align * align; batch.size() > keep; batch.pop_back()) { next_p = batch.back(); acc -= part_keys[batch.back()]; }
+        inflight[lane] = (double)acc * per_key_now();
         return !batch.empty();
     };
-    auto lane_main = [&](hipStream_t st) {
+    auto lane_main = [&](hipStream_t st, int lane) {
         (void)hipSetDevice(c->device);
         gkc_tl_stream = st;
         std::vector<uint32_t> batch;
-        while (carve(batch, st != c->stream)) {
+        while (carve(batch, lane)) {
             const int r = (c->key_words == 1) ? count_batch<1, 2>(c, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, batch, part_keys, segs, outputs);
-            if (r != GKC_OK) { std::lock_guard<std::mutex> lk(plan_mu); if (first_rc == GKC_OK) first_rc = r; break; }
+            std::lock_guard<std::mutex> lk(plan_mu);
+            inflight[lane] = 0;
+            if (r != GKC_OK) { if (first_rc == GKC_OK) first_rc = r; break; }
+            for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)c->pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
         }
         (void)hipStreamSynchronize(st);
         gkc_tl_stream = nullptr;
@@ -1356,11 +1391,13 @@ int gkc_count_pass(gkc_ctx* c)
         if (!c->lane_streams[l - 1] && hipStreamCreateWithFlags(&c->lane_streams[l - 1], hipStreamNonBlocking) != hipSuccess) { c->lane_streams[l - 1] = nullptr; lanes = l; break; }
     {
         std::vector<std::thread> extra;
-        for (int l = 1; l < lanes; l++) extra.emplace_back(lane_main, c->lane_streams[l - 1]);
-        lane_main(c->stream);
+        for (int l = 1; l < lanes; l++) extra.emplace_back(lane_main, c->lane_streams[l - 1], l);
+        lane_main(c->stream, 0);
         for (auto& t : extra) t.join();
     }
     rc = first_rc;
+    if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] mallocs %llu failed %llu trims %llu, %.1f ms in hipMalloc, cached %.2f GB\n", (unsigned long long)c->pool.n_malloc,
+                                          (unsigned long long)c->pool.n_fail, (unsigned long long)c->pool.n_trim, c->pool.malloc_ms, (double)c->pool.cached_bytes / 1e9);
     d_recptr.release(); d_recoff.release();
     return rc;
 }
