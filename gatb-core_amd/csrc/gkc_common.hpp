@@ -56,7 +56,6 @@ struct DevPool {
     std::multimap<size_t, void*> cache;       // free blocks by size
     std::map<void*, size_t> live;             // blocks handed out
     size_t cached_bytes = 0;
-    bool tight = false;                       // set by the Stage-B planner when it had to shrink its batches
     uint64_t n_malloc = 0, n_fail = 0, n_trim = 0; double malloc_ms = 0;   // diagnostics (GKC_POOL_DEBUG)
     // size classes: 256 B granules below 2 MB, 2 MB granules up to 64 MB, then 16 classes per octave (<= 6.25 % slack) so that the
     // slightly different buffer sizes of successive Stage-B batches / passes land in the same class and are reused
@@ -71,7 +70,7 @@ struct DevPool {
         std::lock_guard<std::recursive_mutex> lk(mu);
         const size_t want = round(bytes ? bytes : 1);
         auto it = cache.lower_bound(want);
-        if (it != cache.end() && (it->first <= want + want / 4 + ((size_t)1 << 20) || (tight && want >= ((size_t)64 << 20)))) {   // close enough (memory tight: any larger block): reuse
+        if (it != cache.end() && it->first <= want + want / 4 + ((size_t)1 << 20)) {       // close enough: reuse
             void* p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess; return p;
         }
         void* p = nullptr;
@@ -79,15 +78,17 @@ struct DevPool {
         hipError_t e = hipMalloc(&p, want);
         n_malloc++;
         if (e != hipSuccess) {
+            // out of memory: give parked blocks back, largest first, until the request fits. (Handing out a parked block that is merely
+            // large enough would keep exactly the memory that ran out: a 23 GB result block of the previous pass serving a 10 GB request.)
             (void)hipGetLastError();
-            n_fail++;
-            if (it != cache.end()) {                                   // out of memory: any cached block that is large enough will do
-                p = it->second; live[p] = it->first; cached_bytes -= it->first; cache.erase(it); *err = hipSuccess;
-                malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                return p;
+            n_fail++; n_trim++;
+            if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] hipMalloc of %.2f GB failed; parked %.2f GB in %zu blocks\n", (double)want / 1e9, (double)cached_bytes / 1e9, cache.size());
+            while (e != hipSuccess && !cache.empty()) {
+                auto last = std::prev(cache.end());
+                (void)hipFree(last->second); cached_bytes -= last->first; cache.erase(last);
+                e = hipMalloc(&p, want);
+                if (e != hipSuccess) (void)hipGetLastError();
             }
-            n_trim++;
-            trim(); e = hipMalloc(&p, want);                           // give cached blocks back and retry
         }
         malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         *err = e;
@@ -159,6 +160,8 @@ struct gkc_ctx {
     gkc_stats& stats_now() { return pass_stats[pass]; }
     std::mutex mu;                         // shared bookkeeping (timing, stats, outputs, error text) when Stage B runs two lanes
     hipStream_t lane_streams[3] = {nullptr, nullptr, nullptr};   // extra Stage-B lanes (created on first use)
+    uint64_t slots_hint = 0;                  // key slots the big working buffers of a Stage-B batch are sized for (the pass's batch budget)
+    double d_hint = 0;                        // solid records per key of the last Stage-B pass (0 = none yet): sizes the next pass's batches
     std::map<std::string, Timing> timing;
     // scratch reused across calls
     DevBuf d_scan_counters;    // u64[2P + 8]

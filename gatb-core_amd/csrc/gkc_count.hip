@@ -1039,8 +1039,11 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
 #define CB_TRY(expr) do { int rc__ = (expr); if (rc__ != GKC_OK) { B.release(); return rc__; } } while (0)
 #define CB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { B.release(); c->set_error(GKC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); return GKC_ERR_HIP; } } while (0)
     CB_TRY(c->ensure(B.pd, nb * sizeof(PartDesc)));
-    CB_TRY(c->ensure(B.keysA, (size_t)std::max<uint64_t>(n_slots, 1) * sizeof(key_t)));
-    CB_TRY(c->ensure(B.cnt, (size_t)std::max<uint64_t>(n_slots, 1) * 4)); CB_TRY(c->ensure(B.cnt8, (size_t)std::max<uint64_t>(n_slots, 4)));
+    // the big working buffers are sized for the pass's batch budget, not for this batch: every batch then asks the allocator for exactly
+    // the same blocks (a batch one partition larger or smaller would otherwise land in the next size class now and then)
+    const uint64_t alloc_slots = std::max<uint64_t>(std::max<uint64_t>(n_slots, c->slots_hint), 4);
+    CB_TRY(c->ensure(B.keysA, (size_t)alloc_slots * sizeof(key_t)));
+    CB_TRY(c->ensure(B.cnt, (size_t)alloc_slots * 4)); CB_TRY(c->ensure(B.cnt8, (size_t)alloc_slots));
     CB_TRY(c->ensure(B.b_start[0], (size_t)n_sub * 8)); CB_TRY(c->ensure(B.b_n[0], (size_t)n_sub * 4)); CB_TRY(c->ensure(B.b_cons[0], (size_t)n_sub));
     CB_TRY(c->ensure(B.over, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over2, (size_t)(n_sub + 1) * 4)); CB_TRY(c->ensure(B.over3, (size_t)(n_sub + 1) * 4));
     CB_TRY(c->ensure(B.misc, 64));
@@ -1209,7 +1212,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         }
         const int nxt = cur ^ 1;
         if (!split.empty()) {
-            if (!B.keysB.p) CB_TRY(c->ensure(B.keysB, (size_t)n_slots * sizeof(key_t)));
+            if (!B.keysB.p) CB_TRY(c->ensure(B.keysB, (size_t)alloc_slots * sizeof(key_t)));
             dst = (src == (key_t*)B.keysA.p) ? (key_t*)B.keysB.p : (key_t*)B.keysA.p;
             CB_TRY(c->ensure(B.descs, split.size() * sizeof(SplitDesc)));
             CB_TRY(c->ensure(B.effs, split.size() * 4));
@@ -1296,20 +1299,25 @@ int gkc_count_pass(gkc_ctx* c)
     if (e1 != hipSuccess || e2 != hipSuccess) { d_recptr.release(); d_recoff.release(); GKC_FAIL(c, GKC_ERR_HIP, "segment table upload failed"); }
     SegTable segs{ (const uint8_t* const*)d_recptr.p, (const uint64_t*)d_recoff.p, n_seg, Pn };
 
-    // Batches of consecutive partitions, each bounded by a key budget. The budget is FIXED for the pass (derived once from the memory free
-    // at its start): equal batches ask the caching allocator for the same block sizes again and again, so after the first batches no
-    // hipMalloc / hipFree happens at all (re-deriving it from the shrinking free memory made every batch a new size — at k=63, where
-    // the results take half the HBM, that cost seconds of hipMalloc / hipFree in a pass). Per key slot a batch needs the key twice (a
-    // split level uses the ping-pong buffer) and 5 B of abundance planes — its working set, returned to the pool afterwards — and leaves
-    // one Count record per SOLID distinct key resident. Working sets get at most half of the free memory; before every batch the planner
-    // checks that the working set plus the batch's results (at the distinct ratio seen so far, 1.0 before anything finished) still fit,
-    // and otherwise halves the budget (power-of-two ladder: the cached larger blocks stay usable) or retires the extra lanes.
+    // Batches of consecutive partitions, each bounded by a key budget that stays the SAME through the pass: equal batches ask the caching
+    // allocator for the same block sizes again and again, so after the first batches no hipMalloc / hipFree happens at all (hipMalloc
+    // costs ~22 ms per GB here; re-deriving the budget from the shrinking free memory made every batch a new size and a k=63 pass, where
+    // the results take half the HBM, spent seconds in the allocator). Per key slot a batch needs the key twice (a split level uses
+    // the ping-pong buffer) and 5 B of abundance planes — its working set, returned to the pool afterwards — and leaves one Count
+    // record per SOLID distinct key resident, so the peak is at the END of the pass: all results + the last working sets.
+    //  * the budget is what the working sets may take beside the results the whole pass will leave:
+    //    (0.95 free - keys * rec * 1.05 d) / (lanes * work), d = solid records per key; capped, and cut into equal shares;
+    //  * d comes from a small probe batch the first time the memory may bind (see below) and is kept by the context;
+    //  * safety net: before every batch the commitments (finished results, the other lanes' running batches) are checked, and if the
+    //    batch does not fit the extra lanes retire and the main lane halves its batches (slow: blocks change size; never seen when
+    //    the plan holds).
     const size_t key_bytes = c->key_words == 1 ? 8 : 16, rec_bytes = c->key_words == 1 ? 16 : 32;
     const size_t work_per_key = 2 * key_bytes + 5;
     // Two LANES: Stage B's kernels are bound by different things (expand: store atoms and LDS, sorts: VALU, compaction: HBM), and a single
     // in-order stream leaves most of the chip waiting on whichever bound the current kernel has. Two host threads therefore take batches
     // from one queue, each on its own stream (thread-local stream override, cur_stream()): measured 264 -> 229 ms for the same work.
     const uint64_t total_keys = [&] { uint64_t t = 0; for (uint64_t v : part_keys) t += v; return t; }();
+    const uint64_t max_part = [&] { uint64_t t = 0; for (uint64_t v : part_keys) t = std::max(t, v); return t; }();
     int lanes = getenv("GKC_STAGEB_LANES") ? atoi(getenv("GKC_STAGEB_LANES")) : 2;
     if (lanes < 1) lanes = 1;
     if (lanes > 4) lanes = 4;
@@ -1321,26 +1329,49 @@ int gkc_count_pass(gkc_ctx* c)
         return (double)(free_b + c->pool.cached_bytes);
     }();
     static const size_t cap_env = getenv("GKC_BATCH_KEYS") ? (size_t)atoll(getenv("GKC_BATCH_KEYS")) : 0;
-    const size_t cap = cap_env ? cap_env : (c->key_words == 1 ? (size_t)1600000000ULL : (size_t)1200000000ULL);   // the same with one lane or two
-    const size_t fixed_budget = std::min<size_t>(std::max<size_t>((size_t)(0.5 * avail0) / work_per_key / (size_t)lanes, (size_t)1 << 20), cap);
-    uint64_t done_keys = 0, done_solid = 0;                                  // keys / resident records of this pass's finished batches (guarded by plan_mu)
+    // Few, large batches: every batch ends with the drain of ~12 kernels (the expand kernels run one 6 ms workgroup per partition) and
+    // eight host round trips; 8 -> 4 batches per 1.2e10 keys: 320 -> 304 ms. Equal shares, a whole number of batches per lane.
+    const size_t cap = cap_env ? cap_env : (c->key_words == 1 ? (size_t)3200000000ULL : (size_t)1600000000ULL);   // the same with one lane or two
+    uint64_t done_keys = 0, done_solid = 0;                                  // this pass: finished batches (keys, resident records) (guarded by plan_mu)
+    // budget for a given solid-per-key ratio d. Deterministic in (free memory rounded to GB, total keys, d rounded up to 0.05): every
+    // pass of a context plans the same sizes, so from the second pass on all blocks are parked already.
+    const double avail_q = std::floor(avail0 / 1e9) * 1e9;
+    int plan_lanes = (c->key_budget || total_keys < 50000000ULL) ? 1 : 2;                                  // one lane gets the same batches as two would (same blocks whichever way a pass runs) ...
+    auto plan_budget = [&](double d) -> size_t {
+        const double work = (double)plan_lanes * (double)work_per_key;
+        const double dq = std::min(1.0, std::ceil(1.05 * d / 0.05) * 0.05);
+        const double mem = (0.95 * avail_q - (double)total_keys * (double)rec_bytes * dq) / work;
+        const uint64_t bmem = mem > (double)((size_t)1 << 20) ? (uint64_t)mem : ((uint64_t)1 << 20);
+        const uint64_t b = std::min<uint64_t>(bmem, cap);
+        const uint64_t per_round = b * (uint64_t)plan_lanes;
+        const uint64_t rounds = std::max<uint64_t>((total_keys + per_round - 1) / per_round, 1);
+        const uint64_t share = total_keys / (rounds * (uint64_t)plan_lanes);
+        return (size_t)std::min<uint64_t>(b + max_part, share + share / 64 + max_part);           // a little over the share: no small last batch
+    };
+    size_t fixed_budget = 0;                                                 // set below, after the probe
+    bool probe_pending = false; const size_t probe_keys = (size_t)std::max<uint64_t>(total_keys / 256, 16000000ULL);
     double inflight[4] = { 0, 0, 0, 0 };                                     // bytes each lane's running batch may still claim (working set + its results)
-    c->pool.tight = false;
+    size_t last_b[4] = { 0, 0, 0, 0 };
     auto per_key_now = [&]() -> double {
-        const double d_est = done_keys ? std::min(1.0, 1.05 * (double)done_solid / (double)done_keys) : 1.0;
+        const double d_est = done_keys ? std::min(1.0, 1.05 * (double)done_solid / (double)done_keys) : (c->d_hint > 0 ? std::min(1.0, 1.05 * c->d_hint) : 1.0);
         return (double)work_per_key + (double)rec_bytes * d_est;
     };
     auto budget_now = [&](int lane) -> size_t {                              // keys of the next batch of one lane (called under plan_mu)
         if (c->key_budget) return c->key_budget;
         double committed = 0; for (int l = 0; l < 4; l++) if (l != lane) committed += inflight[l];
-        const double left = 0.9 * avail0 - (double)done_solid * (double)rec_bytes - committed;
+        const double left = 0.98 * avail0 - (double)done_solid * (double)rec_bytes - committed;      // (the plan keeps 0.95: headroom between plan and net)
         const size_t fits = left > 0 ? (size_t)(left / per_key_now()) : 0;
         size_t b = fixed_budget;
         if (b > fits) {
-            c->pool.tight = true;
+            if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc plan] lane %d: budget %.3e does not fit (%.3e): done_solid %.3e committed %.1f GB\n", lane, (double)b, (double)fits, (double)done_solid, committed / 1e9);
             if (lanes > 1) tight = true;                                     // first the extra lanes retire ...
             if (lane != 0) return b;
             while (b > fits && b > ((size_t)1 << 20)) b /= 2;                // ... then the main lane's batches shrink
+            c->slots_hint = 0;                                               // (exact buffer sizes from here on)
+        }
+        if (b != last_b[lane]) {                                             // another batch size: the parked blocks have the wrong sizes, and
+            if (last_b[lane]) c->pool.trim();                                // reusing larger ones would keep exactly the memory that ran out
+            last_b[lane] = b;
         }
         return b;
     };
@@ -1351,8 +1382,9 @@ int gkc_count_pass(gkc_ctx* c)
         batch.clear();
         if (first_rc != GKC_OK) return false;
         inflight[lane] = 0;
-        const size_t budget = budget_now(lane);
+        size_t budget = budget_now(lane);
         if (tight && lane != 0) return false;
+        if (probe_pending) { probe_pending = false; budget = probe_keys; }      // the pass's first batch is the small probe batch, every pass (same batches, same blocks)
         uint64_t acc = 0;
         while (next_p < Pn) {
             const uint32_t p = next_p;
@@ -1387,6 +1419,31 @@ int gkc_count_pass(gkc_ctx* c)
         gkc_tl_stream = nullptr;
     };
     (void)hipStreamSynchronize(c->stream);                                   // Stage A and the table uploads are complete before the lanes start
+    // d not known yet and the memory may bind: count a small PROBE batch first (the first partitions holding ~0.4 % of the keys) and take
+    // its ratio. The context keeps that first estimate (until the configuration changes), so every later pass plans the same sizes.
+    // In later passes the same small batch is simply the first one in the queue (it runs beside the other lane's first batch).
+    probe_pending = !c->key_budget && plan_budget(1.0) < plan_budget(1e-9);
+    if (probe_pending && c->d_hint <= 0) {
+        std::vector<uint32_t> batch;
+        fixed_budget = probe_keys; c->slots_hint = 0;
+        if (carve(batch, 0)) {
+            const int r = (c->key_words == 1) ? count_batch<1, 2>(c, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, batch, part_keys, segs, outputs);
+            inflight[0] = 0; last_b[0] = 0;
+            if (r != GKC_OK) { d_recptr.release(); d_recoff.release(); return r; }
+            for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)c->pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
+            if (done_keys) c->d_hint = std::max(1e-6, (double)done_solid / (double)done_keys);
+        }
+    }
+    fixed_budget = c->d_hint > 0 ? plan_budget(c->d_hint) : plan_budget(1.0);   // without a ratio the memory does not bind even at d = 1
+    if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc plan] avail %.1f GB, keys %.3e, d_hint %.4f, lanes %d, budget %.3e\n", avail0 / 1e9, (double)total_keys, c->d_hint, lanes, (double)fixed_budget);
+    if (!c->key_budget && fixed_budget < 250000000ULL) {                       // ... unless there is little room: one lane, larger batches
+        lanes = 1; plan_lanes = 1; fixed_budget = c->d_hint > 0 ? plan_budget(c->d_hint) : plan_budget(1.0);
+    }
+    {   uint64_t nonempty = 0; for (uint64_t v : part_keys) nonempty += v != 0;
+        const uint64_t avg_part = std::max<uint64_t>(total_keys / std::max<uint64_t>(nonempty, 1), 1);
+        const uint64_t hint = (uint64_t)fixed_budget + ((uint64_t)fixed_budget / avg_part + 2) * ((3ull << MAX_SUB_BITS) + COMPACT_BLK);
+        c->slots_hint = c->key_budget ? 0 : (hint + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;
+    }
     for (int l = 1; l < lanes; l++)
         if (!c->lane_streams[l - 1] && hipStreamCreateWithFlags(&c->lane_streams[l - 1], hipStreamNonBlocking) != hipSuccess) { c->lane_streams[l - 1] = nullptr; lanes = l; break; }
     {
