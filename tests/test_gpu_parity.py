@@ -300,6 +300,48 @@ def test_size_independent_properties(gkc, k, n, parts):
     c.device_free(db); c.device_free(do)
 
 
+def test_multi_pass_with_two_lanes_and_solidity(gkc):
+    """three passes over 6e6 reads (2.4e8 keys per pass: the two-lane Stage B with its probe batch, results of earlier passes
+    resident), abundance window [2, 50]: the records of all passes together == the multiset of valid k-mers with that abundance
+    (checksum of the distinct k-mers is not available for a window, so: pass p holds exactly the minimizers = p mod 3, datasets ascend,
+    sum over the histogram == valid k-mers, and the solid counts equal the one-pass run's)"""
+    c = gkc.Counter(0)
+    k, m, parts, n, L = 31, 10, 512, 6_000_000, 150
+    rep = simple_repart(m, parts)
+    db, do = c.synth_reads_device(5, n, L, n * 5, 10000)
+    c.configure(k, m, parts, rep, nb_passes=1)
+    c.set_solidity(2, 50, 10000)
+    c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+    one = c.stats()
+    ref = {}
+    for p in range(0, parts, 61):
+        lo, hi, ab = c.partition(0, p)
+        ref[p] = (lo.copy(), ab.copy())
+    c.configure(k, m, parts, rep, nb_passes=3)
+    c.set_solidity(2, 50, 10000)
+    for ps in range(3):
+        c.begin_pass(ps); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+    st = c.stats()
+    assert st["kmers_nb_valid"] == one["kmers_nb_valid"] == n * (L - k + 1)
+    assert st["kmers_nb_distinct"] == one["kmers_nb_distinct"] and st["kmers_nb_solid"] == one["kmers_nb_solid"]
+    h = c.histogram()
+    assert int((h * np.arange(len(h), dtype=np.uint64)).sum()) == n * (L - k + 1)
+    for p, (rlo, rab) in ref.items():
+        got_lo, got_ab = [], []
+        for ps in range(3):
+            lo, hi, ab = c.partition(ps, p)
+            assert (lo[1:] > lo[:-1]).all() and ((ab >= 2) & (ab <= 50)).all()
+            for a in lo[:: max(1, len(lo) // 5)].tolist():
+                s_ = "".join("ACTG"[(a >> (2 * (k - 1 - i))) & 3] for i in range(k))
+                mins, _ = gko.minimizers(s_, k, m)
+                assert mins[0] % 3 == ps and rep[mins[0]] == p
+            got_lo.append(lo); got_ab.append(ab)
+        glo = np.concatenate(got_lo); gab = np.concatenate(got_ab)
+        o = np.argsort(glo, kind="stable")
+        assert np.array_equal(glo[o], rlo) and np.array_equal(gab[o], rab)
+    c.device_free(db); c.device_free(do)
+
+
 def test_two_owner_shards_on_one_gpu(gkc):
     """multi-GPU data flow on one device: two contexts scan one half of the reads each, their buckets are routed to the
     partition owners exactly as dist.py does (slices of the arena -> foreign segments), each owner counts its partitions;
