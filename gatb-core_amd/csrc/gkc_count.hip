@@ -133,6 +133,34 @@ __device__ __forceinline__ void for_each_kmer32(const uint64_t (&R)[4], uint32_t
         if (sh >= 64) rh |= c << (sh - 64); else rl |= c << sh;
     }
 }
+// Counting pass for 16-byte keys: only the sub-bucket of every k-mer is needed = the top `bits` (<= 13) bits of min(forward, reverse
+// complement). Those are decided by the TOP 64 bits of the two (the first 32 nt of the k-mer / the reverse complement of its last 32):
+// when the top words tie, both give the same sub-bucket. So the walk keeps two 64-bit words only: one funnel shift for the forward
+// top word, a rolling reverse complement of the last 32 nt. calls f(sub-bucket) for every k-mer of the record (32 <= k <= 63).
+template <class F>
+__device__ __forceinline__ void for_each_sub32(const uint64_t (&R)[4], uint32_t k, uint32_t bits, F f)
+{
+    const uint64_t S0 = (R[0] << 8) | (R[1] >> 56), S1 = (R[1] << 8) | (R[2] >> 56), S2 = (R[2] << 8) | (R[3] >> 56), S3 = R[3] << 8;
+    const uint32_t nbk = (uint32_t)(R[0] >> 56), down = 128 - 2 * k;
+    // first k-mer in full (once per record): its reverse complement, left-aligned, gives the initial top word
+    uint64_t fh, fl;
+    if (down == 64) { fh = 0; fl = S0; } else { fh = S0 >> down; fl = (S1 >> down) | (S0 << (64 - down)); }
+    const u128 rv0 = revcomp128(((u128)fh << 64) | fl, k);
+    const uint64_t rh = (uint64_t)(rv0 >> 64), rl = (uint64_t)rv0;
+    uint64_t rtop = down == 64 ? rl : (rh << down) | (rl >> (64 - down));
+    const uint32_t idx_sh = 64 - bits;
+    for (uint32_t i = 0; i < nbk; i++) {
+        const uint32_t s = 2 * i, t = s & 63;
+        const bool j = s >= 64;
+        const uint64_t A = j ? S1 : S0, B = j ? S2 : S1;
+        const uint64_t ftop = (A << t) | ((B >> 1) >> (63 - t));
+        const uint64_t m = ftop < rtop ? ftop : rtop;
+        f(bits ? (uint32_t)(m >> idx_sh) : 0u);
+        const uint32_t bit = 2 * (i + k), w = bit >> 6, sh = 62 - (bit & 63);       // nucleotide i + k enters the next k-mer at the right
+        const uint64_t W = w == 0 ? S0 : (w == 1 ? S1 : (w == 2 ? S2 : S3));
+        rtop = (rtop >> 2) | ((((W >> sh) & 3ull) ^ 2ull) << 62);
+    }
+}
 // record width -> fastest k-mer walk (the generic per-nucleotide for_each_kmer stays as the reference restatement for other widths)
 template <int KW, int RW, class F>
 __device__ __forceinline__ void for_each_kmer_fast(const uint64_t (&R)[RW], uint32_t k, F f)
@@ -173,7 +201,10 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         const uint8_t* base = segs.rec[s];
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
-            for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[sub_index<KW>(c, pd.shift)], 1u); });
+            if constexpr (KW == 2 && RW == 4) {
+                if (k >= 32) for_each_sub32(R, k, pd.sub_bits, [&](uint32_t sb) { atomicAdd(&s_hist[sb], 1u); });
+                else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[sub_index<KW>(c, pd.shift)], 1u); });
+            } else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[sub_index<KW>(c, pd.shift)], 1u); });
         }
     }
     __syncthreads();
