@@ -130,8 +130,12 @@ public:
         gzFile f = gzopen(path.c_str(), "rb");
         if (!f) throw system::Exception("Unable to open file '%s'", path.c_str());
         std::vector<char> buf(1 << 22);
-        for (;;) { const int n = gzread(f, buf.data(), (unsigned)buf.size()); if (n < 0) { gzclose(f); throw system::Exception("read error in '%s'", path.c_str()); }
-                   if (n == 0) break; _text.append(buf.data(), (size_t)n); }
+        for (;;) {
+            const int n = gzread(f, buf.data(), (unsigned)buf.size());
+            if (n < 0) { gzclose(f); throw system::Exception("read error in '%s'", path.c_str()); }
+            if (n == 0) break;
+            _text.append(buf.data(), (size_t)n);
+        }
         gzclose(f);
     }
     const std::string& text() const { return _text; }
