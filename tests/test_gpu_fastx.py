@@ -92,6 +92,40 @@ def test_refused_texts(gkc):
             c.fastx_parse(t)
 
 
+def _fuzz_text(rng, fastq):
+    """well-formed FASTA (multi-line, blank lines, CRLF, odd header text) or 4-line FASTQ (quality strings full of '@', '>' and '+')"""
+    nl = b"\r\n" if rng.random() < 0.3 else b"\n"
+    out = []
+    alpha = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+    qual = np.frombuffer(b"@>+!IJ#;~ABCDEFGH", dtype=np.uint8)
+    head = np.frombuffer(b"abc XYZ_0123|:>@+ \t", dtype=np.uint8)
+    for _ in range(int(rng.integers(1, 12))):
+        h = rng.choice(head, int(rng.integers(0, 20))).tobytes().replace(b"\r", b"")
+        L = int(rng.integers(0, 200))
+        seq = rng.choice(alpha, L).tobytes()
+        if fastq:
+            out += [b"@" + h, seq, b"+" + (h if rng.random() < 0.5 else b""), rng.choice(qual, L).tobytes()]
+        else:
+            out.append(b">" + h)
+            w = int(rng.integers(1, 90))
+            lines = [seq[i:i + w] for i in range(0, L, w)] if rng.random() < 0.7 else [seq]
+            for ln in lines:
+                out.append(ln)
+                if rng.random() < 0.1:
+                    out.append(b"")
+    text = nl.join(out)
+    if rng.random() < 0.8:
+        text += nl
+    return text
+
+
+def test_fuzz_wellformed_texts(gkc):
+    rng = np.random.default_rng(2024)
+    for it in range(300):
+        t = _fuzz_text(rng, fastq=bool(it & 1))
+        check(gkc, t)
+
+
 def test_chunked_feed_equals_whole(gkc):
     rng = np.random.default_rng(9)
     reads = [bytes(r) for r in synth_reads(5000, 50000, 150, seed=8, ragged=True)]
