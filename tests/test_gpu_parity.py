@@ -79,6 +79,25 @@ def test_multi_batch_multi_pass_and_solidity_window(gkc):
     device_vs_oracle(gkc, reads, 25, 9, 8, passes=3, batches=4, amin=2, amax=40, histo_max=30)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_random_configurations(gkc, seed):
+    """random (k, m, partitions, passes, pushes, solidity window, read shapes): every dataset, statistic and the histogram bit-exact"""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.integers(5, 64))
+    m = int(rng.integers(2, min(k - 1, 11) + 1))
+    parts = int(rng.integers(1, 40))
+    passes = int(rng.integers(1, 4))
+    batches = int(rng.integers(1, 4))
+    amin = int(rng.integers(1, 4)); amax = int(rng.choice([2147483647, 5, 60]))
+    if amax < amin:
+        amax = amin
+    histo_max = int(rng.choice([10000, 7, 100]))
+    n_reads = int(rng.integers(50, 1500)); glen = int(rng.integers(300, 20000)); rlen = int(rng.integers(max(k, 20), 220))
+    reads = synth_reads(n_reads, glen, rlen, seed=seed, sub_rate=float(rng.choice([0.0, 0.01, 0.05])), n_rate=float(rng.choice([0.0, 0.002])),
+                        ragged=bool(rng.integers(0, 2)))
+    device_vs_oracle(gkc, reads, k, m, parts, passes=passes, batches=batches, amin=amin, amax=amax, histo_max=histo_max)
+
+
 def test_frequency_order_minimizers(gkc):
     """-minimizer-type 1 (what GraphUnitigs forces, GraphUnitigs.cpp:861-870)"""
     reads = synth_reads(3000, 15000, 150, seed=6, n_rate=0.001)
