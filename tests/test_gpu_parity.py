@@ -95,7 +95,15 @@ def test_fuzz_random_configurations(gkc, seed):
     n_reads = int(rng.integers(50, 1500)); glen = int(rng.integers(300, 20000)); rlen = int(rng.integers(max(k, 20), 220))
     reads = synth_reads(n_reads, glen, rlen, seed=seed, sub_rate=float(rng.choice([0.0, 0.01, 0.05])), n_rate=float(rng.choice([0.0, 0.002])),
                         ragged=bool(rng.integers(0, 2)))
-    device_vs_oracle(gkc, reads, k, m, parts, passes=passes, batches=batches, amin=amin, amax=amax, histo_max=histo_max)
+    freq = None
+    if seed % 3 == 0:                                      # frequency order of the m-mers of a sample of the reads (RepartitionAlgorithm.cpp:311-492)
+        L = gko.lib()
+        counts = np.zeros(4 ** m, np.uint32)
+        for r in reads[: max(10, n_reads // 4)]:
+            L.gko_count_mmers(r, len(r), m, counts)
+        freq = np.zeros(4 ** m, np.uint32)
+        L.gko_freq_order_from_counts(m, counts, freq)
+    device_vs_oracle(gkc, reads, k, m, parts, passes=passes, batches=batches, amin=amin, amax=amax, histo_max=histo_max, freq=freq)
 
 
 def test_frequency_order_minimizers(gkc):
