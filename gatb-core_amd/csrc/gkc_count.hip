@@ -311,6 +311,63 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[s_cur[i]] = v; }
 }
 
+// B1, 16-byte keys in PAIRS: a single 16-byte store to one of 8192 open sub-buckets costs a whole 32-byte HBM write atom (twice the bytes),
+// two keys leaving together fill it. Same exchange-only protocol as above with a 16-byte parking slot per sub-bucket, exchanged by ONE
+// LDS instruction, ds_wrxchg2_rtn_b64 (two adjacent 8-byte words swapped per lane, returned together). Verified to behave as an atomic 128-bit
+// exchange on gfx950 (tools/xchg128_check: 65536 threads hammering 1..8192 slots, no torn pair, values conserved); a torn pair would also
+// surface as a checksum mismatch in every k > 31 parity test. EMPTY = high word all ones (a key's high word has at most 62 bits).
+// LDS: 8192 x (16 + 4) B = 160 KB, all of the CU.
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_xchg128(unsigned long long* slot, uint64_t in_lo, uint64_t in_hi, uint64_t& out_lo, uint64_t& out_hi)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)slot;
+    v4u_t r;
+    asm volatile("ds_wrxchg2_rtn_b64 %0, %1, %2, %3 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(in_lo), "v"(in_hi) : "memory");
+    out_lo = (uint64_t)r.x | ((uint64_t)r.y << 32); out_hi = (uint64_t)r.z | ((uint64_t)r.w << 32);
+}
+__global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
+                                                                        const uint64_t* __restrict__ b_start, u128* __restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub][2] parked key (low word, high word) or EMPTY
+    const PartDesc pd = parts[blockIdx.x];
+    const uint32_t nsub = 1u << pd.sub_bits;
+    uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + 2 * (size_t)nsub);        // [nsub] next free slot of the sub-bucket
+    constexpr unsigned long long EMPTY = ~0ULL;
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { s_pend[2 * i] = EMPTY; s_pend[2 * i + 1] = EMPTY; s_cur[i] = (uint32_t)(b_start[pd.sub_base + i] - pd.key_base); }
+    __syncthreads();
+    ulonglong2* out = reinterpret_cast<ulonglong2*>(keys + pd.key_base);              // one 16-byte key per element (x = low word, y = high word)
+    for (uint32_t s = 0; s < segs.n_seg; s++) {
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);     // 32-byte records: two elements each
+        uint64_t r = r0 + threadIdx.x;
+        ulonglong2 nx0 = make_ulonglong2(0, 0), nx1 = nx0;
+        if (r < r1) { nx0 = recs[2 * r]; nx1 = recs[2 * r + 1]; }
+        for (; r < r1; r += PAIR_THREADS) {
+            const uint64_t R[4] = {nx0.x, nx0.y, nx1.x, nx1.y};
+            if (r + PAIR_THREADS < r1) { nx0 = recs[2 * (r + PAIR_THREADS)]; nx1 = recs[2 * (r + PAIR_THREADS) + 1]; }   // next record in flight
+            for_each_kmer32(R, k, [&](u128 c) {
+                const uint32_t q = sub_index<2>(c, pd.shift);
+                uint64_t h_lo = (uint64_t)c, h_hi = (uint64_t)(c >> 64);
+                for (;;) {
+                    uint64_t y_lo, y_hi;
+                    lds_xchg128(&s_pend[2 * (size_t)q], EMPTY, EMPTY, y_lo, y_hi);
+                    if (y_hi != EMPTY) {
+                        const uint32_t p = atomicAdd(&s_cur[q], 2u);
+                        out[p] = make_ulonglong2(y_lo, y_hi); out[p + 1] = make_ulonglong2(h_lo, h_hi);
+                        break;
+                    }
+                    uint64_t z_lo, z_hi;
+                    lds_xchg128(&s_pend[2 * (size_t)q], h_lo, h_hi, z_lo, z_hi);
+                    if (z_hi == EMPTY) break;
+                    h_lo = z_lo; h_hi = z_hi;
+                }
+            });
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long lo = s_pend[2 * i], hi = s_pend[2 * i + 1]; if (hi != EMPTY) out[s_cur[i]] = make_ulonglong2(lo, hi); }
+}
+
 // B1, 32-byte version. With the expansion itself cheap the pair kernel is bound by its 16-byte stores: a sub-bucket's next pair arrives
 // long after its line left L2, so every pair costs a whole 32-byte HBM write atom (PMC: 2 x the algorithmic bytes). Here a sub-bucket
 // parks up to THREE keys (slots s0..s2) and the fourth arrival leaves with all of them as one aligned 32-byte quad. That needs 32 B of
@@ -1103,6 +1160,11 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
                                (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p);
+        } else if (KW == 2 && k >= 32 && getenv("GKC_SCATTER_NO_PAIR") == nullptr) {
+            const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
+            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start[0].p, (u128*)B.keysA.p);
         } else
         hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
                            (const uint64_t*)B.b_start[0].p, (key_t*)B.keysA.p);
