@@ -425,6 +425,14 @@ int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint6
     return GKC_OK;
 }
 int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) GKC_HIP(c, hipFree(p)); return GKC_OK; }
+int gkc_host_alloc(void** p, uint64_t n_bytes)
+{
+    if (!p) return GKC_ERR_ARG;
+    *p = nullptr;
+    if (hipHostMalloc(p, n_bytes ? (size_t)n_bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return GKC_ERR_NOMEM; }
+    return GKC_OK;
+}
+int gkc_host_free(void* p) { if (p && hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return GKC_ERR_HIP; } return GKC_OK; }
 int gkc_device_to_host(gkc_ctx* c, void* dst, const void* src, uint64_t n)
 {
     if (!c) return GKC_ERR_ARG;

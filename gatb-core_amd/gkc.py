@@ -21,7 +21,7 @@ SYMBOLS = [
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
-    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free",
+    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free", "gkc_host_alloc", "gkc_host_free",
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
@@ -94,6 +94,8 @@ def lib():
         "gkc_bloom_device_array": (C.c_int, [vp, P(vp), P(u64)]),
         "gkc_synth_reads_device": (C.c_int, [vp, u64, u64, u64, u32, u64, u32, P(vp), P(vp)]),
         "gkc_device_free": (C.c_int, [vp, vp]),
+        "gkc_host_alloc": (C.c_int, [P(vp), u64]),
+        "gkc_host_free": (C.c_int, [vp]),
         "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
         "gkc_fastx_parse_device": (C.c_int, [vp, vp, u64, C.c_int, P(vp), P(vp), P(u64), P(u64), P(u64)]),
         "gkc_push_fastx": (C.c_int, [vp, vp, u64, C.c_int, P(u64)]),
@@ -159,6 +161,25 @@ def synth_reads_np(seed, n_reads, read_len, genome_len, sub_ppm, first_read=0):
     code = np.where(sub, (code + 1 + ((v >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, code)
     bases = np.frombuffer(b"ACTG", dtype=np.uint8)[code]
     return bases.copy(), np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)
+
+
+class HostBuffer:
+    """page-locked host memory (gkc_host_alloc) as a numpy uint8 array: ``buf.a``; freed with the object"""
+
+    def __init__(self, nbytes):
+        self._p = C.c_void_p()
+        rc = lib().gkc_host_alloc(C.byref(self._p), int(nbytes))
+        if rc != 0 or not self._p.value:
+            raise GkcError("gkc_host_alloc(%d) failed (%d)" % (nbytes, rc))
+        self.nbytes = int(nbytes)
+        self.a = np.ctypeslib.as_array((C.c_uint8 * max(1, self.nbytes)).from_address(self._p.value))[: self.nbytes]
+
+    def __del__(self):
+        try:
+            if self._p.value:
+                lib().gkc_host_free(self._p); self._p = C.c_void_p()
+        except Exception:
+            pass
 
 
 class Counter:
@@ -227,10 +248,13 @@ class Counter:
         self._chk(self.L.gkc_partition_info(self.h, pass_, part, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
-    def partition_records(self, pass_, part):
-        """raw Count records (uint8 view)"""
+    def partition_records(self, pass_, part, out=None):
+        """raw Count records (uint8 view); ``out``: a uint8 array to receive them (e.g. HostBuffer.a: page-locked, DMA at PCIe rate)"""
         ns, _, _ = self.partition_info(pass_, part)
-        out = np.zeros(max(1, ns * self.rec_bytes), np.uint8)
+        if out is None:
+            out = np.zeros(max(1, ns * self.rec_bytes), np.uint8)
+        elif out.nbytes < ns * self.rec_bytes:
+            raise GkcError("output buffer too small")
         n = C.c_uint64()
         self._chk(self.L.gkc_partition_counts(self.h, pass_, part, _p(out), ns, C.byref(n)))
         return out[: ns * self.rec_bytes]

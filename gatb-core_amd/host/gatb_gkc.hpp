@@ -24,6 +24,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <zlib.h>
+#include <new>
 #include <algorithm>
 #include <cmath>
 #include <fstream>
@@ -613,7 +614,21 @@ public:
         for (auto* p : _processors) p->begin(_config);
         auto bases = [&]() -> const std::vector<char>& { return _bank->bases(); };
         auto offs = [&]() -> const std::vector<uint64_t>& { return _bank->offsets(); };
-        std::vector<Count> buf; std::vector<typename Kmer<32>::Count> narrow;
+        // the partition buffers live in page-locked memory (gkc_host_alloc): the Count[] arrays come over at PCIe rate
+        struct Pinned {
+            void* p = nullptr; size_t bytes = 0;
+            ~Pinned() { if (p) gkc_host_free(p); }
+            void* need(size_t b) {
+                if (b > bytes) {
+                    if (p) gkc_host_free(p);
+                    p = nullptr; bytes = 0;
+                    const size_t nb = b + b / 4 + 4096;
+                    if (gkc_host_alloc(&p, nb) != GKC_OK) throw system::Exception("unable to allocate %zu bytes of page-locked memory", nb);
+                    bytes = nb;
+                }
+                return p;
+            }
+        } pin, pin_narrow;
         for (uint32_t pass = 0; pass < _config._nb_passes; pass++) {
             check(gkc_begin_pass(_ctx, pass));
             if (!pushText(pass)) check(gkc_push_reads(_ctx, bases().data(), offs().data(), offs().size() - 1));   // fillPartitions
@@ -624,19 +639,20 @@ public:
                 for (uint32_t p = 0; p < P; p++) {
                     uint64_t ns = 0, nd = 0, nk = 0;
                     check(gkc_partition_info(_ctx, pass, p, &ns, &nd, &nk));
-                    buf.resize(ns);
+                    Count* buf = static_cast<Count*>(pin.need((size_t)std::max<uint64_t>(ns, 1) * sizeof(Count)));
                     uint64_t got = 0;
                     if (sizeof(Count) == 32 && _config._kmerSize <= 31) {
                         // span 64 instantiated with k <= 31 (the reference's unit tests do it): the device keys are 64-bit
                         // (its key width follows k, like the reference's run-time Integer dispatch); widen the records here
-                        narrow.resize(ns);
-                        check(gkc_partition_counts(_ctx, pass, p, narrow.data(), ns, &got));
-                        for (uint64_t i = 0; i < got; i++) { buf[i].value.setVal(narrow[i].value.getVal()); buf[i].abundance = narrow[i].abundance; }
+                        typedef typename Kmer<32>::Count NarrowCount;
+                        NarrowCount* narrow = static_cast<NarrowCount*>(pin_narrow.need((size_t)std::max<uint64_t>(ns, 1) * sizeof(NarrowCount)));
+                        check(gkc_partition_counts(_ctx, pass, p, narrow, ns, &got));
+                        for (uint64_t i = 0; i < got; i++) { new (&buf[i]) Count(); buf[i].value.setVal(narrow[i].value.getVal()); buf[i].abundance = narrow[i].abundance; }
                     } else
-                    check(gkc_partition_counts(_ctx, pass, p, buf.data(), ns, &got));
+                    check(gkc_partition_counts(_ctx, pass, p, buf, ns, &got));
                     CountProcessor* clone = proc->clone(); clone->use(); clones.push_back(clone);
                     clone->beginPart(pass, p, 4096, "vector");
-                    clone->processBulk(p, buf.data(), (size_t)got);                                   // ascending k-mer order
+                    clone->processBulk(p, buf, (size_t)got);                                          // ascending k-mer order
                     clone->endPart(pass, p);
                 }
                 proc->finishClones(clones);

@@ -217,6 +217,13 @@ int gkc_fastx_parse_device(gkc_ctx* ctx, const char* d_text, uint64_t n_bytes, i
 int gkc_push_fastx(gkc_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, uint64_t* consumed);
 
 int gkc_device_free(gkc_ctx* ctx, void* d_ptr);
+/* Page-locked host memory for the buffers the host side hands to gkc_push_reads / gkc_push_fastx and receives Count[] records in
+ * (gkc_partition_counts): the DMA engines then move them at PCIe rate, pageable memory is staged by the driver at about half of it
+ * (measured: DESIGN.md section 6). This is the role of the reference's host-side buffer provider for partition data
+ * (tools/misc/impl/Pool.hpp:343-418, MemAllocator, and the BagCache buffers of CountProcessorDump.hpp:134): memory the counting
+ * back-end fills and the processors read. No context needed; *p = NULL and GKC_ERR_NOMEM when the allocation fails. */
+int gkc_host_alloc(void** p, uint64_t n_bytes);
+int gkc_host_free(void* p);
 int gkc_device_to_host(gkc_ctx* ctx, void* dst, const void* d_src, uint64_t n_bytes);
 /* order-independent checksum of the canonical k-mer multiset of device-resident reads, computed by an independent
  * one-thread-per-position kernel (no minimizers, no buckets): sum over valid k-mers of mix(canonical) mod 2^64, and the

@@ -15,6 +15,8 @@ c.configure(k, m, parts, bench.repart_for_bench(m, parts))
 db, do = c.synth_reads_device(2, n, L, n * 5, 10000)
 hb = c.device_to_host(db, n * L)
 ho = np.arange(n + 1, dtype=np.uint64) * L
+pin_in = gkc.HostBuffer(n * L); pin_in.a[:] = hb                   # page-locked copies (gkc_host_alloc)
+pin_out = gkc.HostBuffer(1 << 30)
 for it in range(3):
     t0 = time.perf_counter()
     c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
@@ -25,6 +27,13 @@ for it in range(3):
     for p in range(parts):
         tot += len(c.partition_records(0, p))
     t3 = time.perf_counter()
+    c.begin_pass(0); c.push_reads(pin_in.a, ho); c.finish_pass()
+    t4 = time.perf_counter()
+    tot2 = 0
+    for p in range(parts):
+        tot2 += len(c.partition_records(0, p, out=pin_out.a))
+    t5 = time.perf_counter()
     d = c.stats()["kmers_nb_distinct"]
+    print("page-locked buffers: reads in %.1f ms | records out %.1f ms (%.1f GB/s) | host-to-host %.2e distinct k-mers/s" % ((t4 - t3) * 1e3, (t5 - t4) * 1e3, tot2 / (t5 - t4) / 1e9, d / (t5 - t3)))
     print("resident %.1f ms (%.2e distinct/s) | host reads in %.1f ms | + records out (%.2f GB) %.1f ms | host-to-host %.2e distinct k-mers/s"
           % ((t1 - t0) * 1e3, d / (t1 - t0), (t2 - t1) * 1e3, tot / 1e9, (t3 - t2) * 1e3, d / (t3 - t1)), flush=True)
