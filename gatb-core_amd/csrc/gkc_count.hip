@@ -11,8 +11,8 @@
 //   expand_count   one workgroup per partition streams its 16/32-byte records (coalesced), cuts the canonical k-mers out of the
 //                  record's bit string and histograms their top bits in LDS (<= 8192 key-range sub-buckets per partition, sized
 //                  so a sub-bucket fits one wave's registers); the same workgroup scans the histogram into exact sub-bucket offsets.
-//   expand_scatter same stream again; 8-byte keys leave in aligned 16-byte pairs (one parking slot per sub-bucket in LDS, exchange-only
-//                  protocol, no global atomics), 16-byte keys one by one.
+//   expand_scatter same stream again; keys leave in aligned PAIRS (one parking slot per sub-bucket in LDS, exchange-only protocol, no
+//                  global atomics): 8-byte keys as 16-byte stores, 16-byte keys as 32-byte stores (128-bit LDS exchange, ds_wrxchg2).
 //   bucket_sort    one WAVE per sub-bucket: keys in registers, bitonic network (in-lane steps as v_min/max_f64 on double-tagged keys,
 //                  cross-lane steps as DPP / bpermute exchanges, no LDS, no barrier), run-length count, abundance histogram
 //                  (LDS-aggregated); distinct keys and abundances are written back at the head of the sub-bucket's own slot range.
@@ -22,7 +22,8 @@
 //                  when no key bit is left all keys are one k-mer. Any skew terminates in <= ceil(2k/13)+1 levels.
 //   compact        slot flags (abundance != 0) -> block sums -> prefix -> records {value, abundance} in the reference's
 //                  Count layout, contiguous and ascending per partition (slot order is key order).
-//   Batches of partitions are taken from one queue by two host threads, each on its own stream (gkc_count_pass).
+//   Batches of partitions (equal key budgets planned once per pass, so the caching allocator hands the same blocks out again) are
+//   taken from one queue by two host threads, each on its own stream (gkc_count_pass).
 #include "gkc_common.hpp"
 #include "gkc_device.hpp"
 #include <algorithm>
