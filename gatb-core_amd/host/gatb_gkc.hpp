@@ -183,13 +183,40 @@ namespace kmer { namespace impl {
 
 // ------------------------------------------------------------------------------------------------ k-mer integer + Count
 /** LargeInt<1> / LargeInt<2> as used by the path (tools/math/LargeInt1.pri, LargeInt2.pri): value semantics + toString */
-template <int W> struct LargeInt;
+/** LargeInt<3>, LargeInt<4> (tools/math/LargeInt.hpp:60-830: `u_int64_t value[precision]`, word 0 least significant): the spans 96 and 128
+ *  of the reference's default build. The device counts k <= 63; these types let code instantiated with the larger spans (the reference's
+ *  unit tests run DSK_check2 with span 96 and k = 31, TestDSK.cpp:254-305) use the same classes. */
+template <int W> struct LargeInt {
+    uint64_t value[W];
+    LargeInt() { for (int i = 0; i < W; i++) value[i] = 0; }
+    LargeInt(uint64_t v) { value[0] = v; for (int i = 1; i < W; i++) value[i] = 0; }
+    uint64_t getVal() const { return value[0]; }
+    void setVal(uint64_t v) { value[0] = v; for (int i = 1; i < W; i++) value[i] = 0; }
+    void set128(unsigned __int128 v) { value[0] = (uint64_t)v; value[1] = (uint64_t)(v >> 64); for (int i = 2; i < W; i++) value[i] = 0; }
+    bool operator<(const LargeInt& o) const { for (int i = W - 1; i >= 0; i--) if (value[i] != o.value[i]) return value[i] < o.value[i]; return false; }
+    bool operator==(const LargeInt& o) const { for (int i = 0; i < W; i++) if (value[i] != o.value[i]) return false; return true; }
+    bool operator!=(const LargeInt& o) const { return !(*this == o); }
+    LargeInt& operator+=(const LargeInt& o) {
+        unsigned carry = 0;
+        for (int i = 0; i < W; i++) { const unsigned __int128 t = (unsigned __int128)value[i] + o.value[i] + carry; value[i] = (uint64_t)t; carry = (unsigned)(t >> 64); }
+        return *this;
+    }
+    static size_t getSize() { return 64 * W; }
+    static const char* getName() { return W == 3 ? "LargeInt<3>" : "LargeInt<4>"; }
+    std::string toString(size_t k) const {
+        std::string s(k, 'A');
+        for (size_t i = 0; i < k; i++) { const size_t bit = 2 * i; s[k - 1 - i] = "ACTG"[(value[bit >> 6] >> (bit & 63)) & 3]; }
+        return s;
+    }
+};
+
 template <> struct LargeInt<1> {
     uint64_t value;
     LargeInt() : value(0) {}
     LargeInt(uint64_t v) : value(v) {}
     uint64_t getVal() const { return value; }
     void setVal(uint64_t v) { value = v; }
+    void set128(unsigned __int128 v) { value = (uint64_t)v; }
     bool operator<(const LargeInt& o) const { return value < o.value; }
     bool operator==(const LargeInt& o) const { return value == o.value; }
     bool operator!=(const LargeInt& o) const { return value != o.value; }
@@ -204,6 +231,7 @@ template <> struct LargeInt<2> {
     LargeInt(uint64_t v) : value(v) {}
     uint64_t getVal() const { return (uint64_t)value; }
     void setVal(uint64_t v) { value = v; }
+    void set128(unsigned __int128 v) { value = v; }
     bool operator<(const LargeInt& o) const { return value < o.value; }
     bool operator==(const LargeInt& o) const { return value == o.value; }
     bool operator!=(const LargeInt& o) const { return value != o.value; }
@@ -219,7 +247,7 @@ template <size_t span = KMER_DEFAULT_SPAN> struct Kmer {
     /** {value, abundance}: 16 bytes (span 32) / 32 bytes (span 64) — the layout libgkc_hip.so returns (Abundance.hpp:68-129) */
     struct Count {
         Type value; CountNumber abundance;
-        uint32_t _pad[sizeof(Type) == 8 ? 1 : 3];                  // explicit, zeroed: records are byte-reproducible on disk
+        uint32_t _pad[sizeof(Type) == 16 ? 3 : 1];                 // explicit, zeroed: records are byte-reproducible on disk (16-byte alignment only for the 128-bit integer)
         Count() : abundance(0) { for (auto& x : _pad) x = 0; }
         Count(const Type& v, CountNumber a) : value(v), abundance(a) { for (auto& x : _pad) x = 0; }
         const Type& getValue() const { return value; }
@@ -229,6 +257,7 @@ template <size_t span = KMER_DEFAULT_SPAN> struct Kmer {
 };
 static_assert(sizeof(Kmer<32>::Count) == 16, "Count layout must match the device records (k<=31)");
 static_assert(sizeof(Kmer<64>::Count) == 32, "Count layout must match the device records (k<=63)");
+static_assert(sizeof(Kmer<96>::Count) == 32 && sizeof(Kmer<128>::Count) == 40, "Count layout of the larger spans (Abundance.hpp:68-129: value, then a 4-byte abundance, 8-byte alignment)");
 
 // ------------------------------------------------------------------------------------------------ Configuration
 /** kmer/impl/Configuration.hpp:38-117 (fields the hot path reads) */
@@ -564,8 +593,9 @@ public:
         f.set_attribute("/dsk", "xml", xml("dsk", _info.map()));
         f.set_attribute("/dsk/solid", "nb_partitions", std::to_string(store.size()));
         // Count = {value, abundance} (Abundance.hpp:108-125); value: u64, or the 128-bit integer of LargeInt<2>::hdf5 (LargeInt2.pri:137-142)
-        const gkc_h5::Type vt = span <= 32 ? gkc_h5::Type::integer(8, false) : gkc_h5::Type::integer(16, true, 128);
-        const gkc_h5::Type ct = gkc_h5::Type::compound((uint32_t)sizeof(Count), { {"value", {0, vt}}, {"abundance", {(uint32_t)(span <= 32 ? 8 : 16), gkc_h5::Type::integer(4, false)}} });
+        const gkc_h5::Type vt = span <= 32 ? gkc_h5::Type::integer(8, false)                               // LargeInt<1>: H5T_NATIVE_UINT64
+                                           : gkc_h5::Type::integer((uint32_t)sizeof(Type), true, 8 * (uint32_t)sizeof(Type));   // LargeInt<N>: H5T_NATIVE_INT with precision 64 N (LargeInt2.pri:137-142, LargeInt.hpp:655-660)
+        const gkc_h5::Type ct = gkc_h5::Type::compound((uint32_t)sizeof(Count), { {"value", {0, vt}}, {"abundance", {(uint32_t)sizeof(Type), gkc_h5::Type::integer(4, false)}} });
         for (size_t i = 0; i < store.size(); i++) f.add_dataset("/dsk/solid/" + std::to_string(i), ct, store[i].data(), store[i].size());
         // Histogram::save: entries 1..length as {u16 index (stored on 4 bytes), u64 abundance}, then cutoff and nbsolids (Histogram.cpp:192-240)
         struct HEntry { uint32_t index; uint32_t pad; uint64_t abundance; };
@@ -641,15 +671,23 @@ public:
                     check(gkc_partition_info(_ctx, pass, p, &ns, &nd, &nk));
                     Count* buf = static_cast<Count*>(pin.need((size_t)std::max<uint64_t>(ns, 1) * sizeof(Count)));
                     uint64_t got = 0;
-                    if (sizeof(Count) == 32 && _config._kmerSize <= 31) {
-                        // span 64 instantiated with k <= 31 (the reference's unit tests do it): the device keys are 64-bit
-                        // (its key width follows k, like the reference's run-time Integer dispatch); widen the records here
-                        typedef typename Kmer<32>::Count NarrowCount;
-                        NarrowCount* narrow = static_cast<NarrowCount*>(pin_narrow.need((size_t)std::max<uint64_t>(ns, 1) * sizeof(NarrowCount)));
-                        check(gkc_partition_counts(_ctx, pass, p, narrow, ns, &got));
-                        for (uint64_t i = 0; i < got; i++) { new (&buf[i]) Count(); buf[i].value.setVal(narrow[i].value.getVal()); buf[i].abundance = narrow[i].abundance; }
-                    } else
-                    check(gkc_partition_counts(_ctx, pass, p, buf, ns, &got));
+                    // the device's key width follows k (8-byte keys for k <= 31, 16-byte keys above: like the reference's run-time Integer
+                    // dispatch); a span instantiated with a smaller k (the reference's unit tests do it), or the spans 96 / 128, get
+                    // their records widened here
+                    const bool dev16 = _config._kmerSize <= 31;
+                    const bool same = dev16 ? sizeof(Count) == 16 : (sizeof(Count) == 32 && sizeof(Type) == 16);
+                    if (same) check(gkc_partition_counts(_ctx, pass, p, buf, ns, &got));
+                    else if (dev16) {
+                        typedef typename Kmer<32>::Count DevCount;
+                        DevCount* dev = static_cast<DevCount*>(pin_narrow.need((size_t)std::max<uint64_t>(ns, 1) * sizeof(DevCount)));
+                        check(gkc_partition_counts(_ctx, pass, p, dev, ns, &got));
+                        for (uint64_t i = 0; i < got; i++) { new (&buf[i]) Count(); buf[i].value.setVal(dev[i].value.getVal()); buf[i].abundance = dev[i].abundance; }
+                    } else {
+                        typedef typename Kmer<64>::Count DevCount;
+                        DevCount* dev = static_cast<DevCount*>(pin_narrow.need((size_t)std::max<uint64_t>(ns, 1) * sizeof(DevCount)));
+                        check(gkc_partition_counts(_ctx, pass, p, dev, ns, &got));
+                        for (uint64_t i = 0; i < got; i++) { new (&buf[i]) Count(); buf[i].value.set128(dev[i].value.value); buf[i].abundance = dev[i].abundance; }
+                    }
                     CountProcessor* clone = proc->clone(); clone->use(); clones.push_back(clone);
                     clone->beginPart(pass, p, 4096, "vector");
                     clone->processBulk(p, buf, (size_t)got);                                          // ascending k-mer order

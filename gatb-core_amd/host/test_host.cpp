@@ -156,16 +156,17 @@ int main(int argc, char** argv)
             std::istringstream ss(line); std::string tag; ss >> tag;
             if (tag == "check1") {
                 size_t k, nks, exp, nseq; ss >> k >> nks >> exp >> nseq; std::vector<std::string> seqs(nseq); for (auto& s : seqs) ss >> s;
-                DSK_check1_aux<32>(seqs, k, nks, exp); DSK_check1_aux<64>(seqs, k, nks, exp); n1++;
+                DSK_check1_aux<32>(seqs, k, nks, exp); DSK_check1_aux<64>(seqs, k, nks, exp); DSK_check1_aux<96>(seqs, k, nks, exp); n1++;
             } else if (tag == "check2") {
                 size_t k, nv; std::string cs; ss >> k >> cs >> nv; std::vector<uint64_t> vals(nv); for (auto& v : vals) { std::string h; ss >> h; v = strtoull(h.c_str(), 0, 16); }
                 std::string seq; ss >> seq;
-                DSK_check2_aux<32>(seq, k, vals, strtoull(cs.c_str(), 0, 16)); DSK_check2_aux<64>(seq, k, vals, strtoull(cs.c_str(), 0, 16)); n2++;
+                DSK_check2_aux<32>(seq, k, vals, strtoull(cs.c_str(), 0, 16)); DSK_check2_aux<64>(seq, k, vals, strtoull(cs.c_str(), 0, 16));
+                DSK_check2_aux<96>(seq, k, vals, strtoull(cs.c_str(), 0, 16)); DSK_check2_aux<128>(seq, k, vals, strtoull(cs.c_str(), 0, 16)); n2++;   // spans 32 / 64 / 96 as TestDSK.cpp:300-304 (+128)
             }
         }
         protocol_test();
         bloom_algorithm_test();
-        bloom_test<32>(31); bloom_test<64>(47);
+        bloom_test<32>(31); bloom_test<64>(47); bloom_test<96>(47); bloom_test<128>(21);
         // error behaviour: k too small is refused, k >= span is refused (Model.hpp:398-404)
         bool threw = false;
         try { IProperties* p = SortingCountAlgorithm<32>::getDefaultProperties(); p->setInt(STR_KMER_SIZE, 2); SortingCountAlgorithm<32> d(new bank::BankStrings("ACGTACGT", NULL), p); d.execute(); }
