@@ -1,5 +1,5 @@
 // gkc_dsk — minimal command line over SortingCountAlgorithm<span> (the role tools/dbgh5.cpp plays for the count-only case):
-//   gkc_dsk -in reads.fa|fq -kmer-size 31 [-abundance-min 2] [-minimizer-size 10] [-minimizer-type 0|1] [-nb-partitions N] -out prefix
+//   gkc_dsk -in reads.fa|fq -kmer-size 31 [-abundance-min 2] [-minimizer-size 10] [-minimizer-type 0|1] [-nb-partitions N] [-span 64|96|128] -out prefix
 // writes prefix.solid.<dataset> (raw Count[] records, ascending), prefix.minimRepart, prefix.histo, prefix.info
 #include "gatb_gkc.hpp"
 #include <iostream>
@@ -41,6 +41,10 @@ int main(int argc, char** argv)
     if (in.empty()) { std::cerr << "usage: gkc_dsk -in reads.fa -kmer-size 31 [-abundance-min 2] -out prefix" << std::endl; return 2; }
     try {
         const size_t k = (size_t)params->getInt(STR_KMER_SIZE);
-        return k <= 31 ? run<32>(params, in, out) : run<64>(params, in, out);            // Integer::apply / setVariant (tools/math/Integer.hpp:58-90)
+        const size_t span = params->has("-span") ? (size_t)params->getInt("-span") : 0;       // 0: the smallest span holding k, as Integer::apply / setVariant picks it (tools/math/Integer.hpp:58-90)
+        if (span == 96) return run<96>(params, in, out);                                 // forced larger spans (what a build with KSIZE_LIST "32 64 96 128" instantiates): k <= 63 on this device
+        if (span == 128) return run<128>(params, in, out);
+        if (span == 64) return run<64>(params, in, out);
+        return k <= 31 ? run<32>(params, in, out) : run<64>(params, in, out);
     } catch (system::Exception& e) { std::cerr << "EXCEPTION: " << e.getMessage() << std::endl; return 1; }
 }

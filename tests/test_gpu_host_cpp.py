@@ -98,3 +98,34 @@ def test_cli_dump_matches_oracle(built, tmp_path, k, mtype, fmt):
     # histogram/cutoff, nbsolidsforcutoff (Histogram::compute_threshold) computed by the C++ layer from the device histogram
     cut = [int(x) for x in open(out + ".cutoff").read().split()]
     assert tuple(cut) == gko.histogram_cutoff(rh, 2)
+
+
+@pytest.mark.parametrize("k,span", [(31, 96), (47, 128), (31, 64)])
+def test_cli_larger_spans_write_the_same_solid_sets(built, tmp_path, k, span):
+    """SortingCountAlgorithm<96> / <128> (LargeInt<3>, LargeInt<4>: 32- / 40-byte Count) with k <= 63: the .h5 holds the same k-mers and
+    abundances as the natural span's, with the value widened (integer of 64 N bits, LargeInt.hpp:655-660)"""
+    from tests.h5mini import H5Mini
+    reads = synth_reads(1500, 8000, 120, seed=8, n_rate=0.001)
+    fa = tmp_path / "reads.fa"
+    fa.write_text("".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads)))
+    outs = {}
+    for sp in (0, span):
+        out = str(tmp_path / ("out%d" % sp))
+        cmd = [os.path.join(built, "gkc_dsk"), "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2", "-nb-partitions", "4", "-out", out]
+        if sp:
+            cmd += ["-span", str(sp)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[sp] = H5Mini(open(out + ".h5", "rb").read())
+    nat = 8 if k <= 31 else 16
+    wide = span // 32 * 8
+    total = 0
+    for p in range(4):
+        a = outs[0].dataset("/dsk/solid/%d" % p); b = outs[span].dataset("/dsk/solid/%d" % p)
+        assert len(a) == len(b) and b.dtype.itemsize == (32 if span <= 96 else 40)
+        va = np.frombuffer(a["value"].tobytes(), dtype=np.uint8).reshape(len(a), nat)
+        vb = np.frombuffer(b["value"].tobytes(), dtype=np.uint8).reshape(len(b), wide)
+        assert np.array_equal(vb[:, :nat], va) and not vb[:, nat:].any()
+        assert np.array_equal(a["abundance"], b["abundance"])
+        total += len(a)
+    assert total > 100
