@@ -76,6 +76,39 @@ private:
     std::map<std::string, std::string> _m;
 };
 typedef Properties IProperties;
+
+/** Command-line options of the counting step, the role of IOptionsParser / OptionOneParam for this path (tools/misc/impl/OptionsParser.hpp;
+ *  option list: SortingCountAlgorithm.cpp:202-236). parse() yields the property set the algorithm constructors take. */
+class IOptionsParser {
+public:
+    struct Option { std::string name, help; bool mandatory; bool hasDefault; std::string defaultValue; int nbArgs; };
+    explicit IOptionsParser(const std::string& name) : _name(name) {}
+    void push_back(const Option& o) { _options.push_back(o); }
+    const std::vector<Option>& getOptions() const { return _options; }
+    const std::string& getName() const { return _name; }
+    const Option* find(const std::string& name) const { for (auto& o : _options) if (o.name == name) return &o; return nullptr; }
+    /** argv[1..]: "-name value" pairs (or a bare "-name" for options without argument); unknown options and missing mandatory ones throw */
+    IProperties* parse(int argc, char** argv) const {
+        IProperties* props = new IProperties();
+        for (auto& o : _options) if (o.hasDefault) props->setStr(o.name, o.defaultValue);
+        for (int i = 1; i < argc; i++) {
+            const Option* o = find(argv[i]);
+            if (!o) { delete props; throw system::Exception("Unknown parameter '%s'", argv[i]); }
+            if (o->nbArgs == 0) { props->setStr(o->name, ""); continue; }
+            if (i + 1 >= argc) { delete props; throw system::Exception("Too few arguments for the %s option...", o->name.c_str()); }
+            props->setStr(o->name, argv[++i]);
+        }
+        for (auto& o : _options) if (o.mandatory && !props->has(o.name)) { const std::string n = o.name; delete props; throw system::Exception("Option '%s' is mandatory", n.c_str()); }
+        return props;
+    }
+    std::string help() const {
+        std::string h = "[" + _name + " options]\n";
+        for (auto& o : _options) { char line[512]; snprintf(line, sizeof(line), "   %-22s (%d arg) :    %s%s%s\n", o.name.c_str(), o.nbArgs, o.help.c_str(), o.hasDefault ? "  [default '" : "", o.hasDefault ? (o.defaultValue + "']").c_str() : ""); h += line; }
+        return h;
+    }
+private:
+    std::string _name; std::vector<Option> _options;
+};
 }}  // namespace tools::misc
 
 #define STR_KMER_SIZE            "-kmer-size"
@@ -86,6 +119,7 @@ typedef Properties IProperties;
 #define STR_REPARTITION_TYPE     "-repartition-type"
 #define STR_MAX_MEMORY           "-max-memory"
 #define STR_HISTOGRAM_MAX        "-histo-max"
+#define STR_URI_INPUT            "-in"
 #define STR_URI_OUTPUT           "-out"
 #define STR_NB_PARTITIONS        "-nb-partitions"      /* extension: force the partition count (0 = derive) */
 #define STR_NB_PASSES            "-nb-passes"          /* extension: force the pass count (default 1)       */
@@ -541,6 +575,28 @@ public:
         p->setInt(STR_NB_PARTITIONS, 0); p->setInt(STR_NB_PASSES, 1); p->setInt(STR_GPU_DEVICE, 0);
         return p;
     }
+    /** options of the step (SortingCountAlgorithm.hpp:126): the reference's names for what this path reads, plus the three extensions above */
+    static tools::misc::IOptionsParser* getOptionsParser(bool mandatory = true) {
+        typedef tools::misc::IOptionsParser::Option O;
+        auto* p = new tools::misc::IOptionsParser("kmer count");
+        p->push_back(O{ STR_URI_INPUT, "reads file (FASTA / FASTQ, optionally gzipped)", mandatory, false, "", 1 });
+        p->push_back(O{ STR_KMER_SIZE, "size of a k-mer", false, true, "31", 1 });
+        p->push_back(O{ STR_KMER_ABUNDANCE_MIN, "smallest abundance of a solid k-mer", false, true, "2", 1 });
+        p->push_back(O{ STR_KMER_ABUNDANCE_MAX, "largest abundance of a solid k-mer", false, true, "2147483647", 1 });
+        p->push_back(O{ STR_HISTOGRAM_MAX, "number of abundance values the histogram keeps", false, true, "10000", 1 });
+        p->push_back(O{ STR_MAX_MEMORY, "host memory budget in MBytes (kept for compatibility; batches are sized from the HBM)", false, true, "5000", 1 });
+        p->push_back(O{ STR_URI_OUTPUT, "output prefix", false, false, "", 1 });
+        p->push_back(O{ STR_MINIMIZER_TYPE, "minimizer order (0 = lexicographic / KMC2, 1 = by frequency)", false, true, "0", 1 });
+        p->push_back(O{ STR_MINIMIZER_SIZE, "size of a minimizer", false, true, "10", 1 });
+        p->push_back(O{ STR_REPARTITION_TYPE, "minimizer repartition (0 = unordered, 1 = ordered)", false, true, "0", 1 });
+        p->push_back(O{ STR_NB_PARTITIONS, "force the number of partitions (0 = derive)", false, true, "0", 1 });
+        p->push_back(O{ STR_NB_PASSES, "number of passes", false, true, "1", 1 });
+        p->push_back(O{ STR_GPU_DEVICE, "HIP device index", false, true, "0", 1 });
+        return p;
+    }
+    /** (params) only: the reference's first constructor (SortingCountAlgorithm.hpp:96); without a bank execute() refuses */
+    explicit SortingCountAlgorithm(tools::misc::IProperties* params = 0)
+        : _bank(nullptr), _params(params ? *params : tools::misc::IProperties()), _repartitor(nullptr), _ctx(nullptr), _textRefused(false) {}
     SortingCountAlgorithm(bank::IBank* bank, tools::misc::IProperties* params)
         : _bank(bank), _params(*params), _repartitor(nullptr), _ctx(nullptr), _textRefused(false) { _bank->use(); }
     SortingCountAlgorithm(bank::IBank* bank, const Configuration& config, Repartitor* repartitor, std::vector<CountProcessor*> processors, tools::misc::IProperties* params)
@@ -549,7 +605,9 @@ public:
     }
     ~SortingCountAlgorithm() {
         if (_ctx) gkc_destroy(_ctx);
-        _bank->forget(); if (_repartitor) _repartitor->forget(); for (auto* p : _processors) p->forget();
+        if (_bank) _bank->forget();
+        if (_repartitor) _repartitor->forget();
+        for (auto* p : _processors) p->forget();
     }
     void addProcessor(CountProcessor* p) { p->use(); _processors.push_back(p); }
     size_t getProcessorNumber() const { return _processors.size(); }
@@ -562,6 +620,12 @@ public:
         for (auto* p : _processors) { if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(p)) if (auto* d = ch->template get<CountProcessorDump<span>>()) return d->getSolidCounts();
                                       if (auto* d = dynamic_cast<CountProcessorDump<span>*>(p)) return d->getSolidCounts(); }
         throw system::Exception("no dump processor");
+    }
+    /** the solid k-mers alone, dataset after dataset, ascending inside each (getSolidKmers(), .hpp:171: the Iterable's content) */
+    std::vector<Type> getSolidKmers() {
+        std::vector<Type> v;
+        for (auto& part : getSolidCounts()) for (auto& c : part) v.push_back(c.value);
+        return v;
     }
     gkc_ctx* context() { return _ctx; }
 
@@ -639,6 +703,7 @@ public:
     }
 
     void execute() {
+        if (!_bank) throw system::Exception("SortingCountAlgorithm: no bank to count");
         configure();
         const uint32_t P = _config._nb_partitions;
         for (auto* p : _processors) p->begin(_config);

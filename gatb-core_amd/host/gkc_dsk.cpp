@@ -35,14 +35,20 @@ template <size_t span> static int run(tools::misc::IProperties* params, const st
 }
 int main(int argc, char** argv)
 {
-    tools::misc::IProperties* params = SortingCountAlgorithm<32>::getDefaultProperties();
-    std::string in, out;
-    for (int i = 1; i + 1 < argc; i += 2) { std::string k = argv[i], v = argv[i + 1]; if (k == "-in") in = v; else if (k == "-out") { out = v; params->setStr(k, v); } else params->setStr(k, v); }
-    if (in.empty()) { std::cerr << "usage: gkc_dsk -in reads.fa -kmer-size 31 [-abundance-min 2] -out prefix" << std::endl; return 2; }
+    // the step's own options (SortingCountAlgorithm::getOptionsParser) + the ones of this tool
+    tools::misc::IOptionsParser* parser = SortingCountAlgorithm<32>::getOptionsParser(true);
+    typedef tools::misc::IOptionsParser::Option O;
+    parser->push_back(O{ "-mphf", "also build the MPHF + abundance map of the solid k-mers (1)", false, true, "0", 1 });
+    parser->push_back(O{ "-span", "instantiate the classes with this span (64, 96, 128) instead of the smallest one holding k", false, true, "0", 1 });
+    tools::misc::IProperties* params = nullptr;
+    try { params = parser->parse(argc, argv); }
+    catch (system::Exception& e) { std::cerr << e.getMessage() << std::endl << parser->help(); delete parser; return 2; }
+    delete parser;
+    const std::string in = params->getStr(STR_URI_INPUT), out = params->has(STR_URI_OUTPUT) ? params->getStr(STR_URI_OUTPUT) : "";
     try {
         const size_t k = (size_t)params->getInt(STR_KMER_SIZE);
-        const size_t span = params->has("-span") ? (size_t)params->getInt("-span") : 0;       // 0: the smallest span holding k, as Integer::apply / setVariant picks it (tools/math/Integer.hpp:58-90)
-        if (span == 96) return run<96>(params, in, out);                                 // forced larger spans (what a build with KSIZE_LIST "32 64 96 128" instantiates): k <= 63 on this device
+        const size_t span = (size_t)params->getInt("-span");       // 0: the smallest span holding k, as Integer::apply / setVariant picks it (tools/math/Integer.hpp:58-90)
+        if (span == 96) return run<96>(params, in, out);            // forced larger spans (what a build with KSIZE_LIST "32 64 96 128" instantiates): k <= 63 on this device
         if (span == 128) return run<128>(params, in, out);
         if (span == 64) return run<64>(params, in, out);
         return k <= 31 ? run<32>(params, in, out) : run<64>(params, in, out);

@@ -176,6 +176,33 @@ int main(int argc, char** argv)
         try { IProperties* p = SortingCountAlgorithm<32>::getDefaultProperties(); p->setInt(STR_KMER_SIZE, 33); SortingCountAlgorithm<32> d(new bank::BankStrings("ACGTACGT", NULL), p); d.execute(); }
         catch (system::Exception& e) { threw = true; }
         CHECK(threw);
+        // API surface: options parser (defaults = getDefaultProperties for the shared names), (params)-only constructor, getSolidKmers
+        {
+            tools::misc::IOptionsParser* parser = SortingCountAlgorithm<32>::getOptionsParser(true);
+            const char* av[] = { "prog", "-in", "x.fa", "-kmer-size", "21", "-abundance-min", "3" };
+            IProperties* pp = parser->parse(7, (char**)av);
+            IProperties* dd = SortingCountAlgorithm<32>::getDefaultProperties();
+            CHECK(pp->getInt(STR_KMER_SIZE) == 21 && pp->getInt(STR_KMER_ABUNDANCE_MIN) == 3 && pp->getStr(STR_URI_INPUT) == "x.fa");
+            for (const char* name : { STR_KMER_ABUNDANCE_MAX, STR_MINIMIZER_SIZE, STR_MINIMIZER_TYPE, STR_REPARTITION_TYPE, STR_MAX_MEMORY, STR_HISTOGRAM_MAX })
+                CHECK(pp->getStr(name) == dd->getStr(name));
+            bool t1 = false, t2 = false;
+            const char* bad[] = { "prog", "-in", "x.fa", "-no-such-option", "1" };
+            try { parser->parse(5, (char**)bad); } catch (system::Exception&) { t1 = true; }
+            const char* miss[] = { "prog", "-kmer-size", "21" };
+            try { parser->parse(3, (char**)miss); } catch (system::Exception&) { t2 = true; }
+            CHECK(t1 && t2);
+            CHECK(parser->help().find(STR_KMER_SIZE) != std::string::npos);
+            delete pp; delete dd; delete parser;
+            bool t3 = false;
+            try { SortingCountAlgorithm<32> none; none.execute(); } catch (system::Exception&) { t3 = true; }
+            CHECK(t3);
+            IProperties* p = SortingCountAlgorithm<32>::getDefaultProperties(); p->setInt(STR_KMER_SIZE, 11); p->setInt(STR_KMER_ABUNDANCE_MIN, 1);
+            SortingCountAlgorithm<32> d(new bank::BankStrings("ACGTACGTTTGACCAGTAGGCATTACG", NULL), p);
+            d.execute();
+            size_t nrec = 0; for (auto& part : d.getSolidCounts()) nrec += part.size();
+            CHECK(d.getSolidKmers().size() == nrec && nrec == 17);
+            delete p;
+        }
     } catch (system::Exception& e) { std::cerr << "EXCEPTION: " << e.getMessage() << std::endl; return 3; }
     std::cout << "host tests: check1=" << n1 << " check2=" << n2 << " failures=" << failures << std::endl;
     return failures ? 1 : 0;
