@@ -498,6 +498,9 @@ public:
         tools::misc::Properties p; p.add("kmers_nb_distinct", "%llu", (unsigned long long)_shared->total); p.add("kmers_nb_solid", "%llu", (unsigned long long)_shared->ok);
         p.add("kmers_nb_weak", "%llu", (unsigned long long)(_shared->total - _shared->ok)); return p; }
     const Totals& totals() const { return *_shared; }
+    /** CountProcessorSolidityInfo::setAbundanceMin (CountProcessorSolidity.hpp:60-75): the automatic cutoff arrives after the cutoff processor's pass */
+    void setAbundanceMin(CountNumber m) { _min = m; }
+    CountNumber getAbundanceMin() const { return _min; }
 private:
     CountNumber _min, _max; Totals _own; Totals* _shared;
 };
@@ -554,6 +557,55 @@ public:
     template <class T> T* get() const { for (auto* i : _items) if (T* t = dynamic_cast<T*>(i)) return t; return nullptr; }
 private:
     std::vector<ICountProcessor<span>*> _items;
+};
+
+/** CountProcessorCutoff for one bank (kmer/impl/CountProcessorCutoff.hpp:38-160): histogram of every distinct k-mer; endPass computes the
+ *  automatic abundance threshold with Histogram::compute_threshold(3) (:92-103). Used for "-abundance-min auto". */
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorCutoff : public CountProcessorAbstract<span> {
+public:
+    typedef typename Kmer<span>::Type Type;
+    explicit CountProcessorCutoff(size_t histoMax = 10000) : _histo(new CountProcessorHistogram<span>(histoMax)) { _histo->use(); }
+    explicit CountProcessorCutoff(CountProcessorHistogram<span>* h) : _histo(h) { _histo->use(); }
+    ~CountProcessorCutoff() { _histo->forget(); }
+    ICountProcessor<span>* clone() { return new CountProcessorCutoff(static_cast<CountProcessorHistogram<span>*>(_histo->clone())); }
+    bool process(size_t partId, const Type& kmer, const CountVector& count, CountNumber) {
+        CountNumber sum = 0; for (CountNumber c : count) sum += c;
+        return _histo->process(partId, kmer, count, sum);
+    }
+    void endPass(size_t) { _histo->compute_threshold(3); _cutoffs.assign(1, (CountNumber)_histo->get_solid_cutoff()); }
+    std::string getName() const { return "cutoff"; }
+    tools::misc::Properties getProperties() const { tools::misc::Properties p; std::string v; for (CountNumber c : _cutoffs) v += std::to_string(c) + " "; p.setStr("values", v); return p; }
+    std::vector<CountNumber> getCutoffs() const { return _cutoffs; }
+private:
+    CountProcessorHistogram<span>* _histo; std::vector<CountNumber> _cutoffs;
+};
+/** the proxy that links the cutoff processor to the dsk processor (CountProcessorCustomProxy, SortingCountAlgorithm.cpp:418-444): every call goes to the
+ *  cutoff processor; after its pass the cutoff becomes the abundance min of the dsk chain's solidity processor, which runs next */
+template <size_t span = KMER_DEFAULT_SPAN>
+class CountProcessorCutoffProxy : public ICountProcessor<span> {
+public:
+    typedef typename Kmer<span>::Type Type;
+    CountProcessorCutoffProxy(CountProcessorCutoff<span>* cutoff, ICountProcessor<span>* dsk) : _cutoff(cutoff), _dsk(dsk) { _cutoff->use(); }
+    ~CountProcessorCutoffProxy() { _cutoff->forget(); }
+    void begin(const Configuration& c) { _cutoff->begin(c); }
+    void end() { _cutoff->end(); }
+    void beginPass(size_t p) { _cutoff->beginPass(p); }
+    void endPass(size_t p) {
+        _cutoff->endPass(p);
+        if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(_dsk)) if (auto* sol = ch->template get<CountProcessorSoliditySum<span>>())
+            if (!_cutoff->getCutoffs().empty()) sol->setAbundanceMin(_cutoff->getCutoffs()[0]);
+    }
+    ICountProcessor<span>* clone() { return _cutoff->clone(); }
+    void finishClones(std::vector<ICountProcessor<span>*>& clones) { _cutoff->finishClones(clones); }
+    void beginPart(size_t a, size_t b, size_t c, const char* n) { _cutoff->beginPart(a, b, c, n); }
+    void endPart(size_t a, size_t b) { _cutoff->endPart(a, b); }
+    bool process(size_t partId, const Type& kmer, const CountVector& count, CountNumber sum = 0) { return _cutoff->process(partId, kmer, count, sum); }
+    std::string getName() const { return "cutoffs_auto"; }
+    tools::misc::Properties getProperties() const { return _cutoff->getProperties(); }
+    CountProcessorCutoff<span>* cutoff() { return _cutoff; }
+private:
+    CountProcessorCutoff<span>* _cutoff; ICountProcessor<span>* _dsk;
 };
 
 // ------------------------------------------------------------------------------------------------ SortingCountAlgorithm
@@ -628,12 +680,14 @@ public:
         return v;
     }
     gkc_ctx* context() { return _ctx; }
+    /** the default histogram -> solidity -> dump chain among the processors (it follows the cutoff proxy in "auto" mode), or null */
+    CountProcessorChain<span>* getDskChain() { for (auto* p : _processors) if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(p)) return ch; return nullptr; }
 
     /** the .h5 the DSK step of dbgh5 leaves (tools/storage/impl/StorageHDF5.hpp, CountProcessorDump.hpp:85-131, Histogram::save, Repartitor::save):
      *  /dsk/solid/<dataset> Count datasets, /histogram/{histogram,cutoff,nbsolidsforcutoff}, /minimizers/minimRepart(+minimFrequency),
      *  /configuration, string attributes. Written by the native writer gkc_h5.hpp (contiguous datasets; same names, types and values). */
     void saveH5(const std::string& path) {
-        auto* chain = dynamic_cast<CountProcessorChain<span>*>(_processors.empty() ? nullptr : _processors[0]);
+        auto* chain = getDskChain();
         auto* dump = chain ? chain->template get<CountProcessorDump<span>>() : nullptr;
         auto* histo = chain ? chain->template get<CountProcessorHistogram<span>>() : nullptr;
         if (!dump || !histo) throw system::Exception("saveH5 needs the default processor chain");
@@ -773,6 +827,7 @@ public:
         // the solidity processor sees every distinct k-mer (the device returns all of them; filtering is the chain's job)
         for (auto* p : _processors) if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(p)) if (auto* s = ch->template get<CountProcessorSoliditySum<span>>()) {
             _info.add("kmers_nb_distinct", "%llu", (unsigned long long)s->totals().total); _info.add("kmers_nb_solid", "%llu", (unsigned long long)s->totals().ok); }
+        for (auto* p : _processors) if (auto* px = dynamic_cast<CountProcessorCutoffProxy<span>*>(p)) _info.add("cutoffs_auto.values", "%s", px->getProperties().getStr("values").c_str());
         if (!_info.has("kmers_nb_distinct")) { _info.add("kmers_nb_distinct", "%llu", (unsigned long long)st.kmers_nb_distinct); _info.add("kmers_nb_solid", "%llu", (unsigned long long)st.kmers_nb_solid); }
     }
 
@@ -783,6 +838,16 @@ public:
         items.push_back(new CountProcessorSoliditySum<span>(c._abundance_min, c._abundance_max));
         items.push_back(new CountProcessorDump<span>(c._kmerSize));
         return new CountProcessorChain<span>(items);
+    }
+
+    /** getDefaultProcessorVector (SortingCountAlgorithm.cpp:456-512): with "-abundance-min auto" (abundance min -1) a cutoff processor runs over all
+     *  partitions first and hands its threshold to the dsk chain, which then runs over them */
+    static std::vector<CountProcessor*> getDefaultProcessorVector(const Configuration& c) {
+        std::vector<CountProcessor*> v;
+        CountProcessor* dsk = getDefaultProcessor(c);
+        if (c._abundance_min == -1) v.push_back(new CountProcessorCutoffProxy<span>(new CountProcessorCutoff<span>(c._histo_max), dsk));
+        v.push_back(dsk);
+        return v;
     }
 
 private:
@@ -799,7 +864,8 @@ private:
             if (m == 0) m = 8;                                                                              // ConfigurationAlgorithm.cpp:249-251
             _config._minim_size = std::min(_config._kmerSize - 1, m);
             _config._minimizerType = (size_t)_params.getInt(STR_MINIMIZER_TYPE); _config._repartitionType = (size_t)_params.getInt(STR_REPARTITION_TYPE);
-            _config._abundance_min = (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MIN); _config._abundance_max = (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MAX);
+            _config._abundance_min = _params.getStr(STR_KMER_ABUNDANCE_MIN) == "auto" ? -1 : (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MIN);   // ConfigurationAlgorithm.cpp: "auto" -> -1
+            _config._abundance_max = (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MAX);
             _config._histo_max = (uint32_t)_params.getInt(STR_HISTOGRAM_MAX); _config._max_memory = (uint64_t)_params.getInt(STR_MAX_MEMORY);
             _bank->estimate(_config._estimateSeqNb, _config._estimateSeqTotalSize, _config._estimateSeqMaxSize);
             const uint64_t total = _config._estimateSeqTotalSize, nseq = _config._estimateSeqNb, k = _config._kmerSize;
@@ -817,7 +883,7 @@ private:
         if (rc != GKC_OK) throw system::Exception("gkc_create failed (%d): %s", rc, gkc_last_error(nullptr));
         const size_t m = _config._minim_size; const uint32_t P = _config._nb_partitions;
         if (!_repartitor) { _repartitor = buildRepartitor(m, P); _repartitor->use(); }
-        if (_processors.empty()) { CountProcessor* p = getDefaultProcessor(_config); p->use(); _processors.push_back(p); }
+        if (_processors.empty()) for (CountProcessor* p : getDefaultProcessorVector(_config)) { p->use(); _processors.push_back(p); }
         // the device returns every distinct k-mer; histogram / solidity / dump stay in the processor chain (drop-in behaviour)
         check(gkc_set_solidity(_ctx, 1, 2147483647, _config._histo_max));
         check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, P, _config._nb_passes, _repartitor->getMinimizerFrequencies() ? GKC_MINIMIZER_FREQ : GKC_MINIMIZER_LEXI,

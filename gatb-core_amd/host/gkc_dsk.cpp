@@ -12,7 +12,7 @@ template <size_t span> static int run(tools::misc::IProperties* params, const st
     dsk.execute();
     for (auto& kv : dsk.getInfo()->map()) std::cout << kv.first << " : " << kv.second << std::endl;
     if (!out.empty()) {
-        auto* chain = dynamic_cast<CountProcessorChain<span>*>(dsk.getProcessor(0));
+        auto* chain = dsk.getDskChain();
         if (chain) {
             chain->template get<CountProcessorDump<span>>()->saveRaw(out);
             auto* hp = chain->template get<CountProcessorHistogram<span>>();

@@ -129,3 +129,27 @@ def test_cli_larger_spans_write_the_same_solid_sets(built, tmp_path, k, span):
         assert np.array_equal(a["abundance"], b["abundance"])
         total += len(a)
     assert total > 100
+
+
+def test_cli_abundance_min_auto(built, tmp_path):
+    """-abundance-min auto: a cutoff processor sees every distinct k-mer first (CountProcessorCutoff: Histogram::compute_threshold(3)), its
+    threshold becomes the abundance min of the dsk chain (SortingCountAlgorithm.cpp:418-512) — solid sets equal the oracle's at that cutoff"""
+    reads = synth_reads(6000, 30000, 150, seed=21, sub_rate=0.01)
+    fa = tmp_path / "reads.fa"
+    fa.write_text("".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads)))
+    out = str(tmp_path / "out")
+    k = 25
+    r = subprocess.run([os.path.join(built, "gkc_dsk"), "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "auto", "-nb-partitions", "4", "-out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = dict(l.split("\t") for l in open(out + ".info").read().splitlines())
+    raw = np.fromfile(out + ".minimRepart", dtype=np.uint8)
+    nmin = int(raw[2:10].view(np.uint64)[0]); table = raw[12:12 + 2 * nmin].view(np.uint16).copy(); m = int(np.log2(nmin) / 2)
+    bases, offs = gko.pack_reads(reads)
+    allk = gko.Dsk(bases, offs, k, m, 4, table, abundance_min=1)
+    cutoff = gko.histogram_cutoff(allk.histogram(), 3)[0]
+    assert cutoff >= 3 and int(info["cutoffs_auto.values"].split()[0]) == cutoff
+    ref = gko.Dsk(bases, offs, k, m, 4, table, abundance_min=cutoff)
+    for p in range(4):
+        assert np.array_equal(np.fromfile(out + ".solid.%d" % p, dtype=np.uint8), ref.part_records(p)), p
+    assert int(info["kmers_nb_solid"]) == ref.stats["kmers_nb_solid"] and int(info["kmers_nb_distinct"]) == ref.stats["kmers_nb_distinct"]
