@@ -134,6 +134,9 @@ public:
     virtual ~IBank() {}
     virtual const std::vector<char>& bases() const = 0;
     virtual const std::vector<uint64_t>& offsets() const = 0;     // n+1 entries
+    /** number of files behind the bank (an album of several files is counted as their concatenation: the reference sums the per-bank counts
+     *  of a k-mer when the solidity kind is "sum", its default — CounterBuilder, PartitionsCommand.hpp:57-97) */
+    virtual size_t getNbBanks() const { return 1; }
     int64_t getNbItems() const { return (int64_t)offsets().size() - 1; }
     uint64_t getSize() const { return offsets().back(); }
     void estimate(uint64_t& number, uint64_t& totalSize, uint64_t& maxSize) const {
@@ -161,18 +164,30 @@ protected:
  *  appended up to '\n', one trailing '\r' dropped when the read is longer than 1; '+' starts a quality consumed by length. */
 class BankFasta : public IBank {
 public:
-    explicit BankFasta(const std::string& path) : _parsed(false) {
-        gzFile f = gzopen(path.c_str(), "rb");
-        if (!f) throw system::Exception("Unable to open file '%s'", path.c_str());
+    /** one file, or several separated by commas (the "-in a.fa,b.fa" album of the reference's Bank::open, bank/impl/Bank.cpp / BankAlbum.hpp) */
+    explicit BankFasta(const std::string& uri) : _nbFiles(0), _parsed(false) {
+        size_t from = 0;
         std::vector<char> buf(1 << 22);
-        for (;;) {
-            const int n = gzread(f, buf.data(), (unsigned)buf.size());
-            if (n < 0) { gzclose(f); throw system::Exception("read error in '%s'", path.c_str()); }
-            if (n == 0) break;
-            _text.append(buf.data(), (size_t)n);
+        while (from <= uri.size()) {
+            size_t to = uri.find(',', from); if (to == std::string::npos) to = uri.size();
+            const std::string path = uri.substr(from, to - from);
+            from = to + 1;
+            if (path.empty()) continue;
+            gzFile f = gzopen(path.c_str(), "rb");
+            if (!f) throw system::Exception("Unable to open file '%s'", path.c_str());
+            if (!_text.empty() && _text.back() != '\n') _text.push_back('\n');          // a file without a final newline must not run into the next header
+            for (;;) {
+                const int n = gzread(f, buf.data(), (unsigned)buf.size());
+                if (n < 0) { gzclose(f); throw system::Exception("read error in '%s'", path.c_str()); }
+                if (n == 0) break;
+                _text.append(buf.data(), (size_t)n);
+            }
+            gzclose(f);
+            _nbFiles++;
         }
-        gzclose(f);
+        if (_nbFiles == 0) throw system::Exception("Unable to open file '%s'", uri.c_str());
     }
+    size_t getNbBanks() const { return _nbFiles; }
     const std::string& text() const { return _text; }
     const std::vector<char>& bases() const { parse(); return _bases; }
     const std::vector<uint64_t>& offsets() const { parse(); return _off; }
@@ -208,7 +223,7 @@ private:
             _off.push_back(_bases.size());
         }
     }
-    std::string _text;
+    std::string _text; size_t _nbFiles;
     mutable bool _parsed; mutable std::vector<char> _bases; mutable std::vector<uint64_t> _off;
 };
 }  // namespace bank
@@ -867,6 +882,7 @@ private:
             _config._abundance_min = _params.getStr(STR_KMER_ABUNDANCE_MIN) == "auto" ? -1 : (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MIN);   // ConfigurationAlgorithm.cpp: "auto" -> -1
             _config._abundance_max = (CountNumber)_params.getInt(STR_KMER_ABUNDANCE_MAX);
             _config._histo_max = (uint32_t)_params.getInt(STR_HISTOGRAM_MAX); _config._max_memory = (uint64_t)_params.getInt(STR_MAX_MEMORY);
+            _config._nb_banks = _bank->getNbBanks();
             _bank->estimate(_config._estimateSeqNb, _config._estimateSeqTotalSize, _config._estimateSeqMaxSize);
             const uint64_t total = _config._estimateSeqTotalSize, nseq = _config._estimateSeqNb, k = _config._kmerSize;
             _config._kmersNb = total > nseq * (k - 1) ? total - nseq * (k - 1) : 0;                       // ConfigurationAlgorithm.cpp:308-319

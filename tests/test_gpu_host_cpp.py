@@ -153,3 +153,29 @@ def test_cli_abundance_min_auto(built, tmp_path):
     for p in range(4):
         assert np.array_equal(np.fromfile(out + ".solid.%d" % p, dtype=np.uint8), ref.part_records(p)), p
     assert int(info["kmers_nb_solid"]) == ref.stats["kmers_nb_solid"] and int(info["kmers_nb_distinct"]) == ref.stats["kmers_nb_distinct"]
+
+
+def test_cli_album_of_two_files_counts_like_their_concatenation(built, tmp_path):
+    """-in a.fa,b.fq.gz (two banks, solidity kind sum): the same solid sets as the single concatenated file; the first file has no final newline"""
+    import gzip
+    reads = synth_reads(2400, 12000, 140, seed=33, n_rate=0.001)
+    a, b = reads[:1000], reads[1000:]
+    fa = tmp_path / "a.fa"; fb = tmp_path / "b.fa.gz"; fc = tmp_path / "c.fa"
+    ta = "".join(">a%d\n%s\n" % (i, r.decode()) for i, r in enumerate(a)).rstrip("\n")
+    tb = "".join(">b%d\n%s\n" % (i, r.decode()) for i, r in enumerate(b))
+    fa.write_text(ta)
+    with gzip.open(fb, "wb") as f:
+        f.write(tb.encode())
+    fc.write_text(ta + "\n" + tb)
+    outs = []
+    for name, uri in (("two", "%s,%s" % (fa, fb)), ("one", str(fc))):
+        out = str(tmp_path / name)
+        r = subprocess.run([os.path.join(built, "gkc_dsk"), "-in", uri, "-kmer-size", "27", "-abundance-min", "2", "-nb-partitions", "4", "-out", out],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(out)
+    for p in range(4):
+        x = np.fromfile(outs[0] + ".solid.%d" % p, dtype=np.uint8); y = np.fromfile(outs[1] + ".solid.%d" % p, dtype=np.uint8)
+        assert len(x) > 0 and np.array_equal(x, y)
+    i0 = dict(l.split("\t") for l in open(outs[0] + ".info").read().splitlines()); i1 = dict(l.split("\t") for l in open(outs[1] + ".info").read().splitlines())
+    assert i0["kmers_nb_valid"] == i1["kmers_nb_valid"] and i0["seq_number"] == i1["seq_number"] == "2400"
