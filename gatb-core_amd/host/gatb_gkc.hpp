@@ -970,6 +970,8 @@ public:
     ~BloomDevice() { gkc_bloom_destroy(_b); }
     void insert(const Item& item) { chk(gkc_bloom_insert(_b, &item, 1, sizeof(Item))); }
     void insert(const Item* items, size_t n) { chk(gkc_bloom_insert(_b, items, n, sizeof(Item))); }
+    /** keys at the start of larger records (e.g. Count[]: value first) */
+    void insertStrided(const void* first, size_t n, size_t strideBytes) { if (n) chk(gkc_bloom_insert(_b, first, n, (uint32_t)strideBytes)); }
     /** every solid k-mer of a counted context (BloomAlgorithm::execute, BloomAlgorithm.cpp:155-199) */
     void insertSolid(gkc_ctx* counted) { chk(gkc_bloom_insert_solid(_b, counted)); }
     bool contains(const Item& item) { uint8_t r = 0; chk(gkc_bloom_contains(_b, &item, 1, sizeof(Item), &r)); return r != 0; }
@@ -1019,26 +1021,33 @@ template <size_t span = KMER_DEFAULT_SPAN>
 class BloomAlgorithm {
 public:
     typedef typename Kmer<span>::Type Type;
-    BloomAlgorithm(gkc_ctx* countedCtx, size_t kmerSize, float nbitsPerKmer, tools::collections::impl::BloomKind kind = tools::collections::impl::BLOOM_DEFAULT)
-        : _ctx(countedCtx), _kmerSize(kmerSize), _nbitsPerKmer(nbitsPerKmer), _kind(kind), _bloom(nullptr) {}
+    typedef std::vector<std::vector<typename Kmer<span>::Count>> Store;
+    /** solidCounts = the dump processor's datasets (getSolidCounts()): the SOLID k-mers, as the reference's BloomAlgorithm takes them (its `solidIterable`).
+     *  Without it the k-mers come straight from the counting context's result buffers — every k-mer the device kept, i.e. the solid ones only when
+     *  the context itself filtered with the wanted abundance window (gkc_set_solidity); SortingCountAlgorithm leaves the filtering to its chain. */
+    BloomAlgorithm(gkc_ctx* countedCtx, size_t kmerSize, float nbitsPerKmer, tools::collections::impl::BloomKind kind = tools::collections::impl::BLOOM_DEFAULT,
+                   const Store* solidCounts = nullptr)
+        : _ctx(countedCtx), _kmerSize(kmerSize), _nbitsPerKmer(nbitsPerKmer), _kind(kind), _store(solidCounts), _bloom(nullptr) {}
     ~BloomAlgorithm() { if (_bloom) _bloom->forget(); }
     void execute() {
         gkc_stats st; if (gkc_get_stats(_ctx, &st) != GKC_OK) throw system::Exception("%s", gkc_last_error(_ctx));
-        const uint64_t solidKmersNb = st.kmers_nb_solid;
+        uint64_t solidKmersNb = st.kmers_nb_solid;
+        if (_store) { solidKmersNb = 0; for (auto& d : *_store) solidKmersNb += d.size(); }
         const float NBITS_PER_KMER = _nbitsPerKmer;
         uint64_t estimatedBloomSize = (uint64_t)(solidKmersNb * NBITS_PER_KMER);
         const size_t nbHash = (size_t)(int)floorf(0.7 * NBITS_PER_KMER);
         if (estimatedBloomSize == 0) estimatedBloomSize = 1000;
         auto* b = new tools::collections::impl::BloomDevice<Type>(_ctx, _kind, estimatedBloomSize, nbHash, _kmerSize);
         b->use(); _bloom = b;
-        b->insertSolid(_ctx);
+        if (_store) { for (auto& d : *_store) b->insertStrided(d.data(), d.size(), sizeof(typename Kmer<span>::Count)); }
+        else b->insertSolid(_ctx);
         _info.add("kind", "%s", b->getName().c_str()); _info.add("bitsize", "%llu", (unsigned long long)b->getBitSize());
         _info.add("nb_hash", "%d", (int)nbHash); _info.add("nbits_per_kmer", "%f", _nbitsPerKmer);
     }
     tools::collections::impl::IBloom<Type>* getBloom() { return _bloom; }
     const tools::misc::Properties* getInfo() const { return &_info; }
 private:
-    gkc_ctx* _ctx; size_t _kmerSize; float _nbitsPerKmer; tools::collections::impl::BloomKind _kind;
+    gkc_ctx* _ctx; size_t _kmerSize; float _nbitsPerKmer; tools::collections::impl::BloomKind _kind; const Store* _store;
     tools::collections::impl::IBloom<Type>* _bloom; tools::misc::Properties _info;
 };
 

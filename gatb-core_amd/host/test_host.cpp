@@ -145,6 +145,25 @@ static void bloom_algorithm_test()
     CHECK(miss == 0);
     CHECK(getNbBitsPerKmer(31, DEBLOOM_CASCADING) > 5 && getNbBitsPerKmer(31, DEBLOOM_CASCADING) < 20);
     delete params;
+    // abundance min 2: the Bloom filter holds the SOLID k-mers (the chain filtered them; the device kept every distinct one)
+    {
+        IProperties* p2 = SortingCountAlgorithm<32>::getDefaultProperties();
+        p2->setInt(STR_KMER_SIZE, 9); p2->setInt(STR_MINIMIZER_SIZE, 6); p2->setInt(STR_KMER_ABUNDANCE_MIN, 2);
+        std::string twice = std::string(seq) + "ACGT" + std::string(seq).substr(20, 60);      // 52 k-mers occur twice
+        SortingCountAlgorithm<32> sc(new bank::BankStrings(twice.c_str(), NULL), p2);
+        sc.execute();
+        size_t nsolid = 0; for (auto& part : sc.getSolidCounts()) nsolid += part.size();
+        CHECK(nsolid > 0 && (int64_t)nsolid == sc.getInfo()->getInt("kmers_nb_solid") && sc.getInfo()->getInt("kmers_nb_distinct") > (int64_t)nsolid);
+        BloomAlgorithm<32> bl(sc.context(), 9, 12.0f, BLOOM_CACHE, &sc.getSolidCounts());
+        bl.execute();
+        CHECK(bl.getBloom()->getBitSize() == (uint64_t)(nsolid * 12.0f));
+        IBloom<Kmer<32>::Type>* ref = BloomFactory::createBloom<Kmer<32>::Type>(sc.context(), BLOOM_CACHE, (uint64_t)(nsolid * 12.0f), (size_t)(int)floorf(0.7f * 12.0f), 9);
+        ref->use();
+        for (auto& part : sc.getSolidCounts()) for (auto& c : part) ref->insert(c.value);
+        CHECK(ref->getArray() == bl.getBloom()->getArray());                                      // exactly the solid set, nothing else
+        ref->forget();
+        delete p2;
+    }
 }
 
 int main(int argc, char** argv)
