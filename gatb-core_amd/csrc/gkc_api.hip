@@ -425,6 +425,27 @@ int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint6
     return GKC_OK;
 }
 int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) GKC_HIP(c, hipFree(p)); return GKC_OK; }
+int gkc_release_pass(gkc_ctx* c, uint32_t pass)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->configured || pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "no such pass %u", pass);
+    if (c->in_pass && c->pass == pass) GKC_FAIL(c, GKC_ERR_ARG, "pass %u is still open (gkc_finish_pass first)", pass);
+    GKC_HIP(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    free_pass_outputs(c, pass);
+    for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();   // statistics of the pass stay
+    return GKC_OK;
+}
+int gkc_device_memory(gkc_ctx* c, uint64_t* usable_bytes, uint64_t* total_bytes)
+{
+    if (!c) return GKC_ERR_ARG;
+    GKC_HIP(c, hipSetDevice(c->device));
+    size_t free_b = 0, total_b = 0;
+    GKC_HIP(c, hipMemGetInfo(&free_b, &total_b));
+    if (usable_bytes) *usable_bytes = (uint64_t)free_b + (uint64_t)c->pool.cached_bytes;
+    if (total_bytes) *total_bytes = (uint64_t)total_b;
+    return GKC_OK;
+}
 int gkc_host_alloc(void** p, uint64_t n_bytes)
 {
     if (!p) return GKC_ERR_ARG;

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
-    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free", "gkc_host_alloc", "gkc_host_free",
+    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free", "gkc_host_alloc", "gkc_host_free", "gkc_release_pass", "gkc_device_memory",
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
@@ -96,6 +96,8 @@ def lib():
         "gkc_device_free": (C.c_int, [vp, vp]),
         "gkc_host_alloc": (C.c_int, [P(vp), u64]),
         "gkc_host_free": (C.c_int, [vp]),
+        "gkc_release_pass": (C.c_int, [vp, u32]),
+        "gkc_device_memory": (C.c_int, [vp, P(u64), P(u64)]),
         "gkc_device_to_host": (C.c_int, [vp, vp, vp, u64]),
         "gkc_fastx_parse_device": (C.c_int, [vp, vp, u64, C.c_int, P(vp), P(vp), P(u64), P(u64), P(u64)]),
         "gkc_push_fastx": (C.c_int, [vp, vp, u64, C.c_int, P(u64)]),
@@ -237,6 +239,16 @@ class Counter:
 
     def finish_pass(self):
         self._chk(self.L.gkc_finish_pass(self.h))
+
+    def release_pass(self, p):
+        """gives the result buffers of a finished (and drained) pass back"""
+        self._chk(self.L.gkc_release_pass(self.h, p))
+
+    def device_memory(self):
+        """(usable, total) bytes of HBM"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.gkc_device_memory(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def count(self, bases, offsets):
         """all passes over one host batch"""

@@ -122,7 +122,7 @@ private:
 #define STR_URI_INPUT            "-in"
 #define STR_URI_OUTPUT           "-out"
 #define STR_NB_PARTITIONS        "-nb-partitions"      /* extension: force the partition count (0 = derive) */
-#define STR_NB_PASSES            "-nb-passes"          /* extension: force the pass count (default 1)       */
+#define STR_NB_PASSES            "-nb-passes"          /* extension: force the pass count (0 = derive)      */
 #define STR_GPU_DEVICE           "-gpu"                /* extension: HIP device index                       */
 
 // ------------------------------------------------------------------------------------------------ bank (minimal)
@@ -639,7 +639,7 @@ public:
         p->setInt(STR_KMER_SIZE, 31); p->setInt(STR_KMER_ABUNDANCE_MIN, 2); p->setInt(STR_KMER_ABUNDANCE_MAX, 2147483647);
         p->setInt(STR_MINIMIZER_SIZE, 10); p->setInt(STR_MINIMIZER_TYPE, 0); p->setInt(STR_REPARTITION_TYPE, 0);
         p->setInt(STR_MAX_MEMORY, 5000); p->setInt(STR_HISTOGRAM_MAX, 10000); p->setStr(STR_URI_OUTPUT, "");
-        p->setInt(STR_NB_PARTITIONS, 0); p->setInt(STR_NB_PASSES, 1); p->setInt(STR_GPU_DEVICE, 0);
+        p->setInt(STR_NB_PARTITIONS, 0); p->setInt(STR_NB_PASSES, 0); p->setInt(STR_GPU_DEVICE, 0);
         return p;
     }
     /** options of the step (SortingCountAlgorithm.hpp:126): the reference's names for what this path reads, plus the three extensions above */
@@ -657,7 +657,7 @@ public:
         p->push_back(O{ STR_MINIMIZER_SIZE, "size of a minimizer", false, true, "10", 1 });
         p->push_back(O{ STR_REPARTITION_TYPE, "minimizer repartition (0 = unordered, 1 = ordered)", false, true, "0", 1 });
         p->push_back(O{ STR_NB_PARTITIONS, "force the number of partitions (0 = derive)", false, true, "0", 1 });
-        p->push_back(O{ STR_NB_PASSES, "number of passes", false, true, "1", 1 });
+        p->push_back(O{ STR_NB_PASSES, "number of passes (0 = derive from the HBM)", false, true, "0", 1 });
         p->push_back(O{ STR_GPU_DEVICE, "HIP device index", false, true, "0", 1 });
         return p;
     }
@@ -831,6 +831,7 @@ public:
                 for (auto* c : clones) c->forget();
                 proc->endPass(pass);
             }
+            if (_releasePasses) check(gkc_release_pass(_ctx, pass));                                 // every processor has seen the pass: its results leave the HBM
         }
         for (auto* p : _processors) p->end();
         gkc_stats st; check(gkc_get_stats(_ctx, &st));
@@ -870,6 +871,8 @@ private:
 
     /** configure(), SortingCountAlgorithm.cpp:525-625 + ConfigurationAlgorithm.cpp:245-467 (GPU-aware partition count) */
     void configure() {
+        int rc = gkc_create((int)(_params.has(STR_GPU_DEVICE) ? _params.getInt(STR_GPU_DEVICE) : 0), &_ctx);
+        if (rc != GKC_OK) throw system::Exception("gkc_create failed (%d): %s", rc, gkc_last_error(nullptr));
         if (!_config._isComputed) {
             _config._kmerSize = (size_t)_params.getInt(STR_KMER_SIZE);
             if (_config._kmerSize <= 2) throw system::Exception("Error: kmer size should be > 2");          // .cpp:662-666 (exit(1) there)
@@ -886,7 +889,18 @@ private:
             _bank->estimate(_config._estimateSeqNb, _config._estimateSeqTotalSize, _config._estimateSeqMaxSize);
             const uint64_t total = _config._estimateSeqTotalSize, nseq = _config._estimateSeqNb, k = _config._kmerSize;
             _config._kmersNb = total > nseq * (k - 1) ? total - nseq * (k - 1) : 0;                       // ConfigurationAlgorithm.cpp:308-319
-            _config._nb_passes = _params.has(STR_NB_PASSES) ? (uint32_t)std::max<int64_t>(1, _params.getInt(STR_NB_PASSES)) : 1;
+            // Passes (ConfigurationAlgorithm.cpp:398-425 derives them from -max-memory / -max-disk): here from the HBM. During a pass the device holds the
+            // pass's super-k-mer records (~1.5 B per k-mer), its results (one Count per solid k-mer; the ratio is not known yet: 0.6 assumed) and the
+            // Stage-B working set; a pass is released once the processors have drained it (gkc_release_pass). 0 / absent = derive.
+            const int64_t forcedPasses = _params.has(STR_NB_PASSES) ? _params.getInt(STR_NB_PASSES) : 0;
+            if (forcedPasses > 0) _config._nb_passes = (uint32_t)forcedPasses;
+            else {
+                uint64_t usable = 0, totalMem = 0;
+                check(gkc_device_memory(_ctx, &usable, &totalMem));
+                const double perKmer = 1.5 + 0.6 * (double)sizeof(Count);
+                const double cap = 0.75 * (double)usable / perKmer;
+                _config._nb_passes = (uint32_t)std::max<double>(1.0, std::ceil((double)_config._kmersNb / std::max(cap, 1.0)));
+            }
             uint32_t forced = _params.has(STR_NB_PARTITIONS) ? (uint32_t)_params.getInt(STR_NB_PARTITIONS) : 0;
             // GPU-aware sizing: a partition should hold ~3M k-mers (fits one Stage-B workgroup's sub-bucket fan-out); the scan keeps
             // its partition cursors in LDS up to 8192 partitions
@@ -895,8 +909,7 @@ private:
             _config._nb_partitions = (uint32_t)std::min<uint64_t>(want, 65535);
             _config._isComputed = true;
         }
-        int rc = gkc_create((int)(_params.has(STR_GPU_DEVICE) ? _params.getInt(STR_GPU_DEVICE) : 0), &_ctx);
-        if (rc != GKC_OK) throw system::Exception("gkc_create failed (%d): %s", rc, gkc_last_error(nullptr));
+        _releasePasses = _config._nb_passes > 1 && !(_params.has("-keep-passes") && _params.getInt("-keep-passes"));   // (-keep-passes 1: results of all passes stay on the device)
         const size_t m = _config._minim_size; const uint32_t P = _config._nb_partitions;
         if (!_repartitor) { _repartitor = buildRepartitor(m, P); _repartitor->use(); }
         if (_processors.empty()) for (CountProcessor* p : getDefaultProcessorVector(_config)) { p->use(); _processors.push_back(p); }
@@ -937,7 +950,7 @@ private:
     }
 
     bank::IBank* _bank; tools::misc::Properties _params; Configuration _config; Repartitor* _repartitor;
-    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx; bool _textRefused;
+    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx; bool _textRefused; bool _releasePasses = false;
 };
 
 }}  // namespace kmer::impl

@@ -217,6 +217,14 @@ int gkc_fastx_parse_device(gkc_ctx* ctx, const char* d_text, uint64_t n_bytes, i
 int gkc_push_fastx(gkc_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, uint64_t* consumed);
 
 int gkc_device_free(gkc_ctx* ctx, void* d_ptr);
+/* Gives the result buffers of a finished pass back (its datasets are gone afterwards: gkc_partition_* on them fail). A host that has drained
+ * a pass — the processors have seen every partition — calls it before the next pass, so that a multi-pass count keeps only ONE pass of results
+ * in HBM: the point of nb_passes in the reference, which bounds the footprint of a pass and removes the partition files of a pass before the
+ * next one (SortingCountAlgorithm.cpp:1219-1241, :705-720; pass count from the available memory / disk: ConfigurationAlgorithm.cpp:398-425). */
+int gkc_release_pass(gkc_ctx* ctx, uint32_t pass);
+/* HBM the context can use right now (free on the device + blocks parked in its own allocator) and the device total, in bytes: what a host-side
+ * configuration step sizes nb_passes / nb_partitions from (the reference reads System::info().getMemoryPhysicalTotal / -max-memory there). */
+int gkc_device_memory(gkc_ctx* ctx, uint64_t* usable_bytes, uint64_t* total_bytes);
 /* Page-locked host memory for the buffers the host side hands to gkc_push_reads / gkc_push_fastx and receives Count[] records in
  * (gkc_partition_counts): the DMA engines then move them at PCIe rate, pageable memory is staged by the driver at about half of it
  * (measured: DESIGN.md section 6). This is the role of the reference's host-side buffer provider for partition data

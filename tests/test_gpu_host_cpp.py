@@ -179,3 +179,27 @@ def test_cli_album_of_two_files_counts_like_their_concatenation(built, tmp_path)
         assert len(x) > 0 and np.array_equal(x, y)
     i0 = dict(l.split("\t") for l in open(outs[0] + ".info").read().splitlines()); i1 = dict(l.split("\t") for l in open(outs[1] + ".info").read().splitlines())
     assert i0["kmers_nb_valid"] == i1["kmers_nb_valid"] and i0["seq_number"] == i1["seq_number"] == "2400"
+
+
+def test_cli_three_passes_release_their_results(built, tmp_path):
+    """-nb-passes 3: each pass is drained by the processors and then released on the device (gkc_release_pass); the datasets (part + pass * nb_partitions),
+    statistics and the MPHF (built from the chain's solid counts) equal the oracle's"""
+    reads = synth_reads(2500, 15000, 150, seed=5, n_rate=0.001)
+    fa = tmp_path / "reads.fa"
+    fa.write_text("".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads)))
+    out = str(tmp_path / "out"); k = 31
+    r = subprocess.run([os.path.join(built, "gkc_dsk"), "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2", "-nb-partitions", "4", "-nb-passes", "3", "-mphf", "1", "-out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    info = dict(l.split("\t") for l in open(out + ".info").read().splitlines())
+    raw = np.fromfile(out + ".minimRepart", dtype=np.uint8)
+    nmin = int(raw[2:10].view(np.uint64)[0]); table = raw[12:12 + 2 * nmin].view(np.uint16).copy(); m = int(np.log2(nmin) / 2)
+    bases, offs = gko.pack_reads(reads)
+    ref = gko.Dsk(bases, offs, k, m, 4, table, nb_passes=3, abundance_min=2)
+    order = []
+    for d in range(12):
+        assert np.array_equal(np.fromfile(out + ".solid.%d" % d, dtype=np.uint8), ref.part_records(d)), d
+        lo, hi, a = ref.part(d)
+        order += [int(x) for x in lo]
+    assert info["nb_passes"] == "3" and int(info["kmers_nb_solid"]) == ref.stats["kmers_nb_solid"] and int(info["kmers_nb_valid"]) == ref.stats["kmers_nb_valid"]
+    assert np.array_equal(np.fromfile(out + ".mphf", dtype=np.uint8), gko.Mphf(order, k).save())

@@ -369,6 +369,31 @@ def test_multi_pass_with_two_lanes_and_solidity(gkc):
     c.device_free(db); c.device_free(do)
 
 
+def test_release_pass_gives_the_memory_back(gkc):
+    """gkc_release_pass: the datasets of a drained pass are gone (access fails loudly), its HBM is usable again, the statistics stay; the other
+    pass is untouched"""
+    c = gkc.Counter(0)
+    k, m, parts, n = 31, 10, 64, 2_000_000
+    rep = simple_repart(m, parts)
+    c.configure(k, m, parts, rep, nb_passes=2)
+    db, do = c.synth_reads_device(3, n, 150, n * 5, 10000)
+    for ps in range(2):
+        c.begin_pass(ps); c.push_reads_device(db, do, n, n * 150); c.finish_pass()
+    st = c.stats()
+    keep = c.partition(1, 7)
+    n0 = sum(c.partition_info(0, p)[0] for p in range(parts))
+    u0, total = c.device_memory()
+    c.release_pass(0)
+    u1, _ = c.device_memory()
+    assert total > 200e9 and u1 - u0 >= n0 * 16 * 0.9
+    with pytest.raises(gkc.GkcError):
+        c.partition_info(0, 3)
+    again = c.partition(1, 7)
+    assert all(np.array_equal(a, b) for a, b in zip(keep, again))
+    assert c.stats() == st
+    c.device_free(db); c.device_free(do)
+
+
 def test_two_owner_shards_on_one_gpu(gkc):
     """multi-GPU data flow on one device: two contexts scan one half of the reads each, their buckets are routed to the
     partition owners exactly as dist.py does (slices of the arena -> foreign segments), each owner counts its partitions;
