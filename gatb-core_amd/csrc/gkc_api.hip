@@ -63,6 +63,12 @@ __global__ void k_kmer_checksum(const uint8_t* __restrict__ bases, const uint64_
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], (unsigned long long)cs); atomicAdd(&out[1], (unsigned long long)nv); }
 }
 
+int gkc_require_resident(gkc_ctx* c, const char* who)
+{
+    for (size_t p = 0; p < c->pass_released.size(); p++)
+        if (c->pass_released[p]) GKC_FAIL(c, GKC_ERR_ARG, "%s needs the results of every pass on the device, pass %zu was released (gkc_release_pass)", who, p);
+    return GKC_OK;
+}
 static void free_pass_outputs(gkc_ctx* c, uint32_t pass)
 {
     auto it = c->pass_outputs.find(pass);
@@ -139,7 +145,7 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
     const uint32_t def = k <= 31 ? 28 : 60;                      // min((8*sizeof(Type)-8)/2, 255), Sequence2SuperKmer.hpp:147
     if (c->maxs == 0 || c->maxs > def) c->maxs = def;
     c->datasets.assign((size_t)nb_partitions * nb_passes, Dataset());
-    c->pass_stats.assign(nb_passes, gkc_stats{}); c->pass = 0; c->timing.clear(); c->in_pass = false;
+    c->pass_stats.assign(nb_passes, gkc_stats{}); c->pass_released.assign(nb_passes, 0); c->pass = 0; c->timing.clear(); c->in_pass = false;
 
     GKC_TRY(c->ensure(c->d_repart, nm * 2));
     GKC_HIP(c, hipMemcpy(c->d_repart.p, repart, nm * 2, hipMemcpyHostToDevice));
@@ -212,7 +218,7 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
     clear_segments(c);
     free_pass_outputs(c, pass);
     for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
-    c->pass_stats[pass] = gkc_stats{};
+    c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
     if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
     c->pass = pass; c->in_pass = true;
     return GKC_OK;
@@ -434,6 +440,7 @@ int gkc_release_pass(gkc_ctx* c, uint32_t pass)
     (void)hipStreamSynchronize(c->stream);
     free_pass_outputs(c, pass);
     for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();   // statistics of the pass stay
+    c->pass_released[pass] = 1;
     return GKC_OK;
 }
 int gkc_device_memory(gkc_ctx* c, uint64_t* usable_bytes, uint64_t* total_bytes)
@@ -484,6 +491,7 @@ int gkc_kmer_checksum_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_
 int gkc_result_checksum(gkc_ctx* c, uint64_t* checksum, uint64_t* sum_abundance)
 {
     if (!c || !checksum || !sum_abundance) return GKC_ERR_ARG;
+    GKC_TRY(gkc_require_resident(c, "gkc_result_checksum"));
     return gkc_result_checksum_impl(c, checksum, sum_abundance);
 }
 

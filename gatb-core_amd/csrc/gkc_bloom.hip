@@ -408,6 +408,7 @@ int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* c)
 {
     if (!b || !c) return GKC_ERR_ARG;
     if (c->k != b->k) GKC_FAIL(c, GKC_ERR_ARG, "bloom k (%u) differs from the context's k (%u)", b->k, c->k);
+    GKC_TRY(gkc_require_resident(c, "gkc_bloom_insert_solid"));
     // datasets of one Stage-B batch are consecutive in one output buffer: a handful of arrays in all
     const uint32_t stride = c->key_words == 1 ? 16 : 32;
     std::vector<BSeg> segs;

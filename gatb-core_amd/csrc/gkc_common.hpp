@@ -160,6 +160,7 @@ struct gkc_ctx {
     gkc_stats& stats_now() { return pass_stats[pass]; }
     std::mutex mu;                         // shared bookkeeping (timing, stats, outputs, error text) when Stage B runs two lanes
     hipStream_t lane_streams[3] = {nullptr, nullptr, nullptr};   // extra Stage-B lanes (created on first use)
+    std::vector<uint8_t> pass_released;       // gkc_release_pass was called for the pass: whole-context consumers of the results refuse to run
     uint64_t slots_hint = 0;                  // key slots the big working buffers of a Stage-B batch are sized for (the pass's batch budget)
     double d_hint = 0;                        // solid records per key of the last Stage-B pass (0 = none yet): sizes the next pass's batches
     std::map<std::string, Timing> timing;
@@ -213,3 +214,5 @@ int gkc_count_pass(gkc_ctx* c);
 int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint64_t* h_superkmers, uint64_t* h_kmers);
 int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t* h_counts);
 int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk);
+
+int gkc_require_resident(gkc_ctx* c, const char* who);      // gkc_api.hip: fails when a pass of the context was released

@@ -352,6 +352,7 @@ int gkc_mphf_build_solid(gkc_ctx* c, gkc_mphf** out)
 {
     if (!c || !out) return GKC_ERR_ARG;
     if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "context not configured");
+    GKC_TRY(gkc_require_resident(c, "gkc_mphf_build_solid"));
     const uint32_t stride = c->key_words == 1 ? 16 : 32;
     std::vector<std::pair<const uint8_t*, uint64_t>> segs;
     for (const Dataset& D : c->datasets) {                      // iteration order of getSolidKmers(): dataset by dataset, ascending inside
@@ -425,6 +426,7 @@ int gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* c, uint8_t* out, uint64_t cap, 
     if (!m || !c || !out) return GKC_ERR_ARG;
     if (cap < m->nelem) GKC_FAIL(c, GKC_ERR_CAPACITY, "abundance map needs %llu bytes", (unsigned long long)m->nelem);
     if ((c->k > 31) != (m->wide != 0)) GKC_FAIL(c, GKC_ERR_ARG, "MPHF key width differs from the context's");
+    GKC_TRY(gkc_require_resident(c, "gkc_mphf_abundance_map"));
     static int disc[257]; static bool init = false;
     if (!init) {                                                  // MapMPHF.hpp:96-145
         int total = 0, idx = 1; disc[0] = 0;

@@ -388,6 +388,8 @@ def test_release_pass_gives_the_memory_back(gkc):
     assert total > 200e9 and u1 - u0 >= n0 * 16 * 0.9
     with pytest.raises(gkc.GkcError):
         c.partition_info(0, 3)
+    with pytest.raises(gkc.GkcError):                      # whole-context consumers (checksum, Bloom / MPHF of the solid set) refuse a context with a released pass
+        c.result_checksum()
     again = c.partition(1, 7)
     assert all(np.array_equal(a, b) for a, b in zip(keep, again))
     assert c.stats() == st
