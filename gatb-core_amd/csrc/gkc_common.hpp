@@ -186,7 +186,9 @@ struct gkc_ctx {
         b.bytes = bytes;
         return GKC_OK;
     }
-    void* dalloc(size_t bytes) { hipError_t e; void* p = pool.alloc(bytes, &e); if (!p) set_error(GKC_ERR_NOMEM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return p; }
+    // data-sized buffers (bucket arenas, result arrays). In a multi-pass run the passes ask for slightly different sizes: one size class (1/16) of
+    // slack lets the block a released pass parked serve the next pass's request (otherwise: hipMalloc, out of memory, parked blocks given back, seconds)
+    void* dalloc(size_t bytes) { if (nb_passes > 1 && bytes > ((size_t)64 << 20)) bytes += bytes / 16; hipError_t e; void* p = pool.alloc(bytes, &e); if (!p) set_error(GKC_ERR_NOMEM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return p; }
     void dfree(void* p) { pool.free(p); }
 };
 
