@@ -63,6 +63,15 @@ __global__ void k_kmer_checksum(const uint8_t* __restrict__ bases, const uint64_
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], (unsigned long long)cs); atomicAdd(&out[1], (unsigned long long)nv); }
 }
 
+void gkc_ctx_child_add(gkc_ctx* c) { std::lock_guard<std::mutex> lk(c->mu); c->children++; }
+int gkc_alloc_histo(gkc_ctx* c)
+{
+    const size_t bytes = (size_t)std::max<uint32_t>(c->nb_passes, 1) * ((size_t)c->histo_max + 1) * 8;
+    c->d_histo.release();
+    GKC_TRY(c->ensure(c->d_histo, bytes));
+    GKC_HIP(c, hipMemset(c->d_histo.p, 0, bytes));
+    return GKC_OK;
+}
 int gkc_require_resident(gkc_ctx* c, const char* who)
 {
     for (size_t p = 0; p < c->pass_released.size(); p++)
@@ -80,6 +89,14 @@ static void clear_segments(gkc_ctx* c)
 {
     for (void* p : c->owned_arenas) c->dfree(p);
     c->owned_arenas.clear(); c->segments.clear();
+}
+
+static void ctx_destroy_now(gkc_ctx* c);
+void gkc_ctx_child_release(gkc_ctx* c)
+{
+    bool last;
+    { std::lock_guard<std::mutex> lk(c->mu); c->children--; last = c->closed && c->children == 0; }
+    if (last) ctx_destroy_now(c);
 }
 
 extern "C" {
@@ -102,9 +119,19 @@ int gkc_create(int device, gkc_ctx** out)
     return GKC_OK;
 }
 
+static void ctx_destroy_now(gkc_ctx* c);
 void gkc_destroy(gkc_ctx* c)
 {
     if (!c) return;
+    {   std::lock_guard<std::mutex> lk(c->mu);
+        if (c->closed) return;                  // destroyed twice while children keep it alive
+        c->closed = true;
+        if (c->children > 0) return;            // a gkc_bloom / gkc_mphf still holds memory of this context: the last one frees it
+    }
+    ctx_destroy_now(c);
+}
+static void ctx_destroy_now(gkc_ctx* c)
+{
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     clear_segments(c);
@@ -179,8 +206,7 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
     } else {
         c->default_key = (uint32_t)(nm - 1);
     }
-    GKC_TRY(c->ensure(c->d_histo, ((size_t)c->histo_max + 1) * 8));
-    GKC_HIP(c, hipMemset(c->d_histo.p, 0, ((size_t)c->histo_max + 1) * 8));
+    GKC_TRY(gkc_alloc_histo(c));
     c->configured = true;
     return GKC_OK;
 }
@@ -193,9 +219,7 @@ int gkc_set_solidity(gkc_ctx* c, int32_t amin, int32_t amax, uint32_t histo_max)
     c->amin = amin; c->amax = amax; c->d_hint = 0;
     if (histo_max != c->histo_max || !c->d_histo.p) {
         c->histo_max = histo_max;
-        c->d_histo.release();
-        GKC_TRY(c->ensure(c->d_histo, ((size_t)histo_max + 1) * 8));
-        GKC_HIP(c, hipMemset(c->d_histo.p, 0, ((size_t)histo_max + 1) * 8));
+        GKC_TRY(gkc_alloc_histo(c));
     }
     return GKC_OK;
 }
@@ -219,7 +243,8 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
     free_pass_outputs(c, pass);
     for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
     c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
-    if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
+    if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, (size_t)c->nb_passes * ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
+    else GKC_HIP(c, hipMemsetAsync(c->histo_of(pass), 0, ((size_t)c->histo_max + 1) * 8, c->stream));                         // a pass that is run again starts from zero
     c->pass = pass; c->in_pass = true;
     return GKC_OK;
 }
@@ -350,8 +375,11 @@ int gkc_histogram(gkc_ctx* c, uint64_t* out, uint32_t n_bins)
 {
     if (!c) return GKC_ERR_ARG;
     if (n_bins < c->histo_max + 1) GKC_FAIL(c, GKC_ERR_CAPACITY, "histogram has %u bins", c->histo_max + 1);
-    GKC_HIP(c, hipMemcpyAsync(out, c->d_histo.p, ((size_t)c->histo_max + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    const size_t nb = (size_t)c->histo_max + 1;
+    std::vector<uint64_t> all((size_t)c->nb_passes * nb);
+    GKC_HIP(c, hipMemcpyAsync(all.data(), c->d_histo.p, all.size() * 8, hipMemcpyDeviceToHost, c->stream));
     GKC_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < nb; i++) { uint64_t s = 0; for (uint32_t p = 0; p < c->nb_passes; p++) s += all[(size_t)p * nb + i]; out[i] = s; }
     return GKC_OK;
 }
 int gkc_get_stats(gkc_ctx* c, gkc_stats* out)

@@ -308,10 +308,11 @@ int gkc_bloom_create(gkc_ctx* c, int kind, uint64_t tai_bits, uint32_t nb_hash, 
     int rc = c->ensure(b->bits, bytes);
     if (rc != GKC_OK) { delete b; return rc; }
     if (hipMemsetAsync(b->bits.p, 0, bytes, c->stream) != hipSuccess) { b->bits.release(); delete b; GKC_FAIL(c, GKC_ERR_HIP, "memset failed"); }
+    gkc_ctx_child_add(c);
     *out = b;
     return GKC_OK;
 }
-void gkc_bloom_destroy(gkc_bloom* b) { if (b) { b->bits.release(); delete b; } }
+void gkc_bloom_destroy(gkc_bloom* b) { if (b) { gkc_ctx* c = b->ctx; b->bits.release(); delete b; gkc_ctx_child_release(c); } }
 uint64_t gkc_bloom_nbytes(const gkc_bloom* b) { return b ? b->nchar : 0; }
 uint64_t gkc_bloom_bitsize(const gkc_bloom* b) { return b ? (b->kind == 0 ? b->tai : b->reduced_tai) : 0; }
 

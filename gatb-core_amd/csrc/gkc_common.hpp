@@ -155,7 +155,11 @@ struct gkc_ctx {
     // results
     std::vector<Dataset> datasets;                   // nb_passes * nb_partitions
     std::map<uint32_t, std::vector<void*>> pass_outputs;   // pass -> output buffers
-    DevBuf d_histo;                                  // u64[histo_max+1]
+    DevBuf d_histo;                                  // u64[nb_passes][histo_max+1]: one histogram per pass (a pass that is run again starts from zero), summed by gkc_histogram
+    unsigned long long* histo_of(uint32_t pass_) { return (unsigned long long*)d_histo.p + (size_t)pass_ * ((size_t)histo_max + 1); }
+    // objects built from this context (gkc_bloom, gkc_mphf) hold device memory of its allocator: gkc_destroy with children alive only
+    // marks the context closed; the last child to be destroyed frees it (gkc_ctx_child_release)
+    int children = 0; bool closed = false;
     std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them
     gkc_stats& stats_now() { return pass_stats[pass]; }
     std::mutex mu;                         // shared bookkeeping (timing, stats, outputs, error text) when Stage B runs two lanes
@@ -217,4 +221,7 @@ int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, 
 int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t* h_counts);
 int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk);
 
-int gkc_require_resident(gkc_ctx* c, const char* who);      // gkc_api.hip: fails when a pass of the context was released
+int gkc_require_resident(gkc_ctx* c, const char* who);
+void gkc_ctx_child_add(gkc_ctx* c);          // gkc_api.hip
+void gkc_ctx_child_release(gkc_ctx* c);      // destroys a closed context when its last child goes
+int gkc_alloc_histo(gkc_ctx* c);      // gkc_api.hip: fails when a pass of the context was released

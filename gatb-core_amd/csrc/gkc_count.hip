@@ -1172,7 +1172,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipGetLastError());
     }
     SortOut O{};
-    O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = (unsigned long long*)c->d_histo.p; O.histo_max = c->histo_max;
+    O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = c->histo_of(c->pass); O.histo_max = c->histo_max;
     O.over_count = (uint32_t*)B.over.p; O.over_list = (uint32_t*)B.over.p + 1;
     O.over2_count = (uint32_t*)B.over2.p; O.over2_list = (uint32_t*)B.over2.p + 1;
     O.over3_count = (uint32_t*)B.over3.p; O.over3_list = (uint32_t*)B.over3.p + 1;
@@ -1375,6 +1375,14 @@ int gkc_count_pass(gkc_ctx* c)
 {
     const uint32_t Pn = c->nb_partitions;
     const uint32_t n_seg = (uint32_t)c->segments.size();
+    {   // a pass counted again (a retry after GKC_ERR_NOMEM, or gkc_finish_pass called twice) starts from a clean slate: what the
+        // batches of the failed attempt added to the histogram, to the counters and to the result list must not be counted twice
+        auto it = c->pass_outputs.find(c->pass);
+        if (it != c->pass_outputs.end()) { for (void* p : it->second) c->dfree(p); it->second.clear(); }
+        for (uint32_t p = 0; p < Pn; p++) c->datasets[(size_t)c->pass * Pn + p] = Dataset();
+        gkc_stats& S = c->stats_now(); S.kmers_nb_distinct = 0; S.kmers_nb_solid = 0; S.oversize_buckets = 0;
+        GKC_HIP(c, hipMemsetAsync(c->histo_of(c->pass), 0, ((size_t)c->histo_max + 1) * 8, c->stream));
+    }
     std::vector<uint64_t> part_keys(Pn, 0);
     for (const Segment& s : c->segments) for (uint32_t p = 0; p < Pn; p++) part_keys[p] += s.nkmers[p];
     // device copy of the segment table

@@ -302,7 +302,7 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
 
 extern "C" {
 
-void gkc_mphf_destroy(gkc_mphf* m) { if (m) { m->bits.release(); m->ranks.release(); m->final_keys.release(); delete m; } }
+void gkc_mphf_destroy(gkc_mphf* m) { if (m) { gkc_ctx* c = m->ctx; m->bits.release(); m->ranks.release(); m->final_keys.release(); delete m; gkc_ctx_child_release(c); } }
 uint64_t gkc_mphf_size(const gkc_mphf* m) { return m ? m->nelem : 0; }
 
 static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8_t*, uint64_t>>& segs, uint32_t stride, uint32_t k, bool on_host, gkc_mphf** out)
@@ -312,7 +312,7 @@ static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8
     if (n >= (1ULL << 34)) GKC_FAIL(c, GKC_ERR_ARG, "MPHF: too many keys for one device");
     GKC_HIP(c, hipSetDevice(c->device));
     ScopedTimer tm(c, "mphf_build");
-    gkc_mphf* m = new gkc_mphf(); m->ctx = c; m->wide = k > 31; m->k = k; m->n_final = 0;
+    gkc_mphf* m = new gkc_mphf(); m->ctx = c; m->wide = k > 31; m->k = k; m->n_final = 0; gkc_ctx_child_add(c);
     const size_t kb = m->wide ? 16 : 8;
     DevBuf keys, tmp;
     int rc = c->ensure(keys, (size_t)n * kb);

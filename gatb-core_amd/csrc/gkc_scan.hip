@@ -45,11 +45,15 @@ struct ScanParams {
 // ------------------------------------------------------------------------------------------------
 // read-start bitmask: bit g set iff some read starts at base g, or g == n_bases (offsets[n_reads])
 // ------------------------------------------------------------------------------------------------
-__global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_t n_entries, uint32_t* __restrict__ bits)
+// The offsets come from the caller: an offset beyond n_bases, a decreasing pair, offsets[0] != 0 or offsets[n_reads] != n_bases sets *bad
+// (the push then fails with GKC_ERR_ARG) and never touches memory outside the mask.
+__global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_t n_entries, uint64_t n_bases, uint32_t* __restrict__ bits, uint32_t* __restrict__ bad)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_entries) return;
     uint64_t g = offsets[i];
+    const bool wrong = g > n_bases || (i + 1 < n_entries && offsets[i + 1] < g) || (i == 0 && g != 0) || (i + 1 == n_entries && g != n_bases);
+    if (wrong) { if (bad) *bad = 1u; if (g > n_bases) return; }
     atomicOr(&bits[g >> 5], 1u << (g & 31));
 }
 
@@ -599,7 +603,8 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     {
         uint64_t n_entries = n_reads + 1;
         dim3 g((unsigned)((n_entries + 255) / 256)), b(256);
-        hipLaunchKernelGGL(k_mark_read_starts, g, b, 0, c->stream, d_offsets, n_entries, (uint32_t*)c->d_rsbits.p);
+        // the validity flag lives in the last word of the (zeroed) mask allocation's slack and is read back with the counters below
+        hipLaunchKernelGGL(k_mark_read_starts, g, b, 0, c->stream, d_offsets, n_entries, n_bases, (uint32_t*)c->d_rsbits.p, (uint32_t*)c->d_rsbits.p + rs_words - 1);
         GKC_HIP(c, hipGetLastError());
     }
     // geometry: persistent workgroups when the partition cursors fit in LDS
@@ -657,8 +662,11 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         }
     }
     std::vector<unsigned long long> h(n_cnt);
+    uint32_t bad_offsets = 0;
     GKC_HIP(c, hipMemcpyAsync(h.data(), cnt, n_cnt * 8, hipMemcpyDeviceToHost, c->stream));
+    GKC_HIP(c, hipMemcpyAsync(&bad_offsets, (uint32_t*)c->d_rsbits.p + rs_words - 1, 4, hipMemcpyDeviceToHost, c->stream));
     GKC_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad_offsets) GKC_FAIL(c, GKC_ERR_ARG, "read offsets are not a CSR table of the bases (need offsets[0] == 0, non-decreasing, offsets[n_reads] == n_bases = %llu)", (unsigned long long)n_bases);
     uint64_t total = 0;
     for (uint32_t p = 0; p < Pn; p++) { seg.rec_off[p] = total; total += h[p]; seg.nkmers[p] = h[Pn + p]; }
     seg.rec_off[Pn] = total;
@@ -764,7 +772,7 @@ int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, 
     const size_t rs_words = (size_t)(n_tiles * SCAN_TILE / 32 + 64);
     GKC_TRY(c->ensure(c->d_rsbits, rs_words * 4));
     GKC_HIP(c, hipMemsetAsync(c->d_rsbits.p, 0, rs_words * 4, c->stream));
-    hipLaunchKernelGGL(k_mark_read_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, c->stream, d_offsets, n_reads + 1, (uint32_t*)c->d_rsbits.p);
+    hipLaunchKernelGGL(k_mark_read_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, c->stream, d_offsets, n_reads + 1, n_bases, (uint32_t*)c->d_rsbits.p, (uint32_t*)nullptr);
     DevBuf cnt; GKC_TRY(c->ensure(cnt, (size_t)(2 * nm + 4) * 8));
     hipError_t e = hipMemsetAsync(cnt.p, 0, (size_t)(2 * nm + 4) * 8, c->stream);
     ScanParams P{};
