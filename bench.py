@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pushes", type=int, default=4, help="multi-GPU: pushes (and exchanges) per pass and rank")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: everything else that writes to fd 1 (RCCL prints its version banner there)
@@ -161,8 +162,16 @@ def main():
     c = gkc.Counter(local)
     c.configure(k, m, parts, rep)
     genome = max(L, n_reads * world * L // 30)               # 30x coverage over the whole job
-    # rank r draws reads [r*n, (r+1)*n) of ONE global read stream over the SAME genome (seed 2)
-    d_bases, d_offs = c.synth_reads_device(2, n_reads, L, genome, 10000, first_read=rank * n_reads)
+    # rank r draws reads [r*n, (r+1)*n) of ONE global read stream over the SAME genome (seed 2). Multi-GPU: the rank's reads are pushed in
+    # n_push chunks, each followed by gkc_exchange — the exchange of chunk i (RCCL, the communicator's own stream) overlaps Stage A of chunk i+1
+    n_push = args.pushes if use_dist else 1
+    per_push = (n_reads + n_push - 1) // n_push
+    chunks = []
+    for i in range(n_push):
+        nr = min(per_push, n_reads - i * per_push)
+        if nr > 0:
+            b_, o_ = c.synth_reads_device(2, nr, L, genome, 10000, first_read=rank * n_reads + i * per_push)
+            chunks.append((b_, o_, nr, nr * L))
     n_bases = n_reads * L
 
     if use_dist:
@@ -173,9 +182,10 @@ def main():
 
     def step():
         c.begin_pass(0)
-        c.push_reads_device(d_bases, d_offs, n_reads, n_bases)
-        if runner is not None:
-            runner.exchange()
+        for b_, o_, nr, nb_ in chunks:
+            c.push_reads_device(b_, o_, nr, nb_)
+            if runner is not None:
+                runner.exchange()
         c.finish_pass()
 
     def sync():
@@ -203,6 +213,17 @@ def main():
     if world > 1:
         t = torch.tensor([distinct, valid], device="cuda", dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
     ktime = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
+    exch = None
+    if runner is not None:                                     # per-rank exchange figures over warmup + timed steps (gkc_comm_get_stats)
+        cs = runner.stats(); n_st = max(1, args.steps + args.warmup)
+        mine_x = {"rank": rank, "owned_partitions": len(runner.owned()), "exchanges_per_step": cs["n_exchanges"] / n_st,
+                  "ms_transfer_per_step": cs["ms_transfer"] / n_st, "ms_host_per_step": cs["ms_host"] / n_st,
+                  "bytes_sent_per_step": cs["bytes_sent"] / n_st, "bytes_received_per_step": cs["bytes_received"] / n_st}
+        if world > 1:
+            exch = [None] * world
+            dist.all_gather_object(exch, mine_x)
+        else:
+            exch = [mine_x]
     # Stage B runs two lanes (two streams): inside the timed region a kernel's event duration includes the time it shares the chip with the
     # other lane's kernels. One extra UNTIMED step with a single lane gives the same kernels' durations in isolation (reported beside, never
     # instead of, the timed-region figures).
@@ -289,6 +310,8 @@ def main():
                                               "launch_ms": iso[dom][0] / il, "achieved": alg[dom] / (iso[dom][0] * 1e-3) / 1e9,
                                               "frac": alg[dom] / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                               "kernel_ms_per_step": {n_: round(iso[n_][0], 3) for n_ in names}}
+        if exch is not None:
+            out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push, "per_rank": exch}
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
         if not args.no_cpu_baseline and world == 1:
@@ -296,7 +319,8 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    c.device_free(d_bases); c.device_free(d_offs)
+    for b_, o_, _, _ in chunks:
+        c.device_free(b_); c.device_free(o_)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
 

@@ -87,8 +87,9 @@ static void free_pass_outputs(gkc_ctx* c, uint32_t pass)
 }
 static void clear_segments(gkc_ctx* c)
 {
+    c->drain_pending();                       // an exchange may still be reading / filling arenas on a communicator's stream
     for (void* p : c->owned_arenas) c->dfree(p);
-    c->owned_arenas.clear(); c->segments.clear();
+    c->owned_arenas.clear(); c->segments.clear(); c->n_exchanged_segments = 0;
 }
 
 static void ctx_destroy_now(gkc_ctx* c);
@@ -134,6 +135,7 @@ static void ctx_destroy_now(gkc_ctx* c)
 {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    c->drain_pending();
     clear_segments(c);
     std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first);
     for (uint32_t p : passes) free_pass_outputs(c, p);
@@ -432,7 +434,7 @@ int gkc_segment_import(gkc_ctx* c, const void* d_records, const uint64_t* rec_of
     if (!c) return GKC_ERR_ARG;
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
     if (!rec_offsets || !kmers) GKC_FAIL(c, GKC_ERR_ARG, "offset / k-mer tables are required");
-    Segment s; s.d_records = d_records; s.owned = false;
+    Segment s; s.d_records = d_records; s.owned = false; s.foreign = true;
     s.rec_off.assign(rec_offsets, rec_offsets + c->nb_partitions + 1);
     s.nkmers.assign(kmers, kmers + c->nb_partitions);
     c->segments.push_back(std::move(s));
@@ -493,6 +495,12 @@ int gkc_device_to_host(gkc_ctx* c, void* dst, const void* src, uint64_t n)
 {
     if (!c) return GKC_ERR_ARG;
     GKC_HIP(c, hipMemcpy(dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    return GKC_OK;
+}
+int gkc_host_to_device(gkc_ctx* c, void* dst, const void* src, uint64_t n)
+{
+    if (!c) return GKC_ERR_ARG;
+    GKC_HIP(c, hipMemcpy(dst, src, (size_t)n, hipMemcpyHostToDevice));
     return GKC_OK;
 }
 

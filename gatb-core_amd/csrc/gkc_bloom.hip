@@ -313,6 +313,17 @@ int gkc_bloom_create(gkc_ctx* c, int kind, uint64_t tai_bits, uint32_t nb_hash, 
     return GKC_OK;
 }
 void gkc_bloom_destroy(gkc_bloom* b) { if (b) { gkc_ctx* c = b->ctx; b->bits.release(); delete b; gkc_ctx_child_release(c); } }
+int gkc_bloom_allreduce_or(gkc_bloom* b, gkc_comm* m)
+{
+    if (!b || !m) return GKC_ERR_ARG;
+    gkc_ctx* c = b->ctx;
+    GKC_HIP(c, hipSetDevice(c->device));
+    ScopedTimer tm(c, "bloom_allreduce");
+    // whole 8-byte words of the allocation ((nchar + 3) / 4 * 4 + 8 bytes, zero beyond nchar): covers every byte of the array
+    GKC_TRY(gkc_comm_allreduce_or_words(m, (uint64_t*)b->bits.p, (uint64_t)(b->bits.bytes / 8), c->stream));
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    return GKC_OK;
+}
 uint64_t gkc_bloom_nbytes(const gkc_bloom* b) { return b ? b->nchar : 0; }
 uint64_t gkc_bloom_bitsize(const gkc_bloom* b) { return b ? (b->kind == 0 ? b->tai : b->reduced_tai) : 0; }
 

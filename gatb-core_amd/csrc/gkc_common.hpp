@@ -118,6 +118,7 @@ struct DevBuf {
 struct Segment {
     const void* d_records = nullptr;     // arena, partition-major
     bool owned = false;
+    bool foreign = false;                // arrived through gkc_segment_import / gkc_exchange: never forwarded by a later exchange
     std::vector<uint64_t> rec_off;       // [P+1] in records
     std::vector<uint64_t> nkmers;        // [P]
 };
@@ -152,6 +153,9 @@ struct gkc_ctx {
     bool in_pass = false; uint32_t pass = 0;
     std::vector<Segment> segments;
     std::vector<void*> owned_arenas;
+    size_t n_exchanged_segments = 0;       // segments [0, n) went through gkc_exchange already (multi-GPU)
+    std::vector<hipEvent_t> pending_events; // transfers of gkc_exchange still in flight on a communicator's stream: Stage B (and anything that frees arenas) waits for them
+    void drain_pending() { for (hipEvent_t e : pending_events) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } pending_events.clear(); }
     // results
     std::vector<Dataset> datasets;                   // nb_passes * nb_partitions
     std::map<uint32_t, std::vector<void*>> pass_outputs;   // pass -> output buffers
@@ -222,6 +226,13 @@ int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint
 int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk);
 
 int gkc_require_resident(gkc_ctx* c, const char* who);
+struct gkc_comm;                              // gkc_dist.hip
+int gkc_comm_world(gkc_comm* m);
+int gkc_comm_rank(gkc_comm* m);
+int gkc_comm_allgather_host(gkc_comm* m, const void* mine, size_t n, void* all);
+int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st);
+int gkc_comm_allreduce_or_words(gkc_comm* m, uint64_t* d_words, uint64_t n_words, hipStream_t st);
+int gkc_comm_combine_seen_coll(gkc_comm* m, uint64_t* d_seen, uint64_t* d_coll, uint64_t n_words, hipStream_t st);
 void gkc_ctx_child_add(gkc_ctx* c);          // gkc_api.hip
 void gkc_ctx_child_release(gkc_ctx* c);      // destroys a closed context when its last child goes
 int gkc_alloc_histo(gkc_ctx* c);      // gkc_api.hip: fails when a pass of the context was released

@@ -188,7 +188,9 @@ constexpr int EXPAND_THREADS = 512;
 // ------------------------------------------------------------------------------------------------ B1 expand_count
 template <int KW, int RW>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
-                                                                  uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed)
+                                                                  uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
+                                                                  uint32_t line_slots /* 0: every sub-bucket starts on a multiple of 4 slots (pair scatter);
+                                                                                         n: SUPER-buckets of 4 sub-buckets start on multiples of n slots, sub-buckets packed inside */)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
@@ -209,12 +211,16 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         }
     }
     __syncthreads();
-    // exclusive scan of the nsub counters -> absolute key offsets of the sub-buckets
-    const uint32_t per = (nsub + EXPAND_THREADS - 1) / EXPAND_THREADS;       // <= 8
+    // exclusive scan of the counters -> absolute key offsets of the sub-buckets. Units of the scan: single sub-buckets padded to 4 slots
+    // (pair scatter), or super-buckets of 4 consecutive sub-buckets padded to one 64-byte line (line scatter; sub_bits >= 2 there)
+    const uint32_t grp = line_slots ? 4u : 1u, pad = line_slots ? line_slots - 1u : 3u;
+    const uint32_t nunit = nsub / grp;
+    const uint32_t per = (nunit + EXPAND_THREADS - 1) / EXPAND_THREADS;      // <= 16
     const uint32_t b = threadIdx.x * per;
+    auto unit_size = [&](uint32_t u) { uint32_t z = 0; for (uint32_t d = 0; d < grp; d++) z += s_hist[u * grp + d]; return z; };
     uint32_t loc = 0;
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += (s_hist[b + i] + 3u) & ~3u;     // every sub-bucket starts on a multiple of 4 slots:
-    uint32_t x = loc;                                                                          // the scatter writes 8-byte keys in aligned 32-byte quads
+    for (uint32_t i = 0; i < per; i++) if (b + i < nunit) loc += (unit_size(b + i) + pad) & ~pad;
+    uint32_t x = loc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -223,9 +229,14 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     uint32_t wpre = 0;
     for (int w = 0; w < wave; w++) wpre += s_wsum[w];
     uint32_t run = wpre + x - loc;
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
-        b_start[pd.sub_base + b + i] = pd.key_base + run; b_n[pd.sub_base + b + i] = s_hist[b + i]; b_consumed[pd.sub_base + b + i] = (uint8_t)pd.sub_bits;
-        run += (s_hist[b + i] + 3u) & ~3u;
+    for (uint32_t i = 0; i < per; i++) if (b + i < nunit) {
+        uint32_t o = run;
+        for (uint32_t d = 0; d < grp; d++) {
+            const uint32_t j = (b + i) * grp + d;
+            b_start[pd.sub_base + j] = pd.key_base + o; b_n[pd.sub_base + j] = s_hist[j]; b_consumed[pd.sub_base + j] = (uint8_t)pd.sub_bits;
+            o += s_hist[j];
+        }
+        run += (unit_size(b + i) + pad) & ~pad;
     }
 }
 
@@ -438,6 +449,121 @@ __global__ __launch_bounds__(QUAD_THREADS) void k_expand_scatter_quad(const Part
     for (uint32_t i = threadIdx.x; i < nq; i += QUAD_THREADS) {
         uint32_t p = s_back[i];
         for (int j = 0; j < 3; j++) { const unsigned long long v = s_slot[j * QUAD_SUB + i]; if (v != EMPTY) out[--p] = v; }
+    }
+}
+
+
+// B1, 64-BYTE LINES. What bounds a scattered store on this chip is the number of store requests, not their bytes (tools/scatter_bench,
+// profiles/r02_scatter_store_calibration.txt: 8192 open cursors per workgroup, useful GB/s by bytes per store: 16 B 984, 32 B 1211,
+// 64 B 2470, 128 B 3024; a 16-byte store occupies a 32-byte write at the fabric, WRITE_SIZE 2.07x): the pair kernel above runs exactly
+// at the 16-byte rate (96 GB of keys in 98 ms). A full 64-byte line per store needs 8 staged keys per open bucket, and 160 KB of LDS
+// hold that for 2048 buckets, not for 8192. So the scatter places keys at SUPER-bucket granularity (the top sub_bits - 2 bits: 2048
+// super-buckets of 4 sub-buckets) and the level-1 sort splits every super-bucket 4 ways through LDS (k_super_sort): the sub-bucket sizes
+// are known from the 13-bit histogram of k_expand_count, so nothing else changes downstream.
+// Staging protocol, wait-free and exchange-only like the pair kernel: a key takes a ticket (one LDS add on the bucket's control word,
+// ticket in its top bits) and is swapped into slot ticket % 8; EMPTY came out -> parked. Ticket 7 is the collector: after its own
+// deposit it swaps EMPTY into all 8 slots (4 x ds_wrxchg2) and leaves with the line as ONE aligned 64-byte store at the bucket's
+// front cursor. A depositor that has its ticket but has not swapped yet (another wave) leaves a hole: the collector then writes what
+// it got as single keys at the BACK of the bucket (bucket sizes are exact, front and back meet), and the late key is picked up by a later
+// round; a key that comes out of a deposit (a late one of an earlier round) is inserted again with a new ticket. Every step conserves keys.
+constexpr int LINE_THREADS = 1024, LINE_SUPER_MAX = 2048, LINE_SLOT_WORDS = 8;      // 8 x 8 bytes staged per super-bucket
+template <int KW> struct LineT { static constexpr uint32_t KEYS = 8 / KW, TK_SHIFT = (KW == 1) ? 29 : 30, TK_ONE = 1u << TK_SHIFT, BACK_MASK = TK_ONE - 1; };
+__device__ __forceinline__ void lds_take_line(unsigned long long* slot0, uint64_t (&a)[8])       // swap EMPTY into 8 consecutive words, return what was there
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)slot0;
+    const uint64_t e = ~0ULL;
+    v4u_t r0, r1, r2, r3;
+    asm volatile("ds_wrxchg2_rtn_b64 %0, %4, %5, %5 offset0:0 offset1:1\n\t"
+                 "ds_wrxchg2_rtn_b64 %1, %4, %5, %5 offset0:2 offset1:3\n\t"
+                 "ds_wrxchg2_rtn_b64 %2, %4, %5, %5 offset0:4 offset1:5\n\t"
+                 "ds_wrxchg2_rtn_b64 %3, %4, %5, %5 offset0:6 offset1:7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addr), "v"(e) : "memory");
+    a[0] = (uint64_t)r0.x | ((uint64_t)r0.y << 32); a[1] = (uint64_t)r0.z | ((uint64_t)r0.w << 32);
+    a[2] = (uint64_t)r1.x | ((uint64_t)r1.y << 32); a[3] = (uint64_t)r1.z | ((uint64_t)r1.w << 32);
+    a[4] = (uint64_t)r2.x | ((uint64_t)r2.y << 32); a[5] = (uint64_t)r2.z | ((uint64_t)r2.w << 32);
+    a[6] = (uint64_t)r3.x | ((uint64_t)r3.y << 32); a[7] = (uint64_t)r3.z | ((uint64_t)r3.w << 32);
+}
+template <int KW, int RW>
+__global__ __launch_bounds__(LINE_THREADS) void k_expand_scatter_line(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
+                                                                       const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+                                                                       typename KeyT<KW>::type* __restrict__ keys)
+{
+    typedef typename KeyT<KW>::type key_t;
+    typedef LineT<KW> LT;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_stage[];      // [LINE_SUPER_MAX][8] words: 8 keys of 8 bytes / 4 keys of 16 bytes (low, high)
+    uint32_t* s_tb = reinterpret_cast<uint32_t*>(s_stage + (size_t)LINE_SUPER_MAX * LINE_SLOT_WORDS);   // [ticket : 3 or 2 | keys written at the back : 29 or 30]
+    uint32_t* s_front = s_tb + LINE_SUPER_MAX;                                        // next line of the super-bucket (slot index relative to key_base)
+    const PartDesc pd = parts[blockIdx.x];
+    const uint32_t nsup = 1u << (pd.sub_bits - 2), sshift = pd.shift + 2;
+    constexpr unsigned long long EMPTY = ~0ULL;
+    for (uint32_t i = threadIdx.x; i < nsup * LINE_SLOT_WORDS; i += LINE_THREADS) s_stage[i] = EMPTY;
+    for (uint32_t i = threadIdx.x; i < nsup; i += LINE_THREADS) { s_tb[i] = 0; s_front[i] = (uint32_t)(b_start[pd.sub_base + 4 * i] - pd.key_base); }
+    __syncthreads();
+    uint64_t* out = reinterpret_cast<uint64_t*>(keys + pd.key_base);                  // in 8-byte words: key slot p starts at word p * KW
+    auto bucket_end = [&](uint32_t sb) -> uint32_t { return (uint32_t)(b_start[pd.sub_base + 4 * sb + 3] - pd.key_base) + b_n[pd.sub_base + 4 * sb + 3]; };
+    auto put_singles = [&](uint32_t sb, const uint64_t (&a)[8], uint32_t m) {         // m keys (the non-EMPTY ones of a) to the back of the super-bucket
+        const uint32_t used = atomicAdd(&s_tb[sb], m) & LT::BACK_MASK;
+        uint32_t p = bucket_end(sb) - used - m;
+        if constexpr (KW == 1) { for (int j = 0; j < 8; j++) if (a[j] != EMPTY) out[p++] = a[j]; }
+        else { for (int j = 0; j < 4; j++) if (a[2 * j + 1] != EMPTY) { *reinterpret_cast<ulonglong2*>(out + 2 * (size_t)p) = make_ulonglong2(a[2 * j], a[2 * j + 1]); p++; } }
+    };
+    auto insert = [&](key_t c) {
+        const uint32_t sb = sub_index<KW>(c, sshift);
+        uint64_t h_lo = (uint64_t)c, h_hi = 0;
+        if constexpr (KW == 2) h_hi = (uint64_t)(c >> 64);
+        for (;;) {
+            const uint32_t tk = atomicAdd(&s_tb[sb], LT::TK_ONE) >> LT::TK_SHIFT;
+            uint64_t z_lo, z_hi;
+            if constexpr (KW == 1) { z_lo = atomicExch(&s_stage[(size_t)sb * 8 + tk], (unsigned long long)h_lo); z_hi = z_lo; }
+            else lds_xchg128(&s_stage[(size_t)sb * 8 + 2 * tk], h_lo, h_hi, z_lo, z_hi);
+            const bool came_out = z_hi != EMPTY;                                     // EMPTY = all ones in the (high) word: no key has it
+            if (tk != LT::KEYS - 1) { if (!came_out) return; h_lo = z_lo; h_hi = z_hi; continue; }
+            uint64_t a[8];
+            lds_take_line(&s_stage[(size_t)sb * 8], a);
+            uint32_t m = 0;
+            if constexpr (KW == 1) { for (int j = 0; j < 8; j++) m += a[j] != EMPTY; }
+            else { for (int j = 0; j < 4; j++) m += a[2 * j + 1] != EMPTY; }
+            if (m == LT::KEYS) {
+                const uint32_t p = atomicAdd(&s_front[sb], LT::KEYS);
+#ifdef GKC_EXP_NOSTORE
+                if (h_lo == 0x123456789ULL)
+#endif
+                {   ulonglong2* o = reinterpret_cast<ulonglong2*>(out + (size_t)p * KW);
+                    o[0] = make_ulonglong2(a[0], a[1]); o[1] = make_ulonglong2(a[2], a[3]); o[2] = make_ulonglong2(a[4], a[5]); o[3] = make_ulonglong2(a[6], a[7]); }
+            } else if (m) put_singles(sb, a, m);
+            if (!came_out) return;
+            h_lo = z_lo; h_hi = z_hi;                                                // a late key of an earlier round sat in the collector's slot: insert it again
+        }
+    };
+    for (uint32_t s = 0; s < segs.n_seg; s++) {
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+        uint64_t r = r0 + threadIdx.x;
+        if constexpr (RW == 2) {
+            ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
+            for (; r < r1; r += LINE_THREADS) {
+                const uint64_t R[2] = {nx.x, nx.y};
+                if (r + LINE_THREADS < r1) nx = recs[r + LINE_THREADS];                // next record in flight while this one is expanded
+                for_each_kmer16(R, k, insert);
+            }
+        } else {
+            ulonglong2 nx0 = make_ulonglong2(0, 0), nx1 = nx0;
+            if (r < r1) { nx0 = recs[2 * r]; nx1 = recs[2 * r + 1]; }
+            for (; r < r1; r += LINE_THREADS) {
+                const uint64_t R[4] = {nx0.x, nx0.y, nx1.x, nx1.y};
+                if (r + LINE_THREADS < r1) { nx0 = recs[2 * (r + LINE_THREADS)]; nx1 = recs[2 * (r + LINE_THREADS) + 1]; }
+                for_each_kmer32(R, k, insert);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nsup; i += LINE_THREADS) {                     // what is still parked leaves as single keys
+        uint64_t a[8]; uint32_t m = 0;
+        for (int j = 0; j < 8; j++) a[j] = s_stage[(size_t)i * 8 + j];
+        if constexpr (KW == 1) { for (int j = 0; j < 8; j++) m += a[j] != EMPTY; }
+        else { for (int j = 0; j < 4; j++) m += a[2 * j + 1] != EMPTY; }
+        if (m) put_singles(i, a, m);
     }
 }
 
@@ -733,6 +859,139 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WSB_WAVES) void k_wave_sort_big(c
     }
     wglist_flush(&s_over, O.over3_count, O.over3_list);
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+}
+
+
+// Level 1 after the line scatter: one WORKGROUP of 4 waves per super-bucket (4 sub-buckets whose keys arrive mixed). The keys are loaded
+// once (coalesced), split 4 ways through LDS on the two key bits below the super-bucket index — positions from wave ballots, the group
+// bases are the sub-bucket sizes k_expand_count already knows, so no counting pass and no LDS atomics — and wave w sorts sub-bucket w
+// straight out of LDS with the same register network as k_wave_sort; distinct keys / abundances go to the head of the sub-bucket's own
+// slot range. A sub-bucket beyond the first tier's registers is written back in place and handed to the next tier by its index, a
+// super-bucket beyond the LDS buffer goes to k_super_split_big: everything downstream still works on the 13-bit sub-buckets.
+constexpr int SS_THREADS = 256;
+template <int KW> struct SuperCap { static constexpr int RPT = (KW == 1) ? 12 : 6; static constexpr uint32_t CAP = RPT * SS_THREADS; };   // 3072 / 1536 keys: 24 KB of LDS
+#ifndef GKC_SS_WAVES
+#define GKC_SS_WAVES 4
+#endif
+template <int KW, bool F>
+__global__ __launch_bounds__(SS_THREADS, GKC_SS_WAVES) void k_super_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                                const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint8_t* __restrict__ b_cons,
+                                                                uint32_t n_super, uint32_t two_k, SortOut O, uint32_t* __restrict__ big_count, uint32_t* __restrict__ big_list)
+{
+    typedef typename KeyT<KW>::type key_t;
+    constexpr int RPT = SuperCap<KW>::RPT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    key_t* s_keys = reinterpret_cast<key_t*>(s_raw);
+    __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ WgList s_over;
+    __shared__ uint32_t s_wcnt[4][4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    if (t == 0) s_over.n = 0;
+    __syncthreads();
+    uint32_t nb_done = 0; unsigned long long nk_done = 0;
+    for (uint32_t g = blockIdx.x; g < n_super; g += gridDim.x) {
+        const uint4 nn = *reinterpret_cast<const uint4*>(b_n + 4 * (size_t)g);
+        const uint32_t N = nn.x + nn.y + nn.z + nn.w;
+        if (N == 0) continue;
+        if (N > SuperCap<KW>::CAP) { if (t == 0) { const uint32_t slot = atomicAdd(big_count, 1u); big_list[slot] = g; } continue; }
+        const uint64_t S = b_start[4 * (size_t)g];
+        const uint32_t shift = two_k - b_cons[4 * (size_t)g];
+        key_t v[RPT];
+        uint32_t wc0 = 0, wc1 = 0, wc2 = 0;                       // keys of this wave per group (the fourth is the rest)
+        uint32_t n_mine = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const uint32_t i = (uint32_t)r * SS_THREADS + t;
+            const bool in = i < N;
+            v[r] = in ? src[S + i] : (key_t)0;
+            const uint32_t d = in ? (sub_index<KW>(v[r], shift) & 3u) : 4u;
+            wc0 += (uint32_t)__popcll(__ballot(d == 0)); wc1 += (uint32_t)__popcll(__ballot(d == 1)); wc2 += (uint32_t)__popcll(__ballot(d == 2));
+            n_mine += (uint32_t)__popcll(__ballot(in));
+        }
+        if (lane == 0) { s_wcnt[w][0] = wc0; s_wcnt[w][1] = wc1; s_wcnt[w][2] = wc2; s_wcnt[w][3] = n_mine - wc0 - wc1 - wc2; }
+        __syncthreads();
+        const uint32_t goff[4] = {0u, nn.x, nn.x + nn.y, nn.x + nn.y + nn.z};
+        uint32_t wb0 = goff[0], wb1 = goff[1], wb2 = goff[2], wb3 = goff[3];           // where this wave's keys of each group start in the LDS buffer
+        for (int ww = 0; ww < 4; ww++) if (ww < w) { wb0 += s_wcnt[ww][0]; wb1 += s_wcnt[ww][1]; wb2 += s_wcnt[ww][2]; wb3 += s_wcnt[ww][3]; }
+        if (t < 4) {                                                                 // the 13-bit histogram and the keys that arrived must agree
+            const uint32_t tot = s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t];
+            const uint32_t want = t == 0 ? nn.x : (t == 1 ? nn.y : (t == 2 ? nn.z : nn.w));
+            if (tot != want) atomicAdd(&O.n_sorted[2], 1ULL);
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; r++) {
+            const uint32_t i = (uint32_t)r * SS_THREADS + t;
+            const uint32_t d = i < N ? (sub_index<KW>(v[r], shift) & 3u) : 4u;
+            const uint64_t m0 = __ballot(d == 0), m1 = __ballot(d == 1), m2 = __ballot(d == 2), m3 = __ballot(d == 3);
+            const uint64_t mine = d == 0 ? m0 : (d == 1 ? m1 : (d == 2 ? m2 : m3));
+            const uint32_t base = d == 0 ? wb0 : (d == 1 ? wb1 : (d == 2 ? wb2 : wb3));
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            if (d < 4) s_keys[base + below] = v[r];
+            wb0 += (uint32_t)__popcll(m0); wb1 += (uint32_t)__popcll(m1); wb2 += (uint32_t)__popcll(m2); wb3 += (uint32_t)__popcll(m3);
+        }
+        __syncthreads();
+        const uint32_t n = w == 0 ? nn.x : (w == 1 ? nn.y : (w == 2 ? nn.z : nn.w));
+        const uint32_t go = w == 0 ? goff[0] : (w == 1 ? goff[1] : (w == 2 ? goff[2] : goff[3]));
+        if (n) {
+            const uint64_t start = S + go;                                             // == b_start[4g + w]: sub-buckets are packed inside the super-bucket
+            if (n > WaveCapT1<KW>::CAP) {
+                for (uint32_t i = lane; i < n; i += 64) outk[start + i] = s_keys[go + i];
+                if (lane == 0) wglist_push(&s_over, 4 * g + (uint32_t)w, O.over_count, O.over_list);
+            } else {
+                nb_done++; nk_done += n;
+                wave_sort_dispatch<KW, WaveCapT1<KW>::KPL_MAX, F>(s_keys + go, outk, start, n, O, s_hc, lane);
+            }
+        }
+        __syncthreads();                                                               // the LDS buffer is free for the next super-bucket
+    }
+    wglist_flush(&s_over, O.over_count, O.over_list);
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+    if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
+}
+// super-buckets beyond the LDS buffer (hot key prefixes): split 4 ways out of place (keys -> ping-pong buffer at the sub-buckets' own
+// offsets), copied back by k_super_copy_back; their 4 sub-buckets join the next tier's list
+template <int KW>
+__global__ __launch_bounds__(SS_THREADS) void k_super_split_big(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ dst,
+                                                                 const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint8_t* __restrict__ b_cons,
+                                                                 const uint32_t* __restrict__ big_list, uint32_t two_k, SortOut O)
+{
+    typedef typename KeyT<KW>::type key_t;
+    __shared__ uint32_t s_cur[4];
+    const uint32_t g = big_list[blockIdx.x];
+    const uint4 nn = *reinterpret_cast<const uint4*>(b_n + 4 * (size_t)g);
+    const uint32_t N = nn.x + nn.y + nn.z + nn.w;
+    const uint64_t S = b_start[4 * (size_t)g];
+    const uint32_t shift = two_k - b_cons[4 * (size_t)g];
+    if (threadIdx.x == 0) { s_cur[0] = 0; s_cur[1] = nn.x; s_cur[2] = nn.x + nn.y; s_cur[3] = nn.x + nn.y + nn.z; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i0 = 0; i0 < N; i0 += SS_THREADS) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool in = i < N;
+        const key_t v = in ? src[S + i] : (key_t)0;
+        const uint32_t d = in ? (sub_index<KW>(v, shift) & 3u) : 4u;
+#pragma unroll
+        for (uint32_t dd = 0; dd < 4; dd++) {
+            const uint64_t m = __ballot(d == dd);
+            if (!m) continue;
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&s_cur[dd], (uint32_t)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1, 64);
+            if (d == dd) dst[S + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = v;
+        }
+    }
+    if (threadIdx.x == 0) { const uint32_t slot = atomicAdd(O.over_count, 4u); for (uint32_t d = 0; d < 4; d++) O.over_list[slot + d] = 4 * g + d; }
+}
+template <int KW>
+__global__ __launch_bounds__(SS_THREADS) void k_super_copy_back(typename KeyT<KW>::type* __restrict__ keys, const typename KeyT<KW>::type* __restrict__ from,
+                                                                 const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint32_t* __restrict__ big_list)
+{
+    const uint32_t g = big_list[blockIdx.x];
+    const uint4 nn = *reinterpret_cast<const uint4*>(b_n + 4 * (size_t)g);
+    const uint32_t N = nn.x + nn.y + nn.z + nn.w;
+    const uint64_t S = b_start[4 * (size_t)g];
+    for (uint32_t i = threadIdx.x; i < N; i += SS_THREADS) keys[S + i] = from[S + i];
 }
 
 // Buckets beyond one wave's registers: a WORKGROUP of NW waves holds the bucket in registers (64*KPL keys per wave). Every wave
@@ -1090,8 +1349,8 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
-    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &over3, &misc, &bs_d, &bs_s,
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, bigs, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &over3, &bigs, &misc, &bs_d, &bs_s,
                                         &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot };
                      for (DevBuf* d : all) d->release(); }
 };
@@ -1109,16 +1368,25 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     uint64_t n_slots = 0, n_sub = 0;
     const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;       // mean keys of a level-1 bucket (sorted inside LDS)
     const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
+    // GKC_SCATTER_LINE=1: keys leave Stage B's expansion as whole 64-byte lines into super-buckets of 4 sub-buckets, split again inside the level-1
+    // sort (k_expand_scatter_line + k_super_sort). Bit-exact, but measured SLOWER than the default pair scatter + wave sort on 1e8 reads
+    // (single lane: scatter 117 vs 95 ms, level-1 sort 157 vs 70 ms; profiles/r02_line_scatter_experiment.txt): an LDS atomic costs ~12 clk per
+    // wave-instruction whatever the number of active lanes (profiles/r02_lds_bench.txt), so the collector's 9 extra LDS / store instructions per
+    // divergent k-mer step outweigh the 2.5x cheaper stores. Kept as a measured experiment.
+    static const bool line_env = getenv("GKC_SCATTER_LINE") ? atoi(getenv("GKC_SCATTER_LINE")) != 0 : false;
+    const bool line = line_env && 2 * k >= 2 && max_bits1 >= 2 && getenv("GKC_SCATTER_NO_PAIR") == nullptr && getenv("GKC_SCATTER_QUAD") == nullptr;
+    const uint32_t line_slots = line ? LineT<KW>::KEYS : 0u;
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t np = part_keys[batch_parts[i]];
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
         uint32_t bits = 0;
         while (bits < max_bits1 && bits < 2 * k && (np >> bits) > target) bits++;
+        if (line && bits < 2) bits = 2;                                   // super-buckets are groups of 4 sub-buckets (2k >= 6)
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pblk[i] = n_slots / COMPACT_BLK;
-        n_slots += (np + (3ull << bits) + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;      // partitions start on compaction-block boundaries;
-                                                                                             // + up to 3 pad slots per sub-bucket (starts on multiples of 4)
+        const uint64_t pad_slots = line ? ((uint64_t)(line_slots - 1) << (bits - 2)) : (3ull << bits);   // super-buckets start on whole lines / sub-buckets on multiples of 4
+        n_slots += (np + pad_slots + COMPACT_BLK - 1) / COMPACT_BLK * COMPACT_BLK;           // partitions start on compaction-block boundaries
         n_sub += (1ull << bits);
     }
     pblk[nb] = n_slots / COMPACT_BLK;
@@ -1145,11 +1413,16 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
 
     {   ScopedTimer tm(c, "expand_count");
         hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p);
+                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p, line_slots);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
-        if (KW == 1 && getenv("GKC_SCATTER_QUAD") != nullptr) {           // measured slower (double expansion + 3-slot protocol: 119 vs 96 ms), kept for experiments
+        if (line) {
+            const size_t lds = (size_t)LINE_SUPER_MAX * (LINE_SLOT_WORDS * 8 + 8);          // 144 KB: 64 bytes staged + two control words per super-bucket
+            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_line<KW, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            hipLaunchKernelGGL((k_expand_scatter_line<KW, RW>), dim3(nb), dim3(LINE_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start[0].p, (const uint32_t*)B.b_n[0].p, (key_t*)B.keysA.p);
+        } else if (KW == 1 && getenv("GKC_SCATTER_QUAD") != nullptr) {           // measured slower (double expansion + 3-slot protocol: 119 vs 96 ms), kept for experiments
             const size_t lds = (size_t)QUAD_SUB * 32;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_quad), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             uint32_t max_bits = 0; for (uint32_t i = 0; i < nb; i++) max_bits = std::max(max_bits, pd[i].sub_bits);
@@ -1201,6 +1474,31 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipMemsetAsync(B.over.p, 0, 4, cur_stream(c)));
         CB_HIP(hipMemsetAsync(B.over2.p, 0, 4, cur_stream(c)));
         CB_HIP(hipMemsetAsync(B.over3.p, 0, 4, cur_stream(c)));
+        if (level == 1 && line) {
+            // level 1 after the line scatter: a workgroup per super-bucket splits it through LDS and sorts its 4 sub-buckets (k_super_sort)
+            ScopedTimer tm(c, "bucket_sort");
+            const uint32_t n_super = (uint32_t)(n_buckets / 4);
+            CB_TRY(c->ensure(B.bigs, ((size_t)n_super + 1) * 4));
+            CB_HIP(hipMemsetAsync(B.bigs.p, 0, 4, cur_stream(c)));
+            const size_t lds = (size_t)SuperCap<KW>::CAP * sizeof(key_t);
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_super, 256 * 6);
+            if (tag) hipLaunchKernelGGL((k_super_sort<KW, FT>), dim3(grid), dim3(SS_THREADS), lds, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, n_super, 2 * k, O, (uint32_t*)B.bigs.p, (uint32_t*)B.bigs.p + 1);
+            else hipLaunchKernelGGL((k_super_sort<KW, false>), dim3(grid), dim3(SS_THREADS), lds, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p,
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, n_super, 2 * k, O, (uint32_t*)B.bigs.p, (uint32_t*)B.bigs.p + 1);
+            CB_HIP(hipGetLastError());
+            uint32_t n_big = 0;
+            CB_HIP(hipMemcpyAsync(&n_big, B.bigs.p, 4, hipMemcpyDeviceToHost, cur_stream(c)));
+            CB_HIP(hipStreamSynchronize(cur_stream(c)));
+            if (n_big) {                                                              // super-buckets beyond the LDS buffer: 4-way split out of place, copied back
+                if (!B.keysB.p) CB_TRY(c->ensure(B.keysB, (size_t)alloc_slots * sizeof(key_t)));
+                hipLaunchKernelGGL((k_super_split_big<KW>), dim3(n_big), dim3(SS_THREADS), 0, cur_stream(c), (const key_t*)src, (key_t*)B.keysB.p, (const uint64_t*)B.b_start[cur].p,
+                                   (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, (const uint32_t*)B.bigs.p + 1, 2 * k, O);
+                hipLaunchKernelGGL((k_super_copy_back<KW>), dim3(n_big), dim3(SS_THREADS), 0, cur_stream(c), (key_t*)B.keysA.p, (const key_t*)B.keysB.p, (const uint64_t*)B.b_start[cur].p,
+                                   (const uint32_t*)B.b_n[cur].p, (const uint32_t*)B.bigs.p + 1);
+                CB_HIP(hipGetLastError());
+            }
+        } else
         {   ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
             const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
             if (tag) hipLaunchKernelGGL((k_wave_sort<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p,
@@ -1209,9 +1507,11 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
                                (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
             CB_HIP(hipGetLastError());
         }
-        uint32_t n_mid = 0;
+        uint32_t n_mid = 0; unsigned long long split_bad = 0;
         CB_HIP(hipMemcpyAsync(&n_mid, B.over.p, 4, hipMemcpyDeviceToHost, cur_stream(c)));
+        CB_HIP(hipMemcpyAsync(&split_bad, (unsigned long long*)B.misc.p + 2, 8, hipMemcpyDeviceToHost, cur_stream(c)));
         CB_HIP(hipStreamSynchronize(cur_stream(c)));
+        if (split_bad) { B.release(); GKC_FAIL(c, GKC_ERR_HIP, "internal error: %llu sub-buckets received another number of keys than the expansion counted", split_bad); }
         if (!n_mid) break;
         uint32_t n_mid2 = 0;
         {   ScopedTimer tm(c, "bucket_sort_big");                 // up to 2x the first tier: double-size wave network
@@ -1375,6 +1675,7 @@ int gkc_count_pass(gkc_ctx* c)
 {
     const uint32_t Pn = c->nb_partitions;
     const uint32_t n_seg = (uint32_t)c->segments.size();
+    c->drain_pending();                                     // multi-GPU: the records other ranks sent must have arrived
     {   // a pass counted again (a retry after GKC_ERR_NOMEM, or gkc_finish_pass called twice) starts from a clean slate: what the
         // batches of the failed attempt added to the histogram, to the counters and to the result list must not be counted twice
         auto it = c->pass_outputs.find(c->pass);

@@ -1,0 +1,386 @@
+// gkc_dist.hip — multi-GPU under the C-ABI (include/gkc.h, "Multi-GPU"): communicators, the super-k-mer exchange, and the
+// word-array reductions the distributed Bloom filter and MPHF are built from.
+//
+// What it replaces: the reference has no distributed path. Its hand-over between the two stages is the disk shuffle of
+// SuperKmerBinFiles (tools/storage/impl/Storage.cpp:360-430: fillPartitions appends super-k-mers to one file per partition,
+// SortingCountAlgorithm.cpp:1211-1344; fillSolidKmers reads the files back, :1384-1602). Here the same hand-over between N GPUs is one
+// grouped point-to-point exchange of the device buckets: same canonical k-mer => same minimizer => same partition => one owner rank.
+//
+// MI355X shape: xGMI is point-to-point (7 links per GPU), so the all-to-all is issued as ONE ncclGroup of ncclSend / ncclRecv — every link
+// busy at once, no ring — on the communicator's own HIP stream: the exchange of push i runs while Stage A scans push i+1, and
+// gkc_finish_pass waits for the event. The bytes for one destination are one contiguous slice of the partition-major bucket arena per
+// segment, so nothing is packed. Owner ranges are balanced by the k-mers per partition the ranks report in the first exchange of a pass.
+#include "gkc_common.hpp"
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <chrono>
+#include <numeric>
+
+namespace {
+constexpr uint64_t MSG_CHUNK = 1ull << 30;     // one message stays below 2 GiB (larger single transfers came back corrupted through torch's RCCL path in round 1)
+}
+
+struct gkc_comm {
+    gkc_ctx* ctx = nullptr; int world = 1, rank = 0;
+    bool rccl = false; ncclComm_t nccl = nullptr;
+    gkc_transport t{};
+    hipStream_t xstream = nullptr;
+    std::vector<uint32_t> first;               // owner ranges [world+1]; empty until known
+    bool owners_pinned = false; uint32_t owners_pass = ~0u; uint32_t owners_P = 0;
+    gkc_comm_stats stats{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;      // transfer intervals not yet added to stats.ms_transfer
+    DevBuf ag_send, ag_recv;                   // staging of the host all-gather (RCCL)
+};
+
+static int comm_fail(gkc_comm* m, int code, const char* what, const char* detail) { m->ctx->set_error(code, "%s: %s", what, detail); return code; }
+#define NCCL_TRY(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail((m), GKC_ERR_HIP, #call, ncclGetErrorString(r_)); } while (0)
+
+int gkc_comm_world(gkc_comm* m) { return m->world; }
+int gkc_comm_rank(gkc_comm* m) { return m->rank; }
+
+// every rank contributes n bytes of host memory; all = [world][n]
+int gkc_comm_allgather_host(gkc_comm* m, const void* mine, size_t n, void* all)
+{
+    gkc_ctx* c = m->ctx;
+    if (m->world == 1) { memcpy(all, mine, n); return GKC_OK; }
+    if (!m->rccl) {
+        if (m->t.allgather_host(m->t.user, mine, (uint64_t)n, all) != 0) GKC_FAIL(c, GKC_ERR_HIP, "transport all-gather failed");
+        return GKC_OK;
+    }
+    GKC_TRY(c->ensure(m->ag_send, n + 16)); GKC_TRY(c->ensure(m->ag_recv, n * m->world + 16));
+    GKC_HIP(c, hipMemcpyAsync(m->ag_send.p, mine, n, hipMemcpyHostToDevice, m->xstream));
+    NCCL_TRY(m, ncclAllGather(m->ag_send.p, m->ag_recv.p, n, ncclUint8, m->nccl, m->xstream));
+    GKC_HIP(c, hipMemcpyAsync(all, m->ag_recv.p, n * m->world, hipMemcpyDeviceToHost, m->xstream));
+    GKC_HIP(c, hipStreamSynchronize(m->xstream));
+    return GKC_OK;
+}
+
+// one grouped exchange, ordered on stream st (RCCL: enqueued, not waited for; transport: st is drained first, the callback blocks)
+int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st)
+{
+    gkc_ctx* c = m->ctx;
+    if (sends.empty() && recvs.empty()) return GKC_OK;
+    // split long messages the same way on both sides
+    std::vector<gkc_xfer> s2, r2;
+    auto split = [](const std::vector<gkc_xfer>& in, std::vector<gkc_xfer>& out) {
+        for (const gkc_xfer& x : in)
+            for (uint64_t o = 0; o < x.n_bytes; o += MSG_CHUNK) out.push_back(gkc_xfer{ x.peer, 0, (uint8_t*)x.d_ptr + o, std::min<uint64_t>(MSG_CHUNK, x.n_bytes - o) });
+    };
+    split(sends, s2); split(recvs, r2);
+    if (m->rccl) {
+        NCCL_TRY(m, ncclGroupStart());
+        for (const gkc_xfer& x : s2) NCCL_TRY(m, ncclSend(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
+        for (const gkc_xfer& x : r2) NCCL_TRY(m, ncclRecv(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
+        NCCL_TRY(m, ncclGroupEnd());
+        return GKC_OK;
+    }
+    GKC_HIP(c, hipStreamSynchronize(st));
+    if (m->t.sendrecv_device(m->t.user, s2.data(), (uint32_t)s2.size(), r2.data(), (uint32_t)r2.size()) != 0) GKC_FAIL(c, GKC_ERR_HIP, "transport send/recv failed");
+    return GKC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ word-array reductions
+// seen = OR over ranks; coll = OR over ranks | (a bit seen by two ranks). acc_* live in the rank's own slice of its arrays.
+__global__ void k_or_rows(uint64_t* __restrict__ acc, const uint64_t* __restrict__ rows, uint64_t n, uint32_t n_rows, uint64_t row_stride)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t a = acc[i];
+        for (uint32_t r = 0; r < n_rows; r++) a |= rows[(uint64_t)r * row_stride + i];
+        acc[i] = a;
+    }
+}
+__global__ void k_seen_coll_rows(uint64_t* __restrict__ seen, const uint64_t* __restrict__ coll, const uint64_t* __restrict__ rows_seen, const uint64_t* __restrict__ rows_coll,
+                                 uint64_t n, uint32_t n_rows, uint64_t row_stride)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s = seen[i], k = coll[i];
+        for (uint32_t r = 0; r < n_rows; r++) { const uint64_t rs = rows_seen[(uint64_t)r * row_stride + i]; k |= rows_coll[(uint64_t)r * row_stride + i] | (s & rs); s |= rs; }
+        seen[i] = s & ~k;                                   // clearCollisions (BooPHF.h:511-523) applied to the combined level
+    }
+}
+
+// Reduce-scatter + all-gather over n_words 64-bit words, in place, ordered on st. mode 0: words |= everybody's words.
+// mode 1: (seen, coll) -> seen = (OR seen) & ~(OR coll | seen-by-two), complete on every rank; coll is left undefined.
+static int reduce_words(gkc_comm* m, uint64_t* d_a, uint64_t* d_b, uint64_t n_words, int mode, hipStream_t st)
+{
+    gkc_ctx* c = m->ctx;
+    const int W = m->world, me = m->rank;
+    if (W == 1) {
+        if (mode == 1 && n_words) { hipLaunchKernelGGL(k_seen_coll_rows, dim3((unsigned)std::min<uint64_t>((n_words + 255) / 256, 256 * 16)), dim3(256), 0, st, d_a, d_b, d_a, d_b, n_words, 0u, 0ull); GKC_HIP(c, hipGetLastError()); }
+        return GKC_OK;
+    }
+    const uint64_t slice = (n_words + W - 1) / W;
+    auto lo = [&](int r) { return std::min<uint64_t>((uint64_t)r * slice, n_words); };
+    auto len = [&](int r) { return lo(r + 1) - lo(r); };
+    const uint64_t mine = len(me);
+    const int arrays = mode == 1 ? 2 : 1;
+    DevBuf scratch;
+    GKC_TRY(c->ensure(scratch, (size_t)std::max<uint64_t>((uint64_t)(W - 1) * slice * arrays, 1) * 8));
+    uint64_t* rows = (uint64_t*)scratch.p;                 // [arrays][W-1][slice]
+    std::vector<gkc_xfer> sends, recvs;
+    int row = 0;
+    for (int r = 0; r < W; r++) {
+        if (r == me) continue;
+        if (len(r)) { sends.push_back(gkc_xfer{ r, 0, d_a + lo(r), len(r) * 8 }); if (mode == 1) sends.push_back(gkc_xfer{ r, 0, d_b + lo(r), len(r) * 8 }); }
+        if (mine)   { recvs.push_back(gkc_xfer{ r, 0, rows + (uint64_t)row * slice, mine * 8 }); if (mode == 1) recvs.push_back(gkc_xfer{ r, 0, rows + (uint64_t)(W - 1 + row) * slice, mine * 8 }); }
+        row++;
+    }
+    int rc = gkc_comm_sendrecv(m, sends, recvs, st);
+    if (rc == GKC_OK && mine) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((mine + 255) / 256, 256 * 16);
+        if (mode == 0) hipLaunchKernelGGL(k_or_rows, dim3(grid), dim3(256), 0, st, d_a + lo(me), (const uint64_t*)rows, mine, (uint32_t)(W - 1), slice);
+        else hipLaunchKernelGGL(k_seen_coll_rows, dim3(grid), dim3(256), 0, st, d_a + lo(me), (const uint64_t*)(d_b + lo(me)), (const uint64_t*)rows, (const uint64_t*)(rows + (uint64_t)(W - 1) * slice), mine, (uint32_t)(W - 1), slice);
+        if (hipGetLastError() != hipSuccess) { c->set_error(GKC_ERR_HIP, "reduction kernel failed"); rc = GKC_ERR_HIP; }
+    }
+    if (rc == GKC_OK) {                                     // all-gather of the reduced slices
+        sends.clear(); recvs.clear();
+        for (int r = 0; r < W; r++) {
+            if (r == me) continue;
+            if (mine) sends.push_back(gkc_xfer{ r, 0, d_a + lo(me), mine * 8 });
+            if (len(r)) recvs.push_back(gkc_xfer{ r, 0, d_a + lo(r), len(r) * 8 });
+        }
+        rc = gkc_comm_sendrecv(m, sends, recvs, st);
+    }
+    (void)hipStreamSynchronize(st);                          // scratch goes back to the pool
+    scratch.release();
+    return rc;
+}
+int gkc_comm_allreduce_or_words(gkc_comm* m, uint64_t* d_words, uint64_t n_words, hipStream_t st) { return reduce_words(m, d_words, nullptr, n_words, 0, st); }
+int gkc_comm_combine_seen_coll(gkc_comm* m, uint64_t* d_seen, uint64_t* d_coll, uint64_t n_words, hipStream_t st) { return reduce_words(m, d_seen, d_coll, n_words, 1, st); }
+
+void gkc_comm_settle_timers(gkc_comm* m)
+{
+    for (auto& pr : m->timed) {
+        if (hipEventSynchronize(pr.second) == hipSuccess) { float ms = 0; if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) m->stats.ms_transfer += ms; }
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    m->timed.clear();
+}
+
+extern "C" {
+
+int gkc_balanced_owner_ranges(const uint64_t* weights, uint32_t P, int world, uint32_t* first)
+{
+    if (!weights || !first || world < 1 || P < 1) return GKC_ERR_ARG;
+    // contiguous ranges; boundary r is the first partition whose prefix weight reaches r/world of the total (every partition also counts
+    // for one unit, so that empty tails still spread); ranges may be empty only when there are fewer partitions than ranks
+    unsigned __int128 total = 0;
+    for (uint32_t p = 0; p < P; p++) total += (unsigned __int128)weights[p] + 1;
+    first[0] = 0;
+    unsigned __int128 acc = 0; uint32_t p = 0;
+    for (int r = 1; r < world; r++) {
+        const unsigned __int128 want = total * (unsigned)r / (unsigned)world;
+        while (p < P && acc + ((unsigned __int128)weights[p] + 1) / 2 < want) { acc += (unsigned __int128)weights[p] + 1; p++; }
+        first[r] = p;
+    }
+    first[world] = P;
+    return GKC_OK;
+}
+
+int gkc_exchange_plan(int world, int rank, uint32_t P, const uint32_t* first, const uint64_t* n_segs, uint64_t l_max, const uint64_t* counts,
+                      gkc_plan_msg* sends, uint32_t* n_sends, gkc_plan_msg* recvs, uint32_t* n_recvs, uint64_t* recv_total_recs)
+{
+    if (world < 1 || rank < 0 || rank >= world || !first || !n_segs || !counts || !sends || !n_sends || !recvs || !n_recvs || !recv_total_recs) return GKC_ERR_ARG;
+    if (first[0] != 0 || first[world] != P) return GKC_ERR_ARG;
+    auto cnt = [&](int r, uint64_t j, uint32_t p) -> uint64_t { return counts[(((size_t)r * l_max + j) * 2 + 0) * P + p]; };
+    uint32_t ns = 0, nr = 0; uint64_t pos = 0;
+    for (int r = 0; r < world; r++) {                      // what leaves: per destination, per own segment, one contiguous slice of the arena
+        if (r == rank) continue;
+        for (uint64_t j = 0; j < n_segs[rank]; j++) {
+            uint64_t a = 0, n = 0;
+            for (uint32_t p = 0; p < first[r]; p++) a += cnt(rank, j, p);
+            for (uint32_t p = first[r]; p < first[r + 1]; p++) n += cnt(rank, j, p);
+            if (n) sends[ns++] = gkc_plan_msg{ r, (uint32_t)j, a, n };
+        }
+    }
+    for (int r = 0; r < world; r++) {                      // what arrives: per source, per segment of the source, back to back
+        if (r == rank) continue;
+        for (uint64_t j = 0; j < n_segs[r]; j++) {
+            uint64_t n = 0;
+            for (uint32_t p = first[rank]; p < first[rank + 1]; p++) n += cnt(r, j, p);
+            if (n) { recvs[nr++] = gkc_plan_msg{ r, (uint32_t)j, pos, n }; pos += n; }
+        }
+    }
+    *n_sends = ns; *n_recvs = nr; *recv_total_recs = pos;
+    return GKC_OK;
+}
+
+int gkc_comm_unique_id(uint8_t id[GKC_COMM_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == GKC_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id) return GKC_ERR_ARG;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return GKC_ERR_HIP;
+    memcpy(id, &u, sizeof(u));
+    return GKC_OK;
+}
+
+static int comm_new(gkc_ctx* c, int world, int rank, gkc_comm** out)
+{
+    if (!c || !out) return GKC_ERR_ARG;
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) GKC_FAIL(c, GKC_ERR_ARG, "bad world / rank (%d / %d)", world, rank);
+    GKC_HIP(c, hipSetDevice(c->device));
+    gkc_comm* m = new gkc_comm();
+    m->ctx = c; m->world = world; m->rank = rank;
+    if (hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) != hipSuccess) { delete m; GKC_FAIL(c, GKC_ERR_HIP, "stream creation failed"); }
+    gkc_ctx_child_add(c);
+    *out = m;
+    return GKC_OK;
+}
+int gkc_comm_create_rccl(gkc_ctx* c, const uint8_t id[GKC_COMM_ID_BYTES], int world, int rank, gkc_comm** out)
+{
+    if (!id) return GKC_ERR_ARG;
+    GKC_TRY(comm_new(c, world, rank, out));
+    gkc_comm* m = *out;
+    ncclUniqueId u; memcpy(&u, id, sizeof(u));
+    const ncclResult_t r = ncclCommInitRank(&m->nccl, world, u, rank);
+    if (r != ncclSuccess) { c->set_error(GKC_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
+    m->rccl = true;
+    return GKC_OK;
+}
+int gkc_comm_create_transport(gkc_ctx* c, const gkc_transport* t, int world, int rank, gkc_comm** out)
+{
+    if (!t || !t->allgather_host || !t->sendrecv_device) return GKC_ERR_ARG;
+    GKC_TRY(comm_new(c, world, rank, out));
+    (*out)->t = *t;
+    return GKC_OK;
+}
+void gkc_comm_destroy(gkc_comm* m)
+{
+    if (!m) return;
+    gkc_ctx* c = m->ctx;
+    (void)hipSetDevice(c->device);
+    if (m->xstream) (void)hipStreamSynchronize(m->xstream);
+    gkc_comm_settle_timers(m);
+    if (m->nccl) (void)ncclCommDestroy(m->nccl);
+    m->ag_send.release(); m->ag_recv.release();
+    if (m->xstream) (void)hipStreamDestroy(m->xstream);
+    delete m;
+    gkc_ctx_child_release(c);
+}
+int gkc_comm_set_owners(gkc_comm* m, const uint32_t* first)
+{
+    if (!m) return GKC_ERR_ARG;
+    if (!first) { m->owners_pinned = false; m->first.clear(); m->owners_pass = ~0u; return GKC_OK; }
+    for (int r = 0; r < m->world; r++) if (first[r] > first[r + 1]) GKC_FAIL(m->ctx, GKC_ERR_ARG, "owner ranges must be non-decreasing");
+    if (first[0] != 0) GKC_FAIL(m->ctx, GKC_ERR_ARG, "owner ranges must start at partition 0");
+    m->first.assign(first, first + m->world + 1); m->owners_pinned = true; m->owners_P = first[m->world];
+    return GKC_OK;
+}
+int gkc_comm_get_owners(gkc_comm* m, uint32_t* first)
+{
+    if (!m || !first) return GKC_ERR_ARG;
+    if (m->first.empty()) GKC_FAIL(m->ctx, GKC_ERR_ARG, "owner ranges are not known before the first gkc_exchange of a pass (or gkc_comm_set_owners)");
+    memcpy(first, m->first.data(), (size_t)(m->world + 1) * 4);
+    return GKC_OK;
+}
+int gkc_comm_get_stats(gkc_comm* m, gkc_comm_stats* out)
+{
+    if (!m || !out) return GKC_ERR_ARG;
+    (void)hipSetDevice(m->ctx->device);
+    gkc_comm_settle_timers(m);
+    *out = m->stats;
+    return GKC_OK;
+}
+
+int gkc_exchange(gkc_ctx* c, gkc_comm* m)
+{
+    if (!c || !m || m->ctx != c) return GKC_ERR_ARG;
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_exchange outside a pass (gkc_begin_pass first)");
+    GKC_HIP(c, hipSetDevice(c->device));
+    const auto t_host0 = std::chrono::steady_clock::now();
+    const int W = m->world, me = m->rank;
+    const uint32_t P = c->nb_partitions, rb = c->record_bytes;
+    // segments pushed since the last exchange of this pass (imported ones are never forwarded)
+    std::vector<size_t> mine;
+    for (size_t i = c->n_exchanged_segments; i < c->segments.size(); i++) if (c->segments[i].owned && !c->segments[i].foreign) mine.push_back(i);
+    // 1) how many segments does everybody bring (pushes per rank may differ)
+    uint64_t hdr = mine.size();
+    std::vector<uint64_t> Ls(W);
+    GKC_TRY(gkc_comm_allgather_host(m, &hdr, 8, Ls.data()));
+    const uint64_t Lmax = *std::max_element(Ls.begin(), Ls.end());
+    if (Lmax == 0) { c->n_exchanged_segments = c->segments.size(); return GKC_OK; }
+    // 2) everybody's per-partition record and k-mer counts: [W][Lmax][2][P]
+    std::vector<uint64_t> tab((size_t)Lmax * 2 * P, 0), all((size_t)W * Lmax * 2 * P);
+    for (size_t j = 0; j < mine.size(); j++) {
+        const Segment& sg = c->segments[mine[j]];
+        for (uint32_t p = 0; p < P; p++) { tab[(j * 2 + 0) * P + p] = sg.rec_off[p + 1] - sg.rec_off[p]; tab[(j * 2 + 1) * P + p] = sg.nkmers[p]; }
+    }
+    GKC_TRY(gkc_comm_allgather_host(m, tab.data(), tab.size() * 8, all.data()));
+    auto cnt = [&](int r, uint64_t j, int what, uint32_t p) -> uint64_t { return all[(((size_t)r * Lmax + j) * 2 + what) * P + p]; };
+    // 3) owner ranges of this pass
+    if (!m->owners_pinned && (m->owners_pass != c->pass || m->owners_P != P || m->first.empty())) {
+        std::vector<uint64_t> wgt(P, 0);
+        for (int r = 0; r < W; r++) for (uint64_t j = 0; j < Ls[r]; j++) for (uint32_t p = 0; p < P; p++) wgt[p] += cnt(r, j, 1, p);
+        m->first.assign(W + 1, 0);
+        (void)gkc_balanced_owner_ranges(wgt.data(), P, W, m->first.data());
+        m->owners_pass = c->pass; m->owners_P = P;
+    }
+    if (m->first.size() != (size_t)W + 1 || m->first[W] != P) GKC_FAIL(c, GKC_ERR_ARG, "owner ranges do not cover the %u partitions of the context", P);
+    const uint32_t lo = m->first[me], hi = m->first[me + 1];
+    // 4) the messages (pure host function, shared with the CPU tests): per destination one contiguous slice of every own segment's arena;
+    //    per (source, segment) the records of my partitions, back to back in one receive arena
+    std::vector<gkc_plan_msg> ps((size_t)W * Lmax + 1), pr((size_t)W * Lmax + 1);
+    uint32_t n_ps = 0, n_pr = 0; uint64_t recv_recs = 0;
+    if (gkc_exchange_plan(W, me, P, m->first.data(), Ls.data(), Lmax, all.data(), ps.data(), &n_ps, pr.data(), &n_pr, &recv_recs) != GKC_OK)
+        GKC_FAIL(c, GKC_ERR_ARG, "internal error: exchange plan");
+    uint8_t* rarena = nullptr;
+    if (recv_recs) {
+        rarena = (uint8_t*)c->dalloc((size_t)recv_recs * rb);
+        if (!rarena) return GKC_ERR_NOMEM;
+        c->owned_arenas.push_back(rarena);
+    }
+    std::vector<gkc_xfer> sends, recvs;
+    uint64_t sent_bytes = 0;
+    for (uint32_t i = 0; i < n_ps; i++) {
+        const Segment& sg = c->segments[mine[ps[i].seg]];
+        if (sg.rec_off[m->first[ps[i].peer]] != ps[i].rec_begin) GKC_FAIL(c, GKC_ERR_ARG, "internal error: segment offsets and counts disagree");
+        sends.push_back(gkc_xfer{ ps[i].peer, 0, (uint8_t*)sg.d_records + ps[i].rec_begin * rb, ps[i].n_recs * rb }); sent_bytes += ps[i].n_recs * rb;
+    }
+    std::vector<Segment> imported;
+    for (uint32_t i = 0; i < n_pr; i++) {
+        const int r = pr[i].peer; const uint64_t j = pr[i].seg;
+        recvs.push_back(gkc_xfer{ r, 0, rarena + pr[i].rec_begin * rb, pr[i].n_recs * rb });
+        Segment sg; sg.d_records = rarena + pr[i].rec_begin * rb; sg.owned = false; sg.foreign = true;
+        sg.rec_off.assign(P + 1, 0); sg.nkmers.assign(P, 0);
+        uint64_t run = 0;
+        for (uint32_t p = 0; p < P; p++) { sg.rec_off[p] = run; if (p >= lo && p < hi) { run += cnt(r, j, 0, p); sg.nkmers[p] = cnt(r, j, 1, p); } }
+        sg.rec_off[P] = run;
+        imported.push_back(std::move(sg));
+    }
+    // 5) the transfer: after Stage A of the pushes, on the communicator's stream; gkc_finish_pass waits for `done`
+    hipEvent_t ready = nullptr, t0 = nullptr, done = nullptr;
+    GKC_HIP(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    GKC_HIP(c, hipEventRecord(ready, c->stream));
+    GKC_HIP(c, hipStreamWaitEvent(m->xstream, ready, 0));
+    GKC_HIP(c, hipEventCreate(&t0)); GKC_HIP(c, hipEventCreate(&done));
+    GKC_HIP(c, hipEventRecord(t0, m->xstream));
+    const auto t_x0 = std::chrono::steady_clock::now();
+    int rc = gkc_comm_sendrecv(m, sends, recvs, m->xstream);
+    if (!m->rccl) m->stats.ms_transfer += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_x0).count();
+    GKC_HIP(c, hipEventRecord(done, m->xstream));
+    (void)hipEventDestroy(ready);
+    if (rc != GKC_OK) { (void)hipEventDestroy(t0); (void)hipEventDestroy(done); return rc; }
+    if (m->rccl) m->timed.push_back({ t0, done }); else (void)hipEventDestroy(t0);
+    {   hipEvent_t wait_ev = nullptr;                        // Stage B waits for this one (the timing pair is owned by the communicator)
+        GKC_HIP(c, hipEventCreateWithFlags(&wait_ev, hipEventDisableTiming));
+        GKC_HIP(c, hipEventRecord(wait_ev, m->xstream));
+        c->pending_events.push_back(wait_ev);
+        if (!m->rccl) (void)hipEventDestroy(done);
+    }
+    // 6) my own segments keep the partitions I own; what arrived joins the pass
+    for (size_t i : mine) {
+        Segment& sg = c->segments[i];
+        const uint64_t a = sg.rec_off[lo], b = sg.rec_off[hi];
+        for (uint32_t p = 0; p <= P; p++) sg.rec_off[p] = p < lo ? a : (p > hi ? b : sg.rec_off[p]);
+        for (uint32_t p = 0; p < P; p++) if (p < lo || p >= hi) sg.nkmers[p] = 0;
+    }
+    for (Segment& sg : imported) c->segments.push_back(std::move(sg));
+    c->n_exchanged_segments = c->segments.size();
+    m->stats.n_exchanges++; m->stats.bytes_sent += sent_bytes; m->stats.bytes_received += recv_recs * rb;
+    m->stats.ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return GKC_OK;
+}
+
+}  // extern "C"

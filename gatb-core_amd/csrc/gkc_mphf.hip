@@ -239,8 +239,17 @@ struct gkc_mphf {
     DevBuf bits, ranks, final_keys; uint64_t n_final;
 };
 
-static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t n)
+// comm != nullptr: the keys are this rank's share of a key set spread over the communicator's ranks (in rank order); every rank builds the
+// complete function (level arrays combined per level, see gkc_mphf_build_solid_dist in gkc.h)
+static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t n_local, gkc_comm* comm = nullptr)
 {
+    uint64_t n = n_local;
+    if (comm) {
+        std::vector<uint64_t> ns(gkc_comm_world(comm));
+        GKC_TRY(gkc_comm_allgather_host(comm, &n_local, 8, ns.data()));
+        n = 0; for (uint64_t v : ns) n += v;
+        if (n == 0) GKC_FAIL(c, GKC_ERR_ARG, "MPHF of an empty key set (the reference leaves the object unbuilt)");
+    }
     const int wide = m->wide; const size_t kb = wide ? 16 : 8;
     m->gamma = 3.0; m->nelem = n;                                                                       // BooPHF.hpp:300 (gamma 3)
     const uint64_t hash_domain = (uint64_t)std::ceil((double)n * m->gamma);                               // BooPHF.h:735
@@ -259,14 +268,21 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
     struct Guard { std::vector<DevBuf*> v; ~Guard() { for (DevBuf* b : v) b->release(); } } guard; guard.v = { &keysB, &coll, &flag, &scratch, &d_tot };
     GKC_TRY(c->ensure(coll, (size_t)m->nchar[0] * 8)); GKC_TRY(c->ensure(d_tot, 64));
     DevBuf* cur = &keysA; DevBuf* nxt = &keysB;
-    uint64_t alive = n, offset = 0;
+    uint64_t alive = n_local, offset = 0;      // alive: keys of THIS rank still unplaced; n - offset: keys of all ranks still unplaced
     for (int lv = 0; lv < MPHF_LEVELS; lv++) {
         uint64_t* lbits = (uint64_t*)m->bits.p + m->L.word0[lv];
         uint64_t* lranks = (uint64_t*)m->ranks.p + m->L.rank0[lv];
-        if (lv < MPHF_LEVELS - 1 && alive) {
+        const uint64_t global_alive = n - offset;
+        if (lv < MPHF_LEVELS - 1 && global_alive) {
             GKC_HIP(c, hipMemsetAsync(coll.p, 0, (size_t)m->nchar[lv] * 8, c->stream));
-            const unsigned grid = (unsigned)std::min<uint64_t>((alive + MPHF_THREADS - 1) / MPHF_THREADS, 256 * 32);
-            hipLaunchKernelGGL(k_mphf_insert, dim3(grid), dim3(MPHF_THREADS), 0, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], (uint32_t*)lbits, (uint32_t*)coll.p);
+            if (alive) {
+                const unsigned grid = (unsigned)std::min<uint64_t>((alive + MPHF_THREADS - 1) / MPHF_THREADS, 256 * 32);
+                hipLaunchKernelGGL(k_mphf_insert, dim3(grid), dim3(MPHF_THREADS), 0, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], (uint32_t*)lbits, (uint32_t*)coll.p);
+            }
+            if (comm) {     // the level over all ranks: seen = OR, collided = OR | seen by two ranks; comes back with the collisions cleared
+                GKC_TRY(gkc_comm_combine_seen_coll(comm, lbits, (uint64_t*)coll.p, m->nchar[lv], c->stream));
+                GKC_HIP(c, hipMemsetAsync(coll.p, 0, (size_t)m->nchar[lv] * 8, c->stream));
+            }
         } else GKC_HIP(c, hipMemsetAsync(coll.p, 0, (size_t)m->nchar[lv] * 8, c->stream));
         // clear collisions, block popcounts -> rank samples (exclusive scan + running offset)
         hipLaunchKernelGGL(k_mphf_clear, dim3((unsigned)((m->nranks[lv] + 255) / 256)), dim3(256), 0, c->stream, lbits, (const uint64_t*)coll.p, m->nchar[lv], lranks);
@@ -276,9 +292,10 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
         GKC_HIP(c, hipMemcpyAsync(&placed, d_tot.p, 8, hipMemcpyDeviceToHost, c->stream));
         GKC_HIP(c, hipStreamSynchronize(c->stream));
         offset += placed;
-        if (lv == MPHF_LEVELS - 1 || !alive) continue;
+        if (lv == MPHF_LEVELS - 1 || !global_alive) continue;
         // survivors of this level -> next list (stable)
-        if (placed == alive) { alive = 0; continue; }
+        if (placed == global_alive) { alive = 0; continue; }
+        if (!alive) continue;
         GKC_TRY(c->ensure(flag, (size_t)(alive + 1) * 8)); GKC_TRY(c->ensure(*nxt, (size_t)std::max<uint64_t>(alive - placed, 1) * kb));
         const unsigned g1 = (unsigned)((alive + MPHF_THREADS - 1) / MPHF_THREADS);
         hipLaunchKernelGGL(k_mphf_flag, dim3(g1), dim3(MPHF_THREADS), 0, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], (const uint32_t*)lbits, (uint64_t*)flag.p);
@@ -287,14 +304,32 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
         uint64_t left = 0;
         GKC_HIP(c, hipMemcpyAsync(&left, (uint64_t*)d_tot.p + 1, 8, hipMemcpyDeviceToHost, c->stream));
         GKC_HIP(c, hipStreamSynchronize(c->stream));
-        if (left != alive - placed) GKC_FAIL(c, GKC_ERR_HIP, "internal error: MPHF level %d placed %llu of %llu keys but %llu are left (duplicate keys?)", lv,
+        if (!comm && left != alive - placed) GKC_FAIL(c, GKC_ERR_HIP, "internal error: MPHF level %d placed %llu of %llu keys but %llu are left (duplicate keys?)", lv,
                                              (unsigned long long)placed, (unsigned long long)alive, (unsigned long long)left);
         alive = left; std::swap(cur, nxt);
     }
     m->lastbitsetrank = offset;
     // what survived all filtering levels: exact list, codes lastbitsetrank + i in key order (processLevel :896-903)
-    m->n_final = alive;
-    if (alive) { GKC_TRY(c->ensure(m->final_keys, (size_t)alive * kb)); GKC_HIP(c, hipMemcpyAsync(m->final_keys.p, cur->p, (size_t)alive * kb, hipMemcpyDeviceToDevice, c->stream)); }
+    if (comm) {     // the survivors of all ranks in rank order (= key order of the whole set); a handful of keys at most
+        const int W = gkc_comm_world(comm);
+        std::vector<uint64_t> cnts(W);
+        GKC_TRY(gkc_comm_allgather_host(comm, &alive, 8, cnts.data()));
+        const uint64_t mx = *std::max_element(cnts.begin(), cnts.end());
+        uint64_t tot = 0; for (uint64_t v : cnts) tot += v;
+        m->n_final = tot;
+        if (tot) {
+            std::vector<uint8_t> mine((size_t)mx * kb, 0), all((size_t)mx * kb * W), packed((size_t)tot * kb);
+            if (alive) { GKC_HIP(c, hipMemcpyAsync(mine.data(), cur->p, (size_t)alive * kb, hipMemcpyDeviceToHost, c->stream)); GKC_HIP(c, hipStreamSynchronize(c->stream)); }
+            GKC_TRY(gkc_comm_allgather_host(comm, mine.data(), mine.size(), all.data()));
+            size_t o = 0;
+            for (int r = 0; r < W; r++) { memcpy(packed.data() + o, all.data() + (size_t)r * mx * kb, (size_t)cnts[r] * kb); o += (size_t)cnts[r] * kb; }
+            GKC_TRY(c->ensure(m->final_keys, (size_t)tot * kb));
+            GKC_HIP(c, hipMemcpy(m->final_keys.p, packed.data(), (size_t)tot * kb, hipMemcpyHostToDevice));
+        }
+    } else {
+        m->n_final = alive;
+        if (alive) { GKC_TRY(c->ensure(m->final_keys, (size_t)alive * kb)); GKC_HIP(c, hipMemcpyAsync(m->final_keys.p, cur->p, (size_t)alive * kb, hipMemcpyDeviceToDevice, c->stream)); }
+    }
     GKC_HIP(c, hipStreamSynchronize(c->stream));
     if (m->lastbitsetrank + m->n_final != n) GKC_FAIL(c, GKC_ERR_ARG, "MPHF: %llu keys placed out of %llu: the key set holds duplicates", (unsigned long long)(m->lastbitsetrank + m->n_final), (unsigned long long)n);
     return GKC_OK;
@@ -305,17 +340,17 @@ extern "C" {
 void gkc_mphf_destroy(gkc_mphf* m) { if (m) { gkc_ctx* c = m->ctx; m->bits.release(); m->ranks.release(); m->final_keys.release(); delete m; gkc_ctx_child_release(c); } }
 uint64_t gkc_mphf_size(const gkc_mphf* m) { return m ? m->nelem : 0; }
 
-static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8_t*, uint64_t>>& segs, uint32_t stride, uint32_t k, bool on_host, gkc_mphf** out)
+static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8_t*, uint64_t>>& segs, uint32_t stride, uint32_t k, bool on_host, gkc_mphf** out, gkc_comm* comm = nullptr)
 {
     uint64_t n = 0; for (auto& s : segs) n += s.second;
-    if (n == 0) GKC_FAIL(c, GKC_ERR_ARG, "MPHF of an empty key set (the reference leaves the object unbuilt)");
+    if (n == 0 && !comm) GKC_FAIL(c, GKC_ERR_ARG, "MPHF of an empty key set (the reference leaves the object unbuilt)");
     if (n >= (1ULL << 34)) GKC_FAIL(c, GKC_ERR_ARG, "MPHF: too many keys for one device");
     GKC_HIP(c, hipSetDevice(c->device));
     ScopedTimer tm(c, "mphf_build");
     gkc_mphf* m = new gkc_mphf(); m->ctx = c; m->wide = k > 31; m->k = k; m->n_final = 0; gkc_ctx_child_add(c);
     const size_t kb = m->wide ? 16 : 8;
     DevBuf keys, tmp;
-    int rc = c->ensure(keys, (size_t)n * kb);
+    int rc = c->ensure(keys, (size_t)std::max<uint64_t>(n, 1) * kb);
     uint64_t done = 0;
     for (size_t i = 0; rc == GKC_OK && i < segs.size(); i++) {
         const uint8_t* src = segs[i].first; const uint64_t ni = segs[i].second;
@@ -331,7 +366,7 @@ static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8
         if (on_host) (void)hipStreamSynchronize(c->stream);
         done += ni;
     }
-    if (rc == GKC_OK) rc = mphf_build_from_list(c, m, keys, n);
+    if (rc == GKC_OK) rc = mphf_build_from_list(c, m, keys, n, comm);
     (void)hipStreamSynchronize(c->stream);
     keys.release(); tmp.release();
     if (rc != GKC_OK) { gkc_mphf_destroy(m); return rc; }
@@ -361,6 +396,25 @@ int gkc_mphf_build_solid(gkc_ctx* c, gkc_mphf** out)
         segs.push_back({ (const uint8_t*)D.d_counts, D.n_solid });
     }
     return mphf_build_arrays(c, segs, stride, c->k, false, out);
+}
+
+static void solid_segments(gkc_ctx* c, uint32_t stride, std::vector<std::pair<const uint8_t*, uint64_t>>& segs)
+{
+    for (const Dataset& D : c->datasets) {                      // iteration order of getSolidKmers(): dataset by dataset, ascending inside
+        if (!D.done || !D.n_solid) continue;
+        if (!segs.empty() && (const uint8_t*)D.d_counts == segs.back().first + segs.back().second * stride) { segs.back().second += D.n_solid; continue; }
+        segs.push_back({ (const uint8_t*)D.d_counts, D.n_solid });
+    }
+}
+int gkc_mphf_build_solid_dist(gkc_ctx* c, gkc_comm* comm, gkc_mphf** out)
+{
+    if (!c || !comm || !out) return GKC_ERR_ARG;
+    if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "context not configured");
+    GKC_TRY(gkc_require_resident(c, "gkc_mphf_build_solid_dist"));
+    const uint32_t stride = c->key_words == 1 ? 16 : 32;
+    std::vector<std::pair<const uint8_t*, uint64_t>> segs;
+    solid_segments(c, stride, segs);
+    return mphf_build_arrays(c, segs, stride, c->k, false, out, comm);
 }
 
 int gkc_mphf_lookup(gkc_mphf* m, const void* keys, uint64_t n, uint32_t stride, uint64_t* codes)
@@ -421,7 +475,14 @@ int gkc_mphf_save(gkc_mphf* m, uint8_t* out, uint64_t cap)
 }
 
 // MPHFAlgorithm::populate: abundance map (one byte per key, index into MapMPHF's discretization table) of the context's solid k-mers
-int gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* c, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision)
+static int abundance_map_impl(gkc_mphf* m, gkc_ctx* c, gkc_comm* comm, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision);
+int gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* c, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision) { return abundance_map_impl(m, c, nullptr, out, cap, nb_above_precision); }
+int gkc_mphf_abundance_map_dist(gkc_mphf* m, gkc_ctx* c, gkc_comm* comm, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision)
+{
+    if (!comm) return GKC_ERR_ARG;
+    return abundance_map_impl(m, c, comm, out, cap, nb_above_precision);
+}
+static int abundance_map_impl(gkc_mphf* m, gkc_ctx* c, gkc_comm* comm, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision)
 {
     if (!m || !c || !out) return GKC_ERR_ARG;
     if (cap < m->nelem) GKC_FAIL(c, GKC_ERR_CAPACITY, "abundance map needs %llu bytes", (unsigned long long)m->nelem);
@@ -436,10 +497,11 @@ int gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* c, uint8_t* out, uint64_t cap, 
     }
     GKC_HIP(c, hipSetDevice(c->device));
     GKC_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(c_abund_disc), disc, sizeof(disc)));
-    DevBuf dmap, dst; GKC_TRY(c->ensure(dmap, (size_t)m->nelem + 8));
+    const size_t map_bytes = ((size_t)m->nelem + 15) / 8 * 8;      // whole 8-byte words (the cross-rank OR works on words)
+    DevBuf dmap, dst; GKC_TRY(c->ensure(dmap, map_bytes));
     int rc = c->ensure(dst, 16);
     if (rc != GKC_OK) { dmap.release(); return rc; }
-    hipError_t e = hipMemsetAsync(dmap.p, 0, (size_t)m->nelem + 8, c->stream);
+    hipError_t e = hipMemsetAsync(dmap.p, 0, map_bytes, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(dst.p, 0, 16, c->stream);
     const uint32_t stride = c->key_words == 1 ? 16 : 32;
     {   ScopedTimer tm(c, "mphf_populate");
@@ -458,12 +520,22 @@ int gkc_mphf_abundance_map(gkc_mphf* m, gkc_ctx* c, uint8_t* out, uint64_t cap, 
         }
     }
     unsigned long long st[2] = {0, 0};
+    if (e == hipSuccess && comm) {          // every cell is written by exactly one rank (zero elsewhere): OR over the ranks = the whole map
+        rc = gkc_comm_allreduce_or_words(comm, (uint64_t*)dmap.p, (uint64_t)(map_bytes / 8), c->stream);
+        if (rc != GKC_OK) { dmap.release(); dst.release(); return rc; }
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out, dmap.p, (size_t)m->nelem, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(st, dst.p, 16, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dmap.release(); dst.release();
     if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "abundance map failed: %s", hipGetErrorString(e));
     if (st[1]) GKC_FAIL(c, GKC_ERR_ARG, "MPHF check: value out of bounds (%llu k-mers are not keys of this MPHF)", st[1]);      // MPHFAlgorithm.cpp:247
+    if (comm) {                                                    // counters over all ranks
+        std::vector<unsigned long long> alls((size_t)2 * gkc_comm_world(comm));
+        GKC_TRY(gkc_comm_allgather_host(comm, st, 16, alls.data()));
+        st[0] = st[1] = 0; for (size_t i = 0; i < alls.size(); i += 2) { st[0] += alls[i]; st[1] += alls[i + 1]; }
+        if (st[1]) GKC_FAIL(c, GKC_ERR_ARG, "MPHF check: value out of bounds (%llu k-mers are not keys of this MPHF)", st[1]);
+    }
     if (nb_above_precision) *nb_above_precision = st[0];
     return GKC_OK;
 }

@@ -1,159 +1,119 @@
-"""Multi-GPU sharding of the DSK hot path: one process per GPU, partitions owned by ranks, one exchange.
+"""Multi-GPU driver of the DSK hot path: one process per GPU, partitions owned by ranks, one exchange.
 
-The reference has no distributed path: its inter-stage exchange is the disk shuffle of SuperKmerBinFiles (reference
-tools/storage/impl/Storage.cpp:360-430: every thread appends super-k-mers to one file per partition, the counting stage
-reads the files back). Here the same hand-over is ONE all-to-all of the device super-k-mer buckets over xGMI
-(torch.distributed, backend "nccl" == RCCL on ROCm; "gloo" on CPU for the tests):
+The exchange itself lives under the C-ABI (include/gkc.h "Multi-GPU", csrc/gkc_dist.hip): gkc_exchange routes every rank's
+super-k-mer records to the owner of their partition (the device analogue of the reference's SuperKmerBinFiles disk shuffle,
+tools/storage/impl/Storage.cpp:360-430), gkc_bloom_allreduce_or / gkc_mphf_build_solid_dist combine the per-rank Bloom filters and
+MPHF levels. This module only provides what a Python launcher adds on top:
 
-  * every rank scans its own slice of the reads (Stage A) into per-partition buckets (gkc_push_reads*);
-  * partition p is owned by rank p // (P / world)  (contiguous ranges, so the bytes for one destination are ONE contiguous
-    slice of the bucket arena — nothing is packed or copied before the send);
-  * a small all-gather of the per-partition record / k-mer counts, then the all-to-all of the arena bytes (one batch of
-    point-to-point messages below 2 GiB each — larger single transfers are corrupted by this RCCL/torch stack);
-  * every rank imports the chunks it received as foreign segments (gkc_segment_import) and counts the partitions it
-    owns (Stage B, gkc_finish_pass). Results stay sharded by partition; no further collective.
-
-Volume: ~1.4 B per k-mer x (world-1)/world. xGMI is point-to-point (7 links x ~153 GB/s per GPU) and an all-to-all uses all
-links at once, unlike a ring.
+  * make_comm(): the communicator of this rank. Under torch.distributed with backend "nccl" (= RCCL on ROCm) rank 0 creates the
+    ncclUniqueId and broadcasts it, and every rank opens its OWN RCCL communicator inside libgkc_hip.so (grouped ncclSend / ncclRecv
+    over xGMI on the library's stream); with backend "gloo" — two ranks sharing one GPU in the tests, where RCCL refuses duplicate
+    devices, or a box without xGMI — a host-staged transport (device -> pinned host -> gloo -> device) implements the two callbacks
+    of gkc_transport;
+  * DistributedCounter: per pass begin -> [push -> exchange]* -> finish, and the owner ranges afterwards;
+  * owner_ranges / exchange_buckets: the host-side twins the CPU tests drive (gkc_exchange_plan is the library's planning function).
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import gkc
+
 
 class DevArray:
-    """zero-copy view of library-owned device memory for torch (``torch.as_tensor(DevArray(...), device='cuda')``)"""
+    """zero-copy view of library-owned device memory for torch (``torch.as_tensor(DevArray(ptr, n), device='cuda')``)"""
 
     def __init__(self, ptr, nbytes):
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
 def owner_ranges(nb_partitions, world):
-    """partition ranges [lo, hi) per rank; nb_partitions must be a multiple of world (ConfigurationAlgorithm.cpp:423-425
-    rounds the partition count the same way for its parallel batches)"""
-    if nb_partitions % world:
-        raise ValueError("nb_partitions (%d) must be a multiple of the world size (%d)" % (nb_partitions, world))
-    per = nb_partitions // world
-    return [(r * per, (r + 1) * per) for r in range(world)]
+    """equal-count contiguous ranges [lo, hi) per rank (what gkc_balanced_owner_ranges gives for equal weights)"""
+    first = gkc.balanced_owner_ranges(np.ones(nb_partitions, np.uint64), world)
+    return [(int(first[r]), int(first[r + 1])) for r in range(world)]
 
 
-CHUNK_BYTES = 1 << 30      # per (source, destination) message: RCCL / torch silently corrupt transfers of 2 GiB and more (measured on
-                           # this stack: all_to_all_single of >= 2^31 bytes per peer returns wrong data), so every message stays below
+class HostStagedTransport:
+    """gkc_transport over a torch.distributed process group with CPU tensors (gloo): device buffers are staged through host memory.
+    Used where RCCL cannot connect the ranks (two ranks on one GPU; no xGMI / no RCCL backend)."""
+
+    def __init__(self, counter, group=None):
+        self.c, self.group = counter, group
+        self.world = dist.get_world_size(group); self.rank = dist.get_rank(group)
+
+    def allgather_host(self, mine):
+        t = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(outs, t, group=self.group)
+        return [bytes(o.numpy().tobytes()) for o in outs]
+
+    def sendrecv_device(self, sends, recvs):
+        reqs, keep, landing = [], [], []
+        for peer, ptr, n in recvs:                       # post the receives first, then the sends (all non-blocking), then wait
+            t = torch.empty(int(n), dtype=torch.uint8)
+            reqs.append(dist.irecv(t, src=peer, group=self.group)); landing.append((ptr, t))
+        for peer, ptr, n in sends:
+            t = torch.from_numpy(self.c.device_to_host(ptr, int(n)))
+            keep.append(t); reqs.append(dist.isend(t, dst=peer, group=self.group))
+        for r in reqs:
+            r.wait()
+        for ptr, t in landing:
+            self.c.host_to_device(ptr, t.numpy())
 
 
-def exchange_buckets(send, rec_off, kmers, record_bytes, rank, world, group=None, chunk_bytes=None):
-    """Routes bucket bytes to the owners.
-
-    send      uint8 tensor: this rank's bucket arena (partition-major), on the device of the process group's backend
-    rec_off   int64[P+1] record offsets of the partitions inside ``send``;  kmers int64[P] k-mers per partition
-    Returns (recv uint8 tensor, list over source ranks of (byte offset into recv, rec_off table int64[P+1] relative to that
-    offset, kmers table int64[P])).
-    """
-    P = len(kmers)
-    ranges = owner_ranges(P, world)
-    dev = send.device
-    # 1) everybody learns everybody's per-partition counts (2*P int64 per rank)
-    mine = torch.cat([torch.as_tensor(np.diff(np.asarray(rec_off, dtype=np.int64))), torch.as_tensor(np.asarray(kmers, dtype=np.int64))]).to(dev)
-    allc = torch.empty(world * 2 * P, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allc, mine, group=group)
-    allc = allc.cpu().numpy().reshape(world, 2, P)
-    rec_cnt, km_cnt = allc[:, 0, :], allc[:, 1, :]
-    # 2) the bytes: destination j gets my records of its partitions = one contiguous slice of the arena
-    in_split = [int(rec_cnt[rank, lo:hi].sum()) * record_bytes for lo, hi in ranges]
-    lo, hi = ranges[rank]
-    out_split = [int(rec_cnt[s, lo:hi].sum()) * record_bytes for s in range(world)]
-    recv = torch.empty(sum(out_split), dtype=torch.uint8, device=dev)
-    assert sum(in_split) == send.numel(), (sum(in_split), send.numel())
-    # all-to-all as one batch of point-to-point messages (what RCCL's all-to-all is underneath), chunked below 2 GiB;
-    # the local slice is a plain device copy
-    ch = int(chunk_bytes or CHUNK_BYTES) // record_bytes * record_bytes
-    in_off = np.concatenate([[0], np.cumsum(in_split)]); out_off = np.concatenate([[0], np.cumsum(out_split)])
-    ops = []
-    for peer in range(world):
-        s_sl = send[int(in_off[peer]):int(in_off[peer + 1])]
-        r_sl = recv[int(out_off[peer]):int(out_off[peer + 1])]
-        if peer == rank:
-            r_sl.copy_(s_sl)
-            continue
-        for c0 in range(0, s_sl.numel(), ch):
-            ops.append(dist.P2POp(dist.isend, s_sl[c0:c0 + ch], peer, group))
-        for c0 in range(0, r_sl.numel(), ch):
-            ops.append(dist.P2POp(dist.irecv, r_sl[c0:c0 + ch], peer, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    # 3) per-source tables for gkc_segment_import
-    chunks = []
-    pos = 0
-    for s in range(world):
-        ro = np.zeros(P + 1, dtype=np.int64)
-        ro[lo + 1:hi + 1] = np.cumsum(rec_cnt[s, lo:hi])
-        ro[hi + 1:] = ro[hi]
-        km = np.zeros(P, dtype=np.int64)
-        km[lo:hi] = km_cnt[s, lo:hi]
-        chunks.append((pos, ro, km))
-        pos += out_split[s]
-    return recv, chunks
-
-
-def allreduce_or(t, group=None, slice_bytes=256 << 20):
-    """in-place bitwise-OR all-reduce of a uint8 tensor (Bloom bit arrays: every rank inserted the solid k-mers of the partitions it owns;
-    the OR of the partial filters is the filter of the whole set, bit for bit — SURVEY.md §8e). torch's NCCL/RCCL backend has no bitwise
-    reduce op, so every slice is all-gathered (world x slice_bytes of scratch) and ORed locally."""
-    world = dist.get_world_size(group)
-    flat = t.view(-1)
-    if world == 1:
-        return t
-    step = max(1, int(slice_bytes) // max(1, t.element_size()))
-    tmp = torch.empty((world, min(step, flat.numel())), dtype=flat.dtype, device=flat.device)
-    for i in range(0, flat.numel(), step):
-        part = flat[i:i + step]
-        buf = tmp[:, :part.numel()].contiguous() if part.numel() != tmp.shape[1] else tmp
-        dist.all_gather_into_tensor(buf.view(-1), part.contiguous(), group=group)
-        acc = buf[0]
-        for r in range(1, world):
-            acc = acc | buf[r]
-        part.copy_(acc)
-    return t
-
-
-def allreduce_or_bloom(bloom, group=None):
-    """OR-reduce a gkc.Bloom across the ranks, in place on the device"""
-    ptr, nbytes = bloom.device_array()
-    t = torch.as_tensor(DevArray(ptr, nbytes), device="cuda")
-    allreduce_or(t, group)
-    torch.cuda.synchronize()
-    return bloom
+def make_comm(counter, group=None):
+    """communicator of this rank for ``counter`` (see module docstring). Without an initialised process group: a one-rank RCCL communicator."""
+    if not dist.is_initialized():
+        return gkc.Comm.rccl(counter, gkc.Comm.unique_id(), 1, 0)
+    world = dist.get_world_size(group); rank = dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        box = [gkc.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return gkc.Comm.rccl(counter, box[0], world, rank)
+    return gkc.Comm.transport(counter, HostStagedTransport(counter, group), world, rank)
 
 
 class DistributedCounter:
-    """Host-side driver of one rank. ``counter`` is a gkc.Counter already configured with the SAME model / repartition
-    table on every rank. Call ``exchange()`` between the pushes and ``finish_pass()`` of every pass."""
+    """Host-side driver of one rank. ``counter`` is a gkc.Counter configured with the SAME model / repartition table on every rank.
+    Per pass: counter.begin_pass(p); [counter.push_reads*(...); self.exchange()]*; counter.finish_pass(). The number of pushes may differ
+    between ranks as long as every rank calls exchange() the same number of times (a call without new pushes sends nothing)."""
 
-    def __init__(self, counter, rank, world, nb_partitions, group=None):
+    def __init__(self, counter, rank, world, nb_partitions, group=None, comm=None, owners=None):
         self.c, self.rank, self.world, self.P, self.group = counter, rank, world, nb_partitions, group
-        self.ranges = owner_ranges(nb_partitions, world)
-        self._keep = []            # received buffers must outlive gkc_finish_pass
-
-    def owned(self):
-        return range(*self.ranges[self.rank])
+        self.comm = comm if comm is not None else make_comm(counter, group)
+        if owners is not None:
+            self.comm.set_owners(owners)
 
     def exchange(self):
-        c = self.c
-        nseg = c.segment_count()
-        self._keep = []
-        recvs = []
-        for s in range(nseg):
-            ptr, rb, off, km = c.segment_export(s)
-            nbytes = int(off[-1]) * rb
-            send = torch.as_tensor(DevArray(ptr, nbytes), device="cuda") if nbytes else torch.empty(0, dtype=torch.uint8, device="cuda")
-            recv, chunks = exchange_buckets(send, off.astype(np.int64), km.astype(np.int64), rb, self.rank, self.world, self.group)
-            recvs.append((recv, chunks, rb))
-        torch.cuda.synchronize()   # the sends read the context-owned arenas: finish before they are released
-        c.segments_clear()
-        for recv, chunks, rb in recvs:
-            self._keep.append(recv)
-            base = recv.data_ptr()
-            for pos, ro, km in chunks:
-                if ro[-1]:
-                    c.segment_import(base + pos, ro.astype(np.uint64), km.astype(np.uint64))
+        self.c.exchange(self.comm)
+
+    def owners(self):
+        return self.comm.owners(self.world)
+
+    def owned(self):
+        f = self.owners()
+        return range(int(f[self.rank]), int(f[self.rank + 1]))
+
+    def stats(self):
+        return self.comm.stats()
+
+
+def exchange_buckets(send, rec_counts, first, rank, world, record_bytes, group=None):
+    """Host twin of gkc_exchange for ONE segment per rank, on CPU tensors (the gloo tests): all-gathers the per-partition record counts, asks
+    the library's gkc_exchange_plan for the messages and moves the bytes. Returns (recv uint8 tensor, plan recvs, counts[world][P])."""
+    P = len(rec_counts)
+    mine = torch.as_tensor(np.asarray(rec_counts, dtype=np.int64))
+    outs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(outs, mine, group=group)
+    cnt = np.stack([o.numpy() for o in outs]).astype(np.uint64)                      # [world][P]
+    counts = np.zeros((world, 1, 2, P), np.uint64); counts[:, 0, 0, :] = cnt
+    sends, recvs, total = gkc.exchange_plan(world, rank, first, np.ones(world, np.uint64), counts)
+    recv = torch.empty(int(total) * record_bytes, dtype=torch.uint8)
+    reqs = []
+    for peer, seg, beg, n in recvs:
+        reqs.append(dist.irecv(recv[int(beg) * record_bytes:int(beg + n) * record_bytes], src=peer, group=group))
+    for peer, seg, beg, n in sends:
+        reqs.append(dist.isend(send[int(beg) * record_bytes:int(beg + n) * record_bytes].clone(), dst=peer, group=group))
+    for r in reqs:
+        r.wait()
+    return recv, recvs, cnt

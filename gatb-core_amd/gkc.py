@@ -25,11 +25,35 @@ SYMBOLS = [
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
+    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_destroy", "gkc_comm_set_owners",
+    "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
+    "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
 ]
 
 
 class GkcError(RuntimeError):
     pass
+
+
+class Xfer(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_int32), ("d_ptr", C.c_void_p), ("n_bytes", C.c_uint64)]
+
+
+ALLGATHER_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+SENDRECV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Xfer), C.c_uint32, C.POINTER(Xfer), C.c_uint32)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather_host", ALLGATHER_CB), ("sendrecv_device", SENDRECV_CB)]
+
+
+class PlanMsg(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("seg", C.c_uint32), ("rec_begin", C.c_uint64), ("n_recs", C.c_uint64)]
+
+
+class CommStats(C.Structure):
+    _fields_ = [("n_exchanges", C.c_uint64), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64), ("ms_transfer", C.c_double),
+                ("ms_host", C.c_double), ("reserved", C.c_uint64 * 4)]
 
 
 class Stats(C.Structure):
@@ -109,6 +133,20 @@ def lib():
         "gkc_result_checksum": (C.c_int, [vp, P(u64), P(u64)]),
         "gkc_sample_minimizers": (C.c_int, [vp, vp, vp, u64, vp, vp]),
         "gkc_count_mmers": (C.c_int, [vp, u32, vp, vp, u64, vp]),
+        "gkc_host_to_device": (C.c_int, [vp, vp, vp, u64]),
+        "gkc_comm_unique_id": (C.c_int, [vp]),
+        "gkc_comm_create_rccl": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
+        "gkc_comm_create_transport": (C.c_int, [vp, P(Transport), C.c_int, C.c_int, P(vp)]),
+        "gkc_comm_destroy": (None, [vp]),
+        "gkc_comm_set_owners": (C.c_int, [vp, vp]),
+        "gkc_comm_get_owners": (C.c_int, [vp, vp]),
+        "gkc_balanced_owner_ranges": (C.c_int, [vp, u32, C.c_int, vp]),
+        "gkc_exchange": (C.c_int, [vp, vp]),
+        "gkc_comm_get_stats": (C.c_int, [vp, P(CommStats)]),
+        "gkc_bloom_allreduce_or": (C.c_int, [vp, vp]),
+        "gkc_mphf_build_solid_dist": (C.c_int, [vp, vp, P(vp)]),
+        "gkc_mphf_abundance_map_dist": (C.c_int, [vp, vp, vp, vp, u64, P(u64)]),
+        "gkc_exchange_plan": (C.c_int, [C.c_int, C.c_int, u32, vp, vp, u64, vp, P(PlanMsg), P(u32), P(PlanMsg), P(u32), P(u64)]),
     }
     for name in SYMBOLS:
         f = getattr(L, name)          # raises AttributeError if the symbol is not exported
@@ -380,6 +418,14 @@ class Counter:
         self._chk(self.L.gkc_device_to_host(self.h, _p(out), d_ptr, nbytes))
         return out
 
+    def host_to_device(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.gkc_host_to_device(self.h, d_ptr, _p(arr), arr.nbytes))
+
+    def exchange(self, comm):
+        """multi-GPU: route the records pushed since the last exchange of this pass to the owners of their partitions (collective)"""
+        self._chk(self.L.gkc_exchange(self.h, comm.h))
+
     def kmer_checksum_device(self, d_bases, d_offsets, n_reads, n_bases):
         a = C.c_uint64(); b = C.c_uint64()
         self._chk(self.L.gkc_kmer_checksum_device(self.h, d_bases, d_offsets, n_reads, n_bases, C.byref(a), C.byref(b)))
@@ -391,14 +437,110 @@ class Counter:
         return a.value, b.value
 
 
+def balanced_owner_ranges(weights, world):
+    """contiguous partition ranges per rank balanced by weight (pure host function of the library): first[world+1]"""
+    w = np.ascontiguousarray(weights, dtype=np.uint64)
+    first = np.zeros(world + 1, np.uint32)
+    rc = lib().gkc_balanced_owner_ranges(_p(w), len(w), world, _p(first))
+    if rc != 0:
+        raise GkcError("gkc_balanced_owner_ranges failed (%d)" % rc)
+    return first
+
+
+def exchange_plan(world, rank, first, n_segs, counts):
+    """gkc_exchange_plan (pure host): counts uint64[world][l_max][2][P] -> (sends, recvs, recv_total) with (peer, seg, rec_begin, n_recs) tuples"""
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    l_max, P = counts.shape[1], counts.shape[3]
+    first = np.ascontiguousarray(first, dtype=np.uint32); n_segs = np.ascontiguousarray(n_segs, dtype=np.uint64)
+    cap = world * max(1, l_max) + 1
+    ps = (PlanMsg * cap)(); pr = (PlanMsg * cap)(); a = C.c_uint32(); b = C.c_uint32(); tot = C.c_uint64()
+    rc = lib().gkc_exchange_plan(world, rank, P, _p(first), _p(n_segs), l_max, _p(counts), ps, C.byref(a), pr, C.byref(b), C.byref(tot))
+    if rc != 0:
+        raise GkcError("gkc_exchange_plan failed (%d)" % rc)
+    f = lambda arr, n: [(arr[i].peer, arr[i].seg, arr[i].rec_begin, arr[i].n_recs) for i in range(n)]
+    return f(ps, a.value), f(pr, b.value), tot.value
+
+
+class Comm:
+    """gkc_comm: one rank of a multi-GPU run. ``Comm.rccl(counter, id_bytes, world, rank)`` or ``Comm.transport(counter, t, world, rank)``
+    where ``t`` offers allgather_host(bytes) -> list of bytes and sendrecv_device(sends, recvs) with (peer, device pointer, nbytes) tuples."""
+
+    def __init__(self, counter, h, keep=None):
+        self.c = counter; self.L = counter.L; self.h = h; self._keep = keep
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, np.uint8)
+        if lib().gkc_comm_unique_id(_p(buf)) != 0:
+            raise GkcError("ncclGetUniqueId failed")
+        return buf.tobytes()
+
+    @classmethod
+    def rccl(cls, counter, id_bytes, world, rank):
+        h = C.c_void_p(); buf = np.frombuffer(bytes(id_bytes), dtype=np.uint8).copy()
+        counter._chk(counter.L.gkc_comm_create_rccl(counter.h, _p(buf), world, rank, C.byref(h)))
+        return cls(counter, h)
+
+    @classmethod
+    def transport(cls, counter, t, world, rank):
+        def _ag(user, mine, n, out):
+            try:
+                parts = t.allgather_host(C.string_at(mine, n))
+                C.memmove(out, b"".join(parts), n * world)
+                return 0
+            except Exception as e:      # noqa
+                import traceback; traceback.print_exc()
+                return 1
+
+        def _sr(user, sends, ns, recvs, nr):
+            try:
+                t.sendrecv_device([(sends[i].peer, sends[i].d_ptr, sends[i].n_bytes) for i in range(ns)],
+                                  [(recvs[i].peer, recvs[i].d_ptr, recvs[i].n_bytes) for i in range(nr)])
+                return 0
+            except Exception as e:      # noqa
+                import traceback; traceback.print_exc()
+                return 1
+
+        cb1, cb2 = ALLGATHER_CB(_ag), SENDRECV_CB(_sr)
+        st = Transport(None, cb1, cb2)
+        h = C.c_void_p()
+        counter._chk(counter.L.gkc_comm_create_transport(counter.h, C.byref(st), world, rank, C.byref(h)))
+        return cls(counter, h, keep=(cb1, cb2, st, t))
+
+    def set_owners(self, first):
+        a = None if first is None else np.ascontiguousarray(first, dtype=np.uint32)
+        self.c._chk(self.L.gkc_comm_set_owners(self.h, _p(a)))
+
+    def owners(self, world):
+        a = np.zeros(world + 1, np.uint32)
+        self.c._chk(self.L.gkc_comm_get_owners(self.h, _p(a))); return a
+
+    def stats(self):
+        s = CommStats(); self.c._chk(self.L.gkc_comm_get_stats(self.h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in CommStats._fields_ if n != "reserved"}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gkc_comm_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Mphf:
     """BooPHF minimal perfect hash built on the device (include/gkc.h gkc_mphf_*)"""
 
-    def __init__(self, counter, keys=None, k=None):
-        """keys=None: the solid k-mers of the counter; else a list of ints / uint64 array (k <= 31) or list of ints (k <= 63)"""
-        self.c = counter; self.L = counter.L
+    def __init__(self, counter, keys=None, k=None, comm=None):
+        """keys=None: the solid k-mers of the counter (comm: of all ranks' counters — collective); else a list of ints / uint64 array
+        (k <= 31) or list of ints (k <= 63)"""
+        self.c = counter; self.L = counter.L; self.comm = comm
         h = C.c_void_p()
-        if keys is None:
+        if keys is None and comm is not None:
+            counter._chk(self.L.gkc_mphf_build_solid_dist(counter.h, comm.h, C.byref(h))); self.k = counter.k
+        elif keys is None:
             counter._chk(self.L.gkc_mphf_build_solid(counter.h, C.byref(h))); self.k = counter.k
         else:
             self.k = k
@@ -428,6 +570,8 @@ class Mphf:
 
     def abundance_map(self):
         out = np.zeros(self.size, np.uint8); above = C.c_uint64(0)
+        if self.comm is not None:
+            self.c._chk(self.L.gkc_mphf_abundance_map_dist(self.h, self.c.h, self.comm.h, _p(out), len(out), C.byref(above))); return out, above.value
         self.c._chk(self.L.gkc_mphf_abundance_map(self.h, self.c.h, _p(out), len(out), C.byref(above))); return out, above.value
 
     def close(self):
@@ -480,8 +624,12 @@ class Bloom:
     def bitsize(self):
         return self.L.gkc_bloom_bitsize(self.h)
 
+    def allreduce_or(self, comm):
+        """OR the partial filters of all ranks in place (collective): gkc_bloom_allreduce_or"""
+        self.c._chk(self.L.gkc_bloom_allreduce_or(self.h, comm.h))
+
     def device_array(self):
-        """(device pointer, bytes) of the bit array: zero-copy view for torch.distributed (dist.allreduce_or_bloom)"""
+        """(device pointer, bytes) of the bit array"""
         p = C.c_void_p(); n = C.c_uint64(0)
         self.c._chk(self.L.gkc_bloom_device_array(self.h, C.byref(p), C.byref(n))); return p.value, n.value
 

@@ -42,6 +42,8 @@ typedef struct gkc_ctx gkc_ctx;
  * owns the HIP stream, every device buffer and the per-pass results.
  * ------------------------------------------------------------------------------------------------------------- */
 int         gkc_create(int device, gkc_ctx** out);
+/* Objects built from a context (gkc_bloom, gkc_mphf, gkc_comm) hold device memory of its allocator and keep it alive: gkc_destroy may be
+ * called first, the context is then released when the last of them is destroyed. */
 void        gkc_destroy(gkc_ctx* ctx);
 const char* gkc_last_error(const gkc_ctx* ctx);      /* ctx may be NULL: last error of a failed gkc_create */
 const char* gkc_version(void);
@@ -131,18 +133,72 @@ int gkc_get_timing(gkc_ctx* ctx, const char* name, double* ms, uint64_t* launche
 int gkc_partition_superkmers(gkc_ctx* ctx, uint32_t part, uint8_t* out, uint64_t cap_bytes,
                              uint64_t* n_bytes, uint64_t* n_superkmers, uint64_t* n_kmers);
 
-/* Multi-GPU: partitions are owned by ranks; the host moves each rank's buckets to their owner with one
- * RCCL all-to-all and imports them on the owner. Records of partition p occupy rec_index in
- * [rec_offsets[p], rec_offsets[p+1]) of the segment's arena; record_bytes is 16 (k<=31) or 32.
+/* Segment surface (parity tests, custom exchanges): records of partition p occupy rec_index in [rec_offsets[p], rec_offsets[p+1]) of the
+ * segment's arena; record_bytes is 16 (k<=31) or 32.
  * gkc_segment_export: segment `seg` (one per push) of the current pass. d_records stays owned by the context.
  * gkc_segment_import: adds a foreign segment; the memory stays owned by the caller and must outlive gkc_finish_pass.
- * gkc_segments_clear: forget all segments of the current pass (frees owned arenas). */
+ * gkc_segments_clear: forget all segments of the current pass (frees owned arenas). The multi-GPU exchange itself is gkc_exchange below. */
 int gkc_segment_count(gkc_ctx* ctx, uint32_t* n_segments);
 int gkc_segment_export(gkc_ctx* ctx, uint32_t seg, const void** d_records, uint32_t* record_bytes,
                        uint64_t* rec_offsets /* [nb_partitions+1] */, uint64_t* kmers_per_partition /* [nb_partitions] */);
 int gkc_segment_import(gkc_ctx* ctx, const void* d_records, const uint64_t* rec_offsets /* [nb_partitions+1] */,
                        const uint64_t* kmers_per_partition /* [nb_partitions] */);
 int gkc_segments_clear(gkc_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process = one context = one GPU; partitions are OWNED by ranks (contiguous ranges), every rank scans
+ * its own reads, and one exchange routes each rank's super-k-mer records to the owner of their partition — the device analogue of the
+ * reference's disk shuffle (SuperKmerBinFiles, tools/storage/impl/Storage.cpp:360-430; fillPartitions writes, fillSolidKmers reads:
+ * SortingCountAlgorithm.cpp:1211-1344, 1384-1602). Same canonical k-mer => same minimizer => same partition, so after the exchange every
+ * rank counts the partitions it owns with no further communication.
+ *
+ * A communicator is either RCCL (grouped ncclSend / ncclRecv over xGMI, librccl linked directly, asynchronous on its own HIP stream so
+ * that the exchange of push i overlaps Stage A of push i+1) or a caller-supplied transport (two callbacks; used where RCCL cannot run,
+ * e.g. two ranks sharing one GPU in the tests: gloo with host staging, gatb-core_amd/dist.py).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct gkc_comm gkc_comm;
+#define GKC_COMM_ID_BYTES 128                      /* sizeof(ncclUniqueId) */
+typedef struct gkc_xfer { int32_t peer; int32_t reserved; void* d_ptr; uint64_t n_bytes; } gkc_xfer;   /* d_ptr: DEVICE memory */
+typedef struct gkc_transport {
+    void* user;
+    /* every rank contributes n_bytes of HOST memory; all[r * n_bytes ...] = rank r's contribution. Blocking. */
+    int (*allgather_host)(void* user, const void* mine, uint64_t n_bytes, void* all);
+    /* one grouped point-to-point exchange (ncclGroupStart ... ncclGroupEnd semantics): every send and receive of the call is posted
+     * before any is waited for; messages between one pair of ranks match in list order; returns when all have completed. */
+    int (*sendrecv_device)(void* user, const gkc_xfer* sends, uint32_t n_sends, const gkc_xfer* recvs, uint32_t n_recvs);
+} gkc_transport;
+/* rank 0 makes the id (ncclGetUniqueId) and the launcher hands it to every rank (torch.distributed store, MPI, a file) */
+int  gkc_comm_unique_id(uint8_t id[GKC_COMM_ID_BYTES]);
+int  gkc_comm_create_rccl(gkc_ctx* ctx, const uint8_t id[GKC_COMM_ID_BYTES], int world, int rank, gkc_comm** out);
+int  gkc_comm_create_transport(gkc_ctx* ctx, const gkc_transport* t, int world, int rank, gkc_comm** out);
+void gkc_comm_destroy(gkc_comm* comm);
+/* Owner ranges: rank r owns partitions [first[r], first[r+1]); first[0] = 0, first[world] = nb_partitions. By default the first
+ * exchange of a pass balances them by the k-mers per partition all ranks report ("balanced by weight"); gkc_comm_set_owners
+ * pins them (e.g. from the Repartitor's sample, PartiInfo.cpp:48-106), NULL goes back to balancing. gkc_balanced_owner_ranges is the
+ * pure host function behind it (no context, no GPU). */
+int  gkc_comm_set_owners(gkc_comm* comm, const uint32_t* first /* [world+1] or NULL */);
+int  gkc_comm_get_owners(gkc_comm* comm, uint32_t* first /* [world+1] */);
+int  gkc_balanced_owner_ranges(const uint64_t* weights, uint32_t nb_partitions, int world, uint32_t* first /* [world+1] */);
+/* Routes the records of every push since the last gkc_exchange of this pass to their owners and imports what arrives; the rank's own
+ * segments keep only the partitions it owns. Collective: every rank calls it the same number of times per pass (a rank without new
+ * pushes takes part with nothing to send — pushes per rank may differ). With RCCL the transfers run on the communicator's stream and
+ * gkc_finish_pass waits for them. */
+int  gkc_exchange(gkc_ctx* ctx, gkc_comm* comm);
+/* The message plan of one exchange for one rank — the pure host function gkc_exchange runs after the all-gather of the count tables (no
+ * context, no GPU: the CPU tests drive it with gloo). counts: [world][l_max][2][P] = records, k-mers per partition of segment j of rank r
+ * (zero rows beyond n_segs[r]); first: owner ranges. sends[i]: n_recs records starting at record rec_begin of this rank's own segment
+ * `seg` go to `peer`; recvs[i]: n_recs records of segment `seg` of `peer` arrive at record rec_begin of the receive arena. Messages between
+ * two ranks are listed in the same order on both sides. Capacity of sends / recvs: world * l_max entries each. */
+typedef struct gkc_plan_msg { int32_t peer; uint32_t seg; uint64_t rec_begin; uint64_t n_recs; } gkc_plan_msg;
+int  gkc_exchange_plan(int world, int rank, uint32_t nb_partitions, const uint32_t* first, const uint64_t* n_segs, uint64_t l_max, const uint64_t* counts,
+                       gkc_plan_msg* sends, uint32_t* n_sends, gkc_plan_msg* recvs, uint32_t* n_recvs, uint64_t* recv_total_recs);
+typedef struct gkc_comm_stats {
+    uint64_t n_exchanges, bytes_sent, bytes_received;   /* record bytes that left / reached this rank (not counting what stayed) */
+    double   ms_transfer;                                 /* HIP-event time of the grouped send/recv on the communicator's stream (RCCL) or wall time of the callback */
+    double   ms_host;                                     /* wall time inside gkc_exchange (tables, allocation, enqueue) */
+    uint64_t reserved[4];
+} gkc_comm_stats;
+int  gkc_comm_get_stats(gkc_comm* comm, gkc_comm_stats* out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bloom filter of solid k-mers — replaces BloomBuilder::build / IBloom::insert (kmer/impl/BloomBuilder.hpp:102-128,
@@ -169,6 +225,9 @@ int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes);     
 /* the bit array where it lives (device memory, n_bytes = gkc_bloom_nbytes rounded up to 4): multi-GPU runs insert their own
  * partitions' solid k-mers and OR-reduce the arrays in place (all-reduce with bitwise OR over RCCL) */
 int gkc_bloom_device_array(gkc_bloom* b, void** d_bits, uint64_t* n_bytes);
+/* in-place bitwise-OR all-reduce of the bit array over the communicator: reduce-scatter (every rank ORs one slice of everybody's array)
+ * + all-gather, 2 (world-1)/world of the array per rank instead of (world-1) arrays */
+int gkc_bloom_allreduce_or(gkc_bloom* b, gkc_comm* comm);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Synthetic reads generated in HBM (bench / parity at full size; SURVEY §8d generator): genome of genome_len uniform
@@ -190,6 +249,14 @@ int gkc_synth_reads_device(gkc_ctx* ctx, uint64_t seed, uint64_t first_read, uin
 typedef struct gkc_mphf gkc_mphf;
 int      gkc_mphf_build(gkc_ctx* ctx, const void* keys /* host */, uint64_t n, uint32_t stride, uint32_t k, gkc_mphf** out);
 int      gkc_mphf_build_solid(gkc_ctx* ctx, gkc_mphf** out);          /* keys = the solid k-mers of every finished dataset (getSolidKmers() order) */
+/* Multi-GPU build over the solid k-mers of ALL ranks (each rank holds the partitions it owns): BooPHF's level arrays do not depend on the
+ * order keys are processed in, so every level is built from per-rank partial arrays combined with seen = OR, collided = OR | (seen by two
+ * ranks) — reduce-scatter + all-gather like the Bloom. Every rank ends up with the complete function: gkc_mphf_save / lookup give the
+ * bytes / codes of a single-GPU build over the same key set (rank order = partition order = getSolidKmers() order). Collective. */
+int      gkc_mphf_build_solid_dist(gkc_ctx* ctx, gkc_comm* comm, gkc_mphf** out);
+/* populate() across ranks: every rank fills the cells of its own solid k-mers, the maps are OR-combined; out (host, gkc_mphf_size bytes) is
+ * complete on every rank */
+int      gkc_mphf_abundance_map_dist(gkc_mphf* m, gkc_ctx* ctx, gkc_comm* comm, uint8_t* out, uint64_t cap, uint64_t* nb_above_precision);
 void     gkc_mphf_destroy(gkc_mphf* m);
 uint64_t gkc_mphf_size(const gkc_mphf* m);                             /* number of keys (BooPHF::size) */
 int      gkc_mphf_lookup(gkc_mphf* m, const void* keys /* host */, uint64_t n, uint32_t stride, uint64_t* codes);   /* ~0: not a key (final level miss) */
@@ -233,6 +300,7 @@ int gkc_device_memory(gkc_ctx* ctx, uint64_t* usable_bytes, uint64_t* total_byte
 int gkc_host_alloc(void** p, uint64_t n_bytes);
 int gkc_host_free(void* p);
 int gkc_device_to_host(gkc_ctx* ctx, void* dst, const void* d_src, uint64_t n_bytes);
+int gkc_host_to_device(gkc_ctx* ctx, void* d_dst, const void* src, uint64_t n_bytes);
 /* order-independent checksum of the canonical k-mer multiset of device-resident reads, computed by an independent
  * one-thread-per-position kernel (no minimizers, no buckets): sum over valid k-mers of mix(canonical) mod 2^64, and the
  * number of valid k-mers. Used by the full-size parity property "sum_records count*mix(value) == this". */

@@ -1,0 +1,103 @@
+"""Multi-rank execution for real: TWO processes on the one available GPU, each with its own context, running the whole distributed
+path through the C-ABI — gkc_exchange (owner ranges balanced by weight, unequal numbers of pushes), Stage B on the owned partitions,
+gkc_bloom_allreduce_or, gkc_mphf_build_solid_dist + gkc_mphf_abundance_map_dist — and compared with the oracle / with a single-context
+run over all reads. RCCL refuses two ranks on one device, so the ranks talk through the host-staged gloo transport
+(gatb-core_amd/dist.py:HostStagedTransport = the two callbacks of gkc_transport); everything above the two callbacks is the code the
+RCCL communicator runs. BASELINE configs[2] / configs[4] at test size."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as ge
+from oracle import gko
+from tests.util import simple_repart, synth_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_main(rank, world, port, k, parts, amin, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = ge.load(); gkc = pkg.gkc
+        from gatb_core_amd import dist as gd
+        m = 8
+        reads = synth_reads(3000, 15000, 150, seed=41, n_rate=0.001, ragged=True)
+        rep = simple_repart(m, parts)
+        # rank 0 scans reads [0, 1800) in TWO pushes, rank 1 the rest in ONE push: the second exchange of rank 1 has nothing to send
+        mine = reads[:1800] if rank == 0 else reads[1800:]
+        chunks = [mine[:1000], mine[1000:]] if rank == 0 else [mine, []]
+        c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
+        dc = gd.DistributedCounter(c, rank, world, parts)
+        c.begin_pass(0)
+        for ch in chunks:
+            if ch:
+                b, o = gko.pack_reads(ch); c.push_reads(b, o)
+            dc.exchange()
+        c.finish_pass()
+        first = dc.owners()
+        owned = {}
+        for p in range(parts):
+            lo, hi, ab = c.partition(0, p)
+            if first[rank] <= p < first[rank + 1]:
+                owned[p] = (lo, hi, ab)
+            else:
+                assert len(lo) == 0, "partition %d is not mine but holds records" % p
+        st = c.stats(); cs = dc.stats()
+        # Bloom over the solid k-mers of all ranks: every rank inserts its own, then the OR all-reduce
+        bl = gkc.Bloom(c, "neighbor", 600_000, 7, k); bl.insert_solid(); bl.allreduce_or(dc.comm)
+        # MPHF + abundance map over all ranks
+        mp_ = gkc.Mphf(c, comm=dc.comm)
+        amap, above = mp_.abundance_map()
+        q.put((rank, first.tolist(), owned, st, cs, bl.array(), mp_.save(), amap, above, mp_.size))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,parts,amin", [(31, 12, 2), (41, 8, 1)])
+def test_two_ranks_one_gpu_end_to_end(k, parts, amin):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, k, parts, amin, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    # ---- expected: the oracle over ALL reads, and a single-context run for the Bloom / MPHF bytes
+    gkc = ge.load().gkc
+    m = 8
+    reads = synth_reads(3000, 15000, 150, seed=41, n_rate=0.001, ragged=True)
+    rep = simple_repart(m, parts)
+    bases, offs = gko.pack_reads(reads)
+    ref = gko.Dsk(bases, offs, k, m, parts, rep)            # every distinct k-mer; the solidity window is applied below
+    first = res[0][1]
+    assert res[1][1] == first and first[0] == 0 and first[-1] == parts and 0 < first[1] < parts      # both ranks agree; both own something
+    seen = 0
+    for rank, _, owned, st, cs, *_ in res:
+        assert sorted(owned) == list(range(first[rank], first[rank + 1]))
+        for p, (lo, hi, ab) in owned.items():
+            rlo, rhi, rab = ref.part(p)
+            keep = rab >= amin
+            assert np.array_equal(lo, rlo[keep]) and np.array_equal(hi, rhi[keep]) and np.array_equal(ab, rab[keep]), "partition %d differs from the oracle" % p
+            seen += 1
+        assert cs["n_exchanges"] == 2 and cs["bytes_sent"] > 0 and cs["bytes_received"] > 0
+    assert seen == parts
+    assert res[0][4]["bytes_sent"] == res[1][4]["bytes_received"] and res[1][4]["bytes_sent"] == res[0][4]["bytes_received"]
+    assert sum(r[3]["kmers_nb_valid"] for r in res) == ref.stats["kmers_nb_valid"]
+    assert sum(r[3]["kmers_nb_distinct"] for r in res) == ref.stats["kmers_nb_distinct"]
+    one = gkc.Counter(0); one.configure(k, m, parts, rep); one.set_solidity(amin, 2147483647, 10000); one.count(bases, offs)
+    bl = gkc.Bloom(one, "neighbor", 600_000, 7, k); bl.insert_solid()
+    mp1 = gkc.Mphf(one); amap1, above1 = mp1.abundance_map()
+    for r in res:
+        assert np.array_equal(r[5], bl.array()), "OR-reduced Bloom filter differs from the single-GPU filter"
+        assert r[9] == mp1.size and np.array_equal(r[6], mp1.save()), "multi-rank MPHF stream differs from gkc_mphf_save of the single-GPU run"
+        assert np.array_equal(r[7], amap1) and r[8] == above1

@@ -448,8 +448,8 @@ def test_two_owner_shards_on_one_gpu(gkc):
 
 
 def test_distributed_counter_world1_rccl(gkc):
-    """DistributedCounter over the real backend (nccl == RCCL) with one rank: zero-copy arena view, all_gather +
-    all_to_all_single on the device, foreign-segment import"""
+    """DistributedCounter over the real backend with one rank: torch.distributed (nccl == RCCL) hands the ncclUniqueId around, the library
+    opens its own RCCL communicator and gkc_exchange runs on it (nothing to move with one rank; owners = all partitions)"""
     import os, socket, torch
     import torch.distributed as dist
     ge.load()
@@ -467,38 +467,24 @@ def test_distributed_counter_world1_rccl(gkc):
         dc = gd.DistributedCounter(c, 0, 1, parts)
         c.begin_pass(0); c.push_reads(bases, offs); dc.exchange(); c.finish_pass()
         assert c.all_counts() == ref.all_counts()
+        assert list(dc.owned()) == list(range(parts)) and dc.stats()["n_exchanges"] == 1
     finally:
         dist.destroy_process_group()
 
 
 def test_bloom_or_reduce_world1_rccl(gkc):
-    """two partial filters (the solid k-mers of two owner shards) ORed through torch.distributed (nccl = RCCL, world 1 here) equal the
-    filter of the whole set; exercises gkc_bloom_device_array + dist.allreduce_or_bloom on the device"""
-    import os
-    import torch
-    import torch.distributed as dist
-    from gatb_core_amd import dist as gdist
+    """gkc_bloom_allreduce_or over a one-rank RCCL communicator (ncclCommInitRank inside the library) is the identity; the two-rank
+    reduction runs in tests/test_gpu_dist.py"""
     rng = np.random.default_rng(77)
     k = 31
     keys = [int.from_bytes(rng.bytes(16), "little") & (4 ** k - 1) for _ in range(40000)]
     c = gkc.Counter(0)
     whole = gkc.Bloom(c, "neighbor", 2_000_000, 7, k); whole.insert(keys)
-    a = gkc.Bloom(c, "neighbor", 2_000_000, 7, k); a.insert(keys[:25000])
-    b = gkc.Bloom(c, "neighbor", 2_000_000, 7, k); b.insert(keys[25000:])
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        # world 1: the reduce is the identity; OR the second shard in by hand through the same zero-copy view, then reduce
-        pa, na = a.device_array(); pb, nb = b.device_array()
-        ta = torch.as_tensor(gdist.DevArray(pa, na), device="cuda"); tb = torch.as_tensor(gdist.DevArray(pb, nb), device="cuda")
-        ta |= tb
-        gdist.allreduce_or_bloom(a)
-    finally:
-        if created:
-            dist.destroy_process_group()
-    assert np.array_equal(a.array(), whole.array())
+    comm = gkc.Comm.rccl(c, gkc.Comm.unique_id(), 1, 0)
+    before = whole.array().copy()
+    whole.allreduce_or(comm)
+    assert np.array_equal(whole.array(), before)
+    comm.close()
 
 
 def test_repartitor_sampling_statistics(gkc):
