@@ -120,6 +120,47 @@ def fastq_parse_leg(c, n_reads=1_000_000, L=150):
             "text_GBps": t.numel() / best / 1e9, "gbases_per_s": n_reads * L / best / 1e9, "ms": best * 1e3}
 
 
+def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2):
+    """SURVEY §8(d) wall: from the first push to the last partition's Count[] in (page-locked) host memory. Every Stage-B batch is copied into
+    the host sink on a copy stream while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns when everything has landed.
+    Reported beside `value` (which stops with the results in HBM), at abundance-min 1 (every distinct k-mer travels: PCIe-bound) and 2."""
+    import torch
+    out = {}
+    try:
+        sink = gkc.HostBuffer(int(distinct * 16 * 1.01) + (64 << 20))
+    except Exception as e:      # noqa
+        return {"error": "page-locked sink of %.1f GB: %s" % (distinct * 16 / 1e9, e)}
+    # what the box's PCIe link sustains device -> page-locked host (one 4 GB copy)
+    probe = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+    n_probe = min(4 << 30, sink.nbytes) // (1 << 30)
+    import ctypes as C_
+    t0 = time.perf_counter()
+    for i in range(n_probe):
+        c._chk(c.L.gkc_device_to_host(c.h, C_.c_void_p(sink._p.value + (i << 30)), probe.data_ptr(), 1 << 30))
+    pcie = n_probe * (1 << 30) / (time.perf_counter() - t0) / 1e9
+    del probe
+    out["pcie_d2h_GBps"] = pcie
+    c.set_host_sink(sink)
+    for amin in (1, 2):
+        c.set_solidity(amin, 2147483647, 10000)
+        step(); sync()                                        # the batch plan changes with the solidity window: one untimed step
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        sync()
+        dt = (time.perf_counter() - t0) / n_steps
+        st = c.stats()
+        landed = st["kmers_nb_solid"] * 16
+        err = (c.L.gkc_last_error(c.h) or b"").decode()
+        out["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s with every solid Count[] in page-locked host memory",
+                                          "ms_per_step": dt * 1e3, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
+                                          "landed_GBps_over_the_step": landed / dt / 1e9, "frac_of_pcie": landed / dt / 1e9 / pcie,
+                                          "sink_overflow": "sink" in err}
+    c.set_host_sink(None)
+    c.set_solidity(1, 2147483647, 10000)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +171,7 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-landed", action="store_true", help="skip the host-landed leg (results streamed into page-locked host memory)")
     ap.add_argument("--pushes", type=int, default=4, help="multi-GPU: pushes (and exchanges) per pass and rank")
     args = ap.parse_args()
 
@@ -312,6 +354,10 @@ def main():
                                               "kernel_ms_per_step": {n_: round(iso[n_][0], 3) for n_ in names}}
         if exch is not None:
             out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push, "per_rank": exch}
+        if world == 1 and not args.no_host_landed:
+            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct)
+            if "abundance_min_2" in out["host_landed"]:
+                out["host_landed"]["abundance_min_2"]["vs_value"] = out["host_landed"]["abundance_min_2"]["value"] / value
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
         if not args.no_cpu_baseline and world == 1:

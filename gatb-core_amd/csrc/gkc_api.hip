@@ -63,6 +63,13 @@ __global__ void k_kmer_checksum(const uint8_t* __restrict__ bases, const uint64_
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], (unsigned long long)cs); atomicAdd(&out[1], (unsigned long long)nv); }
 }
 
+// offsets of a slice of the caller's CSR table -> offsets relative to the slice (gkc_push_reads sends the reads in chunks)
+__global__ void k_rebase_offsets(uint64_t* __restrict__ off, uint64_t n, uint64_t base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) off[i] -= base;
+}
+
 void gkc_ctx_child_add(gkc_ctx* c) { std::lock_guard<std::mutex> lk(c->mu); c->children++; }
 int gkc_alloc_histo(gkc_ctx* c)
 {
@@ -134,8 +141,12 @@ void gkc_destroy(gkc_ctx* c)
 static void ctx_destroy_now(gkc_ctx* c)
 {
     (void)hipSetDevice(c->device);
+    if (c->stage_b_thread.joinable()) c->stage_b_thread.join();
     (void)hipStreamSynchronize(c->stream);
     c->drain_pending();
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) { c->h2d_bases[i].release(); c->h2d_offs[i].release(); if (c->h2d_copied[i]) (void)hipEventDestroy(c->h2d_copied[i]); if (c->h2d_scanned[i]) (void)hipEventDestroy(c->h2d_scanned[i]); }
     clear_segments(c);
     std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first);
     for (uint32_t p : passes) free_pass_outputs(c, p);
@@ -240,9 +251,14 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
     if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "gkc_configure must be called first");
     if (pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "pass %u >= nb_passes %u", pass, c->nb_passes);
     GKC_HIP(c, hipSetDevice(c->device));
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)");
     (void)hipStreamSynchronize(c->stream);
     clear_segments(c);
     free_pass_outputs(c, pass);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+    c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;        // the host sink holds ONE pass: the previous pass's records are overwritten from here on
+    for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; }
     for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
     c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
     if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, (size_t)c->nb_passes * ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
@@ -261,6 +277,11 @@ int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_off
     return gkc_scan_push(c, d_bases, d_offsets, n_reads, n_bases);
 }
 
+// Host buffers: the reads go to the device in chunks of about PUSH_CHUNK_BASES through two staging buffers — the H2D copy of chunk j+1
+// (copy stream, DMA engine) runs while Stage A scans chunk j, so a push costs max(PCIe, scan) instead of their sum. Page-locked caller
+// memory (gkc_host_alloc) makes the copies truly asynchronous; pageable memory works at the driver's staging rate. Each chunk is one
+// segment of the pass. The call returns when the caller's buffers have been read completely.
+static const uint64_t PUSH_CHUNK_BASES = getenv("GKC_PUSH_CHUNK") ? (uint64_t)std::max<long long>(64, atoll(getenv("GKC_PUSH_CHUNK"))) : (1ull << 30);   // GKC_PUSH_CHUNK: tests force many small chunks
 int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads)
 {
     if (!c) return GKC_ERR_ARG;
@@ -268,18 +289,51 @@ int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint6
     if (!offsets) GKC_FAIL(c, GKC_ERR_ARG, "offsets is required");
     if (offsets[0] != 0) GKC_FAIL(c, GKC_ERR_ARG, "offsets[0] must be 0");
     GKC_HIP(c, hipSetDevice(c->device));
-    const uint64_t n_bases = offsets[n_reads];
-    DevBuf db, dof;
-    GKC_TRY(c->ensure(db, (size_t)n_bases + 64));
-    int rc = c->ensure(dof, (size_t)(n_reads + 1) * 8);
-    if (rc != GKC_OK) { db.release(); return rc; }
-    hipError_t e = hipSuccess;
-    if (n_bases) e = hipMemcpyAsync(db.p, bases, (size_t)n_bases, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dof.p, offsets, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) { db.release(); dof.release(); GKC_FAIL(c, GKC_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e)); }
-    rc = gkc_push_reads_device(c, (const char*)db.p, (const uint64_t*)dof.p, n_reads, n_bases);
-    (void)hipStreamSynchronize(c->stream);
-    db.release(); dof.release();
+    if (!c->copy_stream) GKC_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        if (!c->h2d_copied[i]) GKC_HIP(c, hipEventCreateWithFlags(&c->h2d_copied[i], hipEventDisableTiming));
+        if (!c->h2d_scanned[i]) GKC_HIP(c, hipEventCreateWithFlags(&c->h2d_scanned[i], hipEventDisableTiming));
+    }
+    // chunk boundaries on read boundaries
+    std::vector<uint64_t> cut{0};
+    while (cut.back() < n_reads) {
+        const uint64_t r0 = cut.back();
+        const uint64_t* e = std::upper_bound(offsets + r0 + 1, offsets + n_reads + 1, offsets[r0] + PUSH_CHUNK_BASES);
+        uint64_t r1 = (uint64_t)(e - offsets) - 1;                // last read that still ends inside the budget
+        if (r1 <= r0) r1 = r0 + 1;                                // one read longer than the budget: alone
+        cut.push_back(std::min(r1, n_reads));
+    }
+    if (n_reads == 0) cut.push_back(0);
+    const size_t n_chunks = cut.size() - 1;
+    auto issue_copy = [&](size_t j) -> int {                      // chunk j -> staging buffer j & 1, on the copy stream
+        const int b = (int)(j & 1);
+        const uint64_t r0 = cut[j], r1 = cut[j + 1], nb = offsets[r1] - offsets[r0];
+        GKC_HIP(c, hipStreamWaitEvent(c->copy_stream, c->h2d_scanned[b], 0));      // the scan that read this buffer two chunks ago is over
+        GKC_TRY(c->ensure(c->h2d_bases[b], (size_t)std::max<uint64_t>(nb, PUSH_CHUNK_BASES / 4) + 64));
+        GKC_TRY(c->ensure(c->h2d_offs[b], (size_t)(r1 - r0 + 1) * 8));
+        if (nb) GKC_HIP(c, hipMemcpyAsync(c->h2d_bases[b].p, bases + offsets[r0], (size_t)nb, hipMemcpyHostToDevice, c->copy_stream));
+        GKC_HIP(c, hipMemcpyAsync(c->h2d_offs[b].p, offsets + r0, (size_t)(r1 - r0 + 1) * 8, hipMemcpyHostToDevice, c->copy_stream));
+        GKC_HIP(c, hipEventRecord(c->h2d_copied[b], c->copy_stream));
+        return GKC_OK;
+    };
+    int rc = n_chunks ? issue_copy(0) : GKC_OK;
+    for (size_t j = 0; rc == GKC_OK && j < n_chunks; j++) {
+        const int b = (int)(j & 1);
+        const uint64_t r0 = cut[j], r1 = cut[j + 1], nb = offsets[r1] - offsets[r0];
+        if (j + 1 < n_chunks) {                                   // the next chunk's copy must not overwrite a buffer whose scan is still running:
+            rc = issue_copy(j + 1);                               // it waits for h2d_scanned[(j+1)&1] (recorded after chunk j-1's scan) on the copy stream
+            if (rc != GKC_OK) break;
+        }
+        GKC_HIP(c, hipStreamWaitEvent(c->stream, c->h2d_copied[b], 0));
+        if (offsets[r0]) {
+            hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)((r1 - r0 + 1 + 255) / 256)), dim3(256), 0, c->stream, (uint64_t*)c->h2d_offs[b].p, r1 - r0 + 1, offsets[r0]);
+            GKC_HIP(c, hipGetLastError());
+        }
+        rc = gkc_push_reads_device(c, (const char*)c->h2d_bases[b].p, (const uint64_t*)c->h2d_offs[b].p, r1 - r0, nb);
+        if (hipEventRecord(c->h2d_scanned[b], c->stream) != hipSuccess) { (void)hipGetLastError(); }
+    }
+    (void)hipStreamSynchronize(c->copy_stream);                  // the caller's buffers are free again
+    if (rc != GKC_OK) (void)hipStreamSynchronize(c->stream);
     return rc;
 }
 
@@ -324,17 +378,76 @@ int gkc_count_mmers(gkc_ctx* c, uint32_t m, const char* bases, const uint64_t* o
     return rc;
 }
 
-int gkc_finish_pass(gkc_ctx* c)
+static int finish_pass_body(gkc_ctx* c)
 {
-    if (!c) return GKC_ERR_ARG;
-    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
-    GKC_HIP(c, hipSetDevice(c->device));
+    (void)hipSetDevice(c->device);
     int rc;
     {   ScopedTimer tm(c, "total_stage_b");
         rc = gkc_count_pass(c);
     }
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // streamed results have landed
+    if (rc == GKC_OK && c->sink_overflow) { c->set_error(GKC_ERR_CAPACITY, "the host sink (%llu bytes) is too small for the pass; the records that did not fit stay on the device (gkc_partition_counts)", (unsigned long long)c->sink_cap); }
+    return rc;
+}
+int gkc_finish_pass(gkc_ctx* c)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)");
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
+    GKC_HIP(c, hipSetDevice(c->device));
+    const int rc = finish_pass_body(c);
     if (rc != GKC_OK) return rc;
     c->in_pass = false;
+    return GKC_OK;
+}
+int gkc_finish_pass_async(gkc_ctx* c)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is already in flight");
+    if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
+    GKC_HIP(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    { std::lock_guard<std::mutex> lk(c->mu); c->stage_b_running = true; c->stage_b_rc = GKC_OK; }
+    c->stage_b_thread = std::thread([c] {
+        const int rc = finish_pass_body(c);
+        { std::lock_guard<std::mutex> lk(c->mu); c->stage_b_rc = rc; c->stage_b_running = false; }
+        c->cv_done.notify_all();
+    });
+    return GKC_OK;
+}
+int gkc_finish_pass_wait(gkc_ctx* c)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "no gkc_finish_pass_async in flight");
+    c->stage_b_thread.join();
+    if (c->stage_b_rc != GKC_OK) return c->stage_b_rc;
+    c->in_pass = false;
+    return GKC_OK;
+}
+int gkc_set_host_sink(gkc_ctx* c, void* pinned, uint64_t cap_bytes)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running) GKC_FAIL(c, GKC_ERR_ARG, "Stage B is running");
+    GKC_HIP(c, hipSetDevice(c->device));
+    if (pinned && !c->copy_stream) GKC_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    c->sink = pinned; c->sink_cap = pinned ? cap_bytes : 0; c->sink_used = 0; c->sink_overflow = false;
+    return GKC_OK;
+}
+int gkc_wait_partition(gkc_ctx* c, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (!c->configured || pass >= c->nb_passes || part >= c->nb_partitions) GKC_FAIL(c, GKC_ERR_ARG, "dataset (%u,%u) out of range", pass, part);
+    Dataset* D = &c->datasets[(size_t)pass * c->nb_partitions + part];
+    hipEvent_t ev = nullptr;
+    {   std::unique_lock<std::mutex> lk(c->mu);
+        c->cv_done.wait(lk, [&] { return D->done || !c->stage_b_running; });
+        if (!D->done) { lk.unlock(); GKC_FAIL(c, GKC_ERR_ARG, "dataset (%u,%u) was not counted (pass not run, or Stage B failed: %s)", pass, part, c->err.msg.c_str()); }
+        ev = D->landed;
+    }
+    if (ev) GKC_HIP(c, hipEventSynchronize(ev));
+    if (host_records) *host_records = D->h_counts;
+    if (n_solid) *n_solid = D->n_solid;
     return GKC_OK;
 }
 

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <thread>
 #include "../../include/gkc.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -127,6 +129,8 @@ struct Dataset {                          // result of (pass, part)
     const void* d_counts = nullptr;       // Count records (points into a pass-level output buffer)
     uint64_t n_solid = 0, n_distinct = 0, n_kmers = 0;
     bool done = false;
+    const void* h_counts = nullptr;       // the same records in the host sink (gkc_set_host_sink), valid once `landed` has completed
+    hipEvent_t landed = nullptr;          // D2H copy of the Stage-B batch this dataset belongs to (owned by the context's landed_events list)
 };
 
 struct Timing { double ms = 0; uint64_t launches = 0; };
@@ -166,6 +170,14 @@ struct gkc_ctx {
     int children = 0; bool closed = false;
     std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them
     gkc_stats& stats_now() { return pass_stats[pass]; }
+    // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted
+    void* sink = nullptr; uint64_t sink_cap = 0, sink_used = 0; bool sink_overflow = false;
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> landed_events;
+    std::condition_variable cv_done;       // a dataset finished / the pass ended (gkc_wait_partition)
+    std::thread stage_b_thread; bool stage_b_running = false; int stage_b_rc = GKC_OK;
+    // double-buffered host -> device staging of gkc_push_reads (H2D of chunk j+1 overlaps the scan of chunk j)
+    DevBuf h2d_bases[2], h2d_offs[2]; hipEvent_t h2d_copied[2] = {nullptr, nullptr}, h2d_scanned[2] = {nullptr, nullptr};
     std::mutex mu;                         // shared bookkeeping (timing, stats, outputs, error text) when Stage B runs two lanes
     hipStream_t lane_streams[3] = {nullptr, nullptr, nullptr};   // extra Stage-B lanes (created on first use)
     std::vector<uint8_t> pass_released;       // gkc_release_pass was called for the pass: whole-context consumers of the results refuse to run

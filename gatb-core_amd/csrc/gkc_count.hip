@@ -1657,13 +1657,31 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             CB_HIP(hipGetLastError());
         }
         CB_HIP(hipStreamSynchronize(cur_stream(c)));
-        for (uint32_t i = 0; i < nb; i++) {
-            Dataset& D = c->datasets[(size_t)c->pass * c->nb_partitions + batch_parts[i]];
-            const uint64_t s0 = ptot[2 * i + 1], s1 = ptot[2 * (i + 1) + 1];
-            D.d_counts = (const uint8_t*)out + s0 * OW * 8;
-            D.n_solid = s1 - s0; D.n_distinct = ptot[2 * (i + 1)] - ptot[2 * i]; D.n_kmers = part_keys[batch_parts[i]]; D.done = true;
-            { std::lock_guard<std::mutex> lk(c->mu); c->stats_now().kmers_nb_distinct += D.n_distinct; c->stats_now().kmers_nb_solid += D.n_solid; }
+        // streamed results: the batch's records go to the host sink on the copy stream while the lanes count the next batches
+        const uint8_t* h_base = nullptr; hipEvent_t landed = nullptr;
+        if (c->sink && total_solid) {
+            const uint64_t bytes = total_solid * OW * 8;
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (c->sink_used + bytes > c->sink_cap) c->sink_overflow = true;          // the records stay on the device (gkc_partition_counts still serves them)
+            else {
+                h_base = (const uint8_t*)c->sink + c->sink_used; c->sink_used += bytes;
+                if (hipEventCreateWithFlags(&landed, hipEventDisableTiming) == hipSuccess &&
+                    hipMemcpyAsync((void*)h_base, out, bytes, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess &&
+                    hipEventRecord(landed, c->copy_stream) == hipSuccess) c->landed_events.push_back(landed);
+                else { (void)hipGetLastError(); if (landed) (void)hipEventDestroy(landed); landed = nullptr; h_base = nullptr; c->sink_overflow = true; }
+            }
         }
+        {   std::lock_guard<std::mutex> lk(c->mu);
+            for (uint32_t i = 0; i < nb; i++) {
+                Dataset& D = c->datasets[(size_t)c->pass * c->nb_partitions + batch_parts[i]];
+                const uint64_t s0 = ptot[2 * i + 1], s1 = ptot[2 * (i + 1) + 1];
+                D.d_counts = (const uint8_t*)out + s0 * OW * 8;
+                D.h_counts = h_base ? h_base + s0 * OW * 8 : nullptr; D.landed = landed;
+                D.n_solid = s1 - s0; D.n_distinct = ptot[2 * (i + 1)] - ptot[2 * i]; D.n_kmers = part_keys[batch_parts[i]]; D.done = true;
+                c->stats_now().kmers_nb_distinct += D.n_distinct; c->stats_now().kmers_nb_solid += D.n_solid;
+            }
+        }
+        c->cv_done.notify_all();
     }
     B.release();
 #undef CB_TRY
@@ -1856,6 +1874,7 @@ int gkc_count_pass(gkc_ctx* c)
         for (auto& t : extra) t.join();
     }
     rc = first_rc;
+    c->cv_done.notify_all();
     if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] mallocs %llu failed %llu trims %llu, %.1f ms in hipMalloc, cached %.2f GB\n", (unsigned long long)c->pool.n_malloc,
                                           (unsigned long long)c->pool.n_fail, (unsigned long long)c->pool.n_trim, c->pool.malloc_ms, (double)c->pool.cached_bytes / 1e9);
     d_recptr.release(); d_recoff.release();

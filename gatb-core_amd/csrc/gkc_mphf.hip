@@ -296,7 +296,8 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
         // survivors of this level -> next list (stable)
         if (placed == global_alive) { alive = 0; continue; }
         if (!alive) continue;
-        GKC_TRY(c->ensure(flag, (size_t)(alive + 1) * 8)); GKC_TRY(c->ensure(*nxt, (size_t)std::max<uint64_t>(alive - placed, 1) * kb));
+        GKC_TRY(c->ensure(flag, (size_t)(alive + 1) * 8));
+        GKC_TRY(c->ensure(*nxt, (size_t)std::max<uint64_t>(comm ? alive : alive - placed, 1) * kb));     // `placed` counts all ranks' keys: with a communicator only `alive` bounds this rank's survivors
         const unsigned g1 = (unsigned)((alive + MPHF_THREADS - 1) / MPHF_THREADS);
         hipLaunchKernelGGL(k_mphf_flag, dim3(g1), dim3(MPHF_THREADS), 0, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], (const uint32_t*)lbits, (uint64_t*)flag.p);
         GKC_TRY(ms_scan(c, (uint64_t*)flag.p, alive, (uint64_t*)d_tot.p + 1, scratch));

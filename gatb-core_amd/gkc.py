@@ -28,6 +28,7 @@ SYMBOLS = [
     "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_destroy", "gkc_comm_set_owners",
     "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
     "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
+    "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
 ]
 
 
@@ -146,6 +147,10 @@ def lib():
         "gkc_bloom_allreduce_or": (C.c_int, [vp, vp]),
         "gkc_mphf_build_solid_dist": (C.c_int, [vp, vp, P(vp)]),
         "gkc_mphf_abundance_map_dist": (C.c_int, [vp, vp, vp, vp, u64, P(u64)]),
+        "gkc_set_host_sink": (C.c_int, [vp, vp, u64]),
+        "gkc_finish_pass_async": (C.c_int, [vp]),
+        "gkc_wait_partition": (C.c_int, [vp, u32, u32, P(vp), P(u64)]),
+        "gkc_finish_pass_wait": (C.c_int, [vp]),
         "gkc_exchange_plan": (C.c_int, [C.c_int, C.c_int, u32, vp, vp, u64, vp, P(PlanMsg), P(u32), P(PlanMsg), P(u32), P(u64)]),
     }
     for name in SYMBOLS:
@@ -277,6 +282,26 @@ class Counter:
 
     def finish_pass(self):
         self._chk(self.L.gkc_finish_pass(self.h))
+
+    def set_host_sink(self, host_buffer):
+        """stream every Stage-B batch's records into ``host_buffer`` (a HostBuffer: page-locked) while Stage B runs; None switches it off"""
+        self._sink = host_buffer
+        self._chk(self.L.gkc_set_host_sink(self.h, None if host_buffer is None else host_buffer._p, 0 if host_buffer is None else host_buffer.nbytes))
+
+    def finish_pass_async(self):
+        self._chk(self.L.gkc_finish_pass_async(self.h))
+
+    def finish_pass_wait(self):
+        self._chk(self.L.gkc_finish_pass_wait(self.h))
+
+    def wait_partition(self, pass_, part):
+        """-> (uint8 view of the partition's Count records inside the host sink or None, n_solid) once they have landed"""
+        p = C.c_void_p(); n = C.c_uint64()
+        self._chk(self.L.gkc_wait_partition(self.h, pass_, part, C.byref(p), C.byref(n)))
+        if not p.value or not n.value:
+            return None, n.value
+        off = p.value - self._sink._p.value
+        return self._sink.a[off: off + n.value * self.rec_bytes], n.value
 
     def release_pass(self, p):
         """gives the result buffers of a finished (and drained) pass back"""

@@ -458,6 +458,8 @@ public:
     bool process(size_t, const Type&, const CountVector&, CountNumber sum) { (*_shared)[(size_t)sum >= _length ? _length : (size_t)sum]++; return true; }
     std::string getName() const { return "histogram"; }
     const std::vector<uint64_t>& getHistogram() const { return *_shared; }
+    /** EXTENSION (device-assisted chain): the abundance histogram the device accumulated while counting (gkc_histogram) */
+    void addCounts(const uint64_t* h, size_t nBins) { for (size_t i = 0; i < nBins && i <= _length; i++) (*_shared)[i] += h[i]; }
 
     /** Histogram::compute_threshold (tools/misc/impl/Histogram.cpp:61-190): smoothed histogram, first increase, first peak after it, cutoff =
      *  the minimum between them, capped where 25 % of the k-mer volume would be eliminated, floored by min_auto_threshold */
@@ -513,6 +515,9 @@ public:
         tools::misc::Properties p; p.add("kmers_nb_distinct", "%llu", (unsigned long long)_shared->total); p.add("kmers_nb_solid", "%llu", (unsigned long long)_shared->ok);
         p.add("kmers_nb_weak", "%llu", (unsigned long long)(_shared->total - _shared->ok)); return p; }
     const Totals& totals() const { return *_shared; }
+    /** EXTENSION (device-assisted chain): totals of a pass whose solidity window was applied on the device */
+    void addTotals(uint64_t total, uint64_t ok) { _shared->total += total; _shared->ok += ok; }
+    CountNumber getAbundanceMax() const { return _max; }
     /** CountProcessorSolidityInfo::setAbundanceMin (CountProcessorSolidity.hpp:60-75): the automatic cutoff arrives after the cutoff processor's pass */
     void setAbundanceMin(CountNumber m) { _min = m; }
     CountNumber getAbundanceMin() const { return _min; }
@@ -793,9 +798,51 @@ public:
                 return p;
             }
         } pin, pin_narrow;
+        // Device-assisted default chain: when the processors are exactly the default histogram -> solidity(sum) -> dump chain, the
+        // solidity window and the histogram are applied on the device (gkc_set_solidity / gkc_histogram) and only SOLID records cross PCIe, streamed
+        // into a page-locked sink while Stage B is still counting (gkc_set_host_sink, gkc_finish_pass_async, gkc_wait_partition): the dump clones
+        // get whole ascending Count[] blocks in partition order. Any other processor set sees every distinct k-mer through the generic path below.
+        CountProcessorHistogram<span>* devHisto = nullptr; CountProcessorSoliditySum<span>* devSol = nullptr;
+        if (_deviceChain) { auto* ch = static_cast<CountProcessorChain<span>*>(_processors[0]); devHisto = ch->template get<CountProcessorHistogram<span>>(); devSol = ch->template get<CountProcessorSoliditySum<span>>(); }
+        Pinned sinkMem;
+        if (_deviceChain) {
+            const uint64_t capMB = _params.has("-host-sink-mb") ? (uint64_t)_params.getInt("-host-sink-mb") : 16384;
+            const uint64_t bound = (_config._kmersNb / std::max<uint32_t>(_config._nb_passes, 1) + 4096) * sizeof(Count);       // every k-mer distinct and solid
+            const uint64_t want = std::max<uint64_t>(std::min<uint64_t>(bound, capMB << 20), 1 << 20);
+            void* sp = nullptr;
+            for (uint64_t b = want; !sp && b >= (1 << 20); b /= 2) if (gkc_host_alloc(&sp, b) == GKC_OK) { sinkMem.p = sp; sinkMem.bytes = (size_t)b; }
+            if (sinkMem.p) check(gkc_set_host_sink(_ctx, sinkMem.p, sinkMem.bytes));
+        }
         for (uint32_t pass = 0; pass < _config._nb_passes; pass++) {
             check(gkc_begin_pass(_ctx, pass));
             if (!pushText(pass)) check(gkc_push_reads(_ctx, bases().data(), offs().data(), offs().size() - 1));   // fillPartitions
+            if (_deviceChain) {
+                check(gkc_finish_pass_async(_ctx));                                                   // fillSolidKmers: Stage B runs while the clones below are fed
+                CountProcessor* proc = _processors[0];
+                proc->beginPass(pass);
+                std::vector<CountProcessor*> clones;
+                try {
+                    for (uint32_t p = 0; p < P; p++) {
+                        const void* hp = nullptr; uint64_t ns = 0;
+                        check(gkc_wait_partition(_ctx, pass, p, &hp, &ns));
+                        const Count* buf = static_cast<const Count*>(hp);
+                        if (!buf && ns) {                                                             // did not fit the sink: plain fetch
+                            Count* b2 = static_cast<Count*>(pin.need((size_t)ns * sizeof(Count))); uint64_t got = 0;
+                            check(gkc_partition_counts(_ctx, pass, p, b2, ns, &got)); buf = b2;
+                        }
+                        CountProcessor* clone = proc->clone(); clone->use(); clones.push_back(clone);
+                        clone->beginPart(pass, p, 4096, "vector");
+                        if (ns) static_cast<CountProcessorChain<span>*>(clone)->template get<CountProcessorDump<span>>()->processBulk(p, buf, (size_t)ns);
+                        clone->endPart(pass, p);
+                    }
+                } catch (...) { (void)gkc_finish_pass_wait(_ctx); for (auto* c : clones) c->forget(); throw; }
+                check(gkc_finish_pass_wait(_ctx));
+                proc->finishClones(clones);
+                for (auto* c : clones) c->forget();
+                proc->endPass(pass);
+                if (_releasePasses) check(gkc_release_pass(_ctx, pass));
+                continue;
+            }
             check(gkc_finish_pass(_ctx));                                                             // fillSolidKmers (device part)
             for (auto* proc : _processors) {
                 proc->beginPass(pass);
@@ -833,6 +880,14 @@ public:
             }
             if (_releasePasses) check(gkc_release_pass(_ctx, pass));                                 // every processor has seen the pass: its results leave the HBM
         }
+        if (_deviceChain) {
+            check(gkc_set_host_sink(_ctx, nullptr, 0));
+            std::vector<uint64_t> h((size_t)_config._histo_max + 1, 0);
+            check(gkc_histogram(_ctx, h.data(), (uint32_t)h.size()));
+            devHisto->addCounts(h.data(), h.size());
+            gkc_stats st0; check(gkc_get_stats(_ctx, &st0));
+            devSol->addTotals(st0.kmers_nb_distinct, st0.kmers_nb_solid);
+        }
         for (auto* p : _processors) p->end();
         gkc_stats st; check(gkc_get_stats(_ctx, &st));
         _info.add("kmers_nb_valid", "%llu", (unsigned long long)st.kmers_nb_valid);
@@ -840,6 +895,15 @@ public:
         _info.add("nb_partitions", "%u", P); _info.add("nb_passes", "%u", _config._nb_passes);
         _info.add("nb_superkmers", "%llu", (unsigned long long)st.nb_superkmers);
         _info.add("seq_number", "%llu", (unsigned long long)st.nb_sequences);
+        {   // the time keys consumers read (SortingCountAlgorithm.cpp:777-780: getTimeInfo() "fill_partitions" / "fill_solid_kmers", _fillTimeInfo
+            // "1.read" / "2.sort" / "3.dump"), in seconds, from the device's own event timers (gkc_get_timing)
+            auto ms = [&](const char* n) { double v = 0; uint64_t l = 0; (void)gkc_get_timing(_ctx, n, &v, &l); return v; };
+            _info.add("fill_partitions", "%.3f", ms("total_stage_a") / 1e3);
+            _info.add("fill_solid_kmers", "%.3f", ms("total_stage_b") / 1e3);
+            _info.add("1.read", "%.3f", (ms("expand_count") + ms("expand_scatter")) / 1e3);
+            _info.add("2.sort", "%.3f", (ms("bucket_sort") + ms("bucket_sort_big") + ms("bucket_sort_wg") + ms("bucket_sort_deep") + ms("split_levels")) / 1e3);
+            _info.add("3.dump", "%.3f", ms("compact") / 1e3);
+        }
         // the solidity processor sees every distinct k-mer (the device returns all of them; filtering is the chain's job)
         for (auto* p : _processors) if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(p)) if (auto* s = ch->template get<CountProcessorSoliditySum<span>>()) {
             _info.add("kmers_nb_distinct", "%llu", (unsigned long long)s->totals().total); _info.add("kmers_nb_solid", "%llu", (unsigned long long)s->totals().ok); }
@@ -871,6 +935,7 @@ private:
 
     /** configure(), SortingCountAlgorithm.cpp:525-625 + ConfigurationAlgorithm.cpp:245-467 (GPU-aware partition count) */
     void configure() {
+        if (_ctx) { gkc_destroy(_ctx); _ctx = nullptr; }                         // execute() called again: the previous run's context goes (objects built from it keep it alive)
         int rc = gkc_create((int)(_params.has(STR_GPU_DEVICE) ? _params.getInt(STR_GPU_DEVICE) : 0), &_ctx);
         if (rc != GKC_OK) throw system::Exception("gkc_create failed (%d): %s", rc, gkc_last_error(nullptr));
         if (!_config._isComputed) {
@@ -913,8 +978,22 @@ private:
         const size_t m = _config._minim_size; const uint32_t P = _config._nb_partitions;
         if (!_repartitor) { _repartitor = buildRepartitor(m, P); _repartitor->use(); }
         if (_processors.empty()) for (CountProcessor* p : getDefaultProcessorVector(_config)) { p->use(); _processors.push_back(p); }
-        // the device returns every distinct k-mer; histogram / solidity / dump stay in the processor chain (drop-in behaviour)
-        check(gkc_set_solidity(_ctx, 1, 2147483647, _config._histo_max));
+        // default chain, fixed abundance window, Count records as wide as the device's: the window and the histogram are applied on the device and only
+        // solid records travel (execute()); otherwise the device returns every distinct k-mer and the processors filter (drop-in behaviour for any chain)
+        _deviceChain = false;
+        {   const bool dev16 = _config._kmerSize <= 31;
+            const bool same = dev16 ? sizeof(Count) == 16 : (sizeof(Count) == 32 && sizeof(Type) == 16);
+            if (same && _processors.size() == 1 && _config._abundance_min >= 1 && !(_params.has("-host-chain") && _params.getInt("-host-chain")))
+                if (auto* ch = dynamic_cast<CountProcessorChain<span>*>(_processors[0])) {
+                    const auto& it = ch->items();
+                    if (it.size() == 3 && dynamic_cast<CountProcessorHistogram<span>*>(it[0]) && dynamic_cast<CountProcessorSoliditySum<span>*>(it[1]) && dynamic_cast<CountProcessorDump<span>*>(it[2]))
+                        _deviceChain = true;
+                }
+        }
+        if (_deviceChain) {
+            auto* sol = static_cast<CountProcessorChain<span>*>(_processors[0])->template get<CountProcessorSoliditySum<span>>();
+            check(gkc_set_solidity(_ctx, sol->getAbundanceMin(), sol->getAbundanceMax(), _config._histo_max));
+        } else check(gkc_set_solidity(_ctx, 1, 2147483647, _config._histo_max));
         check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, P, _config._nb_passes, _repartitor->getMinimizerFrequencies() ? GKC_MINIMIZER_FREQ : GKC_MINIMIZER_LEXI,
                             _repartitor->getTable().data(), _repartitor->getMinimizerFrequencies()));
     }
@@ -950,7 +1029,7 @@ private:
     }
 
     bank::IBank* _bank; tools::misc::Properties _params; Configuration _config; Repartitor* _repartitor;
-    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx; bool _textRefused; bool _releasePasses = false;
+    std::vector<CountProcessor*> _processors; tools::misc::Properties _info; gkc_ctx* _ctx; bool _textRefused; bool _releasePasses = false; bool _deviceChain = false;
 };
 
 }}  // namespace kmer::impl

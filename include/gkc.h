@@ -93,6 +93,21 @@ int gkc_push_reads_device(gkc_ctx* ctx, const char* d_bases, const uint64_t* d_o
  * histogram -> solidity -> dump (CountProcessorChain.hpp:128-135). Results stay in HBM until fetched. */
 int gkc_finish_pass(gkc_ctx* ctx);
 
+/* Streamed results (the wall ends when the last partition's Count[] is in host memory). With a host sink set, every Stage-B
+ * batch is copied into it on a copy stream as soon as it is compacted, while the next batches are counted: the reference's sink it stands
+ * in for is CountProcessorDump -> BagCache -> CollectionHDF5Patch (CountProcessorDump.hpp:148-152, CollectionHDF5Patch.hpp:262-308), fed per
+ * partition by the dump threads. The sink must be page-locked (gkc_host_alloc) and holds ONE pass (gkc_begin_pass rewinds it); what does
+ * not fit stays on the device and gkc_finish_pass reports GKC_ERR_CAPACITY in gkc_last_error while still returning 0 records lost.
+ *   gkc_finish_pass_async : Stage B on a worker thread of the library; returns at once.
+ *   gkc_wait_partition    : blocks until dataset (pass, part) is counted and, with a sink, has landed; *host_records points into the sink
+ *                           (NULL without a sink / for what did not fit). Partitions complete in ascending order inside a batch, batches in
+ *                           ascending order per lane: a consumer walking the partitions in order overlaps its work with Stage B.
+ *   gkc_finish_pass_wait  : joins the worker; the pass is finished like after gkc_finish_pass. */
+int gkc_set_host_sink(gkc_ctx* ctx, void* pinned_host, uint64_t cap_bytes);     /* NULL: no sink */
+int gkc_finish_pass_async(gkc_ctx* ctx);
+int gkc_wait_partition(gkc_ctx* ctx, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid);
+int gkc_finish_pass_wait(gkc_ctx* ctx);
+
 /* Result of dataset (part + pass*nb_partitions) (CountProcessorDump.hpp:131): ascending Count records of the SOLID
  * k-mers, in the exact in-memory layout of Kmer<span>::Count so the host can pass whole arrays to
  * Bag<Count>::insert(const Item*, len) (tools/storage/impl/CollectionHDF5Patch.hpp:262). */

@@ -1,0 +1,65 @@
+#!/bin/bash
+# Compile check of the reference-side binding (integration/gatb_device/*.hpp + SortingCountAlgorithm.device.patch) AGAINST THE REFERENCE.
+#   integration/check_integration.sh [scratch dir] [--link [gatb build dir with lib/Release/libgatbcore.a]]
+# 1. runs the reference's cmake CONFIGURE step in the scratch dir (generates gatb/system/api/config.hpp and the HDF5 configuration headers;
+#    nothing is built, the reference tree is not written);
+# 2. applies the patch to a scratch copy of SortingCountAlgorithm.cpp (integration/make_patched_sources.py);
+# 3. g++ -fsyntax-only of the reference's own template instantiation unit (template/TemplateSpecialization2.cpp.in: SortingCountAlgorithm +
+#    PartitionsCommand) for spans 32 and 64 with -DGATB_WITH_DEVICE_COUNTING, plus explicit instantiations of PartitionsByDeviceCommand and
+#    of BloomDevice<LargeInt<1>>, <LargeInt<2>>;
+# 4. --link: compiles those units for the four spans and links a patched dbgh5 against libgatbcore.a, libhdf5.a and libgkc_hip.so
+#    (link only: running it needs a GPU).
+# This is a compile check in the build container, not an oracle: nothing it produces is used by the tests of the hot path.
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd); REPO=$(dirname "$HERE")
+REF=${GATB_REFERENCE:-/root/reference/gatb-core}
+SCRATCH=${1:-/tmp/gkc_integration}; shift || true
+LINK=0; LIBDIR=""
+if [ "$1" == "--link" ]; then LINK=1; LIBDIR=${2:-/tmp/gatb_build}; fi
+test -d "$REF/src/gatb" || { echo "reference not found at $REF"; exit 3; }
+mkdir -p "$SCRATCH/cfg" "$SCRATCH/inc" "$SCRATCH/obj"
+if [ ! -f "$SCRATCH/cfg/include/gatb/system/api/config.hpp" ]; then
+  (cd "$SCRATCH/cfg" && cmake -DCMAKE_BUILD_TYPE=Release -DGATB_CORE_EXCLUDE_EXAMPLES=1 "$REF" > cmake.log 2>&1) || { tail -20 "$SCRATCH/cfg/cmake.log"; exit 4; }
+fi
+python3 "$HERE/make_patched_sources.py" "$REF" "$SCRATCH/inc" > /dev/null
+# <hdf5/hdf5.h>: the reference's build copies the vendored HDF5 headers under include/Release/hdf5; a configure-only tree has them in two
+# places (sources + the generated H5pubconf.h) -> a directory of symbolic links stands in for that copy step
+mkdir -p "$SCRATCH/inc_hdf5/hdf5"
+for h in "$REF"/thirdparty/hdf5/src/*.h "$SCRATCH"/cfg/thirdparty/hdf5/H5pubconf.h; do ln -sf "$h" "$SCRATCH/inc_hdf5/hdf5/$(basename "$h")"; done
+INC="-I$SCRATCH/inc -I$SCRATCH/inc_hdf5 -I$HERE -I$REPO/include -I$SCRATCH/cfg/include -I$SCRATCH/cfg/include/Release -I$REF/src -I$REF/thirdparty"
+FLAGS="-msse2 -msse4.2 -mpopcnt -std=c++11 -DNDEBUG -DINT128_FOUND -Wno-invalid-offsetof -Wno-unknown-pragmas -Wno-format -DGATB_WITH_DEVICE_COUNTING"
+for K in 32 64 96 128; do
+  { sed "s/\${KSIZE}/$K/g" "$REF/src/gatb/template/TemplateSpecialization2.cpp.in"
+    echo "namespace gatb { namespace core { namespace kmer { namespace impl { template class PartitionsByDeviceCommand<$K>; } } } }"; } > "$SCRATCH/obj/ts2_$K.cpp"
+done
+cat > "$SCRATCH/obj/bloom_device.cpp" <<EOT
+#include <gatb_device/BloomDevice.hpp>
+#include <gatb/tools/math/LargeInt.hpp>
+namespace gatb { namespace core { namespace tools { namespace collections { namespace impl {
+template class BloomDevice<gatb::core::tools::math::LargeInt<1> >;
+template class BloomDevice<gatb::core::tools::math::LargeInt<2> >;
+} } } } }
+EOT
+echo "[check_integration] syntax: SortingCountAlgorithm + PartitionsByDeviceCommand (spans 32, 64), BloomDevice"
+pids=""
+for f in ts2_32 ts2_64 bloom_device; do g++ $FLAGS $INC -fsyntax-only "$SCRATCH/obj/$f.cpp" > "$SCRATCH/obj/$f.log" 2>&1 & pids="$pids $!"; done
+rc=0; for p in $pids; do wait $p || rc=1; done
+for f in ts2_32 ts2_64 bloom_device; do grep -E "error" "$SCRATCH/obj/$f.log" | head -20 || true; done
+[ $rc -eq 0 ] || { echo "[check_integration] SYNTAX CHECK FAILED"; exit 1; }
+echo "[check_integration] syntax ok"
+if [ $LINK -eq 1 ]; then
+  test -f "$LIBDIR/lib/Release/libgatbcore.a" || { echo "no libgatbcore.a under $LIBDIR (build the reference with its own cmake first)"; exit 5; }
+  test -f "$REPO/gatb-core_amd/csrc/libgkc_hip.so" || { echo "libgkc_hip.so missing"; exit 6; }
+  echo "[check_integration] compiling the patched instantiation units (4 spans) and dbgh5"
+  pids=""
+  for K in 32 64 96 128; do g++ $FLAGS -O1 $INC -c "$SCRATCH/obj/ts2_$K.cpp" -o "$SCRATCH/obj/ts2_$K.o" > "$SCRATCH/obj/ts2_$K.clog" 2>&1 & pids="$pids $!"; done
+  g++ $FLAGS -O1 $INC -c "$REF/tools/dbgh5.cpp" -o "$SCRATCH/obj/dbgh5.o" > "$SCRATCH/obj/dbgh5.clog" 2>&1 & pids="$pids $!"
+  rc=0; for p in $pids; do wait $p || rc=1; done
+  [ $rc -eq 0 ] || { grep -h error "$SCRATCH"/obj/*.clog | head; echo "[check_integration] COMPILE FAILED"; exit 1; }
+  g++ -o "$SCRATCH/dbgh5_device" "$SCRATCH/obj/dbgh5.o" "$SCRATCH"/obj/ts2_32.o "$SCRATCH"/obj/ts2_64.o "$SCRATCH"/obj/ts2_96.o "$SCRATCH"/obj/ts2_128.o \
+      "$LIBDIR/lib/Release/libgatbcore.a" "$LIBDIR/lib/Release/libhdf5.a" -L"$REPO/gatb-core_amd/csrc" -lgkc_hip -Wl,-rpath,"$REPO/gatb-core_amd/csrc" -Wl,-rpath,/opt/rocm/lib \
+      -ldl -lpthread -lz -lm > "$SCRATCH/obj/link.log" 2>&1 || { head -30 "$SCRATCH/obj/link.log"; echo "[check_integration] LINK FAILED"; exit 1; }
+  nm -C "$SCRATCH/dbgh5_device" | grep -c "PartitionsByDeviceCommand" | sed 's/^/[check_integration] PartitionsByDeviceCommand symbols in the patched dbgh5: /'
+  nm -D "$SCRATCH/dbgh5_device" | grep -E " U gkc_" | sed 's/^/[check_integration] imports /'
+  echo "[check_integration] link ok: $SCRATCH/dbgh5_device"
+fi

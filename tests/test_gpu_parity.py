@@ -506,3 +506,66 @@ def test_repartitor_sampling_statistics(gkc):
     for r in reads:
         L.gko_count_mmers(r, len(r), m, exp)
     assert np.array_equal(cnt, exp)
+
+
+def test_streamed_results_land_in_the_host_sink(gkc):
+    """gkc_set_host_sink + gkc_finish_pass_async + gkc_wait_partition: every partition's Count[] arrives in page-locked host memory while Stage B
+    runs, byte-identical to gkc_partition_counts; a sink that is too small keeps the rest on the device and says so"""
+    reads = synth_reads(6000, 30000, 150, seed=61, n_rate=0.001, ragged=True)
+    bases, offs = gko.pack_reads(reads)
+    k, m, parts = 31, 9, 32
+    rep = simple_repart(m, parts)
+    c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(2, 2147483647, 10000)
+    sink = gkc.HostBuffer(64 << 20)
+    c.set_host_sink(sink)
+    c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass_async()
+    got = {}
+    for p in range(parts):                                   # consumer walks the partitions in order while Stage B runs
+        view, n = c.wait_partition(0, p)
+        got[p] = (None if view is None else view.copy(), n)
+    c.finish_pass_wait()
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, abundance_min=2)
+    total = 0
+    for p in range(parts):
+        dev = c.partition_records(0, p)
+        view, n = got[p]
+        assert n * 16 == len(dev) and np.array_equal(dev, ref.part_records(p))
+        if n:
+            assert view is not None and np.array_equal(view, dev)
+        total += n
+    assert total == ref.stats["kmers_nb_solid"]
+    # too small a sink: nothing is lost, the records stay fetchable from the device
+    tiny = gkc.HostBuffer(4096)
+    c.set_host_sink(tiny)
+    c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
+    assert b"sink" in (c.L.gkc_last_error(c.h) or b"")
+    for p in range(parts):
+        assert np.array_equal(c.partition_records(0, p), ref.part_records(p))
+    c.set_host_sink(None)
+
+
+def test_push_reads_in_overlapped_chunks(gkc):
+    """gkc_push_reads sends host reads in chunks through two staging buffers (H2D of chunk j+1 under the scan of chunk j): forced to many
+    small chunks (GKC_PUSH_CHUNK) the counts must not change, whatever the read boundaries"""
+    import os, subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+from oracle import gko
+from tests.util import simple_repart, synth_reads
+gkc = ge.load().gkc
+reads = synth_reads(2500, 20000, 150, seed=71, n_rate=0.002, ragged=True)
+bases, offs = gko.pack_reads(reads)
+k, m, parts = 31, 8, 8
+rep = simple_repart(m, parts)
+c = gkc.Counter(0); c.configure(k, m, parts, rep); c.count(bases, offs)
+ref = gko.Dsk(bases, offs, k, m, parts, rep)
+ok = all(np.array_equal(c.partition_records(0, p), ref.part_records(p)) for p in range(parts))
+print(json.dumps({"ok": bool(ok), "segments": c.stats()["nb_sequences"] == len(reads), "valid": c.stats()["kmers_nb_valid"] == ref.stats["kmers_nb_valid"]}))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GKC_PUSH_CHUNK="7000")            # ~54 chunks of this input
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res == {"ok": True, "segments": True, "valid": True}, res

@@ -1,0 +1,48 @@
+"""The reference-side binding really compiles against the reference: integration/check_integration.sh runs the reference's
+cmake CONFIGURE step in a scratch directory (to generate config.hpp), patches a scratch copy of SortingCountAlgorithm.cpp and runs
+g++ -fsyntax-only over the reference's own instantiation unit (SortingCountAlgorithm + PartitionsCommand, spans 32 and 64) with
+PartitionsByDeviceCommand, and over BloomDevice<LargeInt<1>>, <LargeInt<2>>. Needs /root/reference (build container only): skipped
+elsewhere. The link step (patched dbgh5 against libgatbcore.a + libgkc_hip.so) runs when a built reference library is at hand."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("GATB_REFERENCE", "/root/reference/gatb-core")
+SCRIPT = os.path.join(ROOT, "integration", "check_integration.sh")
+
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "gatb")) or shutil.which("cmake") is None or shutil.which("g++") is None,
+                               reason="reference sources / cmake / g++ not available here")
+
+
+@needs_ref
+def test_binding_compiles_against_the_reference_headers(tmp_path_factory):
+    scratch = os.environ.get("GKC_INTEGRATION_SCRATCH", "/tmp/gkc_integration")
+    out = subprocess.run(["bash", SCRIPT, scratch], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "syntax ok" in out.stdout
+
+
+@needs_ref
+def test_patch_file_is_what_the_generator_produces():
+    """integration/SortingCountAlgorithm.device.patch is the diff of the anchored edits (make_patched_sources.py) — and applies to the reference"""
+    import difflib, importlib.util
+    spec = importlib.util.spec_from_file_location("mps", os.path.join(ROOT, "integration", "make_patched_sources.py"))
+    mps = importlib.util.module_from_spec(spec); spec.loader.exec_module(mps)
+    src = open(os.path.join(REF, mps.REL)).read()
+    new = mps.patch(src)
+    diff = "".join(difflib.unified_diff(src.splitlines(True), new.splitlines(True), "a/" + mps.REL, "b/" + mps.REL, n=1))
+    assert diff == open(os.path.join(ROOT, "integration", "SortingCountAlgorithm.device.patch")).read()
+    assert new.count("GATB_WITH_DEVICE_COUNTING") >= 4 and "PartitionsByDeviceCommand<span>" in new
+
+
+@needs_ref
+@pytest.mark.skipif(not os.path.exists(os.environ.get("GATB_BUILD_DIR", "/tmp/gatb_build") + "/lib/Release/libgatbcore.a"),
+                    reason="no built reference library (lib/Release/libgatbcore.a) to link against")
+def test_patched_dbgh5_links_against_libgkc():
+    scratch = os.environ.get("GKC_INTEGRATION_SCRATCH", "/tmp/gkc_integration")
+    out = subprocess.run(["bash", SCRIPT, scratch, "--link", os.environ.get("GATB_BUILD_DIR", "/tmp/gatb_build")], capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "link ok" in out.stdout and "U gkc_wait_partition" in out.stdout and "U gkc_push_reads" in out.stdout
