@@ -43,52 +43,30 @@ def algorithmic_bytes_per_kmer(k, L, nbar, d):
     return b_in + 2 * b_sk + W + 2 * W * P + W + W + R * d
 
 
-def cpu_baseline(k, m, parts, rep, seconds_target=12.0):
-    """the oracle (a scalar C port of the reference algorithm) timed on rank 0's host cores on a bounded sample: first one thread,
-    then one independent copy of the same job per core at once (no merge step between them: an upper bound for a parallel port)"""
-    import threading
+def cpu_baseline(c, k, m, parts, rep, n_reads=10_000_000):
+    """The CPU port (oracle/gkc_oracle.c: the reference's algorithm restated in C) run as a REAL parallel DSK on all host cores of rank 0 — reads
+    shared out over the threads for fillPartitions, partitions dealt to the threads for fillSolidKmers, like the reference's Dispatcher
+    (gko_dsk_run_mt; SortingCountAlgorithm.cpp:1266-1275, 1456-1587) — on a bounded sample of the same synthetic stream (generated on the device,
+    copied to the host before the clock starts). kind "port": the reference itself cannot be built under this project's build rules."""
     from oracle import gko
-    gkc = ge.load().gkc
-    n = 100_000
-    bases, offs = gkc.synth_reads_np(1, n, 150, n * 5, 10000)
+    L = 150
+    cores = os.cpu_count() or 1
+    d_b, d_o = c.synth_reads_device(1, n_reads, L, n_reads * 5, 10000)
+    bases = c.device_to_host(d_b, n_reads * L); offs = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
+    c.device_free(d_b); c.device_free(d_o)
+    n1 = min(n_reads, 500_000)
     t0 = time.time()
-    d = gko.Dsk(bases, offs, k, m, parts, rep)
+    d1 = gko.Dsk(bases[: n1 * L], offs[: n1 + 1], k, m, parts, rep)
+    dt1 = time.time() - t0
+    single = d1.stats["kmers_nb_distinct"] / dt1
+    del d1
+    t0 = time.time()
+    d = gko.Dsk(bases, offs, k, m, parts, rep, threads=cores)
     dt = time.time() - t0
-    # scale the sample once so that a single-thread run takes ~seconds_target / 2
-    n2 = int(min(1_000_000, max(n, n * (seconds_target / 2) / max(dt, 1e-3))))
-    if n2 > 1.5 * n:
-        bases, offs = gkc.synth_reads_np(1, n2, 150, n2 * 5, 10000)
-        t0 = time.time()
-        d = gko.Dsk(bases, offs, k, m, parts, rep)
-        dt = time.time() - t0
-        n = n2
-    single = d.stats["kmers_nb_distinct"] / dt
-    # all cores: a SMALL sample per thread (an oracle run holds every k-mer of its sample: ~0.3 GB per 50 000 reads), thread count bounded
-    # by the cores (at most 32, see below) and by the memory that is available (2 GB per thread) — this leg must never be able to exhaust the host
-    n_mt = 50_000
-    mb, mo = gkc.synth_reads_np(1, n_mt, 150, n_mt * 5, 10000)
-    avail_gb = 8.0
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable:"):
-                avail_gb = int(line.split()[1]) / 1e6
-    except Exception:
-        pass
-    cores = int(max(1, min(os.cpu_count() or 1, 32, avail_gb // 2)))      # measured on the 256-core GPU box (tools/cpu_threads_probe.py): the aggregate rate of this
-                                                                            # port stops growing at 16-32 threads (1.3e8 distinct k-mers/s), more threads lower it
-    reps = 4
-    res = [0] * cores
-    def work(i):
-        for _ in range(reps):
-            res[i] += gko.Dsk(mb, mo, k, m, parts, rep).stats["kmers_nb_distinct"]             # ctypes releases the GIL
-    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    t0 = time.time()
-    [t.start() for t in th]; [t.join() for t in th]
-    dt_all = time.time() - t0
-    return {"value": sum(res) / dt_all, "unit": "distinct k-mers/s", "cores": cores, "kind": "port",
-            "sample": "oracle/gkc_oracle.c on synthetic 150 bp reads (same generator, seed 1, 30x): one thread, %d reads, %.1f s = %.3g distinct k-mers/s; "
-                      "%d threads x %d runs of %d reads each, %.1f s (aggregate rate of independent runs, no merge between threads; %d host cores)"
-                      % (n, dt, single, cores, reps, n_mt, dt_all, os.cpu_count() or 0),
+    return {"value": d.stats["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s", "cores": cores, "kind": "port",
+            "valid_kmers_per_s": d.stats["kmers_nb_valid"] / dt,
+            "sample": "oracle/gkc_oracle.c gko_dsk_run_mt, %d threads (all host cores), %d synthetic 150 bp reads (same generator, seed 1, 30x, %d partitions): %.1f s; "
+                      "one thread on the first %d reads: %.1f s = %.3g distinct k-mers/s" % (cores, n_reads, parts, dt, n1, dt1, single),
             "single_thread": single}
 
 
@@ -171,6 +149,7 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-k63", action="store_true", help="skip the second block (BASELINE configs[3]: k=63 at the same size)")
     ap.add_argument("--no-host-landed", action="store_true", help="skip the host-landed leg (results streamed into page-locked host memory)")
     ap.add_argument("--pushes", type=int, default=4, help="multi-GPU: pushes (and exchanges) per pass and rank")
     args = ap.parse_args()
@@ -360,13 +339,41 @@ def main():
                 out["host_landed"]["abundance_min_2"]["vs_value"] = out["host_landed"]["abundance_min_2"]["value"] / value
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
+        if world == 1 and k == 31 and not args.no_k63:
+            # BASELINE configs[3] (k=63, LargeInt<2> 128-bit k-mer path, same reads per GPU) timed by the same driver run: a second, clearly labelled block —
+            # `value` above stays the k=31 figure of configs[1]
+            for b_, o_, _, _ in chunks:
+                c.device_free(b_); c.device_free(o_)
+            chunks.clear()
+            c.close()
+            c63 = gkc.Counter(local)
+            p63 = int(min(65535, max(64, 2 ** int(np.ceil(np.log2(max(1, n_reads * (L - 63 + 1) / 3.0e6)))))))
+            c63.configure(63, m, p63, repart_for_bench(m, p63))
+            b63, o63 = c63.synth_reads_device(2, n_reads, L, genome, 10000)
+            def step63():
+                c63.begin_pass(0); c63.push_reads_device(b63, o63, n_reads, n_bases); c63.finish_pass()
+            step63(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step63()
+            torch.cuda.synchronize()
+            dt63 = (time.perf_counter() - t0) / 2
+            s63 = c63.stats()
+            out["config"]["k63"] = {"workload": "k=63, %d synthetic 150 bp reads, single-pass count, m=%d, %d partitions (BASELINE configs[3])" % (n_reads, m, p63),
+                                    "steps": 2, "warmup": 1, "ms_per_step": dt63 * 1e3, "value": s63["kmers_nb_distinct"] / dt63, "unit": "distinct k-mers/s", "dtype": "u128",
+                                    "valid_kmers": s63["kmers_nb_valid"], "distinct_kmers": s63["kmers_nb_distinct"], "valid_kmers_per_s": s63["kmers_nb_valid"] / dt63}
+            c63.device_free(b63); c63.device_free(o63); c63.close()
+            c = None
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(k, m, min(parts, 256), repart_for_bench(m, min(parts, 256)))
+            cp = int(min(parts, 4096))
+            cb = c if c is not None else gkc.Counter(local)
+            out["cpu_baseline"] = cpu_baseline(cb, k, m, cp, repart_for_bench(m, cp))
         elif world == 1:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    for b_, o_, _, _ in chunks:
-        c.device_free(b_); c.device_free(o_)
+    if c is not None:
+        for b_, o_, _, _ in chunks:
+            c.device_free(b_); c.device_free(o_)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
 

@@ -493,8 +493,11 @@ struct gko_dsk {
     uint64_t stats[8]; uint64_t* histo; uint32_t histo_max;
 };
 
+/* the super-k-mers of one share of the reads are first logged in arrival order ([u16 partition][record in the wire format]) and then laid out
+ * partition-major (what the reference's per-partition files are): one growing buffer per share instead of one per partition */
 typedef struct {
-    const char* seq; unsigned k; uint32_t pass, nb_passes; const uint16_t* repart; bytebuf* parts;
+    const char* seq; unsigned k; uint32_t pass, nb_passes; const uint16_t* repart; bytebuf* log;
+    uint64_t* part_bytes; uint64_t* part_nk; uint64_t* part_nsk;
     uint64_t nsk; uint64_t bytes;
 } fill_ctx;
 
@@ -503,10 +506,11 @@ static void fill_cb(void* c, uint64_t mn, uint64_t first, unsigned nbk)   /* Fil
     fill_ctx* f = (fill_ctx*)c;
     if ((mn % f->nb_passes) != f->pass) return;
     uint32_t p = f->repart[mn];
-    uint8_t rec[1 + 64 + 80];
-    size_t len = gko_superkmer_encode(f->seq + first, f->k, nbk, rec);
-    bb_push(&f->parts[p], rec, len);
-    f->parts[p].n_kmers += nbk; f->parts[p].n_sk++;
+    uint8_t rec[2 + 1 + 64 + 80];
+    rec[0] = (uint8_t)(p & 255); rec[1] = (uint8_t)(p >> 8);
+    size_t len = gko_superkmer_encode(f->seq + first, f->k, nbk, rec + 2);
+    bb_push(f->log, rec, len + 2);
+    f->part_bytes[p] += len; f->part_nk[p] += nbk; f->part_nsk[p]++;
     f->nsk++; f->bytes += len;
 }
 
@@ -527,77 +531,179 @@ static void sort_u64_radix(uint64_t* a, uint64_t* tmp, uint64_t n, unsigned key_
     if (((key_bits + 7) / 8) & 1) memcpy(tmp, a, n * sizeof(uint64_t));   /* result back into the caller's array */
 }
 
-gko_dsk* gko_dsk_run(const char* bases, const uint64_t* offsets, uint64_t n_reads,
-                     unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
-                     const uint16_t* repart, const uint32_t* freq_order,
-                     int32_t amin, int32_t amax, uint32_t histo_max, int maxs)
+/* The run is organised the way the reference parallelises it: fillPartitions is data-parallel over the reads (Dispatcher::iterate,
+ * SortingCountAlgorithm.cpp:1266-1275: every thread cuts super-k-mers of its share of the reads into per-partition caches), fillSolidKmers is
+ * parallel over the partitions (one PartitionsByVectorCommand per partition, nb_partitions_in_parallel at a time, :1456-1587). With one
+ * thread (gko_dsk_run) this is the plain sequential restatement; gko_dsk_run_mt runs the same two functions on n_threads pthreads. */
+typedef struct {
+    const char* bases; const uint64_t* offsets; uint64_t r0, r1;
+    unsigned k, m; uint32_t nb_partitions, nb_passes, pass; const uint16_t* repart; const uint32_t* freq_order; const uint32_t* lut; int maxs;
+    uint8_t* arena; uint64_t* part_off;   /* [nb_partitions+1] byte offsets of the partitions inside arena: this share's "partition files" */
+    uint64_t* part_nk; uint64_t* part_nsk;
+    uint64_t stats[8];
+} fill_job;
+
+static void fill_range(fill_job* J)
 {
+    const uint32_t P = J->nb_partitions;
+    bytebuf log = { NULL, 0, 0, 0, 0 };
+    uint64_t* pb = (uint64_t*)calloc(P, sizeof(uint64_t));
+    J->part_nk = (uint64_t*)calloc(P, sizeof(uint64_t)); J->part_nsk = (uint64_t*)calloc(P, sizeof(uint64_t));
+    fill_ctx fc = { NULL, J->k, J->pass, J->nb_passes, J->repart, &log, pb, J->part_nk, J->part_nsk, 0, 0 };
+    for (uint64_t r = J->r0; r < J->r1; r++) {
+        const char* seq = J->bases + J->offsets[r]; uint64_t len = J->offsets[r + 1] - J->offsets[r];
+        fc.seq = seq;
+        uint64_t v = 0, iv = 0;
+        split_superkmers(seq, len, J->k, J->m, J->lut, J->freq_order, J->maxs, fill_cb, &fc, &v, &iv);
+        if (J->pass == 0) {                                    /* bank stats merged only for pass 0 (Sequence2SuperKmer.hpp:183) */
+            J->stats[0] += v; J->stats[1] += iv; J->stats[5]++;
+            if (len < J->k) J->stats[7]++;
+        }
+    }
+    J->stats[4] += fc.nsk; J->stats[6] += fc.bytes;
+    /* partition-major layout */
+    J->part_off = (uint64_t*)malloc(sizeof(uint64_t) * ((size_t)P + 1));
+    uint64_t run = 0;
+    for (uint32_t p = 0; p < P; p++) { J->part_off[p] = run; run += pb[p]; }
+    J->part_off[P] = run;
+    J->arena = (uint8_t*)malloc(run ? run : 1);
+    for (uint32_t p = 0; p < P; p++) pb[p] = J->part_off[p];   /* cursors */
+    for (uint64_t off = 0; off < log.n; ) {
+        const uint32_t p = (uint32_t)log.data[off] | ((uint32_t)log.data[off + 1] << 8);
+        const unsigned nbk = log.data[off + 2];
+        const size_t len = 1 + ((size_t)J->k + nbk - 1 + 3) / 4;               /* [u8 nbK][ceil((k+nbK-1)/4) bytes] (Model.hpp:1386-1471) */
+        memcpy(J->arena + pb[p], log.data + off + 2, len); pb[p] += len;
+        off += 2 + len;
+    }
+    free(log.data); free(pb);
+}
+
+/* one "PartitionsByVectorCommand": partition p of the pass, its records spread over n_src byte buffers (one per fill thread) */
+static void count_partition(dataset* D, const fill_job* src, uint32_t n_src, uint32_t p, unsigned k, int32_t amin, int32_t amax, uint32_t histo_max,
+                            uint64_t* histo, uint64_t* n_distinct, uint64_t* n_solid)
+{
+    const int wide = k > 31;
+    uint64_t nk = 0;
+    for (uint32_t s = 0; s < n_src; s++) { nk += src[s].part_nk[p]; D->n_kmers += src[s].part_nk[p]; D->n_sk += src[s].part_nsk[p]; }
+    gko_u128* keys = (gko_u128*)malloc(sizeof(gko_u128) * (nk ? nk : 1));
+    uint64_t* lo = (uint64_t*)malloc(sizeof(uint64_t) * 256), *hi = (uint64_t*)malloc(sizeof(uint64_t) * 256);
+    uint64_t w = 0;
+    for (uint32_t s = 0; s < n_src; s++) {                     /* executeRead */
+        const uint8_t* data = src[s].arena + src[s].part_off[p]; const uint64_t nb = src[s].part_off[p + 1] - src[s].part_off[p]; uint64_t off = 0;
+        while (off < nb) {
+            unsigned nbk;
+            off += gko_superkmer_decode(data + off, k, lo, hi, &nbk);
+            for (unsigned i = 0; i < nbk; i++) keys[w++] = ((gko_u128)hi[i] << 64) | lo[i];
+        }
+    }
+    free(lo); free(hi);
+    if (!wide) {                                               /* executeSort (ascending Type order) */
+        uint64_t* a = (uint64_t*)malloc(sizeof(uint64_t) * (nk ? nk : 1)), *t = (uint64_t*)malloc(sizeof(uint64_t) * (nk ? nk : 1));
+        for (uint64_t i = 0; i < nk; i++) a[i] = (uint64_t)keys[i];
+        sort_u64_radix(a, t, nk, 2 * k);
+        for (uint64_t i = 0; i < nk; i++) keys[i] = a[i];
+        free(a); free(t);
+    } else qsort(keys, nk, sizeof(gko_u128), u128_cmp);
+    /* executeDump: run-length count, then CountProcessorChain::process (histogram, solidity sum, dump) */
+    D->v = (gko_u128*)malloc(sizeof(gko_u128) * (nk ? nk : 1));
+    D->a = (int32_t*)malloc(sizeof(int32_t) * (nk ? nk : 1));
+    uint64_t i = 0;
+    while (i < nk) {
+        uint64_t j = i + 1; while (j < nk && keys[j] == keys[i]) j++;
+        int32_t cnt = (int32_t)(j - i);                        /* CountNumber is int32 (system/api/types.hpp:49) */
+        (*n_distinct)++;
+        histo[(uint32_t)cnt >= histo_max ? histo_max : (uint32_t)cnt]++;       /* Histogram::inc (Histogram.hpp:92) */
+        if (cnt >= amin && cnt <= amax) {                      /* CountRange::includes, closed interval */
+            D->v[D->n] = keys[i]; D->a[D->n] = cnt; D->n++; (*n_solid)++;
+        }
+        i = j;
+    }
+    free(keys);
+}
+
+#include <pthread.h>
+#include <time.h>
+#include <stdio.h>
+typedef struct {
+    fill_job* fills; uint32_t n_fill; uint32_t* next_fill;    /* phase 1: shares of the reads */
+    gko_dsk* R; const fill_job* src; uint32_t n_src; uint32_t pass; uint32_t* next_part; int32_t amin, amax;   /* phase 2: partitions */
+    uint64_t* histo; uint64_t n_distinct, n_solid;            /* private, merged by the caller */
+    int phase;
+} mt_worker;
+static void* mt_main(void* arg)
+{
+    mt_worker* W = (mt_worker*)arg;
+    if (W->phase == 1) {
+        for (;;) { const uint32_t i = __atomic_fetch_add(W->next_fill, 1, __ATOMIC_RELAXED); if (i >= W->n_fill) break; fill_range(&W->fills[i]); }
+    } else {
+        gko_dsk* R = W->R;
+        for (;;) {
+            const uint32_t p = __atomic_fetch_add(W->next_part, 1, __ATOMIC_RELAXED);
+            if (p >= R->nb_parts) break;
+            count_partition(&R->ds[p + W->pass * R->nb_parts], W->src, W->n_src, p, R->k, W->amin, W->amax, R->histo_max, W->histo, &W->n_distinct, &W->n_solid);
+        }
+    }
+    return NULL;
+}
+
+gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                        unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
+                        const uint16_t* repart, const uint32_t* freq_order,
+                        int32_t amin, int32_t amax, uint32_t histo_max, int maxs, uint32_t n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
     gko_dsk* R = (gko_dsk*)calloc(1, sizeof(gko_dsk));
     R->k = k; R->nb_parts = nb_partitions; R->nb_passes = nb_passes; R->histo_max = histo_max;
     R->ds = (dataset*)calloc((size_t)nb_partitions * nb_passes, sizeof(dataset));
     R->histo = (uint64_t*)calloc((size_t)histo_max + 1, sizeof(uint64_t));
     uint32_t* lut = (uint32_t*)malloc(sizeof(uint32_t) << (2 * m));
     gko_mmer_lut(m, freq_order != NULL, lut);
-    int wide = k > 31;
+    /* shares of the reads: a few per thread, so that threads finish together */
+    const uint32_t n_fill = n_threads == 1 ? 1 : (uint32_t)(n_reads < 4ull * n_threads ? (n_reads ? n_reads : 1) : 4ull * n_threads);
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
+    mt_worker* W = (mt_worker*)calloc(n_threads, sizeof(mt_worker));
+    for (uint32_t t = 0; t < n_threads; t++) W[t].histo = (uint64_t*)calloc((size_t)histo_max + 1, sizeof(uint64_t));
 
     for (uint32_t pass = 0; pass < nb_passes; pass++) {
         /* ---- fillPartitions ---- */
-        bytebuf* parts = (bytebuf*)calloc(nb_partitions, sizeof(bytebuf));
-        fill_ctx fc = { NULL, k, pass, nb_passes, repart, parts, 0, 0 };
-        for (uint64_t r = 0; r < n_reads; r++) {
-            const char* seq = bases + offsets[r]; uint64_t len = offsets[r + 1] - offsets[r];
-            fc.seq = seq;
-            uint64_t v = 0, iv = 0;
-            split_superkmers(seq, len, k, m, lut, freq_order, maxs, fill_cb, &fc, &v, &iv);
-            if (pass == 0) {                                   /* bank stats merged only for pass 0 (Sequence2SuperKmer.hpp:183) */
-                R->stats[0] += v; R->stats[1] += iv; R->stats[5]++;
-                if (len < k) R->stats[7]++;
-            }
+        fill_job* fills = (fill_job*)calloc(n_fill, sizeof(fill_job));
+        for (uint32_t i = 0; i < n_fill; i++) {
+            fill_job* J = &fills[i];
+            J->bases = bases; J->offsets = offsets; J->r0 = n_reads * i / n_fill; J->r1 = n_reads * (i + 1) / n_fill;
+            J->k = k; J->m = m; J->nb_partitions = nb_partitions; J->nb_passes = nb_passes; J->pass = pass; J->repart = repart;
+            J->freq_order = freq_order; J->lut = lut; J->maxs = maxs;
         }
-        R->stats[4] += fc.nsk; R->stats[6] += fc.bytes;
+        uint32_t next = 0;
+        for (uint32_t t = 0; t < n_threads; t++) { W[t].phase = 1; W[t].fills = fills; W[t].n_fill = n_fill; W[t].next_fill = &next; }
+        if (n_threads == 1) mt_main(&W[0]);
+        else { for (uint32_t t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, mt_main, &W[t]); for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL); }
+        for (uint32_t i = 0; i < n_fill; i++) for (int q = 0; q < 8; q++) R->stats[q] += fills[i].stats[q];
+        if (getenv("GKO_TIMING")) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[gko] pass %u fill done at %.3f\n", pass, ts.tv_sec + ts.tv_nsec * 1e-9); }
 
-        /* ---- fillSolidKmers: one "PartitionsByVectorCommand" per partition ---- */
-        for (uint32_t p = 0; p < nb_partitions; p++) {
-            bytebuf* b = &parts[p];
-            dataset* D = &R->ds[p + pass * nb_partitions];
-            D->n_kmers = b->n_kmers; D->n_sk = b->n_sk;
-            uint64_t nk = b->n_kmers;
-            gko_u128* keys = (gko_u128*)malloc(sizeof(gko_u128) * (nk ? nk : 1));
-            uint64_t* lo = (uint64_t*)malloc(sizeof(uint64_t) * 256), *hi = (uint64_t*)malloc(sizeof(uint64_t) * 256);
-            uint64_t w = 0, off = 0;
-            while (off < b->n) {                               /* executeRead */
-                unsigned nbk;
-                off += gko_superkmer_decode(b->data + off, k, lo, hi, &nbk);
-                for (unsigned i = 0; i < nbk; i++) keys[w++] = ((gko_u128)hi[i] << 64) | lo[i];
-            }
-            free(lo); free(hi);
-            if (!wide) {                                       /* executeSort (ascending Type order) */
-                uint64_t* a = (uint64_t*)malloc(sizeof(uint64_t) * (nk ? nk : 1)), *t = (uint64_t*)malloc(sizeof(uint64_t) * (nk ? nk : 1));
-                for (uint64_t i = 0; i < nk; i++) a[i] = (uint64_t)keys[i];
-                sort_u64_radix(a, t, nk, 2 * k);
-                for (uint64_t i = 0; i < nk; i++) keys[i] = a[i];
-                free(a); free(t);
-            } else qsort(keys, nk, sizeof(gko_u128), u128_cmp);
-            /* executeDump: run-length count, then CountProcessorChain::process (histogram, solidity sum, dump) */
-            D->v = (gko_u128*)malloc(sizeof(gko_u128) * (nk ? nk : 1));
-            D->a = (int32_t*)malloc(sizeof(int32_t) * (nk ? nk : 1));
-            uint64_t i = 0;
-            while (i < nk) {
-                uint64_t j = i + 1; while (j < nk && keys[j] == keys[i]) j++;
-                int32_t cnt = (int32_t)(j - i);                /* CountNumber is int32 (system/api/types.hpp:49) */
-                R->stats[2]++;
-                R->histo[(uint32_t)cnt >= histo_max ? histo_max : (uint32_t)cnt]++;   /* Histogram::inc (Histogram.hpp:92) */
-                if (cnt >= amin && cnt <= amax) {              /* CountRange::includes, closed interval */
-                    D->v[D->n] = keys[i]; D->a[D->n] = cnt; D->n++; R->stats[3]++;
-                }
-                i = j;
-            }
-            free(keys); free(b->data);
-        }
-        free(parts);
+        /* ---- fillSolidKmers: partitions dealt to the threads ---- */
+        uint32_t next_p = 0;
+        for (uint32_t t = 0; t < n_threads; t++) { W[t].phase = 2; W[t].R = R; W[t].src = fills; W[t].n_src = n_fill; W[t].pass = pass; W[t].next_part = &next_p; W[t].amin = amin; W[t].amax = amax; }
+        if (n_threads == 1) mt_main(&W[0]);
+        else { for (uint32_t t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, mt_main, &W[t]); for (uint32_t t = 0; t < n_threads; t++) pthread_join(th[t], NULL); }
+        if (getenv("GKO_TIMING")) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); fprintf(stderr, "[gko] pass %u count done at %.3f\n", pass, ts.tv_sec + ts.tv_nsec * 1e-9); }
+        for (uint32_t i = 0; i < n_fill; i++) { free(fills[i].arena); free(fills[i].part_off); free(fills[i].part_nk); free(fills[i].part_nsk); }
+        free(fills);
     }
-    free(lut);
+    for (uint32_t t = 0; t < n_threads; t++) {
+        R->stats[2] += W[t].n_distinct; R->stats[3] += W[t].n_solid;
+        for (uint32_t h = 0; h <= histo_max; h++) R->histo[h] += W[t].histo[h];
+        free(W[t].histo);
+    }
+    free(W); free(th); free(lut);
     return R;
+}
+
+gko_dsk* gko_dsk_run(const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                     unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
+                     const uint16_t* repart, const uint32_t* freq_order,
+                     int32_t amin, int32_t amax, uint32_t histo_max, int maxs)
+{
+    return gko_dsk_run_mt(bases, offsets, n_reads, k, m, nb_partitions, nb_passes, repart, freq_order, amin, amax, histo_max, maxs, 1);
 }
 
 void gko_dsk_free(gko_dsk* R)

@@ -80,6 +80,12 @@ gko_dsk* gko_dsk_run(const char* bases, const uint64_t* offsets, uint64_t n_read
                      unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
                      const uint16_t* repart, const uint32_t* freq_order,
                      int32_t abundance_min, int32_t abundance_max, uint32_t histo_max, int maxs);
+/* the same run on n_threads pthreads, parallelised like the reference (fillPartitions over the reads, fillSolidKmers over the partitions):
+ * identical results; this is what bench.py times as cpu_baseline ("port") on all host cores */
+gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                        unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
+                        const uint16_t* repart, const uint32_t* freq_order,
+                        int32_t abundance_min, int32_t abundance_max, uint32_t histo_max, int maxs, uint32_t n_threads);
 void     gko_dsk_free(gko_dsk*);
 uint64_t gko_dsk_part_size(const gko_dsk*, uint32_t dataset);
 /* copies dataset as (lo, hi, abundance) arrays */

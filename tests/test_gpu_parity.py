@@ -290,9 +290,9 @@ def test_synth_generator_and_checksum_property(gkc):
     c.device_free(db); c.device_free(do)
 
 
-@pytest.mark.parametrize("k,n,parts", [(31, 2_000_000, 512), (31, 100_000_000, 4096), (63, 50_000_000, 2048), (21, 100_000_000, 32768), (47, 30_000_000, 9000)])
+@pytest.mark.parametrize("k,n,parts", [(31, 2_000_000, 512), (31, 100_000_000, 4096), (63, 50_000_000, 2048), (63, 100_000_000, 4096), (21, 100_000_000, 32768), (47, 30_000_000, 9000)])
 def test_size_independent_properties(gkc, k, n, parts):
-    """2e6 reads, then BASELINE configs[1] (k=31, 1e8 reads) and configs[3]-shaped (k=63, 5e7 reads) at full size:
+    """2e6 reads, then BASELINE configs[1] (k=31, 1e8 reads) and configs[3] (k=63, 1e8 reads; also 5e7) at full size:
     size-independent properties — multiset checksum (independent one-thread-per-read kernel vs counted records), sum of
     abundances == valid k-mers, strictly ascending partitions, partition membership of sampled records, histogram sums"""
     c = gkc.Counter(0)

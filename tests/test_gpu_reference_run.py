@@ -11,7 +11,7 @@ import pytest
 import __graft_entry__ as ge
 from oracle import gko
 from tests.h5mini import H5Mini
-from tests.test_reference_run import FIX, load
+from tests.test_reference_run import FIX, load, freq_order_of
 
 pytestmark = pytest.mark.gpu
 
@@ -27,8 +27,8 @@ def gkc():
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[:-4] for p in FIX])
 def test_device_equals_reference_run(gkc, path):
     z, k, m, nbpart, table, parts = load(path)
-    freq = None
-    if "freq" in path:                                             # one partition: any valid frequency order gives the same dataset
+    freq = freq_order_of(z, m)                                     # the reference's own minimFrequency table where the fixture carries it
+    if path.endswith("k21_freq.npz"):                              # one partition, no stored order: any valid frequency order gives the same dataset
         freq = np.arange(4 ** m, dtype=np.uint32)
     c = gkc.Counter(0); c.set_solidity(2, 2147483647, 10000); c.configure(k, m, nbpart, table, freq_order=freq)
     c.begin_pass(0)
@@ -81,3 +81,29 @@ def test_h5_written_by_the_cpp_layer(gkc, tmp_path):
     assert int(h.dataset("/histogram/cutoff")[0]) == int(z["cutoff"]) and int(h.dataset("/histogram/nbsolidsforcutoff")[0]) == int(z["nbsolidsforcutoff"])
     rep = h.dataset("/minimizers/minimRepart")
     assert len(rep) == len(z["minimRepart"]) and int(rep[:2].view("<u2")[0]) == 2
+
+
+@pytest.mark.parametrize("tag,extra", [("k21_freq_4parts", ["-minimizer-type", "1", "-repartition-type", "1"]),
+                                       ("k21_lexi_grouped_parts", ["-repartition-type", "1"])])
+def test_cpp_repartitor_reproduces_the_reference_tables(gkc, tmp_path, tag, extra):
+    """the Repartitor the C++ layer builds from the device statistics (gkc_count_mmers, gkc_sample_minimizers -> computeFrequencies /
+    justGroup / justGroupLexi restated on the host) equals the reference's own /minimizers/minimRepart and /minimizers/minimFrequency BYTE FOR BYTE on the
+    fixture FASTA — the modes GraphUnitigs / bcalm2 force (-minimizer-type 1 -repartition-type 1) and the lexicographic grouping; with identical tables
+    every /dsk/solid/<p> dataset is the reference's dataset, record for record. (Scope of the identity: DESIGN.md section 12.)"""
+    built = os.path.join(ge.ROOT, "gatb-core_amd", "host")
+    subprocess.run(["make", "-C", built], check=True, capture_output=True)
+    z, k, m, nbpart, table, parts = load(os.path.join(os.path.dirname(FIX[0]), tag + ".npz"))
+    fa = tmp_path / "in.fa"; fa.write_bytes(bytes(z["fasta"]))
+    out = str(tmp_path / "ours")
+    r = subprocess.run([os.path.join(built, "gkc_dsk"), "-in", str(fa), "-kmer-size", str(k), "-abundance-min", "2", "-nb-partitions", str(nbpart), "-out", out] + extra,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    h = H5Mini(open(out + ".h5", "rb").read())
+    rep = np.asarray(h.dataset("/minimizers/minimRepart"), dtype=np.uint8)
+    assert np.array_equal(rep, z["minimRepart"]), "minimRepart differs from the reference's table"
+    if "minimFrequency" in z:
+        fr = np.asarray(h.dataset("/minimizers/minimFrequency"), dtype=np.uint8)
+        assert np.array_equal(fr, z["minimFrequency"]), "minimFrequency differs from the reference's table"
+    for p in range(nbpart):                                        # identical tables => identical datasets, in order
+        d = h.dataset("/dsk/solid/%d" % p)
+        assert list(zip(d["value"].tolist(), d["abundance"].tolist())) == parts[p], p

@@ -296,3 +296,18 @@ def test_abundance_discretization():
     # MapMPHF.hpp:96-145: steps 1 (x70), 2 (x15), 10 (x40), 20 (x25), 100 (x40), 200 (x25), 1000 (x40); MPHFAlgorithm.cpp:253-266
     assert [gko.abundance_index(a) for a in (0, 1, 70, 71, 72, 100, 500, 501)] == [0, 1, 70, 70, 71, 85, 125, 125]
     assert gko.abundance_index(50000) == 255 and gko.abundance_index(49999) == 254
+
+
+def test_parallel_oracle_equals_sequential_oracle():
+    """gko_dsk_run_mt (the cpu_baseline of bench.py: fillPartitions over the reads, fillSolidKmers over the partitions, like the reference's
+    Dispatcher) gives exactly the sequential restatement's datasets, statistics and histogram"""
+    from tests.util import simple_repart, synth_reads
+    reads = synth_reads(1500, 9000, 150, seed=9, n_rate=0.002, ragged=True)
+    bases, offs = gko.pack_reads(reads)
+    for k, m, parts, passes in ((31, 8, 7, 1), (41, 7, 5, 2)):
+        rep = simple_repart(m, parts)
+        a = gko.Dsk(bases, offs, k, m, parts, rep, nb_passes=passes, abundance_min=2)
+        b = gko.Dsk(bases, offs, k, m, parts, rep, nb_passes=passes, abundance_min=2, threads=5)
+        assert a.stats == b.stats and np.array_equal(a.histogram(), b.histogram())
+        for d in range(parts * passes):
+            assert np.array_equal(a.part_records(d), b.part_records(d))

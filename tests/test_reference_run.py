@@ -28,17 +28,29 @@ def load(path):
     return z, k, m, nbpart, table, parts
 
 
+def freq_order_of(z, m):
+    """the reference's own /minimizers/minimFrequency (u32 freq_order[4^m] + magic) when the fixture carries it"""
+    if "minimFrequency" not in z:
+        return None
+    raw = z["minimFrequency"]
+    assert len(raw) == 4 * 4 ** m + 4 and int(raw[-4:].view("<u4")[0]) == 0x12345678
+    return raw[:4 * 4 ** m].view("<u4").copy()
+
+
 def oracle_run(z, k, m, nbpart, table):
     bases, offs = gko.fastx_parse(bytes(z["fasta"]))
-    # partition membership only depends on the table in lexicographic mode; in frequency mode (one partition here) every minimizer maps to 0
-    return gko.Dsk(bases, offs, k, m, nbpart, table, abundance_min=2)
+    # partition membership depends on the table and, in frequency mode, on the order (freq_order[c], c) of the reference's own minimFrequency;
+    # the one-partition frequency fixture (k21_freq) has no stored order: every minimizer maps to partition 0 whatever the order
+    return gko.Dsk(bases, offs, k, m, nbpart, table, abundance_min=2, freq_order=freq_order_of(z, m))
 
 
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[:-4] for p in FIX])
 def test_oracle_equals_reference_run(path):
     z, k, m, nbpart, table, parts = load(path)
-    if "freq" in path:
+    if path.endswith("k21_freq.npz"):
         assert nbpart == 1
+    if "4parts" in path:
+        assert nbpart == 4 and freq_order_of(z, m) is not None and min(len(p) for p in parts) > 0     # frequency order really decides membership here
     d = oracle_run(z, k, m, nbpart, table)
     assert d.stats["kmers_nb_solid"] == int(z["nb_solid_kmers"]) == sum(len(p) for p in parts)
     for p in range(nbpart):

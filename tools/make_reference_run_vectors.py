@@ -37,14 +37,14 @@ def attr(h5, path):
     return m.group(1) if m else None
 
 
-def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1):
+def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1, max_memory=2000, want_freq=False):
     with tempfile.TemporaryDirectory() as td:
         fa = os.path.join(td, "in.fa")
         text = "".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads))
         open(fa, "w").write(text)
         out = os.path.join(td, "ref")
         cmd = [os.path.join(BIN, "dbgh5"), "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", td, "-nb-cores", str(cores),
-               "-max-memory", "2000", "-verbose", "0"] + extra
+               "-max-memory", str(max_memory), "-verbose", "0"] + extra
         subprocess.run(cmd, check=True, capture_output=True)
         h5 = out + ".h5"
         nparts = int(attr(h5, "/dsk/solid/nb_partitions"))
@@ -70,6 +70,8 @@ def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1):
                 fx["bloom_" + a] = np.frombuffer((v or "").encode(), dtype=np.uint8)
         if want_mphf:
             fx["mphf"] = dataset_bytes(h5, "/dsk/mphf", "LE")
+        if want_freq:                                              # u32 freq_order[4^m] + u32 magic (RepartitionAlgorithm.cpp:352-380, PartiInfo.cpp:271-295)
+            fx["minimFrequency"] = dataset_bytes(h5, "/minimizers/minimFrequency", "LE")
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
         print(tag, "partitions", nparts, "solid", int(fx["nb_solid_kmers"]), {k_: (v.shape if hasattr(v, "shape") else v) for k_, v in fx.items() if k_ in ("bloom", "mphf")})
 
@@ -82,5 +84,10 @@ if __name__ == "__main__":
     run("k31_basic", reads, 31, ["-bloom", "basic", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"], want_bloom=True)
     run("k31_cache", reads, 31, ["-bloom", "cache", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"], want_bloom=True)
     run("k21_freq", reads, 21, count_only + ["-minimizer-type", "1", "-repartition-type", "1"])
+    # frequency-order minimizers with SEVERAL partitions (what GraphUnitigs forces: -minimizer-type 1 -repartition-type 1): -max-memory 1 makes the
+    # reference cut this input into 4 partitions; minimFrequency and minimRepart are the reference's own tables
+    run("k21_freq_4parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only + ["-minimizer-type", "1", "-repartition-type", "1"], max_memory=1, want_freq=True)
+    # the same input with the default (lexicographic) minimizers and the bcalm-friendly lexicographic grouping (-repartition-type 1)
+    run("k21_lexi_grouped_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only + ["-repartition-type", "1"], max_memory=1)
     run("k31_2parts_mphf", synth_reads(2000, 10000, 150, seed=3), 31, ["-bloom", "none", "-debloom", "none", "-branching-nodes", "none"], want_mphf=True, cores=2)
     run("k63_neighbor_mphf", reads[:300], 63, ["-bloom", "neighbor", "-debloom", "none", "-branching-nodes", "none"], want_bloom=True, want_mphf=True)
