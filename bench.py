@@ -310,6 +310,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
                          "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))},
         }
+        if dom == "expand_scatter" and k <= 31:
+            # what actually bounds this kernel: the rate of scattered 16-byte stores with 8192 open cursors per workgroup measured on this chip
+            # (tools/scatter_bench -> profiles/r02_scatter_store_calibration.txt: 984 GB/s of useful bytes; requests, not bytes, are the limit)
+            key_gbs = keys_per_rank * key_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            out["roofline"]["scattered_store_ceiling"] = {"GBps": 984.0, "store_bytes": 16, "achieved_key_GBps": key_gbs, "frac": key_gbs / 984.0,
+                                                          "source": "profiles/r02_scatter_store_calibration.txt (tools/scatter_bench, WRITE_SIZE-checked)"}
         # the nominal 8 TB/s beside what a plain device copy reaches on this box (read + write bytes / time)
         try:
             a_ = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b_ = torch.empty_like(a_)
