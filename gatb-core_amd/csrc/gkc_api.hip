@@ -365,6 +365,16 @@ int gkc_sample_minimizers(gkc_ctx* c, const char* bases, const uint64_t* offsets
     return rc;
 }
 
+int gkc_sample_exact(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t max_superkmers,
+                     uint64_t* superkmers_per_minim, uint64_t* kmers_per_minim, uint64_t* kxmers_per_minim, uint64_t* reads_used)
+{
+    if (!c || !offsets || (!bases && n_reads)) return GKC_ERR_ARG;
+    if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "gkc_configure must be called first (any repartition table)");
+    if (offsets[0] != 0) GKC_FAIL(c, GKC_ERR_ARG, "offsets[0] must be 0");
+    GKC_HIP(c, hipSetDevice(c->device));
+    return gkc_scan_sample_exact(c, bases, offsets, n_reads, max_superkmers, superkmers_per_minim, kmers_per_minim, kxmers_per_minim, reads_used);
+}
+
 int gkc_count_mmers(gkc_ctx* c, uint32_t m, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t* counts)
 {
     if (!c || !counts) return GKC_ERR_ARG;

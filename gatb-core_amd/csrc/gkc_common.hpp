@@ -234,6 +234,7 @@ struct ScopedTimer {
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases);
 int gkc_count_pass(gkc_ctx* c);
 int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint64_t* h_superkmers, uint64_t* h_kmers);
+int gkc_scan_sample_exact(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t max_superkmers, uint64_t* h_nsk, uint64_t* h_nk, uint64_t* h_nkx, uint64_t* reads_used);
 int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t* h_counts);
 int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk);
 

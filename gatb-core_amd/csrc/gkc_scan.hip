@@ -799,6 +799,78 @@ int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, 
     return GKC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// EXACT Repartitor sample (RepartitionAlgorithm.cpp:135-215 SampleRepart over Sequence2SuperKmer.hpp:81-159): one thread per read walks the read the
+// way the reference does — k-mer by k-mer, the super-k-mer closed when the minimizer VALUE changes, at an invalid k-mer, at the length cap or at the
+// end of the read — and records per minimizer the number of super-k-mers, of k-mers and of kx-mers (runs of successive k-mers on one strand, cut after
+// _kx = 4 extensions: :186-203), which is what Repartitor::computeDistrib balances on (PartiInfo.cpp:48-106). No tiles here: the tile scan of Stage A
+// may split a super-k-mer at a tile border, harmless for counting, not for these statistics. The sample is a few 10^4..10^6 reads: speed is irrelevant.
+// mode 0: per read, the number of super-k-mers of the pass (the reference stops its sample when their running total exceeds a threshold, :205-212);
+// mode 1: the statistics of reads [0, n_reads).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sample_exact(ScanParams P, const uint64_t* __restrict__ offsets, uint64_t n_reads, int mode, uint32_t* __restrict__ per_read,
+                               unsigned long long* __restrict__ nsk, unsigned long long* __restrict__ nk, unsigned long long* __restrict__ nkx)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t b = offsets[r], e = offsets[r + 1];
+    const uint32_t k = P.k, m = P.m;
+    uint32_t n_here = 0;
+    if (e - b >= k) {
+        const u128 kmask = KeyT<2>::mask(k);
+        const uint32_t DEFAULT = 0xFFFFFFFFu;                    // SuperKmer::DEFAULT_MINIMIZER (Model.hpp:1349): "no minimizer yet"
+        u128 fw = 0, rv = 0; uint32_t good = 0;                  // rolling k-mer (Model.hpp:637-657); good = valid nucleotides in a row
+        uint32_t sk_min = DEFAULT, sk_size = 0, kx_size = 0, n_kx = 0; bool prev_which = false;
+        auto close_sk = [&]() {                                  // Sequence2SuperKmer::processSuperkmer -> SampleRepart::processSuperkmer
+            if (sk_size > 0 && sk_min != DEFAULT && (sk_min % P.nb_passes) == P.pass) {
+                n_here++;
+                if (mode == 1) { atomicAdd(&nsk[sk_min], 1ULL); atomicAdd(&nk[sk_min], (unsigned long long)sk_size); atomicAdd(&nkx[sk_min], (unsigned long long)(n_kx + 1)); }
+            }
+            sk_size = 0; n_kx = 0; kx_size = 0;
+        };
+        for (uint64_t g = b; g < e; g++) {
+            const uint32_t ch = P.bases[g];
+            const bool ok = nt_valid(ch) != 0;
+            const uint32_t code = nt_code(ch);
+            fw = ((fw << 2) | (u128)code) & kmask;
+            rv = (rv >> 2) | ((u128)(code ^ 2u) << (2 * (k - 1)));
+            good = ok ? good + 1 : 0;
+            if (g + 1 < b + k) continue;                         // the first k-mer ends at base b + k - 1
+            if (good < k) { close_sk(); sk_min = DEFAULT; continue; }       // invalid k-mer: close, restart "from new" (Sequence2SuperKmer.hpp:94-106)
+            // minimizer of this k-mer: minimum order key over its k-m+1 m-mers, the default minimizer taking part (Model.hpp:1254-1287)
+            uint32_t best = P.default_key;
+            const uint64_t k0 = g + 1 - k;                       // first base of the k-mer
+            uint32_t mf = 0;
+            for (uint32_t j = 0; j < k; j++) {
+                mf = ((mf << 2) | nt_code(P.bases[k0 + j])) & P.mmask;
+                if (j + 1 < m) continue;
+                uint32_t key;
+                if (P.freq_mode) key = P.mkey_lut[mf];
+                else {
+                    const uint32_t rc = (uint32_t)revcomp64(mf, m);
+                    const uint32_t cn = mf < rc ? mf : rc;
+                    uint32_t a = ~(cn | (cn >> 2));
+                    a = (a >> 1) & a & P.mask_ma1;
+                    key = a ? P.mmask : cn;
+                }
+                best = key < best ? key : best;
+            }
+            const uint32_t h = P.freq_mode ? P.key2val[best] : best;
+            const bool which = fw < rv;                          // strand of the canonical k-mer (Model.hpp:294)
+            if (sk_min == DEFAULT) sk_min = h;
+            if (h != sk_min || sk_size >= P.maxs) close_sk();
+            sk_min = h;
+            if (sk_size > 0) {                                   // kx-mer bookkeeping of SampleRepart::processSuperkmer (:186-203), done on the fly
+                if (which != prev_which || kx_size >= 4) { n_kx++; kx_size = 0; } else kx_size++;
+            }
+            prev_which = which;
+            sk_size++;
+        }
+        close_sk();                                              // "output last superK"
+    }
+    if (mode == 0) per_read[r] = n_here;
+}
+
 // MmersFrequency (RepartitionAlgorithm.cpp:88-120): occurrences of every canonical m-mer at VALID m-mer positions
 __global__ void k_count_mmers(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ offsets, uint64_t n_reads, uint32_t m,
                               unsigned int* __restrict__ counts)
@@ -872,5 +944,52 @@ int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap,
         }
     }
     *nb = bytes; *nsk = n_sk; *nk = n_k;
+    return GKC_OK;
+}
+
+// exact sample statistics of the first reads of a bank, stopped like SampleRepart (see k_sample_exact)
+int gkc_scan_sample_exact(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t max_superkmers,
+                          uint64_t* h_nsk, uint64_t* h_nk, uint64_t* h_nkx, uint64_t* reads_used)
+{
+    const uint64_t nm = 1ULL << (2 * c->m);
+    DevBuf d_stats, d_per, db, dof;
+    struct Guard { std::vector<DevBuf*> v; ~Guard() { for (DevBuf* b : v) b->release(); } } guard; guard.v = { &d_stats, &d_per, &db, &dof };
+    GKC_TRY(c->ensure(d_stats, (size_t)3 * nm * 8));
+    GKC_HIP(c, hipMemsetAsync(d_stats.p, 0, (size_t)3 * nm * 8, c->stream));
+    ScanParams P{};
+    P.k = c->k; P.m = c->m; P.maxs = c->maxs; P.mmask = (uint32_t)(nm - 1);
+    P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
+    P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
+    P.mkey_lut = (const uint32_t*)c->d_mkey_lut.p; P.key2val = (const uint32_t*)c->d_key2val.p; P.default_key = c->default_key;
+    P.nb_passes = c->nb_passes; P.pass = 0;
+    unsigned long long* st = (unsigned long long*)d_stats.p;
+    const uint64_t CHUNK = 1u << 18;
+    uint64_t seen = 0, used = 0; bool stop = false;
+    for (uint64_t r0 = 0; r0 < n_reads && !stop; r0 += CHUNK) {
+        const uint64_t n = std::min<uint64_t>(CHUNK, n_reads - r0), nb = offsets[r0 + n] - offsets[r0];
+        GKC_TRY(c->ensure(db, (size_t)nb + 64)); GKC_TRY(c->ensure(dof, (size_t)(n + 1) * 8)); GKC_TRY(c->ensure(d_per, (size_t)n * 4));
+        std::vector<uint64_t> rel(offsets + r0, offsets + r0 + n + 1);
+        for (uint64_t& v : rel) v -= offsets[r0];
+        if (nb) GKC_HIP(c, hipMemcpyAsync(db.p, bases + offsets[r0], (size_t)nb, hipMemcpyHostToDevice, c->stream));
+        GKC_HIP(c, hipMemcpyAsync(dof.p, rel.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        P.bases = (const uint8_t*)db.p; P.n_bases = nb;
+        const unsigned grid = (unsigned)((n + 127) / 128);
+        hipLaunchKernelGGL(k_sample_exact, dim3(grid), dim3(128), 0, c->stream, P, (const uint64_t*)dof.p, n, 0, (uint32_t*)d_per.p, st, st + nm, st + 2 * nm);
+        GKC_HIP(c, hipGetLastError());
+        std::vector<uint32_t> per(n);
+        GKC_HIP(c, hipMemcpyAsync(per.data(), d_per.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        GKC_HIP(c, hipStreamSynchronize(c->stream));
+        // the reference checks its cancel flag between sequences: the read in which the running total first EXCEEDS the threshold is still counted
+        uint64_t take = n;
+        for (uint64_t i = 0; i < n; i++) { seen += per[i]; if (seen > max_superkmers) { take = i + 1; stop = true; break; } }
+        hipLaunchKernelGGL(k_sample_exact, dim3((unsigned)((take + 127) / 128)), dim3(128), 0, c->stream, P, (const uint64_t*)dof.p, take, 1, (uint32_t*)nullptr, st, st + nm, st + 2 * nm);
+        GKC_HIP(c, hipGetLastError());
+        GKC_HIP(c, hipStreamSynchronize(c->stream));
+        used += take;
+    }
+    std::vector<uint64_t> h((size_t)3 * nm);
+    GKC_HIP(c, hipMemcpy(h.data(), d_stats.p, h.size() * 8, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < nm; i++) { if (h_nsk) h_nsk[i] += h[i]; if (h_nk) h_nk[i] += h[nm + i]; if (h_nkx) h_nkx[i] += h[2 * nm + i]; }
+    if (reads_used) *reads_used = used;
     return GKC_OK;
 }

@@ -28,7 +28,7 @@ SYMBOLS = [
     "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_destroy", "gkc_comm_set_owners",
     "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
     "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
-    "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
+    "gkc_sample_exact", "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
 ]
 
 
@@ -147,6 +147,7 @@ def lib():
         "gkc_bloom_allreduce_or": (C.c_int, [vp, vp]),
         "gkc_mphf_build_solid_dist": (C.c_int, [vp, vp, P(vp)]),
         "gkc_mphf_abundance_map_dist": (C.c_int, [vp, vp, vp, vp, u64, P(u64)]),
+        "gkc_sample_exact": (C.c_int, [vp, vp, vp, u64, u64, vp, vp, vp, P(u64)]),
         "gkc_set_host_sink": (C.c_int, [vp, vp, u64]),
         "gkc_finish_pass_async": (C.c_int, [vp]),
         "gkc_wait_partition": (C.c_int, [vp, u32, u32, P(vp), P(u64)]),
@@ -384,6 +385,13 @@ class Counter:
         nsk = np.zeros(4 ** self.m, np.uint64); nk = np.zeros(4 ** self.m, np.uint64)
         self._chk(self.L.gkc_sample_minimizers(self.h, _p(bases), _p(offsets), len(offsets) - 1, _p(nsk), _p(nk)))
         return nsk, nk
+
+    def sample_exact(self, bases, offsets, max_superkmers):
+        """-> (superkmers, kmers, kxmers per minimizer, reads used): SampleRepart restated read by read on the device"""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8); offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        a = np.zeros(4 ** self.m, np.uint64); b = np.zeros(4 ** self.m, np.uint64); d = np.zeros(4 ** self.m, np.uint64); used = C.c_uint64()
+        self._chk(self.L.gkc_sample_exact(self.h, _p(bases), _p(offsets), len(offsets) - 1, max_superkmers, _p(a), _p(b), _p(d), C.byref(used)))
+        return a, b, d, used.value
 
     def count_mmers(self, m, bases, offsets):
         bases = np.ascontiguousarray(bases, dtype=np.uint8); offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

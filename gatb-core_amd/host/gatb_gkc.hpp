@@ -31,6 +31,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <queue>
 #include "../../include/gkc.h"
 #include "gkc_h5.hpp"
 
@@ -334,20 +335,26 @@ public:
     const uint32_t* getMinimizerFrequencies() const { return _freq_order.empty() ? nullptr : _freq_order.data(); }
     void setMinimizerFrequencies(const std::vector<uint32_t>& f) { _freq_order = f; }
 
-    /** largest bin into the emptiest partition (computeDistrib, PartiInfo.cpp:48-106). Weights = k-mers per minimizer. */
+    /** largest bin into the emptiest partition (computeDistrib, PartiInfo.cpp:48-106). Weights = kx-mers per minimizer of the sample
+     *  (getNbKxmer_per_minim). The same standard-library calls with the same comparators as the reference (std::sort with compBin: size only;
+     *  std::priority_queue with compSpaceTriple: space used only — PartiInfo.hpp:347-370): ties then fall the way they fall in the reference and
+     *  the table is the reference's byte for byte (most of the 4^m bins are empty, so ties decide most of the table). */
     void computeDistrib(const std::vector<uint64_t>& weight) {
+        typedef std::pair<uint64_t, uint64_t> ipair;                            // (bin size, bin number)
+        struct itriple { uint64_t first, second, third; };
+        struct compBin { bool operator()(ipair l, ipair r) { return l.first > r.first; } } comp_bins;
+        struct compSpaceTriple { bool operator()(itriple l, itriple r) { return l.second > r.second; } };
         _repart_table.assign(_nb_minims, 0);
-        std::vector<std::pair<uint64_t, uint64_t>> bins(_nb_minims);
-        for (uint64_t i = 0; i < _nb_minims; i++) bins[i] = { weight[i], i };
-        std::stable_sort(bins.begin(), bins.end(), [](const std::pair<uint64_t, uint64_t>& a, const std::pair<uint64_t, uint64_t>& b) { return a.first > b.first; });
-        typedef std::pair<uint64_t, uint32_t> slot;                 // (space used, partition)
-        std::vector<slot> heap; for (uint32_t j = 0; j < _nbpart; j++) heap.push_back({ 0, j });
-        auto cmp = [](const slot& a, const slot& b) { return a.first != b.first ? a.first > b.first : a.second > b.second; };
-        std::make_heap(heap.begin(), heap.end(), cmp);
-        for (uint64_t c = 0; c < _nb_minims; c++) {
-            std::pop_heap(heap.begin(), heap.end(), cmp); slot s = heap.back(); heap.pop_back();
-            _repart_table[bins[c].second] = (Value)s.second; s.first += bins[c].first;
-            heap.push_back(s); std::push_heap(heap.begin(), heap.end(), cmp);
+        std::vector<ipair> bin_size_vec;
+        std::priority_queue<itriple, std::vector<itriple>, compSpaceTriple> pq;
+        for (uint64_t ii = 0; ii < _nb_minims; ii++) bin_size_vec.push_back(ipair(weight[ii], ii));
+        for (int jj = 0; jj < (int)_nbpart; jj++) pq.push(itriple{ (uint64_t)jj, 0, 0 });
+        std::sort(bin_size_vec.begin(), bin_size_vec.end(), comp_bins);
+        for (uint64_t cur = 0; cur < _nb_minims; cur++) {
+            itriple smallest = pq.top(); pq.pop();
+            _repart_table[bin_size_vec[cur].second] = (Value)smallest.first;
+            smallest.second += bin_size_vec[cur].first; smallest.third++;
+            pq.push(smallest);
         }
     }
     /** keeps minimizers in lexicographic order (justGroupLexi, PartiInfo.cpp:185-218; what bcalm2 needs) */
@@ -1018,13 +1025,15 @@ private:
             freq[nm - 1] = (uint32_t)(nm - 1);
             rep->setMinimizerFrequencies(freq);
         }
-        // computeRepartition (:395-475): super-k-mer statistics of a sample prefix of the bank
-        uint64_t ns = std::max<uint64_t>((uint64_t)(nseq * 0.05), 1000000ULL); ns = std::min<uint64_t>(ns, nseq);
-        std::vector<uint64_t> nsk(nm, 0), nk(nm, 0);
-        check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, 1, 1, freq.empty() ? GKC_MINIMIZER_LEXI : GKC_MINIMIZER_FREQ, dummy.data(), freq.empty() ? nullptr : freq.data()));
-        check(gkc_sample_minimizers(_ctx, bases.data(), offs.data(), ns, nsk.data(), nk.data()));
+        // computeRepartition (:395-475): SampleRepart over the first reads of the bank, stopped like the reference: with the read in which the running
+        // number of super-k-mers (of pass 0) first exceeds max(5 % of the sequences, 10^6) (:451, :205-212). gkc_sample_exact walks the reads one by one on
+        // the device and also counts the kx-mers computeDistrib balances on.
+        const uint64_t nbSeqSample = std::max<uint64_t>((uint64_t)(nseq * 0.05), 1000000ULL);
+        std::vector<uint64_t> nsk(nm, 0), nk(nm, 0), nkx(nm, 0); uint64_t used = 0;
+        check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, 1, (uint32_t)_config._nb_passes, freq.empty() ? GKC_MINIMIZER_LEXI : GKC_MINIMIZER_FREQ, dummy.data(), freq.empty() ? nullptr : freq.data()));
+        check(gkc_sample_exact(_ctx, bases.data(), offs.data(), nseq, nbSeqSample, nsk.data(), nk.data(), nkx.data(), &used));
         if (_config._minimizerType == 1) rep->justGroup(nk, counts);
-        else { rep->computeDistrib(nk); if (_config._repartitionType == 1) rep->justGroupLexi(nk); }
+        else { rep->computeDistrib(nkx); if (_config._repartitionType == 1) rep->justGroupLexi(nk); }
         return rep;
     }
 

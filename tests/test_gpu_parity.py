@@ -569,3 +569,45 @@ print(json.dumps({"ok": bool(ok), "segments": c.stats()["nb_sequences"] == len(r
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res == {"ok": True, "segments": True, "valid": True}, res
+
+
+@pytest.mark.parametrize("k,m,freq", [(31, 8, False), (21, 7, True), (41, 9, False)])
+def test_exact_repartitor_sample(gkc, k, m, freq):
+    """gkc_sample_exact (SampleRepart restated read by read on the device: super-k-mers, k-mers and kx-mers per minimizer, and the reference's stop rule)
+    against the oracle's super-k-mer split of every read + the kx-mer rule of RepartitionAlgorithm.cpp:186-203 stated here in Python"""
+    reads = synth_reads(500, 6000, 150, seed=83, n_rate=0.004, ragged=True)
+    bases, offs = gko.pack_reads(reads)
+    fo = None
+    if freq:
+        cnt = np.zeros(4 ** m, np.uint32)
+        for r in reads:
+            gko.lib().gko_count_mmers(r, len(r), m, cnt)
+        fo = np.zeros(4 ** m, np.uint32); gko.lib().gko_freq_order_from_counts(m, cnt, fo)
+    c = gkc.Counter(0); c.configure(k, m, 4, np.zeros(4 ** m, np.uint16), freq_order=fo)
+
+    def expected(n_reads_limit=None, threshold=None):
+        nsk = np.zeros(4 ** m, np.uint64); nk = np.zeros(4 ** m, np.uint64); nkx = np.zeros(4 ** m, np.uint64)
+        seen = 0; used = 0
+        for r in reads:
+            mn, st, nb, nv, ni = gko.superkmers(r, k, m, freq_order=fo)
+            km = gko.kmers(r, k)
+            which = (km["fwd_lo"] == km["can_lo"]) & (km["fwd_hi"] == km["can_hi"])       # canonical == forward strand
+            for a, s0, n in zip(mn.tolist(), st.tolist(), nb.tolist()):
+                nsk[a] += 1; nk[a] += n
+                kx = 1; run = 0; prev = which[s0]
+                for i in range(1, n):
+                    if which[s0 + i] != prev or run >= 4:
+                        kx += 1; run = 0
+                    else:
+                        run += 1
+                    prev = which[s0 + i]
+                nkx[a] += kx
+            seen += len(mn); used += 1
+            if threshold is not None and seen > threshold:
+                break
+        return nsk, nk, nkx, used
+
+    for thr in (10 ** 9, 700):
+        a, b, d, used = c.sample_exact(bases, offs, thr)
+        ea, eb, ed, eused = expected(threshold=thr)
+        assert used == eused and np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(d, ed), (thr, used, eused)

@@ -84,11 +84,13 @@ def test_h5_written_by_the_cpp_layer(gkc, tmp_path):
 
 
 @pytest.mark.parametrize("tag,extra", [("k21_freq_4parts", ["-minimizer-type", "1", "-repartition-type", "1"]),
-                                       ("k21_lexi_grouped_parts", ["-repartition-type", "1"])])
+                                       ("k21_lexi_grouped_parts", ["-repartition-type", "1"]),
+                                       ("k21_default_parts", [])])
 def test_cpp_repartitor_reproduces_the_reference_tables(gkc, tmp_path, tag, extra):
     """the Repartitor the C++ layer builds from the device statistics (gkc_count_mmers, gkc_sample_minimizers -> computeFrequencies /
     justGroup / justGroupLexi restated on the host) equals the reference's own /minimizers/minimRepart and /minimizers/minimFrequency BYTE FOR BYTE on the
-    fixture FASTA — the modes GraphUnitigs / bcalm2 force (-minimizer-type 1 -repartition-type 1) and the lexicographic grouping; with identical tables
+    fixture FASTA — the modes GraphUnitigs / bcalm2 force (-minimizer-type 1 -repartition-type 1), the lexicographic grouping, and the default mode (computeDistrib on the
+    kx-mers per minimizer of the exact sample, gkc_sample_exact); with identical tables
     every /dsk/solid/<p> dataset is the reference's dataset, record for record. (Scope of the identity: DESIGN.md section 12.)"""
     built = os.path.join(ge.ROOT, "gatb-core_amd", "host")
     subprocess.run(["make", "-C", built], check=True, capture_output=True)

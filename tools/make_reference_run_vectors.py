@@ -89,5 +89,7 @@ if __name__ == "__main__":
     run("k21_freq_4parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only + ["-minimizer-type", "1", "-repartition-type", "1"], max_memory=1, want_freq=True)
     # the same input with the default (lexicographic) minimizers and the bcalm-friendly lexicographic grouping (-repartition-type 1)
     run("k21_lexi_grouped_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only + ["-repartition-type", "1"], max_memory=1)
+    # ... and with everything default (lexicographic minimizers, computeDistrib balancing on kx-mers): pins the default Repartitor table
+    run("k21_default_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only, max_memory=1)
     run("k31_2parts_mphf", synth_reads(2000, 10000, 150, seed=3), 31, ["-bloom", "none", "-debloom", "none", "-branching-nodes", "none"], want_mphf=True, cores=2)
     run("k63_neighbor_mphf", reads[:300], 63, ["-bloom", "neighbor", "-debloom", "none", "-branching-nodes", "none"], want_bloom=True, want_mphf=True)

@@ -19,6 +19,7 @@ from tests.test_reference_run import load             # noqa: E402
 EXE = os.path.join(ROOT, "integration", "_build", "dbgh5_device")
 CASES = [("k21_freq_4parts", ["-minimizer-type", "1", "-repartition-type", "1"], "1"),
          ("k21_lexi_grouped_parts", ["-repartition-type", "1"], "1"),
+         ("k21_default_parts", [], "1"),
          ("k31_2parts_mphf", [], "2000")]
 
 
