@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bloom-mphf", action="store_true", help="skip the Bloom + MPHF block (BASELINE configs[4] on one GPU's share)")
     ap.add_argument("--no-k63", action="store_true", help="skip the second block (BASELINE configs[3]: k=63 at the same size)")
     ap.add_argument("--no-host-landed", action="store_true", help="skip the host-landed leg (results streamed into page-locked host memory)")
     ap.add_argument("--pushes", type=int, default=4, help="multi-GPU: pushes (and exchanges) per pass and rank")
@@ -345,6 +346,31 @@ def main():
                 out["host_landed"]["abundance_min_2"]["vs_value"] = out["host_landed"]["abundance_min_2"]["value"] / value
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
+        if world == 1 and k == 31 and not args.no_bloom_mphf:
+            # BASELINE configs[4] on ONE GPU's share (k=31, abundance-min 2, Bloom solid filter + MPHF + abundance map over the solid k-mers of this workload),
+            # a clearly labelled block: count with the solidity window on the device, Bloom of the three kinds (11 bits per k-mer, 7 hashes like the
+            # reference's defaults), BooPHF build, populate. The multi-rank combination of these (OR all-reduce, per-level reduce) is in tests/test_gpu_dist.py.
+            c.set_solidity(2, 2147483647, 10000)
+            step(); sync()
+            t0 = time.perf_counter(); step(); sync(); dt_cnt = time.perf_counter() - t0
+            ns = c.stats()["kmers_nb_solid"]
+            blk = {"workload": "k=31, abundance-min 2, %d reads: count -> Bloom (11 bits / solid k-mer, 7 hashes) -> MPHF + abundance map" % n_reads,
+                   "solid_kmers": ns, "count_ms": dt_cnt * 1e3}
+            for kind in ("neighbor", "cache", "basic"):
+                bl = gkc.Bloom(c, kind, int(ns * 11.0), 7, k)
+                torch.cuda.synchronize(); t0 = time.perf_counter(); bl.insert_solid(); torch.cuda.synchronize()
+                blk["bloom_%s_ms" % kind] = (time.perf_counter() - t0) * 1e3
+                bl.close()
+            mp_ = gkc.Mphf(c); mp_.close()                      # first build warms the allocator
+            torch.cuda.synchronize(); t0 = time.perf_counter(); mp_ = gkc.Mphf(c); torch.cuda.synchronize(); t1 = time.perf_counter()
+            amap, above = mp_.abundance_map(); t2 = time.perf_counter()
+            blk.update({"mphf_build_ms": (t1 - t0) * 1e3, "mphf_keys_per_s": mp_.size / (t1 - t0), "mphf_bits_per_key": mp_.L.gkc_mphf_save_size(mp_.h) * 8 / max(1, mp_.size),
+                        "abundance_map_ms_incl_d2h": (t2 - t1) * 1e3})
+            blk["bloom_and_mphf_ready_ms"] = blk["count_ms"] + blk["bloom_neighbor_ms"] + blk["mphf_build_ms"]
+            blk["distinct_kmers_per_s_to_bloom_and_mphf"] = c.stats()["kmers_nb_distinct"] / (blk["bloom_and_mphf_ready_ms"] * 1e-3)
+            mp_.close(); del amap
+            c.set_solidity(1, 2147483647, 10000)
+            out["config"]["bloom_mphf"] = blk
         if world == 1 and k == 31 and not args.no_k63:
             # BASELINE configs[3] (k=63, LargeInt<2> 128-bit k-mer path, same reads per GPU) timed by the same driver run: a second, clearly labelled block —
             # `value` above stays the k=31 figure of configs[1]

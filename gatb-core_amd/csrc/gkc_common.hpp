@@ -168,6 +168,7 @@ struct gkc_ctx {
     // objects built from this context (gkc_bloom, gkc_mphf) hold device memory of its allocator: gkc_destroy with children alive only
     // marks the context closed; the last child to be destroyed frees it (gkc_ctx_child_release)
     int children = 0; bool closed = false;
+    int comm_world = 1;                    // world size of the communicator built on this context (multi-GPU): Stage A then leaves a few CUs to the exchange kernels
     std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them
     gkc_stats& stats_now() { return pass_stats[pass]; }
     // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted

@@ -1100,6 +1100,140 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
 }
 
+// ------------------------------------------------------------------------------------------------ tail: buckets beyond one wave, inside LDS
+// Buckets larger than the first tier (k-mers that start with their minimizer pile up under one 20-bit prefix: a few hundred such clusters per
+// partition, 11 % of the keys) used to go through three more tiers — a double-size wave network, a 4-wave merge through LDS, key -> key split levels in
+// HBM with host round trips — at 2.7x / 3.5x / 27x the first tier's cost per key. Here ONE workgroup takes such a bucket (<= TailCap keys) into LDS and
+// resolves it there: split the item on its next informative key bits (the bits every key of the item shares are skipped, so a cluster that was isolated by
+// one split spreads over the next one), counting sort in place (keys wait in registers between the histogram and the scatter), repeat for the pieces that
+// are still too large, then the waves sort the pieces with the register network straight out of LDS. No HBM traffic but the one load and the result, no
+// host involvement. Larger buckets (poly-A, tandem repeats) still take the HBM split levels.
+constexpr int TAIL_THREADS = 512, TAIL_RPT = 16, TAIL_MAX_ITEMS = 1024, TAIL_MAX_BIG = 128, TAIL_MAX_GROUPS = 256;
+constexpr uint32_t TAIL_UNIFORM = 0xFFFFFFFFu;          // TailItem::cons of an item whose keys are all the same k-mer
+template <int KW> struct TailCap { static constexpr uint32_t CAP = (KW == 1) ? (uint32_t)TAIL_THREADS * TAIL_RPT : (uint32_t)TAIL_THREADS * TAIL_RPT / 2; };   // 8192 / 4096 keys: 64 KB
+struct TailItem { uint32_t off_n; uint32_t cons; };              // off:16 | n-1:16 (n <= 8192 -> fits), consumed key bits
+template <int KW, bool F>
+__global__ __launch_bounds__(TAIL_THREADS, 4) void k_lds_tail_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                                     const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint8_t* __restrict__ b_cons,
+                                                                     const uint32_t* __restrict__ list, uint32_t n_list, uint32_t two_k, SortOut O)
+{
+    typedef typename KeyT<KW>::type key_t;
+    constexpr int RPT = (KW == 1) ? TAIL_RPT : TAIL_RPT / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    key_t* s_keys = reinterpret_cast<key_t*>(s_raw);                                 // [TailCap]
+    __shared__ TailItem s_small[TAIL_MAX_ITEMS]; __shared__ TailItem s_big[TAIL_MAX_BIG];
+    __shared__ uint32_t s_nsmall, s_nbig, s_fail;
+    __shared__ uint32_t s_cnt[TAIL_MAX_GROUPS], s_cur[TAIL_MAX_GROUPS];
+    __shared__ unsigned long long s_or[2];
+    __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ WgList s_over;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    constexpr int NW = TAIL_THREADS / 64;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    if (t == 0) s_over.n = 0;
+    __syncthreads();
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t g = list[li];
+        const uint32_t N = b_n[g];
+        if (N > TailCap<KW>::CAP) { if (t == 0) wglist_push(&s_over, g, O.over2_count, O.over2_list); continue; }      // HBM split levels
+        const uint64_t S = b_start[g];
+        for (uint32_t i = t; i < N; i += TAIL_THREADS) s_keys[i] = src[S + i];
+        if (t == 0) { s_nsmall = 0; s_nbig = 1; s_fail = 0; s_big[0] = TailItem{ (0u << 16) | (N - 1), b_cons[g] }; }
+        __syncthreads();
+        // ---- split the items that are still too large, one at a time, all threads together
+        for (uint32_t bi = 0; ; bi++) {
+            __syncthreads();
+            if (bi >= s_nbig || s_fail) break;
+            const TailItem it = s_big[bi];
+            const uint32_t off = it.off_n >> 16, n = (it.off_n & 0xFFFFu) + 1;
+            key_t v[RPT];
+            const key_t k0 = s_keys[off];
+            key_t acc = 0;
+#pragma unroll
+            for (int r = 0; r < RPT; r++) { const uint32_t i = (uint32_t)r * TAIL_THREADS + t; v[r] = i < n ? s_keys[off + i] : k0; acc |= v[r] ^ k0; }
+            if (t < 2) s_or[t] = 0;
+            if (t < TAIL_MAX_GROUPS) s_cnt[t] = 0;
+            __syncthreads();
+            {   unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
+#pragma unroll
+                for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); }
+                if (lane == 0) { atomicOr(&s_or[0], lo); if (KW == 2) atomicOr(&s_or[1], hi); }
+            }
+            __syncthreads();
+            const unsigned long long olo = s_or[0], ohi = s_or[1];
+            const uint32_t diff_bits = ohi ? 128 - __clzll((long long)ohi) : (olo ? 64 - __clzll((long long)olo) : 0);
+            const uint32_t left0 = two_k - it.cons;
+            const uint32_t left = diff_bits < left0 ? diff_bits : left0;                  // informative bits still unused
+            if (left == 0) {                                                              // every key of the item is the same k-mer: one record, abundance n (emitted with the pieces)
+                if (t == 0) { const uint32_t q = atomicAdd(&s_nsmall, 1u); if (q < (uint32_t)TAIL_MAX_ITEMS) s_small[q] = TailItem{ it.off_n, TAIL_UNIFORM }; else s_fail = 1; }
+                continue;
+            }
+            uint32_t sb = 1; while (sb < 8 && sb < left && (n >> sb) > 384) sb++;
+            const uint32_t shift = left - sb, G = 1u << sb, cons_child = it.cons + (left0 - left) + sb;
+            uint32_t dg[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const uint32_t i = (uint32_t)r * TAIL_THREADS + t;
+                dg[r] = (uint32_t)(v[r] >> shift) & (G - 1);                             // (a generic shift: 0 <= shift < 2k)
+                if (i < n) atomicAdd(&s_cnt[dg[r]], 1u);
+            }
+            __syncthreads();
+            if (w == 0) {                                                                 // exclusive scan of G <= 256 counters by one wave
+                uint32_t c4[4], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { c4[j] = (uint32_t)(lane * 4 + j) < G ? s_cnt[lane * 4 + j] : 0u; sum += c4[j]; }
+                uint32_t x = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+                uint32_t run = x - sum;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if ((uint32_t)(lane * 4 + j) < G) {
+                    s_cur[lane * 4 + j] = run;
+                    const uint32_t nd = c4[j];
+                    if (nd) {                                                             // the piece joins the small or the big list
+                        const TailItem child{ ((off + run) << 16) | (nd - 1), cons_child };
+                        if (nd <= WaveCapT1<KW>::CAP) { const uint32_t q = atomicAdd(&s_nsmall, 1u); if (q < (uint32_t)TAIL_MAX_ITEMS) s_small[q] = child; else s_fail = 1; }
+                        else if (nd == n) s_fail = 1;                                     // cannot happen (left > 0 splits at least two ways); guards an endless loop
+                        else { const uint32_t q = atomicAdd(&s_nbig, 1u); if (q < (uint32_t)TAIL_MAX_BIG) s_big[q] = child; else s_fail = 1; }
+                    }
+                    run += nd;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RPT; r++) {
+                const uint32_t i = (uint32_t)r * TAIL_THREADS + t;
+                if (i < n) { const uint32_t p = atomicAdd(&s_cur[dg[r]], 1u); s_keys[off + p] = v[r]; }
+            }
+        }
+        __syncthreads();
+        if (s_fail) {                                                                     // lists overflowed (pathological key sets): the HBM split levels take the bucket as it was
+            for (uint32_t i = t; i < N; i += TAIL_THREADS) outk[S + i] = s_keys[i];
+            if (t == 0) wglist_push(&s_over, g, O.over2_count, O.over2_list);
+            __syncthreads();
+            continue;
+        }
+        // ---- the pieces: one wave each, register network straight out of LDS
+        const uint32_t ns = s_nsmall;
+        for (uint32_t i = w; i < ns; i += NW) {
+            const TailItem it = s_small[i];
+            const uint32_t off = it.off_n >> 16, n = (it.off_n & 0xFFFFu) + 1;
+            if (it.cons == TAIL_UNIFORM) {
+                if (lane == 0) {
+                    outk[S + off] = s_keys[off]; put_count(O, S + off, n);
+                    const uint32_t hb = n >= O.histo_max ? O.histo_max : n;
+                    if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
+                }
+                continue;
+            }
+            wave_sort_dispatch<KW, WaveCapT1<KW>::KPL_MAX, F>(s_keys + off, outk, S + off, n, O, s_hc, lane);
+        }
+        __syncthreads();
+    }
+    wglist_flush(&s_over, O.over2_count, O.over2_list);
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+}
+
 // ------------------------------------------------------------------------------------------------ deeper levels
 // A bucket too large for one wave (skewed key ranges: k-mers that START with their minimizer share their top 2m bits;
 // repeats; too few partitions) is split again on its next key bits by one workgroup, keys -> keys (ping-pong buffers).
@@ -1513,7 +1647,29 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipStreamSynchronize(cur_stream(c)));
         if (split_bad) { B.release(); GKC_FAIL(c, GKC_ERR_HIP, "internal error: %llu sub-buckets received another number of keys than the expansion counted", split_bad); }
         if (!n_mid) break;
+        // GKC_TAIL_LDS=1: every bucket beyond the first tier is resolved by one workgroup inside LDS (k_lds_tail_sort) instead of the double-size wave network,
+        // the 4-wave merge and (up to 8192 keys) the HBM split levels. Bit-exact, measured SLOWER (1e8 reads, k=31: 348 vs 302 ms per step, the tail kernel
+        // ~60 ms single lane for 11 % of the keys against 23 + 8 ms of the tiers it replaces; k=63: 650 vs 469 ms; profiles/r02_tail_lds_experiment.txt):
+        // one bucket per workgroup serialises ~10 barriers and LDS atomics on a handful of counters per split. Kept as a measured experiment.
+        static const bool tail_lds = getenv("GKC_TAIL_LDS") ? atoi(getenv("GKC_TAIL_LDS")) != 0 : false;
+        if (tail_lds) {
+            // every bucket beyond the first tier that fits the LDS buffer is resolved by one workgroup inside LDS (k_lds_tail_sort); larger ones join over2
+            ScopedTimer tm(c, "bucket_sort_tail");
+            const size_t lds = (size_t)TailCap<KW>::CAP * sizeof(key_t);
+            static std::once_flag once;
+            std::call_once(once, [&] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_tail_sort<KW, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds_tail_sort<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            });
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_mid, 256 * 2);
+            if (tag) hipLaunchKernelGGL((k_lds_tail_sort<KW, FT>), dim3(grid), dim3(TAIL_THREADS), lds, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p, (const uint64_t*)B.b_start[cur].p,
+                               (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, (const uint32_t*)O.over_list, n_mid, 2 * k, O);
+            else hipLaunchKernelGGL((k_lds_tail_sort<KW, false>), dim3(grid), dim3(TAIL_THREADS), lds, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p, (const uint64_t*)B.b_start[cur].p,
+                               (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, (const uint32_t*)O.over_list, n_mid, 2 * k, O);
+            CB_HIP(hipGetLastError());
+        }
         uint32_t n_mid2 = 0;
+        if (!tail_lds) {
         {   ScopedTimer tm(c, "bucket_sort_big");                 // up to 2x the first tier: double-size wave network
             const unsigned grid = (unsigned)std::min<uint64_t>((n_mid + 3) / 4, 256 * 16);
             constexpr int KB = WaveCapHuge<KW>::KPL;
@@ -1559,6 +1715,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             }
             CB_HIP(hipGetLastError());
         }
+        }   // !tail_lds
         uint32_t n_over = 0;
         CB_HIP(hipMemcpyAsync(&n_over, B.over2.p, 4, hipMemcpyDeviceToHost, cur_stream(c)));
         CB_HIP(hipStreamSynchronize(cur_stream(c)));

@@ -225,6 +225,7 @@ static int comm_new(gkc_ctx* c, int world, int rank, gkc_comm** out)
     m->ctx = c; m->world = world; m->rank = rank;
     if (hipStreamCreateWithFlags(&m->xstream, hipStreamNonBlocking) != hipSuccess) { delete m; GKC_FAIL(c, GKC_ERR_HIP, "stream creation failed"); }
     gkc_ctx_child_add(c);
+    c->comm_world = std::max(c->comm_world, world);
     *out = m;
     return GKC_OK;
 }

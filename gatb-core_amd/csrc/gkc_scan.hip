@@ -615,6 +615,9 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         int cus = 256; hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         unsigned per_cu = (unsigned)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (SCAN_STATIC_LDS + dyn_lds)));
+        // multi-GPU: the exchange of the previous push runs on the communicator's stream while this scan runs; the scan's workgroups are persistent (they
+        // hold their CU until the last tile), so 16 CUs are left to the RCCL send / receive kernels instead of making them wait for the scan to drain
+        if (c->comm_world > 1 && cus > 64) cus -= 16;
         grid_n = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)cus * per_cu);
     } else grid_n = (unsigned)std::min<uint64_t>(n_tiles, 1u << 20);
 
