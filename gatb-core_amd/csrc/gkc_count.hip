@@ -831,6 +831,148 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const 
     if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
 }
 
+// COUNT FIRST, SORT THE DISTINCT KEYS (8-byte keys). With 30x coverage two thirds of the keys of a bucket are repeats of a k-mer that is already there: the
+// sort network above moves all of them through ~45 compare-exchange stages only to collapse them afterwards. Here the wave first counts its bucket in a small
+// LDS hash table (512 slots per wave: 64-bit CAS on the key, 32-bit add on the count; linear probing), then compacts the distinct entries into one 64-bit word
+// each — [the key's bits below the bucket prefix | abundance] — and runs the register network over those only (a 128 / 256 wide network instead of 512 / 1024).
+// The order of the packed words is the order of the keys, the abundance rides along for free, no run-length pass. A bucket whose distinct k-mers do not fit
+// the table (low coverage, repeats-free data) is handed to the plain sort tier by index.
+constexpr int WH_SLOTS = 512, WH_WAVES = SORT_THREADS / 64;
+template <bool F_UNUSED>
+__global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_hash_count(const uint64_t* __restrict__ src, uint64_t* __restrict__ outk,
+                                                                                 const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint8_t* __restrict__ b_cons,
+                                                                                 uint32_t n_buckets, uint32_t two_k, SortOut O, uint32_t* __restrict__ plain_count, uint32_t* __restrict__ plain_list)
+{
+    __shared__ unsigned long long s_tk[WH_WAVES][WH_SLOTS];                      // keys (or, after the counting, the packed distinct entries)
+    __shared__ uint32_t s_tc[WH_WAVES][WH_SLOTS];                                // counts
+    __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ WgList s_over, s_plain;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    if (t == 0) { s_over.n = 0; s_plain.n = 0; }
+    unsigned long long* tk = s_tk[wv]; uint32_t* tc = s_tc[wv];
+    constexpr unsigned long long EMPTY = ~0ULL;
+#pragma unroll
+    for (int j = 0; j < WH_SLOTS / 64; j++) { tk[j * 64 + lane] = EMPTY; tc[j * 64 + lane] = 0; }
+    __syncthreads();
+    const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
+    for (uint32_t g = wave; g < n_buckets; g += n_waves) {
+        const uint32_t n = b_n[g];
+        if (n == 0) continue;
+        if (n > WaveCapT1<1>::CAP) { if (lane == 0) wglist_push(&s_over, g, O.over_count, O.over_list); continue; }
+        const uint64_t start = b_start[g];
+        const uint32_t low_bits = two_k - b_cons[g];                             // key bits below the bucket's shared prefix
+        if (low_bits > 53) { if (lane == 0) wglist_push(&s_plain, g, plain_count, plain_list); continue; }     // no room for an 11-bit abundance beside the key
+        const uint32_t cnt_bits = 64 - low_bits;
+        const uint64_t low_mask = (1ULL << low_bits) - 1;
+        // ---- count: every key goes into the table
+        bool fail = false;
+        uint64_t top = 0;
+        for (uint32_t base = 0; base < n; base += 256) {                          // four keys per lane in flight: the LDS round trips of their CAS chains overlap
+            uint64_t key[4]; uint32_t slot[4]; uint32_t pending = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i = base + q * 64 + lane;
+                key[q] = i < n ? src[start + i] : 0;
+                if (i < n) { pending |= 1u << q; top = key[q] & ~low_mask; }
+                slot[q] = (uint32_t)(mix64(key[q]) >> 40) & (WH_SLOTS - 1);
+            }
+            for (uint32_t probes = 0; pending; probes++) {
+                unsigned long long old[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) if ((pending >> q) & 1) old[q] = atomicCAS(&tk[slot[q]], EMPTY, (unsigned long long)key[q]);
+#pragma unroll
+                for (int q = 0; q < 4; q++) if ((pending >> q) & 1) {
+                    if (old[q] == EMPTY || old[q] == key[q]) { atomicAdd(&tc[slot[q]], 1u); pending &= ~(1u << q); }
+                    else slot[q] = (slot[q] + 1) & (WH_SLOTS - 1);
+                }
+                if (probes >= 48) { fail = true; break; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        top = __shfl(top, 0, 64);                                                // lane 0 always holds a key (n >= 1)
+        // ---- collect the distinct entries (and leave the table empty for the next bucket)
+        uint64_t e[WH_SLOTS / 64]; uint32_t nd_lane = 0;
+#pragma unroll
+        for (int j = 0; j < WH_SLOTS / 64; j++) {
+            const unsigned long long kk = tk[j * 64 + lane]; const uint32_t cc = tc[j * 64 + lane];
+            e[j] = kk == EMPTY ? EMPTY : (((kk & low_mask) << cnt_bits) | cc);
+            nd_lane += kk != EMPTY;
+        }
+#pragma unroll
+        for (int j = 0; j < WH_SLOTS / 64; j++) { tk[j * 64 + lane] = EMPTY; tc[j * 64 + lane] = 0; }
+        if (__any(fail)) {                                                        // too many distinct k-mers for the table: the plain sort tier takes the bucket
+            if (lane == 0) wglist_push(&s_plain, g, plain_count, plain_list);
+            continue;
+        }
+        uint32_t x = nd_lane;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        const uint32_t nd = __shfl(x, 63, 64);
+        uint32_t o = x - nd_lane;
+#pragma unroll
+        for (int j = 0; j < WH_SLOTS / 64; j++) if (e[j] != EMPTY) tk[o++] = e[j];      // packed entries, compact, in the (now empty) key table
+        __builtin_amdgcn_wave_barrier();
+        // ---- sort the distinct entries: 64 / 128 / 256 wide network on the packed words
+        auto emit = [&](uint64_t pv, uint32_t j) {
+            const uint32_t c = (uint32_t)(pv & ((1ULL << cnt_bits) - 1));
+            outk[start + j] = top | (pv >> cnt_bits);
+            put_count(O, start + j, c);
+            const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
+            if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
+        };
+        if (nd <= 64) {
+            uint64_t v[1] = { (uint32_t)lane < nd ? tk[lane] : EMPTY };
+            bitonic_wave<1, 1, false>(v, lane);
+            if ((uint32_t)lane < nd) emit(v[0], (uint32_t)lane);
+        } else if (nd <= 128) {
+            uint64_t v[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) { const uint32_t i = r * 64 + lane; v[r] = i < nd ? tk[i] : EMPTY; }
+            bitonic_wave<1, 2, false>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 2; r++) { const uint32_t j = lane * 2 + r; if (j < nd) emit(v[r], j); }
+        } else if (nd <= 256) {
+            uint64_t v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const uint32_t i = r * 64 + lane; v[r] = i < nd ? tk[i] : EMPTY; }
+            bitonic_wave<1, 4, false>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const uint32_t j = lane * 4 + r; if (j < nd) emit(v[r], j); }
+        } else {
+            uint64_t v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const uint32_t i = r * 64 + lane; v[r] = i < nd ? tk[i] : EMPTY; }
+            bitonic_wave<1, 8, false>(v, lane);
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const uint32_t j = lane * 8 + r; if (j < nd) emit(v[r], j); }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < WH_SLOTS / 64; j++) tk[j * 64 + lane] = EMPTY;       // the compacted entries go, the table is empty again
+    }
+    wglist_flush(&s_over, O.over_count, O.over_list);
+    wglist_flush(&s_plain, plain_count, plain_list);
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+}
+// the buckets k_wave_hash_count handed back: plain sort network (first tier) on a list of bucket indices
+template <int KW, bool F>
+__global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort_list(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
+                                                                  const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint32_t* __restrict__ list, uint32_t n_list, SortOut O)
+{
+    __shared__ uint32_t s_hc[HIST_LDS];
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    __syncthreads();
+    const uint32_t wave = (blockIdx.x * SORT_THREADS + t) >> 6, n_waves = (gridDim.x * SORT_THREADS) >> 6;
+    for (uint32_t li = wave; li < n_list; li += n_waves) {
+        const uint32_t g = list[li]; const uint32_t n = b_n[g]; const uint64_t start = b_start[g];
+        wave_sort_dispatch<KW, WaveCapT1<KW>::KPL_MAX, F>(src + start, outk, start, n, O, s_hc, lane);
+    }
+    __syncthreads();
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+}
+
 // second tier: buckets up to twice the first tier's size (2048 / 1024 keys), one wave each with a double-size network; only
 // ~10 % of the keys come here, so the lower occupancy of this kernel (64+ key registers) does not touch the first tier
 template <int KW> struct WaveCapHuge { static constexpr int KPL = (KW == 1) ? 32 : 16; static constexpr uint32_t CAP = 64 * KPL; };
@@ -1590,6 +1732,11 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
     const bool tag = KW == 1 && 2 * k - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
     constexpr bool FT = KW == 1;
+    // GKC_HASH_COUNT=1: count-first first tier (8-byte keys): duplicates counted in a per-wave LDS hash table, only the distinct k-mers sorted (k_wave_hash_count).
+    // Bit-exact; on the 30x synthetic reads it breaks even with the plain network (first tier 69 vs 69 ms single lane, deeper levels 16 vs 12 ms, 312 vs 304 ms
+    // per step: profiles/r02_hash_count_experiment.txt) — the CAS chains cost what the smaller network saves. Kept as a measured experiment.
+    static const bool hash_env = getenv("GKC_HASH_COUNT") ? atoi(getenv("GKC_HASH_COUNT")) != 0 : false;
+    const bool hash_count = hash_env && KW == 1 && !line;
     int cur = 0;                                 // bucket arrays b_*[cur]
     uint64_t n_buckets = n_sub;
     key_t* src = (key_t*)B.keysA.p;
@@ -1630,6 +1777,30 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
                                    (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, (const uint32_t*)B.bigs.p + 1, 2 * k, O);
                 hipLaunchKernelGGL((k_super_copy_back<KW>), dim3(n_big), dim3(SS_THREADS), 0, cur_stream(c), (key_t*)B.keysA.p, (const key_t*)B.keysB.p, (const uint64_t*)B.b_start[cur].p,
                                    (const uint32_t*)B.b_n[cur].p, (const uint32_t*)B.bigs.p + 1);
+                CB_HIP(hipGetLastError());
+            }
+        } else
+        if (KW == 1 && hash_count) {
+            // first tier, count-first variant: duplicates are counted in a per-wave LDS hash table, only the distinct k-mers are sorted (k_wave_hash_count);
+            // what does not fit its table comes back in a list for the plain network
+            ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
+            CB_TRY(c->ensure(B.bigs, ((size_t)n_buckets + 1) * 4));
+            CB_HIP(hipMemsetAsync(B.bigs.p, 0, 4, cur_stream(c)));
+            const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
+            if constexpr (KW == 1) {
+                hipLaunchKernelGGL((k_wave_hash_count<false>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const uint64_t*)src, (uint64_t*)B.keysA.p, (const uint64_t*)B.b_start[cur].p,
+                                   (const uint32_t*)B.b_n[cur].p, (const uint8_t*)B.b_cons[cur].p, (uint32_t)n_buckets, 2 * k, O, (uint32_t*)B.bigs.p, (uint32_t*)B.bigs.p + 1);
+            }
+            CB_HIP(hipGetLastError());
+            uint32_t n_plain = 0;
+            CB_HIP(hipMemcpyAsync(&n_plain, B.bigs.p, 4, hipMemcpyDeviceToHost, cur_stream(c)));
+            CB_HIP(hipStreamSynchronize(cur_stream(c)));
+            if (n_plain) {
+                const unsigned g2 = (unsigned)std::min<uint64_t>((n_plain + 3) / 4, 256 * 32);
+                if (tag) hipLaunchKernelGGL((k_wave_sort_list<KW, FT>), dim3(g2), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p, (const uint64_t*)B.b_start[cur].p,
+                                   (const uint32_t*)B.b_n[cur].p, (const uint32_t*)B.bigs.p + 1, n_plain, O);
+                else hipLaunchKernelGGL((k_wave_sort_list<KW, false>), dim3(g2), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p, (const uint64_t*)B.b_start[cur].p,
+                                   (const uint32_t*)B.b_n[cur].p, (const uint32_t*)B.bigs.p + 1, n_plain, O);
                 CB_HIP(hipGetLastError());
             }
         } else
