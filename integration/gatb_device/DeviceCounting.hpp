@@ -25,6 +25,10 @@
 
 #include <vector>
 #include <mutex>
+#include <string>
+#include <stdio.h>
+#include <stdlib.h>
+#include <unistd.h>
 
 namespace gatb { namespace core { namespace kmer { namespace impl {
 
@@ -42,6 +46,7 @@ public:
     void configure (const Configuration& config, Repartitor& repartitor)
     {
         open();
+        enableMultiGpuFromEnvironment();
         const u_int64_t nbMinims = (u_int64_t)1 << (2 * config._minim_size);
         std::vector<uint16_t> table (nbMinims);
         for (u_int64_t m = 0; m < nbMinims; m++)  { table[m] = (uint16_t) repartitor (m); }
@@ -56,15 +61,46 @@ public:
         if (rc != GKC_OK)  { throw system::Exception ("device counting: error %d: %s", rc, gkc_last_error(_ctx)); }
     }
 
-    ~DeviceSession ()  { if (_ctx) { gkc_destroy (_ctx); } }
+    /** Multi-GPU (one process per GPU): GATB_DEVICE_RANKS / GATB_DEVICE_RANK / GATB_DEVICE_COMM_ID (a file: rank 0 writes the 128-byte
+     *  ncclUniqueId, the other ranks wait for it) in the environment of each process turn the session into one rank of an RCCL communicator. Each
+     *  process reads ITS share of the reads; after every block pushed to Stage A the super-k-mers are routed to the rank owning their partition
+     *  (gkc_exchange), and each process counts — and writes into its own .h5 — the partitions it owns (the other datasets stay empty). */
+    void enableMultiGpuFromEnvironment ()
+    {
+        const char* ranks = getenv ("GATB_DEVICE_RANKS");  const char* rank = getenv ("GATB_DEVICE_RANK");  const char* idFile = getenv ("GATB_DEVICE_COMM_ID");
+        if (_comm != 0  ||  ranks == 0  ||  rank == 0  ||  idFile == 0  ||  atoi(ranks) < 2)  { return; }
+        open();
+        uint8_t id [GKC_COMM_ID_BYTES];
+        if (atoi(rank) == 0)
+        {
+            check (gkc_comm_unique_id (id));
+            std::string tmp = std::string(idFile) + ".tmp";
+            FILE* f = fopen (tmp.c_str(), "wb");  if (f == 0) { throw system::Exception ("device counting: cannot write %s", tmp.c_str()); }
+            fwrite (id, 1, sizeof(id), f);  fclose (f);  rename (tmp.c_str(), idFile);
+        }
+        else
+        {
+            FILE* f = 0;
+            for (int tries = 0; tries < 6000 && (f = fopen (idFile, "rb")) == 0; tries++)  { usleep (10000); }
+            if (f == 0  ||  fread (id, 1, sizeof(id), f) != sizeof(id))  { throw system::Exception ("device counting: no communicator id in %s", idFile); }
+            fclose (f);
+        }
+        check (gkc_comm_create_rccl (_ctx, id, atoi(ranks), atoi(rank), &_comm));
+    }
+    gkc_comm* comm ()  { return _comm; }
+    /** collective, ONCE per pass on every rank, after the rank's last push: every block pushed so far goes to the owners of its partitions */
+    void exchange ()  { if (_comm != 0) { check (gkc_exchange (_ctx, _comm)); } }
+
+    ~DeviceSession ()  { if (_comm) { gkc_comm_destroy (_comm); }  if (_ctx) { gkc_destroy (_ctx); } }
 
 private:
-    DeviceSession () : _ctx(0) {}
+    DeviceSession () : _ctx(0), _comm(0) {}
     void open ()
     {
         if (_ctx == 0  &&  gkc_create (0, &_ctx) != GKC_OK)  { throw system::Exception ("device counting: %s", gkc_last_error(0)); }
     }
     gkc_ctx* _ctx;
+    gkc_comm* _comm;
 };
 
 /********************************************************************************/
@@ -86,6 +122,7 @@ public:
                 DeviceSession::singleton().check (gkc_push_reads (DeviceSession::singleton().ctx(), bases.data(), offsets.data(), offsets.size()-1));
                 bases.clear();  offsets.assign (1, 0);
             }
+
         }
     };
 

@@ -31,6 +31,7 @@ FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 \t\t\ttypename FillPartitionsDevice<span>::Packer packer;
 \t\t\tgetDispatcher()->iterate (itSeq, FillPartitionsDevice<span> (packer, _progress, _config._kmerSize), groupSize, deleteSynchro);
 \t\t\tpacker.flush();
+\t\t\tdevice.exchange();          /* multi-GPU (GATB_DEVICE_RANKS ...): the super-k-mers go to the rank owning their partition */
 \t\t\titSeq->finalize();
 \t\t\tif (pass == 0)
 \t\t\t{

@@ -4,9 +4,9 @@
 # Outputs land in gpurun_out/prof_round/ and are copied into profiles/ by hand afterwards.
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/prof_round; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline > $O/kt.log 2>&1
-GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pf.log 2>&1
-GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pw.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf > $O/kt.log 2>&1
+GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf > $O/pf.log 2>&1
+GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf > $O/pw.log 2>&1
 cd $R
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -n 1) > $O/kernel_stats.txt 2>&1
 ( echo "# PMC (separate rocprofv3 passes, GKC_STAGEB_LANES=1, --steps 1 --warmup 0: --pmc FETCH_SIZE | WRITE_SIZE on the default bench (1e8 reads); --kernel-trace only)"
@@ -16,5 +16,5 @@ python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -n 1) > $O/kern
 python tools/pmc_traffic.py $(find $O/pf -name "*.db" | head -n 1) $(find $O/pw -name "*.db" | head -n 1) "k=31, 100000000 synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=10, 4096 partitions" $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
 cp $O/pmc_traffic.json profiles/pmc_traffic.json
 python bench.py > $O/bench_k31.json 2> $O/bench_k31.err
-python bench.py --k 63 --no-cpu-baseline > $O/bench_k63.json 2> $O/bench_k63.err
+
 tail -c 400 $O/bench_k31.json; tail -n 5 $O/pmc_traffic.log; head -n 12 $O/kernel_stats.txt
