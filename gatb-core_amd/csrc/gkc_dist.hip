@@ -17,7 +17,8 @@
 #include <numeric>
 
 namespace {
-constexpr uint64_t MSG_CHUNK = 1ull << 30;     // one message stays below 2 GiB (larger single transfers came back corrupted through torch's RCCL path in round 1)
+constexpr uint64_t MSG_CHUNK = 1ull << 28;     // 256 MiB per message: through torch's all_to_all_single a 1 GiB transfer is intact, a 1.9 GiB one comes back corrupt from
+                                               // byte 973 Mi on and 2 GiB and more fail outright on this stack (tools/rccl_2gib_probe.py, profiles/r02_rccl_2gib_probe.txt)
 }
 
 struct gkc_comm {
