@@ -185,12 +185,26 @@ template <int KW> __device__ __forceinline__ uint32_t sub_index(typename KeyT<KW
 
 constexpr int EXPAND_THREADS = 512;
 
+// bin tables of a batch (written by k_expand_count, read by k_expand_coarse and k_bin_sort)
+constexpr uint32_t BIN_WINDOW_LOG = 12, BIN_WINDOW = 1u << BIN_WINDOW_LOG;     // slots
+constexpr uint32_t BIN_ISO = 4096;                                               // a sub-bucket beyond this many keys is a bin of its own
+constexpr uint32_t BIN_SUBS_MAX = 1024;                                          // sub-buckets of a bin (LDS cursors of k_bin_sort)
+constexpr uint32_t BIN_NBMAX = 2048;                                             // bins of a partition (LDS counters / cursors of k_expand_coarse)
+struct BinTables {
+    uint16_t* of_sub;          // [n_sub] bin of the sub-bucket inside its partition
+    uint32_t* first;           // [nb][nbmax + 1] first sub-bucket of every bin, then the sentinel nsub
+    uint32_t* n;               // [nb] bins of the partition
+    uint32_t* bad;             // set when a partition has more than nbmax bins: the batch takes the pair scatter + wave sort instead
+    uint32_t nbmax;
+};
+
 // ------------------------------------------------------------------------------------------------ B1 expand_count
 template <int KW, int RW>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                   uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
                                                                   uint32_t line_slots /* 0: every sub-bucket starts on a multiple of 4 slots (pair scatter);
-                                                                                         n: SUPER-buckets of 4 sub-buckets start on multiples of n slots, sub-buckets packed inside */)
+                                                                                         n: SUPER-buckets of 4 sub-buckets start on multiples of n slots, sub-buckets packed inside */,
+                                                                  BinTables bins /* nbmax == 0: no bin tables (see k_expand_coarse) */)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
@@ -229,6 +243,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     uint32_t wpre = 0;
     for (int w = 0; w < wave; w++) wpre += s_wsum[w];
     uint32_t run = wpre + x - loc;
+    const uint32_t run0 = run;
     for (uint32_t i = 0; i < per; i++) if (b + i < nunit) {
         uint32_t o = run;
         for (uint32_t d = 0; d < grp; d++) {
@@ -237,6 +252,40 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
             o += s_hist[j];
         }
         run += (unit_size(b + i) + pad) & ~pad;
+    }
+    if (bins.nbmax == 0 || line_slots) return;
+    // BINS (coarse scatter + in-LDS split, k_expand_coarse / k_bin_sort): consecutive sub-buckets whose first slots lie in the same window of BIN_WINDOW slots
+    // form a bin; a sub-bucket beyond BIN_ISO keys is a bin of its own (it goes to the deeper tiers as it is), and bins do not cross multiples of
+    // BIN_SUBS_MAX sub-buckets. So a bin spans < BIN_WINDOW + BIN_ISO slots and <= BIN_SUBS_MAX sub-buckets: it fits k_bin_sort's LDS whatever the skew.
+    auto new_bin = [&](uint32_t j, uint32_t start_j) -> bool {
+        if (j == 0 || (j & (BIN_SUBS_MAX - 1)) == 0 || s_hist[j] > BIN_ISO) return true;
+        const uint32_t np = s_hist[j - 1];
+        if (np > BIN_ISO) return true;
+        const uint32_t start_p = start_j - ((np + 3u) & ~3u);
+        return (start_j >> BIN_WINDOW_LOG) != (start_p >> BIN_WINDOW_LOG);
+    };
+    uint32_t floc = 0;
+    { uint32_t o = run0; for (uint32_t i = 0; i < per; i++) if (b + i < nsub) { floc += new_bin(b + i, o) ? 1u : 0u; o += (s_hist[b + i] + 3u) & ~3u; } }
+    uint32_t fx = floc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(fx, d, 64); if (lane >= d) fx += y; }
+    __syncthreads();                                             // s_wsum is reused
+    if (lane == 63) s_wsum[wave] = fx;
+    __syncthreads();
+    uint32_t fpre = 0, ftot = 0;
+    for (int w = 0; w < EXPAND_THREADS / 64; w++) { if (w < wave) fpre += s_wsum[w]; ftot += s_wsum[w]; }
+    uint32_t bid = fpre + fx - floc;                             // bins that start before this thread's first sub-bucket
+    uint32_t* first = bins.first + (uint64_t)blockIdx.x * (bins.nbmax + 1);
+    { uint32_t o = run0;
+      for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+          const uint32_t j = b + i;
+          if (new_bin(j, o)) { if (bid < bins.nbmax) first[bid] = j; bid++; }
+          bins.of_sub[pd.sub_base + j] = (uint16_t)(bid - 1);
+          o += (s_hist[j] + 3u) & ~3u;
+      } }
+    if (threadIdx.x == 0) {
+        bins.n[blockIdx.x] = ftot;
+        if (ftot <= bins.nbmax) first[ftot] = nsub; else atomicOr(bins.bad, 1u);
     }
 }
 
@@ -281,9 +330,11 @@ constexpr int PAIR_THREADS = 1024;
 // Nothing came out -> it swaps h in: EMPTY came out -> parked; a key came out (someone parked in between) -> it now holds
 // that key instead and starts over. Keys are conserved by every exchange, nobody waits on anybody; 1.5 exchanges per key.
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
-                                                                       const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys)
+                                                                       const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
+                                                                       const uint32_t* __restrict__ only_if /* nullptr, or: run only when this word is set */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub] parked key or EMPTY
+    if (only_if && !*only_if) return;
     const PartDesc pd = parts[blockIdx.x];
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + nsub);                     // [nsub] next free slot of the sub-bucket
@@ -321,6 +372,74 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[s_cur[i]] = v; }
+}
+
+// B1, COARSE scatter (8-byte keys): the keys of a partition leave the expansion grouped by BIN (a run of consecutive sub-buckets, ~4096 slots:
+// BinTables) instead of by sub-bucket, and in whole runs: every bin owns S = STAGE_KEYS / nbins staging slots in LDS; one round = every thread
+// expands one record into the staging area (one LDS counter add per key), then the workgroup writes every bin's staged keys as ONE contiguous
+// run at the bin's cursor (lanes <-> consecutive slots: 64..256-byte runs instead of 16-byte pairs — the scattered-store ceiling of this chip is
+// set by the number of store requests, profiles/r02_scatter_store_calibration.txt). A key that finds its bin's slots full this round goes to its
+// final slot directly (cursor + rank, the cursor only moves in the flush). Inside a bin the keys are in no particular order: k_bin_sort
+// finishes the split by sub-bucket inside LDS, where a random access costs no HBM transaction.
+constexpr int COARSE_THREADS = 1024;
+constexpr uint32_t COARSE_STAGE_KEYS = 16384;        // 128 KB of staging
+__global__ __launch_bounds__(COARSE_THREADS) void k_expand_coarse(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
+                                                                   const uint64_t* __restrict__ b_start, BinTables bins, uint64_t* __restrict__ keys)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_stage[];      // [COARSE_STAGE_KEYS]
+    if (*bins.bad) return;
+    const PartDesc pd = parts[blockIdx.x];
+    const uint32_t nsub = 1u << pd.sub_bits;
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_stage + COARSE_STAGE_KEYS);        // [BIN_NBMAX] keys of the bin this round
+    uint32_t* s_gcur = s_cnt + BIN_NBMAX;                                              // [BIN_NBMAX] next free slot of the bin (relative to key_base)
+    uint16_t* s_map = reinterpret_cast<uint16_t*>(s_gcur + BIN_NBMAX);                 // [nsub] sub-bucket -> bin
+    const uint32_t nbins = bins.n[blockIdx.x];
+    const uint32_t* first = bins.first + (uint64_t)blockIdx.x * (bins.nbmax + 1);
+    for (uint32_t i = threadIdx.x; i < nsub; i += COARSE_THREADS) s_map[i] = bins.of_sub[pd.sub_base + i];
+    for (uint32_t i = threadIdx.x; i < nbins; i += COARSE_THREADS) { s_cnt[i] = 0; s_gcur[i] = (uint32_t)(b_start[pd.sub_base + first[i]] - pd.key_base); }
+    const uint32_t S = nbins ? COARSE_STAGE_KEYS / nbins : COARSE_STAGE_KEYS;          // >= 16
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // flush geometry: S < 64: a wave instruction serves G = 64 / S bins (lane -> bin gi, slot fj); S >= 64: one bin, strided
+    const uint32_t G = S < 64 ? 64u / S : 1u;
+    const uint32_t gi = S < 64 ? (uint32_t)lane / S : 0u, fj = S < 64 ? (uint32_t)lane % S : (uint32_t)lane;
+    __syncthreads();
+    uint64_t* out = keys + pd.key_base;
+    for (uint32_t s = 0; s < segs.n_seg; s++) {
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+        uint64_t r = r0 + threadIdx.x;
+        ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
+        for (uint64_t base = r0; base < r1; base += COARSE_THREADS, r += COARSE_THREADS) {
+            if (r < r1) {
+                const uint64_t R[2] = {nx.x, nx.y};
+                if (r + COARSE_THREADS < r1) nx = recs[r + COARSE_THREADS];            // next record in flight while this one is expanded
+                for_each_kmer16(R, k, [&](uint64_t c) {
+                    const uint32_t bn = s_map[(uint32_t)(c >> pd.shift)];
+                    const uint32_t pos = atomicAdd(&s_cnt[bn], 1u);
+                    if (pos < S) s_stage[bn * S + pos] = c;
+                    else out[s_gcur[bn] + pos] = c;                                   // staging slots of the bin are full this round: straight to its slot
+                });
+            }
+            __syncthreads();
+            if (S < 64) {
+                for (uint32_t bb = wave * G; bb < nbins; bb += (COARSE_THREADS / 64) * G) {
+                    const uint32_t bn = bb + gi;
+                    if (gi < G && bn < nbins) {
+                        const uint32_t n = s_cnt[bn], g0 = s_gcur[bn];
+                        if (fj < (n < S ? n : S)) out[g0 + fj] = s_stage[bn * S + fj];
+                        if (fj == 0 && n) { s_gcur[bn] = g0 + n; s_cnt[bn] = 0; }
+                    }
+                }
+            } else {
+                for (uint32_t bn = wave; bn < nbins; bn += COARSE_THREADS / 64) {
+                    const uint32_t n = s_cnt[bn], g0 = s_gcur[bn], mm = n < S ? n : S;
+                    for (uint32_t j = fj; j < mm; j += 64) out[g0 + j] = s_stage[bn * S + j];
+                    if (lane == 0 && n) { s_gcur[bn] = g0 + n; s_cnt[bn] = 0; }
+                }
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // B1, 16-byte keys in PAIRS: a single 16-byte store to one of 8192 open sub-buckets costs a whole 32-byte HBM write atom (twice the bytes),
@@ -807,10 +926,12 @@ __device__ __forceinline__ void wglist_push(WgList* L, uint32_t g, uint32_t* cou
 template <int KW> struct WaveCapT1 { static constexpr int KPL_MAX = GKC_T1_MID ? WaveCap<KW>::KPL_MAX : WaveCapBig<KW>::KPL_MAX; static constexpr uint32_t CAP = 64 * KPL_MAX; };
 template <int KW, bool F>
 __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const typename KeyT<KW>::type* __restrict__ src, typename KeyT<KW>::type* __restrict__ outk,
-                                                             const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O)
+                                                             const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, uint32_t n_buckets, SortOut O,
+                                                             const uint32_t* __restrict__ only_if /* nullptr, or: run only when this word is set */)
 {
     __shared__ uint32_t s_hc[HIST_LDS];
     __shared__ WgList s_over;
+    if (only_if && !*only_if) return;
     const int t = threadIdx.x, lane = t & 63;
     if (t < HIST_LDS) s_hc[t] = 0;
     if (t == 0) s_over.n = 0;
@@ -825,6 +946,114 @@ __global__ __launch_bounds__(SORT_THREADS, GKC_WS_WAVES) void k_wave_sort(const 
         if (n > WaveCapT1<KW>::CAP) { if (lane == 0) wglist_push(&s_over, g, O.over_count, O.over_list); continue; }
         nb_done++; nk_done += n;
         wave_sort_dispatch<KW, WaveCapT1<KW>::KPL_MAX, F>(src + start, outk, start, n, O, s_hc, lane);
+    }
+    wglist_flush(&s_over, O.over_count, O.over_list);
+    if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
+    if (lane == 0 && nb_done) { atomicAdd(&O.n_sorted[0], (unsigned long long)nb_done); atomicAdd(&O.n_sorted[1], nk_done); }
+}
+
+// Level 1 after the coarse scatter: one WORKGROUP per bin. The bin's keys (one contiguous run in HBM, in no particular order) are loaded once, coalesced,
+// and dropped into their sub-bucket's range inside LDS (cursor per sub-bucket seeded with the exact offsets k_expand_count computed: one LDS add per key,
+// no counting pass); then the waves take the bin's sub-buckets one after the other and sort them straight out of LDS with the register network of
+// k_wave_sort — distinct keys / abundances go to the head of the sub-bucket's own slot range in HBM, as everywhere else. A sub-bucket beyond the first
+// tier's registers is written back grouped and handed to the next tier by its index; a bin that is one such sub-bucket is not even loaded.
+constexpr int BIN_THREADS = 512;
+constexpr uint32_t BIN_KEYS_MAX = BIN_WINDOW + BIN_ISO;                           // slots a bin can span
+__global__ void k_bin_prefix(const uint32_t* __restrict__ bin_n, uint32_t nb, uint32_t* __restrict__ bin_pre /* [nb + 1] */)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t v = base + t < nb ? bin_n[base + t] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int w = 0; w < wave; w++) pre += s_w[w];
+        if (base + t < nb) bin_pre[base + t] = pre + x - v;
+        __syncthreads();
+        if (t == 1023) s_carry = pre + x;
+        __syncthreads();
+    }
+    if (t == 0) bin_pre[nb] = s_carry;
+}
+template <int KW, bool F>
+__global__ __launch_bounds__(BIN_THREADS, 4) void k_bin_sort(const PartDesc* __restrict__ parts, typename KeyT<KW>::type* __restrict__ keys,
+                                                             const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, BinTables bins, SortOut O, uint32_t dbg)
+{
+    typedef typename KeyT<KW>::type key_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    key_t* s_keys = reinterpret_cast<key_t*>(s_raw);                                // [BIN_KEYS_MAX]
+    uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_keys + BIN_KEYS_MAX);           // [BIN_SUBS_MAX] fill cursor of the sub-bucket inside s_keys
+    uint32_t* s_off = s_cur + BIN_SUBS_MAX;                                         // [BIN_SUBS_MAX] first slot of the sub-bucket inside s_keys
+    uint32_t* s_n = s_off + BIN_SUBS_MAX;                                           // [BIN_SUBS_MAX] its keys
+    __shared__ uint32_t s_hc[HIST_LDS];
+    __shared__ WgList s_over;
+    __shared__ uint32_t s_next, s_total;
+    if (*bins.bad) return;
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < HIST_LDS) s_hc[t] = 0;
+    if (t == 0) s_over.n = 0;
+    const PartDesc pd = parts[blockIdx.y];                                          // grid: (workgroups per partition, partitions of the batch)
+    const uint32_t nbins = bins.n[blockIdx.y];
+    const uint32_t* first = bins.first + (uint64_t)blockIdx.y * (bins.nbmax + 1);
+    const uint64_t* p_start = b_start + pd.sub_base;
+    const uint32_t* p_n = b_n + pd.sub_base;
+    uint32_t nb_done = 0; unsigned long long nk_done = 0;
+    for (uint32_t bn = blockIdx.x; bn < nbins; bn += gridDim.x) {
+        const uint32_t j0 = first[bn], j1 = first[bn + 1], ns = j1 - j0;
+        const uint64_t start0 = p_start[j0];
+        if (ns == 1) {
+            const uint32_t n = p_n[j0];
+            if (n > WaveCapT1<KW>::CAP) { if (t == 0) wglist_push(&s_over, (uint32_t)(pd.sub_base + j0), O.over_count, O.over_list); continue; }
+        }
+        __syncthreads();                                                            // LDS of the previous bin fully consumed
+        if (t == 0) { s_next = 0; s_total = 0; }
+        __syncthreads();
+        {   uint32_t mine = 0;
+            for (uint32_t i = t; i < ns; i += BIN_THREADS) {
+                const uint32_t o = (uint32_t)(p_start[j0 + i] - start0), n = p_n[j0 + i];
+                s_cur[i] = o; s_off[i] = o; s_n[i] = n; mine += n;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d, 64);
+            if (lane == 0 && mine) atomicAdd(&s_total, mine);
+        }
+        __syncthreads();
+        const uint32_t n = s_total;
+        const key_t* src = keys + start0;
+        if (!(dbg & 2u))
+        for (uint32_t i0 = 0; i0 < n; i0 += 4 * BIN_THREADS) {
+            key_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * BIN_THREADS + t; if (i < n) v[u] = src[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t i = i0 + u * BIN_THREADS + t;
+                if (i < n) { const uint32_t q = sub_index<KW>(v[u], pd.shift) - j0; const uint32_t pos = atomicAdd(&s_cur[q], 1u); s_keys[pos] = v[u]; } }
+        }
+        __syncthreads();
+        for (;;) {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(&s_next, 1u);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i >= ns) break;
+            const uint32_t sn = s_n[i];
+            if (sn == 0) continue;
+            const uint32_t off = s_off[i];
+            const uint64_t sstart = start0 + off;
+            if (sn > WaveCapT1<KW>::CAP) {                                          // next tier: grouped copy back, index to the list
+                for (uint32_t x = lane; x < sn; x += 64) keys[sstart + x] = s_keys[off + x];
+                if (lane == 0) wglist_push(&s_over, (uint32_t)(pd.sub_base + j0 + i), O.over_count, O.over_list);
+                continue;
+            }
+            nb_done++; nk_done += sn;
+            if (!(dbg & 1u)) wave_sort_dispatch<KW, WaveCapT1<KW>::KPL_MAX, F>(s_keys + off, keys, sstart, sn, O, s_hc, lane);
+        }
     }
     wglist_flush(&s_over, O.over_count, O.over_list);
     if (t < HIST_LDS && s_hc[t]) atomicAdd(&O.histo[t], (unsigned long long)s_hc[t]);
@@ -1625,9 +1854,9 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, bigs, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot;
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, bigs, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot, bin_of, bin_first, bin_n, bin_pre;
     void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &over3, &bigs, &misc, &bs_d, &bs_s,
-                                        &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot };
+                                        &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot, &bin_of, &bin_first, &bin_n, &bin_pre };
                      for (DevBuf* d : all) d->release(); }
 };
 
@@ -1686,13 +1915,45 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     CB_HIP(hipMemcpyAsync(B.pidx.p, pblk.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
     CB_HIP(hipMemsetAsync(B.cnt8.p, 0, (size_t)std::max<uint64_t>(n_slots, 4), cur_stream(c)));
     CB_HIP(hipMemsetAsync(B.misc.p, 0, 64, cur_stream(c)));
+    // GKC_BIN (8-byte keys): coarse scatter by bin + in-LDS split (k_expand_coarse, k_bin_sort) instead of the pair scatter + wave sort from HBM
+    static const bool bin_env = getenv("GKC_BIN") ? atoi(getenv("GKC_BIN")) != 0 : false;
+    const bool bin = bin_env && KW == 1 && RW == 2 && !line && getenv("GKC_SCATTER_NO_PAIR") == nullptr && getenv("GKC_SCATTER_QUAD") == nullptr &&
+                     getenv("GKC_HASH_COUNT") == nullptr && k <= 31;
+    BinTables BT{};
+    if (bin) {
+        static const uint32_t nbmax_env = getenv("GKC_BIN_NBMAX") ? (uint32_t)atoi(getenv("GKC_BIN_NBMAX")) : BIN_NBMAX;      // tests: force the fallback
+        CB_TRY(c->ensure(B.bin_of, (size_t)n_sub * 2)); CB_TRY(c->ensure(B.bin_first, (size_t)nb * (BIN_NBMAX + 1) * 4));
+        CB_TRY(c->ensure(B.bin_n, (size_t)nb * 4)); CB_TRY(c->ensure(B.bin_pre, (size_t)(nb + 1) * 4));
+        BT.of_sub = (uint16_t*)B.bin_of.p; BT.first = (uint32_t*)B.bin_first.p; BT.n = (uint32_t*)B.bin_n.p; BT.bad = (uint32_t*)B.misc.p + 8;
+        BT.nbmax = std::min<uint32_t>(nbmax_env, BIN_NBMAX);
+    }
 
     {   ScopedTimer tm(c, "expand_count");
         hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p, line_slots);
+                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p, line_slots, BT);
         CB_HIP(hipGetLastError());
     }
+    if (bin && getenv("GKC_VERBOSE")) {
+        std::vector<uint32_t> hb(nb); uint32_t bad = 0;
+        CB_HIP(hipMemcpyAsync(hb.data(), B.bin_n.p, (size_t)nb * 4, hipMemcpyDeviceToHost, cur_stream(c)));
+        CB_HIP(hipMemcpyAsync(&bad, BT.bad, 4, hipMemcpyDeviceToHost, cur_stream(c)));
+        CB_HIP(hipStreamSynchronize(cur_stream(c)));
+        uint64_t sum = 0, mx = 0, mxk = 0; for (uint32_t i = 0; i < nb; i++) { sum += hb[i]; if (hb[i] > mx) { mx = hb[i]; mxk = part_keys[batch_parts[i]]; } }
+        fprintf(stderr, "[gkc] bins: %u partitions, %llu bins, max %llu (partition of %llu keys), fallback flag %u\n", nb, (unsigned long long)sum, (unsigned long long)mx, (unsigned long long)mxk, bad);
+    }
     {   ScopedTimer tm(c, "expand_scatter");
+        if constexpr (KW == 1 && RW == 2) if (bin) {
+            // coarse scatter (whole runs per bin); the pair scatter behind it only runs when the bin tables did not fit (flag set by k_expand_count)
+            const size_t lds = (size_t)COARSE_STAGE_KEYS * 8 + (size_t)BIN_NBMAX * 8 + (size_t)MAX_SUB * 2;
+            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            hipLaunchKernelGGL(k_expand_coarse, dim3(nb), dim3(COARSE_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start[0].p, BT, (uint64_t*)B.keysA.p);
+            const size_t lds2 = (size_t)MAX_SUB * 12;
+            static std::once_flag once2; std::call_once(once2, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); });
+            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds2, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p, (const uint32_t*)BT.bad);
+        }
+        if (bin) {} else
         if (line) {
             const size_t lds = (size_t)LINE_SUPER_MAX * (LINE_SLOT_WORDS * 8 + 8);          // 144 KB: 64 bytes staged + two control words per super-bucket
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_line<KW, RW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
@@ -1709,7 +1970,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             const size_t lds = (size_t)MAX_SUB * 12;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p);
+                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p, (const uint32_t*)nullptr);
         } else if (KW == 2 && k >= 32 && getenv("GKC_SCATTER_NO_PAIR") == nullptr) {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
@@ -1806,10 +2067,29 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         } else
         {   ScopedTimer tm(c, level == 1 ? "bucket_sort" : "bucket_sort_deep");
             const unsigned grid = (unsigned)std::min<uint64_t>((n_buckets + 3) / 4, 256 * 32);
+            const uint32_t* only_if = nullptr;
+            if (level == 1 && bin) {
+                // level 1 after the coarse scatter: a workgroup per bin splits it inside LDS and sorts its sub-buckets (k_bin_sort); the plain wave sort
+                // below then only runs when the batch fell back to the pair scatter (more bins in a partition than the coarse scatter has counters for)
+                const size_t lds = (size_t)BIN_KEYS_MAX * sizeof(key_t) + (size_t)BIN_SUBS_MAX * 12;
+                static std::once_flag once;
+                std::call_once(once, [&] {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_sort<KW, FT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_sort<KW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                });
+                static const unsigned bwg = getenv("GKC_BIN_GRID") ? (unsigned)atoi(getenv("GKC_BIN_GRID")) : 2048u;       // workgroups of the launch, about
+                static const uint32_t dbg = getenv("GKC_BIN_DBG") ? (uint32_t)atoi(getenv("GKC_BIN_DBG")) : 0u;
+                const unsigned gx = std::min(64u, std::max(2u, (bwg + nb - 1) / nb));
+                if (tag) hipLaunchKernelGGL((k_bin_sort<KW, FT>), dim3(gx, nb), dim3(BIN_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, (key_t*)B.keysA.p,
+                                   (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, BT, O, dbg);
+                else hipLaunchKernelGGL((k_bin_sort<KW, false>), dim3(gx, nb), dim3(BIN_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, (key_t*)B.keysA.p,
+                                   (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, BT, O, dbg);
+                only_if = BT.bad;
+            }
             if (tag) hipLaunchKernelGGL((k_wave_sort<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p,
-                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O, only_if);
             else hipLaunchKernelGGL((k_wave_sort<KW, false>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)src, (key_t*)B.keysA.p,
-                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O);
+                               (const uint64_t*)B.b_start[cur].p, (const uint32_t*)B.b_n[cur].p, (uint32_t)n_buckets, O, only_if);
             CB_HIP(hipGetLastError());
         }
         uint32_t n_mid = 0; unsigned long long split_bad = 0;

@@ -613,9 +613,10 @@ def test_exact_repartitor_sample(gkc, k, m, freq):
         assert used == eused and np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(d, ed), (thr, used, eused)
 
 
-@pytest.mark.parametrize("switch", ["GKC_SCATTER_LINE", "GKC_TAIL_LDS", "GKC_HASH_COUNT", "GKC_SCATTER_NO_PAIR", "GKC_NO_F64"])
+@pytest.mark.parametrize("switch", ["GKC_SCATTER_LINE", "GKC_TAIL_LDS", "GKC_HASH_COUNT", "GKC_SCATTER_NO_PAIR", "GKC_NO_F64", "GKC_BIN", "GKC_BIN,GKC_BIN_NBMAX=4"])
 def test_experimental_kernel_paths_stay_bit_exact(gkc, switch):
-    """the measured-and-kept alternative kernels (64-byte line scatter + LDS-split sort, LDS tail sort, count-first first tier) and two older
+    """the measured-and-kept alternative kernels (64-byte line scatter + LDS-split sort, LDS tail sort, count-first first tier, coarse scatter by bin + in-LDS
+    split — also with its fallback forced —) and two older
     A/B switches select other HIP code paths of the same library: each must give the oracle's records on an input with N's, ragged reads, low-complexity
     reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31 and k = 41"""
     import json, os, subprocess, sys
@@ -637,7 +638,9 @@ for k, m, parts in ((31, 8, 3), (41, 9, 2)):
     res[str(k)] = bool(all(np.array_equal(c.partition_records(0, p), ref.part_records(p)) for p in range(parts)) and np.array_equal(c.histogram(), ref.histogram()))
 print(json.dumps(res))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ); env[switch] = "1"
+    env = dict(os.environ)
+    for kv in switch.split(","):                                          # "NAME" or "NAME=value"
+        name, _, val = kv.partition("="); env[name] = val or "1"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert json.loads(out.stdout.strip().splitlines()[-1]) == {"31": True, "41": True}
