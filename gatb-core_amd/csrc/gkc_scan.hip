@@ -133,6 +133,14 @@ __device__ __forceinline__ void load16(const uint8_t* bases, uint64_t g0, uint64
     }
 }
 
+#ifdef GKC_EXP_SCAN_PROF
+// timing experiment (tools/build_variant.sh scanprof -DGKC_EXP_SCAN_PROF=1): cycles of wave 0 of every workgroup between the marks of k_scan_tile
+__device__ unsigned long long g_scan_prof[16];
+#define SCAN_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define SCAN_MARK(i) do {} while (0)
+#endif
+
 // LDSPART: persistent workgroups with a static tile assignment (tile = blockIdx.x, += gridDim.x, identical in the count
 // and the emit launch). Per-partition counters / record cursors live in LDS (64-bit LDS atomics): the count launch
 // leaves a [workgroup][partition] matrix, a tiny prefix kernel turns it into private record ranges, and the emit launch
@@ -165,6 +173,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             s_part[p] = 0u;
     }
     uint32_t nv_acc = 0, ni_acc = 0, n_rec = 0;
+#ifdef GKC_EXP_SCAN_PROF
+    unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
+#endif
 
   // the tile's bases (16 per thread + the halo words) and read-start bits are fetched one tile AHEAD into registers: with two workgroups
   // per CU and ~7 barriers per tile nothing else hides the global-load latency (measured: a third of the kernel)
@@ -183,6 +194,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
     asm volatile("" : "+v"(t));                                // keep per-lane address math inside the loop: hoisting it
                                                                // (LICM) costs ~150 VGPRs and halves the occupancy
     __syncthreads();                                           // LDS of the previous tile fully consumed
+    SCAN_MARK(0);
 
     // ---- step 0: ASCII -> bit planes (A1) ----
     {
@@ -193,7 +205,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         if (t < SCAN_TILE / 32 + 8) s_rs[t] = pfR;
     }
     if (tile + gridDim.x < P.n_tiles) prefetch(tile + gridDim.x);     // in flight during the rest of this tile
+    SCAN_MARK(1);
     __syncthreads();
+    SCAN_MARK(2);
 
     // ---- step 1: order key of the m-mer starting at every position (A3: LUT semantics) ----
     for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
@@ -218,7 +232,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             s_mk[17 * w + j] = key;
         }
     }
+    SCAN_MARK(3);
     __syncthreads();
+    SCAN_MARK(4);
 
     // ---- step 2: minimizer = window minimum of nb_mm keys (always the true minimum: Model.hpp:1107-1139 keeps it by
     //      rescanning whenever the tracked one leaves the window) ----
@@ -258,6 +274,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         }
     }
 
+    SCAN_MARK(5);
     // ---- step 3: which positions hold a k-mer, and which of those are valid (A2) ----
     // window-OR of the invalid / read-start bit planes over k (k-1) positions for all 16 positions of the thread at once:
     // doubling (windows 1,2,4,...,32) on a 128-bit value, then the binary decomposition of the window length.
@@ -282,8 +299,32 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             }
             return acc & 0xFFFFu;
         };
-        const uint32_t rsany = window_or16(rlo, rhi, k - 1);
-        const uint32_t badany = window_or16(blo, bhi, k);
+        // read starts (one per read) and invalid letters (rare) are SPARSE: instead of the doubling network, walk the set bits of the
+        // window and OR in the range of positions each one reaches — 0..2 iterations per wave on ordinary reads, any density stays exact
+        auto window_or16_sparse = [](uint64_t lo, uint64_t hi, uint32_t len) -> uint32_t {
+            // bits j=0..15 : OR of input bits j .. j+len-1   (len in [0,63]): input bit b reaches j in [b-len+1, b]
+            if (len == 0) return 0u;
+            uint32_t acc = 0;
+            const uint32_t top = 15u + len;                                   // first input bit that no longer matters (<= 78)
+            uint64_t w = top >= 64 ? lo : (lo & ((1ULL << top) - 1));
+            while (w) {
+                const uint32_t b = (uint32_t)__builtin_ctzll(w); w &= w - 1;
+                const uint32_t j1 = b < 15u ? b : 15u, j0 = b + 1u > len ? b + 1u - len : 0u;
+                acc |= ((2u << j1) - 1u) & ~((1u << j0) - 1u);
+            }
+            if (top > 64) {
+                uint64_t v = hi & ((1ULL << (top - 64)) - 1);
+                while (v) {
+                    const uint32_t b = 64u + (uint32_t)__builtin_ctzll(v); v &= v - 1;
+                    const uint32_t j0 = b + 1u - len;                         // b >= 64 > 15: reaches j in [b-len+1, 15]
+                    if (j0 <= 15u) acc |= 0xFFFFu & ~((1u << j0) - 1u);
+                }
+            }
+            return acc & 0xFFFFu;
+        };
+        (void)window_or16;
+        const uint32_t rsany = window_or16_sparse(rlo, rhi, k - 1);
+        const uint32_t badany = window_or16_sparse(blo, bhi, k);
         // k-mers may not run past the end of the batch
         const long long lim = (long long)P.n_bases - (long long)k - (long long)(t0 + p0);      // last j that still fits
         const uint32_t fits = lim >= 15 ? 0xFFFFu : (lim < 0 ? 0u : ((2u << (uint32_t)lim) - 1u));
@@ -294,6 +335,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 #endif
     }
 
+    SCAN_MARK(6);
     // ---- step 4: natural super-k-mer starts and the workgroup-wide "last start" max-scan (A4) ----
     s_lastmz[t] = mz[15]; s_lastvalid[t] = (validmask >> 15) & 1;
     s_firstmz[t] = mz[0]; s_firstvalid[t] = validmask & 1;
@@ -301,15 +343,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
     __syncthreads();
     uint32_t nsmask = 0;
     {
-        bool pv = t > 0 ? (s_lastvalid[t - 1] != 0) : false;  // tile start forces a new super-k-mer
-        uint32_t pm = t > 0 ? s_lastmz[t - 1] : 0;
+        const bool pv = t > 0 ? (s_lastvalid[t - 1] != 0) : false;  // tile start forces a new super-k-mer
+        const uint32_t pm = t > 0 ? s_lastmz[t - 1] : 0;
+        // a valid position starts a run when the position before is not valid or holds another minimizer: whole-thread bit masks
+        uint32_t neq = mz[0] != pm ? 1u : 0u;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            bool v = (validmask >> j) & 1;
-            bool ns = v && (!pv || mz[j] != pm);
-            nsmask |= (uint32_t)ns << j;
-            pv = v; pm = mz[j];
-        }
+        for (int j = 1; j < 16; j++) neq |= (mz[j] != mz[j - 1] ? 1u : 0u) << j;
+        const uint32_t pvmask = (validmask << 1) | (pv ? 1u : 0u);
+        nsmask = validmask & (~pvmask | neq) & 0xFFFFu;
     }
     int carry;   // position (tile-local) of the last natural start before p0, or -1
     {
@@ -327,6 +368,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         carry = ex > wc ? ex : wc;
     }
 
+    SCAN_MARK(7);
     // ---- step 5: emit one record per run end (A4 cap, A5 pass filter + partition, A6 bucket write) ----
     // run ends are first compacted per thread into LDS (own 16 slots), so the divergent emission loop runs
     // max-over-lanes(#ends) times instead of 16
@@ -335,6 +377,23 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         const bool nxt_valid = s_firstvalid[t + 1] != 0;       // t==255: sentinel (tile end)
         const uint32_t nxt_mz = s_firstmz[t + 1];
         const int maxs = (int)P.maxs;
+        // The cap (a run cut every maxs k-mers) only ever bites on runs of a REPEATED minimizer value (a minimizer stays at most nb_mm <= maxs
+        // positions in the window otherwise): a thread whose positions cannot reach rank maxs-1 of their run takes run ends straight from
+        // the bit masks (no division, no per-position arithmetic); the test is wave-uniform so both loops stay divergence-free.
+        const uint32_t goes_on = validmask & ~nsmask;                      // positions that continue the run of the position before
+        const int jcap = carry + maxs - 1 - p0;                           // where the run entering this thread would reach rank maxs-1
+        const bool may_cap = maxs < 18 || ((goes_on & 1u) && (jcap <= 0 || (jcap <= 15 && (goes_on & ((2u << jcap) - 1u)) == ((2u << jcap) - 1u))));
+        const bool fast = __ballot(may_cap) == 0ull;
+        uint32_t ends = 0;
+        if (fast) {
+            // run ends as a bit mask; the 16 minimizers go to the thread's own slots with static indices (no per-position branch), the
+            // emission loop below walks the set bits
+            const uint32_t b15 = (!nxt_valid || (nxt_mz != mz[15])) ? 1u : 0u;
+            ends = validmask & ((((~(validmask >> 1)) | (nsmask >> 1)) & 0x7FFFu) | (b15 << 15));
+#pragma unroll
+            for (int j = 0; j < 16; j++) s_mk[MKI(p0) + j] = mz[j];
+            n_end = __popc(ends);
+        } else
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const bool v = (validmask >> j) & 1;
@@ -359,21 +418,42 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         // descriptor stream of the count pass (LDSPART): (partition, nbK, start) per record, so that the emit pass does
         // not have to recompute minimizers. Slots are reserved per thread; filtered-out records leave a ~0 hole.
         uint32_t dbase = 0; bool dstore = false;
-        if (!EMIT && LDSPART && P.desc && n_end) {
-            dbase = s_toff + atomicAdd(&s_tcnt, (uint32_t)n_end);
-            dstore = dbase + (uint32_t)n_end <= P.desc_cap_wg;
-            if (!dstore) *P.desc_overflow = 1u;
+        if (!EMIT && LDSPART && P.desc) {
+            // one LDS add per WAVE (512 returning adds on one word serialise): wave prefix of the counts, lane 0 reserves the wave's total
+            const int lane = t & 63;
+            uint32_t x = (uint32_t)n_end;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+            const uint32_t wtot = __shfl(x, 63, 64);
+            uint32_t wbase = 0;
+            if (lane == 0 && wtot) wbase = atomicAdd(&s_tcnt, wtot);
+            wbase = __shfl(wbase, 0, 64);
+            if (n_end) {
+                dbase = s_toff + wbase + x - (uint32_t)n_end;
+                dstore = dbase + (uint32_t)n_end <= P.desc_cap_wg;
+                if (!dstore) *P.desc_overflow = 1u;
+            }
         }
 #ifdef GKC_EXP_SCAN_NOEMIT
         n_end = n_end > 1000 ? n_end : 0;
 #endif
+        SCAN_MARK(8);
 #pragma unroll 1
         for (int e = 0; e < n_end; e++) {
             if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = 0xFFFFFFFFu;
-            const uint32_t info = s_end[MKI(p0) + e];
-            const uint32_t nbk = (info >> 4) + 1;
-            const int start = p0 + (int)(info & 15u) - (int)(info >> 4);
-            const uint32_t key = s_mk[MKI(p0) + e];
+            uint32_t nbk, key; int start;
+            if (fast) {
+                const uint32_t j = (uint32_t)__builtin_ctz(ends); ends &= ends - 1u;
+                const uint32_t below = nsmask & ((2u << j) - 1u);                       // run starts at or before j inside the thread
+                start = below ? p0 + 31 - __clz((int)below) : carry;
+                nbk = (uint32_t)(p0 + (int)j - start) + 1u;
+                key = s_mk[MKI(p0) + j];
+            } else {
+                const uint32_t info = s_end[MKI(p0) + e];
+                nbk = (info >> 4) + 1;
+                start = p0 + (int)(info & 15u) - (int)(info >> 4);
+                key = s_mk[MKI(p0) + e];
+            }
             const uint32_t value = P.freq_mode ? P.key2val[key] : key;
             if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
             const uint32_t part = P.identity_part ? value : P.repart[value];
@@ -392,12 +472,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         }
     }
 
+    SCAN_MARK(9);
     nv_acc += __popc(validmask); ni_acc += __popc(existsmask & ~validmask);
     if (!EMIT && LDSPART && P.desc) {                          // close the tile's descriptor range
         __syncthreads();
         if (t == 0) { P.desc_tile[tile] = make_uint2(s_toff, s_tcnt); s_toff += s_tcnt; s_tcnt = 0; }
     }
+    SCAN_MARK(10);
   }   // tile loop
+#ifdef GKC_EXP_SCAN_PROF
+    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_scan_prof[i], prof_acc[i]);
+#endif
 
     // ---- statistics (Sequence2SuperKmer.hpp:103,108) ----
     {
@@ -503,6 +588,17 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
     }
 #undef GKC_LAUNCH
     GKC_HIP(c, hipGetLastError());
+#ifdef GKC_EXP_SCAN_PROF
+    {   unsigned long long h[16];
+        GKC_HIP(c, hipStreamSynchronize(c->stream));
+        GKC_HIP(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_scan_prof), sizeof(h)));
+        unsigned long long tot = 0; for (int i = 0; i < 11; i++) tot += h[i];
+        fprintf(stderr, "[gkc] scan marks (emit=%d), cumulative %% of wave-0 cycles:", (int)emit);
+        static const char* nm[] = {"barrier0", "step0+prefetch", "barrier1", "step1", "barrier2", "step2", "step3", "step4", "step5 collect", "step5 emit", "tile end"};
+        for (int i = 0; i < 11; i++) fprintf(stderr, " %s %.1f;", nm[i], tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
     return GKC_OK;
 }
 
