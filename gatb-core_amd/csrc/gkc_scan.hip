@@ -194,6 +194,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
     asm volatile("" : "+v"(t));                                // keep per-lane address math inside the loop: hoisting it
                                                                // (LICM) costs ~150 VGPRs and halves the occupancy
     __syncthreads();                                           // LDS of the previous tile fully consumed
+    if (!EMIT && LDSPART && P.desc && t == 0 && tile != blockIdx.x) {      // close the previous tile's descriptor range (its reservations are all in:
+        P.desc_tile[tile - gridDim.x] = make_uint2(s_toff, s_tcnt);        // the barrier above; nobody touches the two words again before step 5)
+        s_toff += s_tcnt; s_tcnt = 0;
+    }
     SCAN_MARK(0);
 
     // ---- step 0: ASCII -> bit planes (A1) ----
@@ -211,16 +215,19 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 
     // ---- step 1: order key of the m-mer starting at every position (A3: LUT semantics) ----
     for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
-        uint64_t X = ((uint64_t)s_be[w] << 32) | s_be[w + 1];
-        uint64_t Y = (uint64_t)s_le[w] | ((uint64_t)s_le[w + 1] << 32);
+        const uint32_t xh = s_be[w], xl = s_be[w + 1], yl = s_le[w], yh = s_le[w + 1];
+        const uint32_t fsh = 32u - 2u * m, rcx = 0xAAAAAAAAu & P.mmask;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            uint32_t fw = (uint32_t)(X >> (64 - 2 * (j + m))) & P.mmask;
+            // forward m-mer = the top 2m bits of the big-endian window shifted left by j nucleotides; reverse complement = the low 2m bits of the
+            // little-endian window shifted right by j: one funnel shift (v_alignbit) each instead of 64-bit shifts
+            const uint32_t f32 = j ? __builtin_amdgcn_alignbit(xh, xl, 32 - 2 * j) : xh;
+            uint32_t fw = f32 >> fsh;
             uint32_t key;
             if (P.freq_mode) {
                 key = P.mkey_lut[fw];                         // order key of canonical(fw) under (freq_order[c], c)
             } else {
-                uint32_t rc = ((uint32_t)(Y >> (2 * j)) & P.mmask) ^ (0xAAAAAAAAu & P.mmask);
+                uint32_t rc = ((j ? __builtin_amdgcn_alignbit(yh, yl, 2 * j) : yl) & P.mmask) ^ rcx;
                 uint32_t c = fw < rc ? fw : rc;               // canonical m-mer
                 uint32_t a = ~(c | (c >> 2));
                 a = (a >> 1) & a & P.mask_ma1;                // "AA" anywhere but as prefix (KMC2 rule)
@@ -246,19 +253,22 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 #else
     if (Wn >= 16) {
 #endif
+        // MKI(16 t + i) = 17 t + i + (i >> 4): the part that depends on i is wave-uniform (scalar), one vector add per LDS address
+        const uint32_t* mk_t = s_mk + 17 * t;
         uint32_t core = P.default_key;                        // the default minimizer 4^m-1 takes part (Model.hpp:1260)
-        for (uint32_t i = 15; i < Wn; i++) { uint32_t v = s_mk[MKI(p0 + i)]; core = v < core ? v : core; }
+        for (uint32_t i = 15; i < Wn; i++) { uint32_t v = mk_t[i + (i >> 4)]; core = v < core ? v : core; }
         uint32_t suf = 0xFFFFFFFFu;
         uint32_t sufL[16];
         sufL[15] = suf;
 #pragma unroll
-        for (int j = 14; j >= 0; j--) { uint32_t v = s_mk[MKI(p0 + j)]; suf = v < suf ? v : suf; sufL[j] = suf; }
+        for (int j = 14; j >= 0; j--) { uint32_t v = mk_t[j]; suf = v < suf ? v : suf; sufL[j] = suf; }
         uint32_t pre = 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             uint32_t r = sufL[j] < core ? sufL[j] : core;
             mz[j] = pre < r ? pre : r;
-            uint32_t v = s_mk[MKI(p0 + Wn + j)]; pre = v < pre ? v : pre;
+            const uint32_t i = Wn + (uint32_t)j;
+            uint32_t v = mk_t[i + (i >> 4)]; pre = v < pre ? v : pre;
         }
     } else {
 #pragma unroll
@@ -438,10 +448,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         n_end = n_end > 1000 ? n_end : 0;
 #endif
         SCAN_MARK(8);
-#pragma unroll 1
-        for (int e = 0; e < n_end; e++) {
-            if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = 0xFFFFFFFFu;
-            uint32_t nbk, key; int start;
+        auto next_end = [&](int e, uint32_t& nbk, uint32_t& key, int& start) {          // the e-th run end of the thread (called in order)
             if (fast) {
                 const uint32_t j = (uint32_t)__builtin_ctz(ends); ends &= ends - 1u;
                 const uint32_t below = nsmask & ((2u << j) - 1u);                       // run starts at or before j inside the thread
@@ -454,16 +461,48 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                 start = p0 + (int)(info & 15u) - (int)(info >> 4);
                 key = s_mk[MKI(p0) + e];
             }
+        };
+        if (!EMIT && LDSPART) {
+            // count pass: the minimizer -> partition gathers (L2) of up to 4 run ends are issued back to back, then consumed: a thread has 1..3 ends
+            // on ordinary reads, and a divergent one-end-per-iteration loop would expose one gather latency per end
+            uint32_t* dst = P.desc + (uint64_t)blockIdx.x * P.desc_cap_wg + dbase;
+#pragma unroll 1
+            for (int e0 = 0; e0 < n_end; e0 += 4) {
+                uint32_t dpart[4], dlow[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    dlow[u] = 0xFFFFFFFFu; dpart[u] = 0;
+                    if (e0 + u < n_end) {
+                        uint32_t nbk, key; int start;
+                        next_end(e0 + u, nbk, key, start);
+                        const uint32_t value = P.freq_mode ? P.key2val[key] : key;
+                        if (!(P.nb_passes > 1 && (value % P.nb_passes) != P.pass)) {     // SortingCountAlgorithm.cpp:1083
+                            dpart[u] = P.identity_part ? value : P.repart[value];
+                            dlow[u] = ((nbk - 1) << DESC_START_BITS) | (uint32_t)start;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (e0 + u < n_end) {
+                    if (dlow[u] == 0xFFFFFFFFu) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }      // filtered out: a hole in the descriptor stream
+                    n_rec++;
+                    if (P.dbg_noatomic) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }
+                    atomicAdd(&s_part[dpart[u]], 1u);
+                    if (dstore) dst[e0 + u] = (dpart[u] << (DESC_START_BITS + DESC_NBK_BITS)) | dlow[u];
+                }
+            }
+        } else
+#pragma unroll 1
+        for (int e = 0; e < n_end; e++) {
+            uint32_t nbk, key; int start;
+            next_end(e, nbk, key, start);
             const uint32_t value = P.freq_mode ? P.key2val[key] : key;
             if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
             const uint32_t part = P.identity_part ? value : P.repart[value];
             n_rec++;
             if (!EMIT) {
                 if (P.dbg_noatomic) continue;
-                if (LDSPART) {
-                    atomicAdd(&s_part[part], 1u);
-                    if (dstore) P.desc[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e] = (part << (DESC_START_BITS + DESC_NBK_BITS)) | ((nbk - 1) << DESC_START_BITS) | (uint32_t)start;
-                } else { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
+                { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
             } else {
                 const unsigned long long slot = LDSPART ? (P.wg_base[(uint64_t)blockIdx.x * P.n_parts + part] + atomicAdd(&s_part[part], 1u))
                                                         : atomicAdd(&P.cursor[part], 1ULL);
@@ -474,12 +513,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 
     SCAN_MARK(9);
     nv_acc += __popc(validmask); ni_acc += __popc(existsmask & ~validmask);
-    if (!EMIT && LDSPART && P.desc) {                          // close the tile's descriptor range
-        __syncthreads();
-        if (t == 0) { P.desc_tile[tile] = make_uint2(s_toff, s_tcnt); s_toff += s_tcnt; s_tcnt = 0; }
-    }
     SCAN_MARK(10);
   }   // tile loop
+    if (!EMIT && LDSPART && P.desc && blockIdx.x < P.n_tiles) { // close the last tile's descriptor range
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t last = blockIdx.x + (P.n_tiles - 1 - blockIdx.x) / gridDim.x * (uint64_t)gridDim.x;
+            P.desc_tile[last] = make_uint2(s_toff, s_tcnt);
+        }
+    }
 #ifdef GKC_EXP_SCAN_PROF
     if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_scan_prof[i], prof_acc[i]);
 #endif
