@@ -758,6 +758,9 @@ template <> struct Shfl<2> {
         return ((u128)hi << 64) | lo; }
 };
 
+#ifndef GKC_CROSS_MINMAX
+#define GKC_CROSS_MINMAX 1     // cross-lane steps of tagged keys as exec-masked v_min_f64 / v_max_f64 blocks (0: 64-bit compare + selects)
+#endif
 // In-lane compare-exchange. F (8-byte keys only): the keys of the bucket carry the exponent tag of a double in their 12 top bits (see
 // TAG64 below), so they are positive normal doubles whose order is the integer order, and the exchange is the two native 64-bit
 // instructions v_min_f64 / v_max_f64 instead of a 64-bit compare and four selects. Cross-lane steps compare the same bit patterns as integers.
@@ -785,8 +788,27 @@ template <int KW, int KPL, int S, bool F = false> struct HalfClean {            
             } else {
                 constexpr int LS = S / KPL;
                 const bool low = (lane & LS) == 0;
+                if constexpr (F && KW == 1 && GKC_CROSS_MINMAX) {
+                    // tagged keys are doubles in integer order: the lower lane of a pair keeps min, the upper max. Two exec-masked blocks of native
+                    // 64-bit min / max per group of keys instead of a 64-bit compare (SGPR result, wait state) + xor + two selects per key
+                    constexpr int C = KPL < 4 ? KPL : 4;
+#pragma unroll
+                    for (int r0 = 0; r0 < KPL; r0 += C) {
+                        double y[C];
+#pragma unroll
+                        for (int u = 0; u < C; u++) y[u] = __longlong_as_double((long long)Shfl<KW>::template x<LS>(v[r0 + u]));
+                        if (low) {
+#pragma unroll
+                            for (int u = 0; u < C; u++) { double d; asm volatile("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(__longlong_as_double((long long)v[r0 + u])), "v"(y[u])); v[r0 + u] = (uint64_t)__double_as_longlong(d); }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < C; u++) { double d; asm volatile("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(__longlong_as_double((long long)v[r0 + u])), "v"(y[u])); v[r0 + u] = (uint64_t)__double_as_longlong(d); }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LS>(v[r]); const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
+                }
             }
             HalfClean<KW, KPL, S / 2, F>::run(v, lane);
         }
@@ -804,11 +826,38 @@ template <int KW, int KPL, int SIZE, bool F = false> struct BitonicMerge {      
             } else {
                 constexpr int LMASK = SIZE / KPL - 1, TOP = (SIZE / KPL) >> 1;
                 const bool low = (lane & TOP) == 0;
+                if constexpr (F && KW == 1 && GKC_CROSS_MINMAX) {
+                    // partner of (lane, r) is (lane ^ LMASK, KPL-1-r): registers r and KPL-1-r are exchanged together, so nothing is overwritten early
+                    constexpr int H = KPL >= 2 ? KPL / 2 : 1, C = H < 2 ? H : 2;
+#pragma unroll
+                    for (int r0 = 0; r0 < H; r0 += C) {
+                        double ya[C], yb[C];
+#pragma unroll
+                        for (int u = 0; u < C; u++) {
+                            ya[u] = __longlong_as_double((long long)Shfl<KW>::template x<LMASK>(v[KPL - 1 - (r0 + u)]));
+                            yb[u] = __longlong_as_double((long long)Shfl<KW>::template x<LMASK>(v[r0 + u]));
+                        }
+                        if (low) {
+#pragma unroll
+                            for (int u = 0; u < C; u++) {
+                                double d; asm volatile("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(__longlong_as_double((long long)v[r0 + u])), "v"(ya[u])); v[r0 + u] = (uint64_t)__double_as_longlong(d);
+                                if (KPL - 1 - (r0 + u) != r0 + u) { double e; asm volatile("v_min_f64 %0, %1, %2" : "=v"(e) : "v"(__longlong_as_double((long long)v[KPL - 1 - (r0 + u)])), "v"(yb[u])); v[KPL - 1 - (r0 + u)] = (uint64_t)__double_as_longlong(e); }
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < C; u++) {
+                                double d; asm volatile("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(__longlong_as_double((long long)v[r0 + u])), "v"(ya[u])); v[r0 + u] = (uint64_t)__double_as_longlong(d);
+                                if (KPL - 1 - (r0 + u) != r0 + u) { double e; asm volatile("v_max_f64 %0, %1, %2" : "=v"(e) : "v"(__longlong_as_double((long long)v[KPL - 1 - (r0 + u)])), "v"(yb[u])); v[KPL - 1 - (r0 + u)] = (uint64_t)__double_as_longlong(e); }
+                            }
+                        }
+                    }
+                } else {
                 key_t w[KPL];
 #pragma unroll
                 for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LMASK>(v[KPL - 1 - r]); const bool ylt = y < v[r]; w[r] = (ylt == low) ? y : v[r]; }
 #pragma unroll
                 for (int r = 0; r < KPL; r++) v[r] = w[r];
+                }
             }
             HalfClean<KW, KPL, SIZE / 4, F>::run(v, lane);
         }
