@@ -1910,10 +1910,15 @@ struct BatchBufs {
 };
 
 template <int KW, int RW>
-static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, const std::vector<uint64_t>& part_keys,
+static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts_in, const std::vector<uint64_t>& part_keys,
                        const SegTable& segs, std::vector<void*>& outputs)
 {
     typedef typename KeyT<KW>::type key_t;
+    // the expansion kernels run one workgroup per partition: largest partitions first, so that the launch does not end on one long workgroup
+    // (partition sizes spread 2-3x around their mean); nothing downstream depends on the order of the partitions inside a batch
+    std::vector<uint32_t> batch_parts(batch_parts_in);
+    static const bool lpt = getenv("GKC_BATCH_LPT") ? atoi(getenv("GKC_BATCH_LPT")) != 0 : true;
+    if (lpt) std::stable_sort(batch_parts.begin(), batch_parts.end(), [&](uint32_t a, uint32_t b) { return part_keys[a] > part_keys[b]; });
     const uint32_t nb = (uint32_t)batch_parts.size();
     const uint32_t k = c->k;
     // --- host-built tables (sizes are known exactly from Stage A)
