@@ -889,16 +889,17 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     // run-length count (B3). e = lane*KPL + r is the sorted rank
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
     const key_t next_first = Shfl<KW>::down(v[0]);
-    uint32_t headm = 0, tailm = 0;
+    // whole-lane bit masks (bit r = rank lane*KPL + r): one compare per key, the head / tail logic on the masks
+    uint32_t neq = (lane == 0 || v[0] != prev_last) ? 1u : 0u;                    // key differs from the one before it (rank 0: always)
 #pragma unroll
-    for (int r = 0; r < KPL; r++) {
-        const uint32_t e = lane * KPL + r;
-        const key_t pv = r ? v[r - 1] : prev_last;
-        const key_t nx = (r < KPL - 1) ? v[r + 1] : next_first;
-        const bool in = e < n;
-        headm |= (uint32_t)(in && (e == 0 || v[r] != pv)) << r;
-        tailm |= (uint32_t)(in && (e == n - 1 || v[r] != nx)) << r;
-    }
+    for (int r = 1; r < KPL; r++) neq |= (v[r] != v[r - 1] ? 1u : 0u) << r;
+    const uint32_t lane0 = (uint32_t)lane * KPL;
+    const uint32_t have = n > lane0 ? (n - lane0 < (uint32_t)KPL ? n - lane0 : (uint32_t)KPL) : 0u;     // ranks of this lane below n
+    const uint32_t inm = have >= 32u ? 0xFFFFFFFFu : ((1u << have) - 1u);
+    const uint32_t nxt_differs = (v[KPL - 1] != next_first) ? 1u : 0u;
+    const uint32_t lastm = (have && lane0 + have == n) ? (1u << (have - 1u)) : 0u;                    // rank n-1 closes its run
+    const uint32_t headm = neq & inm;
+    const uint32_t tailm = inm & ((neq >> 1) | (nxt_differs << (KPL - 1)) | lastm);
     const uint32_t nt = __popc(tailm);
     int lh = headm ? (int)(lane * KPL + 31 - __clz((int)headm)) : -1;
     uint32_t x = nt; int hx = lh;
@@ -908,10 +909,10 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     int cur = __shfl_up(hx, 1, 64); if (lane == 0) cur = -1;
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
-        const int e = lane * KPL + r;
-        if ((headm >> r) & 1) cur = e;
         if ((tailm >> r) & 1) {
-            const uint32_t c = (uint32_t)(e - cur + 1);
+            // the run that ends here started at the last head at or before r in this lane, else at the carried-in head of an earlier lane
+            const uint32_t hb_ = headm & ((2u << r) - 1u);
+            const uint32_t c = hb_ ? (uint32_t)(r - (31 - __clz((int)hb_)) + 1) : (uint32_t)((int)(lane * KPL + r) - cur + 1);
 #ifndef GKC_EXP_NORLESTORE
             if constexpr (F && KW == 1) outk[start + idx] = (v[r] & TAG64_MANT) | top; else outk[start + idx] = v[r];
             put_count(O, start + idx, c);
