@@ -204,12 +204,14 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
                                                                   uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
                                                                   uint32_t line_slots /* 0: every sub-bucket starts on a multiple of 4 slots (pair scatter);
                                                                                          n: SUPER-buckets of 4 sub-buckets start on multiples of n slots, sub-buckets packed inside */,
-                                                                  BinTables bins /* nbmax == 0: no bin tables (see k_expand_coarse) */)
+                                                                  BinTables bins /* nbmax == 0: no bin tables (see k_expand_coarse) */,
+                                                                  const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
     __shared__ uint32_t s_wsum[EXPAND_THREADS / 64];
-    const PartDesc pd = parts[blockIdx.x];
+    const uint32_t bi = order ? order[blockIdx.x] : blockIdx.x;
+    const PartDesc pd = parts[bi];
     const uint32_t nsub = 1u << pd.sub_bits;
     for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) s_hist[i] = 0;
     __syncthreads();
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     uint32_t fpre = 0, ftot = 0;
     for (int w = 0; w < EXPAND_THREADS / 64; w++) { if (w < wave) fpre += s_wsum[w]; ftot += s_wsum[w]; }
     uint32_t bid = fpre + fx - floc;                             // bins that start before this thread's first sub-bucket
-    uint32_t* first = bins.first + (uint64_t)blockIdx.x * (bins.nbmax + 1);
+    uint32_t* first = bins.first + (uint64_t)bi * (bins.nbmax + 1);
     { uint32_t o = run0;
       for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
           const uint32_t j = b + i;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
           o += (s_hist[j] + 3u) & ~3u;
       } }
     if (threadIdx.x == 0) {
-        bins.n[blockIdx.x] = ftot;
+        bins.n[bi] = ftot;
         if (ftot <= bins.nbmax) first[ftot] = nsub; else atomicOr(bins.bad, 1u);
     }
 }
@@ -331,11 +333,12 @@ constexpr int PAIR_THREADS = 1024;
 // that key instead and starts over. Keys are conserved by every exchange, nobody waits on anybody; 1.5 exchanges per key.
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
-                                                                       const uint32_t* __restrict__ only_if /* nullptr, or: run only when this word is set */)
+                                                                       const uint32_t* __restrict__ only_if /* nullptr, or: run only when this word is set */,
+                                                                       const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub] parked key or EMPTY
     if (only_if && !*only_if) return;
-    const PartDesc pd = parts[blockIdx.x];
+    const PartDesc pd = parts[order ? order[blockIdx.x] : blockIdx.x];
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + nsub);                     // [nsub] next free slot of the sub-bucket
     constexpr unsigned long long EMPTY = ~0ULL;
@@ -384,17 +387,19 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
 constexpr int COARSE_THREADS = 1024;
 constexpr uint32_t COARSE_STAGE_KEYS = 16384;        // 128 KB of staging
 __global__ __launch_bounds__(COARSE_THREADS) void k_expand_coarse(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
-                                                                   const uint64_t* __restrict__ b_start, BinTables bins, uint64_t* __restrict__ keys)
+                                                                   const uint64_t* __restrict__ b_start, BinTables bins, uint64_t* __restrict__ keys,
+                                                                   const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_stage[];      // [COARSE_STAGE_KEYS]
     if (*bins.bad) return;
-    const PartDesc pd = parts[blockIdx.x];
+    const uint32_t bi = order ? order[blockIdx.x] : blockIdx.x;
+    const PartDesc pd = parts[bi];
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_stage + COARSE_STAGE_KEYS);        // [BIN_NBMAX] keys of the bin this round
     uint32_t* s_gcur = s_cnt + BIN_NBMAX;                                              // [BIN_NBMAX] next free slot of the bin (relative to key_base)
     uint16_t* s_map = reinterpret_cast<uint16_t*>(s_gcur + BIN_NBMAX);                 // [nsub] sub-bucket -> bin
-    const uint32_t nbins = bins.n[blockIdx.x];
-    const uint32_t* first = bins.first + (uint64_t)blockIdx.x * (bins.nbmax + 1);
+    const uint32_t nbins = bins.n[bi];
+    const uint32_t* first = bins.first + (uint64_t)bi * (bins.nbmax + 1);
     for (uint32_t i = threadIdx.x; i < nsub; i += COARSE_THREADS) s_map[i] = bins.of_sub[pd.sub_base + i];
     for (uint32_t i = threadIdx.x; i < nbins; i += COARSE_THREADS) { s_cnt[i] = 0; s_gcur[i] = (uint32_t)(b_start[pd.sub_base + first[i]] - pd.key_base); }
     const uint32_t S = nbins ? COARSE_STAGE_KEYS / nbins : COARSE_STAGE_KEYS;          // >= 16
@@ -457,10 +462,11 @@ __device__ __forceinline__ void lds_xchg128(unsigned long long* slot, uint64_t i
     out_lo = (uint64_t)r.x | ((uint64_t)r.y << 32); out_hi = (uint64_t)r.z | ((uint64_t)r.w << 32);
 }
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
-                                                                        const uint64_t* __restrict__ b_start, u128* __restrict__ keys)
+                                                                        const uint64_t* __restrict__ b_start, u128* __restrict__ keys,
+                                                                        const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub][2] parked key (low word, high word) or EMPTY
-    const PartDesc pd = parts[blockIdx.x];
+    const PartDesc pd = parts[order ? order[blockIdx.x] : blockIdx.x];
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + 2 * (size_t)nsub);        // [nsub] next free slot of the sub-bucket
     constexpr unsigned long long EMPTY = ~0ULL;
@@ -1904,9 +1910,9 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, bigs, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot, bin_of, bin_first, bin_n, bin_pre;
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start[2], b_n[2], b_cons[2], over, over2, over3, bigs, misc, bs_d, bs_s, descs, effs, g_start, g_n, g_cons, pidx, ptot, bin_of, bin_first, bin_n, bin_pre, order;
     void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start[0], &b_start[1], &b_n[0], &b_n[1], &b_cons[0], &b_cons[1], &over, &over2, &over3, &bigs, &misc, &bs_d, &bs_s,
-                                        &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot, &bin_of, &bin_first, &bin_n, &bin_pre };
+                                        &descs, &effs, &g_start, &g_n, &g_cons, &pidx, &ptot, &bin_of, &bin_first, &bin_n, &bin_pre, &order };
                      for (DevBuf* d : all) d->release(); }
 };
 
@@ -1915,11 +1921,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts_in, 
                        const SegTable& segs, std::vector<void*>& outputs)
 {
     typedef typename KeyT<KW>::type key_t;
-    // the expansion kernels run one workgroup per partition: largest partitions first, so that the launch does not end on one long workgroup
-    // (partition sizes spread 2-3x around their mean); nothing downstream depends on the order of the partitions inside a batch
-    std::vector<uint32_t> batch_parts(batch_parts_in);
-    static const bool lpt = getenv("GKC_BATCH_LPT") ? atoi(getenv("GKC_BATCH_LPT")) != 0 : true;
-    if (lpt) std::stable_sort(batch_parts.begin(), batch_parts.end(), [&](uint32_t a, uint32_t b) { return part_keys[a] > part_keys[b]; });
+    const std::vector<uint32_t>& batch_parts = batch_parts_in;
     const uint32_t nb = (uint32_t)batch_parts.size();
     const uint32_t k = c->k;
     // --- host-built tables (sizes are known exactly from Stage A)
@@ -1966,6 +1968,14 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts_in, 
     CB_TRY(c->ensure(B.misc, 64));
     CB_TRY(c->ensure(B.bs_d, (size_t)(n_blocks + 1) * 8)); CB_TRY(c->ensure(B.bs_s, (size_t)(n_blocks + 1) * 8));
     CB_TRY(c->ensure(B.pidx, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.ptot, (size_t)(nb + 1) * 16));
+    // the expansion kernels run one workgroup per partition: workgroup i takes the i-th LARGEST partition, so that the launch does not end on one long
+    // workgroup (partition sizes spread 2-3x around their mean). Only the assignment changes: the layout of the batch stays in partition order.
+    std::vector<uint32_t> order(nb);
+    for (uint32_t i = 0; i < nb; i++) order[i] = i;
+    static const bool lpt = getenv("GKC_BATCH_LPT") ? atoi(getenv("GKC_BATCH_LPT")) != 0 : true;
+    if (lpt) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return part_keys[batch_parts[a]] > part_keys[batch_parts[b]]; });
+    CB_TRY(c->ensure(B.order, (size_t)nb * 4));
+    CB_HIP(hipMemcpyAsync(B.order.p, order.data(), (size_t)nb * 4, hipMemcpyHostToDevice, cur_stream(c)));
     CB_HIP(hipMemcpyAsync(B.pd.p, pd.data(), nb * sizeof(PartDesc), hipMemcpyHostToDevice, cur_stream(c)));
     CB_HIP(hipMemcpyAsync(B.pidx.p, pblk.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
     CB_HIP(hipMemsetAsync(B.cnt8.p, 0, (size_t)std::max<uint64_t>(n_slots, 4), cur_stream(c)));
@@ -1985,7 +1995,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts_in, 
 
     {   ScopedTimer tm(c, "expand_count");
         hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p, line_slots, BT);
+                           (uint64_t*)B.b_start[0].p, (uint32_t*)B.b_n[0].p, (uint8_t*)B.b_cons[0].p, line_slots, BT, (const uint32_t*)B.order.p);
         CB_HIP(hipGetLastError());
     }
     if (bin && getenv("GKC_VERBOSE")) {
@@ -2002,11 +2012,11 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts_in, 
             const size_t lds = (size_t)COARSE_STAGE_KEYS * 8 + (size_t)BIN_NBMAX * 8 + (size_t)MAX_SUB * 2;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_coarse, dim3(nb), dim3(COARSE_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start[0].p, BT, (uint64_t*)B.keysA.p);
+                               (const uint64_t*)B.b_start[0].p, BT, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p);
             const size_t lds2 = (size_t)MAX_SUB * 12;
             static std::once_flag once2; std::call_once(once2, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); });
             hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds2, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p, (const uint32_t*)BT.bad);
+                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p, (const uint32_t*)BT.bad, (const uint32_t*)B.order.p);
         }
         if (bin) {} else
         if (line) {
@@ -2025,12 +2035,12 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts_in, 
             const size_t lds = (size_t)MAX_SUB * 12;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p, (const uint32_t*)nullptr);
+                               (const uint64_t*)B.b_start[0].p, (uint64_t*)B.keysA.p, (const uint32_t*)nullptr, (const uint32_t*)B.order.p);
         } else if (KW == 2 && k >= 32 && getenv("GKC_SCATTER_NO_PAIR") == nullptr) {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start[0].p, (u128*)B.keysA.p);
+                               (const uint64_t*)B.b_start[0].p, (u128*)B.keysA.p, (const uint32_t*)B.order.p);
         } else
         hipLaunchKernelGGL((k_expand_scatter<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
                            (const uint64_t*)B.b_start[0].p, (key_t*)B.keysA.p);
