@@ -169,6 +169,25 @@ def test_edge_cases(gkc):
     device_vs_oracle(gkc, [long], 63, m, parts, rep=rep)
 
 
+def test_superkmer_cap_at_every_thread_phase(gkc):
+    """A4: the cap (a run of one minimizer value cut every maxs k-mers) only bites on repeated minimizers; Stage A decides per wave whether any thread can
+    reach it and otherwise takes run ends from bit masks. Runs of a repeated minimizer (poly-A, dinucleotide and 7-mer repeats) entered at every offset
+    relative to the 16-position threads and to the scan tile, cut by N, by read ends and by ordinary sequence, for 16- and 32-byte records, must give the
+    oracle's records — including the partition statistics (records per partition depend on where the cap cuts)"""
+    rng = np.random.default_rng(41)
+    def rnd(n): return "".join(rng.choice(list("ACGT"), n))
+    reads = []
+    for off in range(0, 50):
+        reads.append(rnd(off) + "A" * (90 + off) + rnd(37))
+        reads.append(rnd(off) + "AC" * 60 + "N" + "T" * 70)
+        reads.append(rnd(3 * off) + "ACGTTGC" * 25 + rnd(off))
+    reads.append(rnd(8192 - 40) + "A" * 300 + rnd(50))                       # a capped run across a scan-tile boundary
+    reads.append("A" * 9000)                                                 # one read, one run, many tiles
+    for (k, m, parts) in [(31, 10, 4), (21, 7, 2), (63, 10, 2), (41, 9, 3)]:
+        c, ref = device_vs_oracle(gkc, reads, k, m, parts)
+        assert c.stats()["nb_superkmers"] >= ref.stats["nb_superkmers"]          # tile boundaries may add cuts, the cap never removes one
+
+
 def test_oversize_buckets_low_complexity(gkc):
     """massively repeated k-mers (poly-A, tandem repeats) overflow the LDS sort and take the global-memory path"""
     reads = ["A" * 150] * 3000 + ["AC" * 75] * 2000 + synth_reads(500, 5000, 150, seed=8)
