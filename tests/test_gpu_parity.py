@@ -632,10 +632,12 @@ def test_exact_repartitor_sample(gkc, k, m, freq):
         assert used == eused and np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(d, ed), (thr, used, eused)
 
 
-@pytest.mark.parametrize("switch", ["GKC_SCATTER_LINE", "GKC_TAIL_LDS", "GKC_HASH_COUNT", "GKC_SCATTER_NO_PAIR", "GKC_NO_F64", "GKC_BIN", "GKC_BIN,GKC_BIN_NBMAX=4"])
+@pytest.mark.parametrize("switch", ["GKC_SCATTER_LINE", "GKC_TAIL_LDS", "GKC_HASH_COUNT", "GKC_SCATTER_NO_PAIR", "GKC_NO_F64", "GKC_BIN", "GKC_BIN,GKC_BIN_NBMAX=4",
+                                    "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0"])
 def test_experimental_kernel_paths_stay_bit_exact(gkc, switch):
     """the measured-and-kept alternative kernels (64-byte line scatter + LDS-split sort, LDS tail sort, count-first first tier, coarse scatter by bin + in-LDS
-    split — also with its fallback forced —) and two older
+    split — also with its fallback forced —), the Stage A fallbacks (emit pass that recomputes instead of reading descriptors, global-atomic
+    cursors instead of LDS ones), partitions in batch order, and two older
     A/B switches select other HIP code paths of the same library: each must give the oracle's records on an input with N's, ragged reads, low-complexity
     reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31 and k = 41"""
     import json, os, subprocess, sys
