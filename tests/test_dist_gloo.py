@@ -128,3 +128,45 @@ def test_exchange_plan_pairs_match_with_unequal_pushes():
             assert beg == pos; pos += n
         for peer, seg, beg, n in sends:                      # a send is the slice of the own segment that belongs to the peer
             assert beg == int(counts[r, seg, 0, :first[peer]].sum()) and n == int(counts[r, seg, 0, first[peer]:first[peer + 1]].sum())
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_exchange_plan_random_worlds(seed):
+    """gkc_exchange_plan over random worlds (2..8 ranks, up to 5 pushes per rank, partitions fewer or more than ranks, empty partitions and empty segments, pinned or
+    balanced owner ranges): what rank a sends to b is what b expects from a, in the same order (RCCL matches grouped sends and receives of a pair by order); every record
+    has exactly one destination; receive slots tile the receive arena; a send is one contiguous slice of the sender's partition-major segment"""
+    ge.load()
+    from gatb_core_amd import gkc
+    rng = np.random.default_rng(100 + seed)
+    world = int(rng.integers(2, 9)); P = int(rng.choice([1, 3, world, 17, 64, 257])); l_max = int(rng.integers(1, 6))
+    n_segs = rng.integers(0, l_max + 1, world).astype(np.uint64)
+    n_segs[int(rng.integers(0, world))] = l_max
+    counts = np.zeros((world, l_max, 2, P), np.uint64)
+    for r in range(world):
+        for j in range(int(n_segs[r])):
+            counts[r, j, 0] = rng.integers(0, 50, P) * (rng.random(P) < 0.7); counts[r, j, 1] = counts[r, j, 0] * 11
+    if seed % 3 == 0:                                        # pinned ranges, possibly empty for some ranks
+        cuts = np.sort(rng.integers(0, P + 1, world - 1)); first = np.concatenate([[0], cuts, [P]]).astype(np.uint32)
+    else:
+        first = gkc.balanced_owner_ranges(counts[:, :, 1, :].sum(axis=(0, 1)), world)
+    assert first[0] == 0 and first[-1] == P and np.all(np.diff(first.astype(np.int64)) >= 0)
+    plans = [gkc.exchange_plan(world, r, first, n_segs, counts) for r in range(world)]
+    sent_total = 0
+    for a in range(world):
+        for b in range(world):
+            if a == b:
+                continue
+            s = [(seg, n) for peer, seg, beg, n in plans[a][0] if peer == b]
+            r = [(seg, n) for peer, seg, beg, n in plans[b][1] if peer == a]
+            assert s == r, (world, P, a, b, s, r)
+            sent_total += sum(n for _, n in s)
+    own = sum(int(counts[r, j, 0, first[r]:first[r + 1]].sum()) for r in range(world) for j in range(int(n_segs[r])))
+    assert sent_total + own == int(counts[:, :, 0, :].sum())                # every record stays or leaves exactly once
+    for r in range(world):
+        sends, recvs, total = plans[r]
+        pos = 0
+        for peer, seg, beg, n in recvs:
+            assert beg == pos and n > 0; pos += n
+        assert pos == total
+        for peer, seg, beg, n in sends:
+            assert n > 0 and beg == int(counts[r, seg, 0, :first[peer]].sum()) and n == int(counts[r, seg, 0, first[peer]:first[peer + 1]].sum())
