@@ -632,14 +632,14 @@ def test_exact_repartitor_sample(gkc, k, m, freq):
         assert used == eused and np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(d, ed), (thr, used, eused)
 
 
-@pytest.mark.parametrize("switch", ["GKC_SCATTER_LINE", "GKC_TAIL_LDS", "GKC_HASH_COUNT", "GKC_SCATTER_NO_PAIR", "GKC_NO_F64", "GKC_BIN", "GKC_BIN,GKC_BIN_NBMAX=4",
-                                    "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0"])
-def test_experimental_kernel_paths_stay_bit_exact(gkc, switch):
-    """the measured-and-kept alternative kernels (64-byte line scatter + LDS-split sort, LDS tail sort, count-first first tier, coarse scatter by bin + in-LDS
-    split — also with its fallback forced —), the Stage A fallbacks (emit pass that recomputes instead of reading descriptors, global-atomic
-    cursors instead of LDS ones), partitions in batch order, and two older
-    A/B switches select other HIP code paths of the same library: each must give the oracle's records on an input with N's, ragged reads, low-complexity
-    reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31 and k = 41"""
+@pytest.mark.parametrize("switch", ["GKC_NO_F64", "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0", "GKC_SPLIT_EXTRA=0", "GKC_WG_MAX=1024", "GKC_MAX_SUB_BITS=1", "GKC_MAX_SUB_BITS=6"])
+def test_alternative_kernel_paths_stay_bit_exact(gkc, switch):
+    """A/B switches that select another HIP code path of the same library (integer instead of f64-tagged compare-exchange; the Stage A fallbacks: emit pass
+    that recomputes instead of reading descriptors, global-atomic cursors instead of LDS ones; partitions in batch order; coarser split levels, which
+    forces more of them than the fixed launches; no workgroup tier; 2 / 64 sub-buckets per partition, which makes every sub-bucket a root of the split levels —
+    with 2 they are "giants" split by many workgroups together): each must give the oracle's records on an input with N's, ragged reads,
+    low-complexity reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31 and k = 41.
+    (The measured-slower round-2 kernels left the product: branch experiments-r02, logs in profiles/r02_*_experiment.txt.)"""
     import json, os, subprocess, sys
     code = r'''
 import sys, json, numpy as np

@@ -14,3 +14,11 @@ try:
             print("%-60s %-24s %20.0f %8d" % (k.split("(")[0][:60], cn, v, n))
 except Exception as e:
     print("# no PMC data:", e)
+
+# optional: --seq N  prints the last N dispatches in launch order (name, duration, grid, registers): where a step's time goes launch by launch
+if "--seq" in sys.argv:
+    n = int(sys.argv[sys.argv.index("--seq") + 1])
+    rows = list(db.execute("select name, duration, grid_x, grid_y, workgroup_x, vgpr_count, accum_vgpr_count, scratch_size, lds_size from kernels order by start desc limit %d" % n))[::-1]
+    print("\n# last %d dispatches in launch order: kernel, us, grid (threads), workgroup, vgpr+agpr, scratch, lds" % n)
+    for nm, dur, gx, gy, wx, vg, ag, sc, lds in rows:
+        print("%-50s %9.1f  %9d x %-4d %5d  %3d+%-3d %5d %6d" % (nm.split("(")[0][:50], dur / 1000.0, gx, gy, wx, vg, ag, sc, lds))
