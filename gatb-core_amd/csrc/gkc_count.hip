@@ -854,22 +854,24 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
 // at once (round 2 fetched the lists to the host between the levels: ~1 ms of latency per level and batch for 1.3 % of the keys). Results land in the
 // primary key buffer at the piece's own slots; the root's nd / ns counters collect them.
 struct SplitPlan { uint32_t left, bits, shift; };
-__device__ __forceinline__ SplitPlan split_plan(unsigned long long or_lo, unsigned long long or_hi, uint32_t n, uint32_t consumed, uint32_t two_k, uint32_t target, uint32_t extra_bits, uint32_t max_bits = MAX_SUB_BITS)
+__device__ __forceinline__ SplitPlan split_plan(unsigned long long or_lo, unsigned long long or_hi, uint32_t consumed, uint32_t two_k, uint32_t max_bits)
 {
     const uint32_t diff_bits = or_hi ? 128 - __clzll((long long)or_hi) : (or_lo ? 64 - __clzll((long long)or_lo) : 0);   // number of low bits that may differ between keys
     const uint32_t have = two_k - consumed;
     SplitPlan p; p.left = diff_bits < have ? diff_bits : have; p.bits = 0; p.shift = 0;       // informative bits still unused
     if (p.left == 0) return p;
-    // deeper levels see clustered keys (that is why the bucket was oversize): split finer than the mean asks for
-    uint32_t bits = 1;
-    while (bits < max_bits && bits < p.left && (n >> bits) > target) bits++;
-    p.bits = min(min(bits + extra_bits, max_bits), p.left);
+    // always as many bits as the tables hold: the pieces that come out small are listed in runs (see k_deep_split), and a cluster under a longer shared prefix spreads
+    p.bits = min(max_bits, p.left);
     p.shift = p.left - p.bits;
     return p;
 }
 struct DeepItem { uint64_t start; uint32_t n; uint32_t root; uint32_t consumed; uint32_t buf; };      // buf: 0 = keys are in the primary buffer, 1 = in the ping-pong buffer
 struct SortItem { uint64_t start; uint32_t n_buf; uint32_t root; };                                     // n_buf: n | buf << 31
-constexpr int DEEP_THREADS = 256, DEEP_MLP = 8, DEEP_BITS_MAX = 10, DEEP_SUB = 1 << DEEP_BITS_MAX;   // non-giant items hold <= 32768 keys (8 bits); 8 KB of LDS -> 8 workgroups per CU walk 8 items at a time
+constexpr int DEEP_THREADS = 256, DEEP_MLP = 8, DEEP_WINDOWS = 1024;
+// Two launches per level share the items by size: items up to DEEP_SMALL_N keys are cut on DEEP_SMALL_BITS bits (16 KB of LDS: 8 workgroups per CU, the items are
+// latency-bound: ~10 barriers and ~6 dependent memory round trips each), larger ones on MAX_SUB_BITS bits (72 KB: 2 per CU) so that a cluster of 10^4 keys under a
+// 7-bit longer prefix still comes out in pieces a wave can sort instead of coming back at the next level.
+constexpr uint32_t DEEP_SMALL_BITS = 10, DEEP_SMALL_N = 8192;
 template <int KW>
 __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::type* keysA, typename KeyT<KW>::type* keysB,
                                                               const uint32_t* __restrict__ root_list /* level 1: the split list of k_expand_count; else nullptr */,
@@ -877,11 +879,14 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
                                                               const DeepItem* __restrict__ q_in, const uint32_t* __restrict__ n_in_p, uint32_t* __restrict__ ticket,
                                                               DeepItem* __restrict__ q_out, uint32_t* __restrict__ n_out_p,
                                                               SortItem* __restrict__ sort_list, uint32_t* __restrict__ n_sort_p,
-                                                              uint32_t two_k, uint32_t target, uint32_t extra_bits, uint32_t cap1, SortOut O)
+                                                              uint32_t two_k, uint32_t max_bits /* <= log2 of the LDS tables */, uint32_t n_lo, uint32_t n_hi /* this launch: items with n_lo < n <= n_hi */,
+                                                              uint32_t cap1, SortOut O)
 {
     typedef typename KeyT<KW>::type key_t;
-    __shared__ uint32_t s_cnt[DEEP_SUB];                    // keys of every piece
-    __shared__ uint32_t s_cur[DEEP_SUB];                    // scatter cursor of the piece; after the scatter: one past its last key (relative to the item)
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    uint32_t* s_cnt = s_dyn;                                // [1 << max_bits] keys of every piece
+    uint32_t* s_cur = s_dyn + (1u << max_bits);             // [1 << max_bits] first slot of the piece, then its scatter cursor (relative to the item)
+    __shared__ uint32_t s_gs[DEEP_WINDOWS], s_ge[DEEP_WINDOWS];    // runs of small pieces by window of their first slot: first slot, one past the last
     __shared__ uint32_t s_wsum[DEEP_THREADS / 64];
     __shared__ unsigned long long s_or[2];
     __shared__ uint32_t s_item, s_base_sort, s_base_q;
@@ -900,6 +905,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
             if (cb & 0x80u) continue;                         // a giant: split by many workgroups (k_giant_*)
             d.start = b_start[g]; d.n = b_n[g]; d.root = g; d.consumed = cb; d.buf = 0;
         } else d = q_in[it];
+        if (d.n <= n_lo || d.n > n_hi) continue;              // the other launch's item
         const key_t* src = (d.buf ? keysB : keysA) + d.start;
         key_t* dst = (d.buf ? keysA : keysB) + d.start;
         // the root's abundance plane is read slot by slot by the gather (its records are not at the head of its range): clear it first
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
             if (lane == 0) { if (lo) atomicOr(&s_or[0], lo); if (KW == 2 && hi) atomicOr(&s_or[1], hi); }
         }
         __syncthreads();
-        const SplitPlan P = split_plan(s_or[0], s_or[1], d.n, d.consumed, two_k, target, extra_bits, DEEP_BITS_MAX);
+        const SplitPlan P = split_plan(s_or[0], s_or[1], d.consumed, two_k, max_bits);
         const uint32_t left = P.left;
         if (left == 0) {                                       // one k-mer, abundance n (CountNumber is int32)
             if (t == 0) {
@@ -955,19 +961,39 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
             for (; i < d.n; i += DEEP_THREADS) atomicAdd(&s_cnt[(uint32_t)(src[i] >> shift) & mask], 1u);
         }
         __syncthreads();
-        // exclusive scan of the piece sizes -> cursors; in the same sweep: how many pieces go to the sort list (low half) / the next level (high half)
+        // exclusive scan of the piece sizes -> first slot of every piece
         const uint32_t per = (nsub + DEEP_THREADS - 1) / DEEP_THREADS, b = t * per;
-        uint32_t loc = 0, cls = 0;
-        for (uint32_t i = 0; i < per; i++) if (b + i < nsub) { const uint32_t v = s_cnt[b + i]; loc += v; if (v) cls += v <= cap1 ? 1u : 0x10000u; }
-        uint32_t x = loc, y = cls;
+        uint32_t loc = 0;
+        for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += s_cnt[b + i];
+        uint32_t x = loc;
 #pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t xx = __shfl_up(x, dd, 64), yy = __shfl_up(y, dd, 64); if (lane >= dd) { x += xx; y += yy; } }
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t xx = __shfl_up(x, dd, 64); if (lane >= dd) x += xx; }
         if (lane == 63) s_wsum[wave] = x;
         __syncthreads();
         uint32_t run = x - loc;
         for (int w = 0; w < wave; w++) run += s_wsum[w];
         for (uint32_t i = 0; i < per; i++) if (b + i < nsub) { s_cur[b + i] = run; run += s_cnt[b + i]; }
+        // What is listed for the sort is not the single piece: the item is always cut on as many bits as the tables hold (a cluster under a longer shared
+        // prefix then still spreads over several pieces instead of coming back whole at the next level), and pieces of at most M = cap1 / 2 keys whose first
+        // slot lies in the same window of M slots are listed as ONE run of < cap1 keys (consecutive pieces are consecutive key ranges and consecutive in
+        // memory) — the sparse background of a clustered item becomes a few full sorts instead of hundreds of tiny ones.
+        const uint32_t M = cap1 / 2, nwin = d.n / M + 1;
+        const bool merge = nwin <= (uint32_t)DEEP_WINDOWS;
+        if (merge) for (uint32_t i = t; i < nwin; i += DEEP_THREADS) { s_gs[i] = 0xFFFFFFFFu; s_ge[i] = 0u; }
         __syncthreads();
+        uint32_t cls = 0;                                      // items this thread lists: sort list (low half) / next level (high half)
+        for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+            const uint32_t v = s_cnt[b + i];
+            if (!v) continue;
+            if (v > cap1) cls += 0x10000u;
+            else if (v > M || !merge) cls += 1u;
+            else { const uint32_t e = s_cur[b + i], w = e / M; atomicMin(&s_gs[w], e); atomicMax(&s_ge[w], e + v); }
+        }
+        __syncthreads();
+        if (merge) for (uint32_t w = t; w < nwin; w += DEEP_THREADS) if (s_ge[w]) cls += 1u;
+        uint32_t y = cls;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t yy = __shfl_up(y, dd, 64); if (lane >= dd) y += yy; }
         if (lane == 63) s_wsum[wave] = y;
         __syncthreads();
         uint32_t ypre = y - cls, ytot = 0;
@@ -976,6 +1002,21 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
             s_base_sort = (ytot & 0xFFFFu) ? atomicAdd(n_sort_p, ytot & 0xFFFFu) : 0u;
             s_base_q = (ytot >> 16) ? atomicAdd(n_out_p, ytot >> 16) : 0u;
         }
+        __syncthreads();
+        {   uint32_t is = s_base_sort + (ypre & 0xFFFFu), iq = s_base_q + (ypre >> 16);
+            const uint32_t buf_bit = (d.buf ^ 1u) << 31;
+            for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+                const uint32_t v = s_cnt[b + i];
+                if (!v) continue;
+                const uint64_t st = d.start + s_cur[b + i];
+                if (v > cap1) { DeepItem c; c.start = st; c.n = v; c.root = d.root; c.consumed = cons_child; c.buf = d.buf ^ 1u; q_out[iq++] = c; }
+                else if (v > M || !merge) { SortItem si; si.start = st; si.n_buf = v | buf_bit; si.root = d.root; sort_list[is++] = si; }
+            }
+            if (merge) for (uint32_t w = t; w < nwin; w += DEEP_THREADS) if (s_ge[w]) {
+                SortItem si; si.start = d.start + s_gs[w]; si.n_buf = (s_ge[w] - s_gs[w]) | buf_bit; si.root = d.root; sort_list[is++] = si;
+            }
+        }
+        __syncthreads();                                      // the first slots in s_cur have been read: they now become the scatter's cursors
         {   uint32_t i = t;
             for (; i + (DEEP_MLP - 1) * DEEP_THREADS < d.n; i += DEEP_MLP * DEEP_THREADS) {
                 key_t v[DEEP_MLP];
@@ -985,15 +1026,6 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
                 for (int u = 0; u < DEEP_MLP; u++) { const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(v[u] >> shift) & mask], 1u); dst[slot] = v[u]; }
             }
             for (; i < d.n; i += DEEP_THREADS) { const key_t key = src[i]; const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(key >> shift) & mask], 1u); dst[slot] = key; }
-        }
-        __syncthreads();                                      // s_cur[j] is now one past the last key of piece j; the list bases are set
-        uint32_t is = s_base_sort + (ypre & 0xFFFFu), iq = s_base_q + (ypre >> 16);
-        for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
-            const uint32_t sn = s_cnt[b + i];
-            if (!sn) continue;
-            const uint64_t st = d.start + (s_cur[b + i] - sn);
-            if (sn <= cap1) { SortItem si; si.start = st; si.n_buf = sn | ((d.buf ^ 1u) << 31); si.root = d.root; sort_list[is++] = si; }
-            else { DeepItem c; c.start = st; c.n = sn; c.root = d.root; c.consumed = cons_child; c.buf = d.buf ^ 1u; q_out[iq++] = c; }
         }
     }
 }
@@ -1034,7 +1066,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<
 }
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
-                                                               const uint8_t* __restrict__ b_cons, uint32_t two_k, uint32_t target, uint32_t extra_bits)
+                                                               const uint8_t* __restrict__ b_cons, uint32_t two_k, uint32_t max_bits)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_cnt[MAX_SUB];
@@ -1043,7 +1075,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename Key
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     if ((uint64_t)blockIdx.x * GIANT_CHUNK >= n) return;
-    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], n, b_cons[g] & 0x7Fu, two_k, target, extra_bits);
+    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
     if (P.left == 0) return;
     const uint32_t nsub = 1u << P.bits, mask = nsub - 1u;
     for (uint32_t i = threadIdx.x; i < nsub; i += GIANT_THREADS) s_cnt[i] = 0;
@@ -1064,7 +1096,7 @@ template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                                const uint8_t* __restrict__ b_cons, DeepItem* __restrict__ q_out, uint32_t* __restrict__ n_out_p,
                                                                SortItem* __restrict__ sort_list, uint32_t* __restrict__ n_sort_p,
-                                                               uint32_t two_k, uint32_t target, uint32_t extra_bits, uint32_t cap1, SortOut O)
+                                                               uint32_t two_k, uint32_t max_bits, uint32_t cap1, SortOut O)
 {
     __shared__ uint32_t s_wsum[GIANT_THREADS / 64];
     __shared__ uint32_t s_base_sort, s_base_q;
@@ -1073,7 +1105,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(const typename Key
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], n, b_cons[g] & 0x7Fu, two_k, target, extra_bits);
+    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
     if (P.left == 0) {                                         // one k-mer, abundance n (CountNumber is int32)
         if (t == 0) {
             const uint32_t c = n > 0x7FFFFFFFu ? 0x7FFFFFFFu : n;
@@ -1087,15 +1119,42 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(const typename Key
     const uint32_t nsub = 1u << P.bits, cons_child = two_k - P.shift;
     const uint32_t* hist = G.ghist + (size_t)y * MAX_SUB; uint32_t* cur = G.gcur + (size_t)y * MAX_SUB;
     const uint32_t per = (nsub + GIANT_THREADS - 1) / GIANT_THREADS, b = t * per;
-    uint32_t loc = 0, cls = 0;
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) { const uint32_t v = hist[b + i]; loc += v; if (v) cls += v <= cap1 ? 1u : 0x10000u; }
-    uint32_t x = loc, yv = cls;
+    uint32_t loc = 0;
+    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) loc += hist[b + i];
+    uint32_t x = loc;
 #pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t xx = __shfl_up(x, dd, 64), yy = __shfl_up(yv, dd, 64); if (lane >= dd) { x += xx; yv += yy; } }
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t xx = __shfl_up(x, dd, 64); if (lane >= dd) x += xx; }
     if (lane == 63) s_wsum[wave] = x;
     __syncthreads();
-    uint32_t run = x - loc;
-    for (int w = 0; w < wave; w++) run += s_wsum[w];
+    uint32_t run0 = x - loc;
+    for (int w = 0; w < wave; w++) run0 += s_wsum[w];
+    // the thread's consecutive pieces are listed in runs of <= cap1 keys (consecutive pieces are consecutive key ranges and consecutive in memory); a piece beyond
+    // cap1 goes to the next level. walk(emit): the same walk counts (emit = false) and writes (emit = true)
+    uint32_t is = 0, iq = 0;
+    auto walk = [&](bool emit) -> uint32_t {
+        uint32_t cls = 0, run = run0, rs = 0, rn = 0;
+        auto flush = [&]() { if (rn) { if (emit) { SortItem si; si.start = start + rs; si.n_buf = rn | (1u << 31); si.root = g; sort_list[is++] = si; } cls += 1u; rn = 0; } };   // (the pieces are in the ping-pong buffer)
+        for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+            const uint32_t sn = hist[b + i];
+            if (emit) cur[b + i] = run;
+            if (sn > cap1) {
+                flush();
+                if (emit) { DeepItem c; c.start = start + run; c.n = sn; c.root = g; c.consumed = cons_child; c.buf = 1u; q_out[iq++] = c; }
+                cls += 0x10000u;
+            } else if (sn) {
+                if (rn + sn > cap1) flush();
+                if (!rn) rs = run;
+                rn += sn;
+            }
+            run += sn;
+        }
+        flush();
+        return cls;
+    };
+    const uint32_t cls = walk(false);
+    uint32_t yv = cls;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t yy = __shfl_up(yv, dd, 64); if (lane >= dd) yv += yy; }
     __syncthreads();
     if (lane == 63) s_wsum[wave] = yv;
     __syncthreads();
@@ -1106,22 +1165,13 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(const typename Key
         s_base_q = (ytot >> 16) ? atomicAdd(n_out_p, ytot >> 16) : 0u;
     }
     __syncthreads();
-    uint32_t is = s_base_sort + (ypre & 0xFFFFu), iq = s_base_q + (ypre >> 16);
-    for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
-        const uint32_t sn = hist[b + i];
-        cur[b + i] = run;
-        if (sn) {
-            const uint64_t st = start + run;
-            if (sn <= cap1) { SortItem si; si.start = st; si.n_buf = sn | (1u << 31); si.root = g; sort_list[is++] = si; }          // the pieces are in the ping-pong buffer
-            else { DeepItem c; c.start = st; c.n = sn; c.root = g; c.consumed = cons_child; c.buf = 1u; q_out[iq++] = c; }
-        }
-        run += sn;
-    }
+    is = s_base_sort + (ypre & 0xFFFFu); iq = s_base_q + (ypre >> 16);
+    (void)walk(true);
 }
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_scatter(const typename KeyT<KW>::type* __restrict__ keysA, typename KeyT<KW>::type* __restrict__ keysB, GiantTables G,
                                                                   const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint8_t* __restrict__ b_cons,
-                                                                  uint32_t two_k, uint32_t target, uint32_t extra_bits)
+                                                                  uint32_t two_k, uint32_t max_bits)
 {
     typedef typename KeyT<KW>::type key_t;
     const uint32_t y = blockIdx.y;
@@ -1129,7 +1179,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_scatter(const typename 
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     if ((uint64_t)blockIdx.x * GIANT_CHUNK >= n) return;
-    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], n, b_cons[g] & 0x7Fu, two_k, target, extra_bits);
+    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
     if (P.left == 0) return;
     const uint32_t mask = (1u << P.bits) - 1u;
     const key_t* src = keysA + start; key_t* dst = keysB + start;
@@ -1567,8 +1617,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     }
     // split levels: level 1 takes the split list, level l > 1 the queue level l-1 filled; queue buffers alternate, the counters are used cyclically. Every level
     // is followed by the launch that sorts the pieces it listed (<= keys / 64 of them per level: the list is reused)
-    static const uint32_t extra_env = getenv("GKC_SPLIT_EXTRA") ? (uint32_t)atoi(getenv("GKC_SPLIT_EXTRA")) : 2u;
-    const uint64_t sort_cap = (n_slots << (std::min<uint32_t>(extra_env, 13u) + 1)) / target + nb + 64 + (uint64_t)GIANT_MAX * MAX_SUB;     // an item of n keys lists <= 2^(extra+1) n / target pieces
+    static const uint32_t deep_bits = getenv("GKC_DEEP_BITS") ? std::max<uint32_t>(1u, (uint32_t)atoi(getenv("GKC_DEEP_BITS"))) : (uint32_t)MAX_SUB_BITS;   // tests: few bits per level force many levels
+    const uint64_t sort_cap = n_slots / (CAP1 / 4) + list_cap + 64 + (uint64_t)GIANT_MAX * MAX_SUB;     // an item of n keys lists <= 2 n / (cap1 / 2) + 1 runs and pieces
     CB_TRY(c->ensure(B.sitems, (size_t)sort_cap * sizeof(SortItem)));
     const unsigned deep_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(list_cap, 256 * 8));
     auto counters_of = [&](int level) -> uint32_t* { return misc + 8 + 4 * (level % DEEP_COUNTERS); };     // [0] items for the next level [1] pieces to sort [2] ticket
@@ -1578,8 +1628,12 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         const DeepItem* q_in = (const DeepItem*)B.q[(level - 1) & 1].p; DeepItem* q_out = (DeepItem*)B.q[level & 1].p;
         uint32_t* cn = counters_of(level);
         if (level > DEEP_FIXED) CB_HIP(hipMemsetAsync(cn, 0, 16, cur_stream(c)));                         // (the first ones were cleared with the whole block)
-        hipLaunchKernelGGL((k_deep_split<KW>), dim3(deep_grid), dim3(DEEP_THREADS), 0, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 2, q_out, cn + 0,
-                           (SortItem*)B.sitems.p, cn + 1, 2 * k, target, extra_env, CAP1, O);
+        const uint32_t bits_small = std::min<uint32_t>(deep_bits, DEEP_SMALL_BITS), bits_large = std::min<uint32_t>(deep_bits, (uint32_t)MAX_SUB_BITS);
+        static std::once_flag once_deep; std::call_once(once_deep, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_deep_split<KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)8 << MAX_SUB_BITS)); });
+        hipLaunchKernelGGL((k_deep_split<KW>), dim3(deep_grid), dim3(DEEP_THREADS), (size_t)8 << bits_small, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 2, q_out, cn + 0,
+                           (SortItem*)B.sitems.p, cn + 1, 2 * k, bits_small, 0u, DEEP_SMALL_N, CAP1, O);
+        hipLaunchKernelGGL((k_deep_split<KW>), dim3(std::min(deep_grid, 512u)), dim3(DEEP_THREADS), (size_t)8 << bits_large, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 3, q_out, cn + 0,
+                           (SortItem*)B.sitems.p, cn + 1, 2 * k, bits_large, DEEP_SMALL_N, 0xFFFFFFFFu, CAP1, O);
         const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((sort_cap + 3) / 4, 256 * 8));
         if (tag) hipLaunchKernelGGL((k_sort_items<KW, FT>), dim3(sgrid), dim3(SORT_THREADS), 0, cur_stream(c), keysA, (const key_t*)keysB, (const SortItem*)B.sitems.p, (const uint32_t*)(cn + 1), 0u, O);
         else hipLaunchKernelGGL((k_sort_items<KW, false>), dim3(sgrid), dim3(SORT_THREADS), 0, cur_stream(c), keysA, (const key_t*)keysB, (const SortItem*)B.sitems.p, (const uint32_t*)(cn + 1), 0u, O);
@@ -1595,10 +1649,10 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
                            (const uint32_t*)T.giant_list, (const uint32_t*)T.giant_count };
             uint32_t* cn = counters_of(1);
             hipLaunchKernelGGL((k_giant_or<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, (uint8_t*)B.cnt8.p);
-            hipLaunchKernelGGL((k_giant_hist<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, 2 * k, target, extra_env);
+            hipLaunchKernelGGL((k_giant_hist<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, 2 * k, deep_bits);
             hipLaunchKernelGGL((k_giant_plan<KW>), dim3(GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, (DeepItem*)B.q[1].p, cn + 0,
-                               (SortItem*)B.sitems.p, cn + 1, 2 * k, target, extra_env, CAP1, O);
-            hipLaunchKernelGGL((k_giant_scatter<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysB, G, bs, bn, bc, 2 * k, target, extra_env);
+                               (SortItem*)B.sitems.p, cn + 1, 2 * k, deep_bits, CAP1, O);
+            hipLaunchKernelGGL((k_giant_scatter<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysB, G, bs, bn, bc, 2 * k, deep_bits);
             CB_HIP(hipGetLastError());
         }
         for (int level = 1; level <= DEEP_FIXED; level++) CB_TRY(launch_deep(level));
