@@ -5,10 +5,13 @@ batch of synthetic 150 bp reads that is already resident in HBM when the timed r
 Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run, one rank per GPU).
 Rank 0 prints ONE JSON line. metric = BASELINE.json's "distinct k-mers/s at k=31".
 
-N=1 workload = BASELINE configs[1] shape (k=31, synthetic 150 bp reads, 30x coverage, 1 % substitutions, single pass,
-no Bloom), --reads per GPU (default 10^8 = the full config; a step takes < 1 s).
-N>1: weak scaling — every rank scans its own --reads reads; super-k-mer buckets are routed to the partition's owner
-rank with one RCCL all-to-all (torch.distributed, backend nccl == RCCL), each rank counts the partitions it owns.
+N=1 workload = BASELINE configs[1] (k=31, 10^8 synthetic 150 bp reads, 30x coverage, 1 % substitutions, single pass,
+no Bloom); a step takes < 1 s.
+N>1: weak scaling on BASELINE configs[2]'s per-GPU share — every rank scans 1.25e8 reads of one global stream (N=8: the 10^9 reads of
+configs[2]); super-k-mer buckets are routed to the partition's owner rank by gkc_exchange (grouped ncclSend/ncclRecv inside
+libgkc_hip.so, RCCL over xGMI), each rank counts the partitions it owns. The N=1 line also carries `config.share_of_8`: that same
+per-GPU share (1.25e8 reads, the partition count of the 8-GPU run, 4 pushes + exchanges through a one-rank RCCL communicator) timed
+on this GPU, i.e. the per-GPU cost of configs[2] before any byte moves over xGMI.
 """
 import argparse
 import ctypes as C
@@ -70,6 +73,90 @@ def cpu_baseline(c, k, m, parts, rep, n_reads=10_000_000):
             "single_thread": single}
 
 
+def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct):
+    """algorithmic bytes of every timed kernel group (SURVEY §8d per-unit figures x the units of one step) -> the dominant one's roofline entry.
+    ktime: {name: (ms, launches)} over `steps` steps; keys / distinct: this rank's share."""
+    rec_bytes = 16 if k <= 31 else 32; key_bytes = 8 if k <= 31 else 16
+    alg = {
+        "scan_count": n_bases * 1.0,
+        "scan_emit": n_bases * 1.0 + st["nb_superkmers"] * (rec_bytes + 4),
+        "expand_count": st["nb_superkmers"] * rec_bytes,
+        "expand_scatter": st["nb_superkmers"] * rec_bytes + keys * key_bytes,
+        "bucket_sort": keys * key_bytes + distinct * (key_bytes + 1),
+        "compact": distinct * (key_bytes + 1 + rec_bytes),             # gather: key + abundance byte in, Count record out
+    }
+    dom = max(alg, key=lambda n_: ktime[n_][0])
+    dom_ms = ktime[dom][0] / max(1, steps)
+    achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    launches = max(1, ktime[dom][1] // max(1, steps))
+    return alg, dom, dom_ms, achieved, launches
+
+
+REF_DIR = os.path.join(ROOT, "integration", "_build", "ref")      # unpatched reference tools built by integration/build_reference.sh (git-ignored, shipped by gpurun)
+
+
+def cpu_baseline_reference(c, k, n_reads=10_000_000):
+    """The REFERENCE ITSELF as the CPU baseline (kind "reference"): the unpatched `dbgh5` of GATB-Core, built from /root/reference with its own cmake by
+    integration/build_reference.sh, runs its multithreaded SortingCountAlgorithm (SortingCountAlgorithm.cpp:636-781) on all host cores of this box over a
+    FASTA of the same synthetic stream (bounded sample, written to /dev/shm before the clock starts; temporary super-k-mer files and the .h5 also in /dev/shm:
+    no disk in the measurement). `value` = distinct k-mers / the DSK step's own clock (`dsk.time` = fill_partitions + fill_solid_kmers, read back with the
+    reference's `dbginfo`; the process wall, which adds the bank estimate, the Repartitor sample and start-up, is reported beside it). None if the tools are absent."""
+    import shutil, subprocess, tempfile
+    dbgh5, dbginfo = os.path.join(REF_DIR, "dbgh5"), os.path.join(REF_DIR, "dbginfo")
+    if not (os.path.exists(dbgh5) and os.path.exists(dbginfo)):
+        return None
+    L = 150
+    cores = os.cpu_count() or 1
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    work = tempfile.mkdtemp(prefix="gkc_refbase_", dir=shm)
+    try:
+        d_b, d_o = c.synth_reads_device(1, n_reads, L, n_reads * 5, 10000)
+        bases = c.device_to_host(d_b, n_reads * L)
+        c.device_free(d_b); c.device_free(d_o)
+        rec = np.empty((n_reads, L + 4), dtype=np.uint8)                 # ">r\n" + bases + "\n"
+        rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 2] = 10; rec[:, 3:3 + L] = bases.reshape(n_reads, L); rec[:, 3 + L] = 10
+        fa = os.path.join(work, "reads.fa")
+        rec.tofile(fa)
+        del rec, bases
+        try:
+            mem_mb = int(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / (1 << 20) * 0.5)
+        except (ValueError, OSError):
+            mem_mb = 64000
+        cmd = [dbgh5, "-in", fa, "-kmer-size", str(k), "-abundance-min", "1", "-nb-cores", str(cores), "-max-memory", str(mem_mb),
+               "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-out", os.path.join(work, "ref"), "-verbose", "0"]
+        t0 = time.time()
+        r = subprocess.run(cmd, cwd=work, capture_output=True, text=True, timeout=900)
+        wall = time.time() - t0
+        if r.returncode != 0:
+            return {"error": "reference dbgh5 failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
+        info = subprocess.run([dbginfo, "-in", os.path.join(work, "ref.h5")], cwd=work, capture_output=True, text=True, timeout=300).stdout
+        vals = {}
+        for line in info.splitlines():                                   # "   key   : value"
+            key, sep, val = line.partition(":")
+            if sep and val.strip():
+                vals.setdefault(key.strip(), val.strip())
+        def f(name):
+            try:
+                return float(vals[name])
+            except (KeyError, ValueError):
+                return None
+        distinct, valid, t_dsk = f("kmers_nb_distinct"), f("kmers_nb_valid"), f("time")
+        if not distinct or not t_dsk:
+            return {"error": "could not read kmers_nb_distinct / time from dbginfo", "wall_s": wall}
+        return {"value": distinct / t_dsk, "unit": "distinct k-mers/s", "cores": cores, "kind": "reference",
+                "valid_kmers_per_s": (valid or 0) / t_dsk, "dsk_time_s": t_dsk, "process_wall_s": wall,
+                "fill_partitions_s": f("fill_partitions"), "fill_solid_kmers_s": f("fill_solid_kmers"),
+                "fillsolid_read_sort_dump_s": [f("1.read"), f("2.sort"), f("3.dump")],
+                "nb_partitions": f("nb_partitions"), "nb_passes": f("nb_passes"), "distinct_kmers": distinct,
+                "sample": "GATB-Core's own dbgh5 (unpatched, built from the reference sources by integration/build_reference.sh): -kmer-size %d -abundance-min 1 -nb-cores %d "
+                          "-max-memory %d -bloom none -debloom none -branching-nodes none, on %d synthetic 150 bp reads (same generator, seed 1, 30x) as FASTA in %s; "
+                          "value = kmers_nb_distinct / dsk.time (SortingCountAlgorithm::execute: fill_partitions + fill_solid_kmers)" % (k, cores, mem_mb, n_reads, shm)}
+    except Exception as e:      # noqa
+        return {"error": "reference baseline: %r" % (e,)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def fastq_parse_leg(c, n_reads=1_000_000, L=150):
     """input side, reported beside the metric (never inside it): a 4-line FASTQ text of n_reads reads already resident in HBM ->
     flat bases + offsets on the device (gkc_fastx_parse_device). Returns text GB/s and bases/s."""
@@ -98,7 +185,7 @@ def fastq_parse_leg(c, n_reads=1_000_000, L=150):
             "text_GBps": t.numel() / best / 1e9, "gbases_per_s": n_reads * L / best / 1e9, "ms": best * 1e3}
 
 
-def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2):
+def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2):
     """SURVEY §8(d) wall: from the first push to the last partition's Count[] in (page-locked) host memory. Every Stage-B batch is copied into
     the host sink on a copy stream while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns when everything has landed.
     Reported beside `value` (which stops with the results in HBM), at abundance-min 1 (every distinct k-mer travels: PCIe-bound) and 2."""
@@ -122,18 +209,42 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2):
     for amin in (1, 2):
         c.set_solidity(amin, 2147483647, 10000)
         step(); sync()                                        # the batch plan changes with the solidity window: one untimed step
+        ns_ = n_steps_amin2 if amin == 2 else n_steps
         t0 = time.perf_counter()
-        for _ in range(n_steps):
+        for _ in range(ns_):
             step()
         sync()
-        dt = (time.perf_counter() - t0) / n_steps
+        dt = (time.perf_counter() - t0) / ns_
         st = c.stats()
         landed = st["kmers_nb_solid"] * 16
         err = (c.L.gkc_last_error(c.h) or b"").decode()
         out["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s with every solid Count[] in page-locked host memory",
-                                          "ms_per_step": dt * 1e3, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
+                                          "ms_per_step": dt * 1e3, "steps": ns_, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
                                           "landed_GBps_over_the_step": landed / dt / 1e9, "frac_of_pcie": landed / dt / 1e9 / pcie,
                                           "sink_overflow": "sink" in err}
+    # PCIe at BOTH ends (never `value`): bases in page-locked host memory in (gkc_push_reads: H2D of chunk j+1 under the scan of chunk j), every solid Count[]
+    # into the page-locked sink out; 5e7 reads of the same generator (30x over their own genome)
+    try:
+        n2, L = 50_000_000, 150
+        db, do = c.synth_reads_device(2, n2, L, n2 * 5, 10000)
+        pin = gkc.HostBuffer(n2 * L)
+        c._chk(c.L.gkc_device_to_host(c.h, pin._p, db, n2 * L))
+        c.device_free(db); c.device_free(do)
+        ho = np.arange(n2 + 1, dtype=np.uint64) * np.uint64(L)
+        h2h = {"reads": n2, "bases_in_GB": n2 * L / 1e9}
+        def step2():
+            c.begin_pass(0); c.push_reads(pin.a, ho); c.finish_pass()
+        for amin in (2, 1):
+            c.set_solidity(amin, 2147483647, 10000)
+            step2(); sync()
+            t0 = time.perf_counter(); step2(); step2(); sync(); dt = (time.perf_counter() - t0) / 2
+            st = c.stats()
+            h2h["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s, pinned host bases in -> solid Count[] in pinned host memory",
+                                              "ms_per_step": dt * 1e3, "steps": 2, "count_bytes_out_GB": st["kmers_nb_solid"] * 16 / 1e9}
+        out["host_to_host"] = h2h
+        del pin
+    except Exception as e:      # noqa
+        out["host_to_host"] = {"error": repr(e)}
     c.set_host_sink(None)
     c.set_solidity(1, 2147483647, 10000)
     return out
@@ -144,14 +255,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (default = BASELINE configs[1]: 10^8)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 10^8 = BASELINE configs[1] on one GPU; 1.25e8 = configs[2]'s per-GPU share on several)")
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bloom-mphf", action="store_true", help="skip the Bloom + MPHF block (BASELINE configs[4] on one GPU's share)")
     ap.add_argument("--no-k63", action="store_true", help="skip the second block (BASELINE configs[3]: k=63 at the same size)")
-    ap.add_argument("--no-host-landed", action="store_true", help="skip the host-landed leg (results streamed into page-locked host memory)")
+    ap.add_argument("--no-host-landed", action="store_true", help="skip the host-landed / host-to-host legs (results streamed into page-locked host memory)")
+    ap.add_argument("--no-share-of-8", action="store_true", help="skip the N=1 block that times BASELINE configs[2]'s per-GPU share")
     ap.add_argument("--pushes", type=int, default=4, help="multi-GPU: pushes (and exchanges) per pass and rank")
     args = ap.parse_args()
 
@@ -175,7 +287,8 @@ def main():
         raise SystemExit("libgkc_hip.so missing: run __graft_entry__.build()")
 
     k, m, L = args.k, args.m, 150
-    n_reads = args.reads
+    SHARE_OF_8 = 125_000_000                                  # BASELINE configs[2]: 10^9 reads on 8 GPUs
+    n_reads = args.reads or (100_000_000 if world == 1 else SHARE_OF_8)
     n_kmers = n_reads * (L - k + 1)
     parts = args.partitions or int(min(65535, max(64 * world, 2 ** int(np.ceil(np.log2(max(1, n_kmers * world / 3.0e6)))))))
     parts = (parts + world - 1) // world * world
@@ -220,7 +333,7 @@ def main():
         step()
     sync()
     # per-kernel timers are HIP events on the context's own stream, accumulated inside the library
-    names = ["scan_count", "scan_emit", "scan_refine", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "bucket_sort_deep", "split_levels", "compact",
+    names = ["scan_count", "scan_emit", "scan_refine", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "split_levels", "compact",
              "total_stage_a", "total_stage_b"]
     base = {nme: c.timing(nme) for nme in names}
     t0 = time.perf_counter()
@@ -268,22 +381,15 @@ def main():
         d = distinct / max(1, valid)
         # dominant kernel = the one with the largest accumulated time; its algorithmic bytes per launch are stated in DESIGN.md §Kernels
         keys_per_rank = valid / world
-        rec_bytes = 16 if k <= 31 else 32; key_bytes = 8 if k <= 31 else 16
-        alg = {
-            "scan_count": n_bases * 1.0,
-            "scan_emit": n_bases * 1.0 + st["nb_superkmers"] * (rec_bytes + 4),
-            "expand_count": st["nb_superkmers"] * rec_bytes,
-            "expand_scatter": st["nb_superkmers"] * rec_bytes + keys_per_rank * key_bytes,
-            "bucket_sort": keys_per_rank * key_bytes + (distinct / world) * (key_bytes + 4),
-            "compact": (distinct / world) * (key_bytes + 4 + 2 * key_bytes),
-        }
-        dom = max(alg, key=lambda n_: ktime[n_][0])
-        dom_ms = ktime[dom][0] / max(1, args.steps)            # per step (a step may launch the kernel once per Stage-B batch)
-        achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        key_bytes = 8 if k <= 31 else 16
+        alg, dom, dom_ms, achieved, launches_per_step = kernel_roofline(ktime, args.steps, n_bases, st, k, keys_per_rank, distinct / world)
         workload = ("k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions" % (k, n_reads, m, parts))
+        if world > 1:
+            workload = ("BASELINE configs[2] at %d GPU(s): k=%d, %d synthetic 150 bp reads per GPU (%d in all), minimizer-partition exchange (gkc_exchange: RCCL send/recv over xGMI), "
+                        "m=%d, %d partitions" % (world, k, n_reads, n_reads * world, m, parts))
         traffic = None
         kname = {"scan_count": "k_scan_tile<false, 2, true>", "scan_emit": "k_emit_desc<2>", "expand_count": "k_expand_count<1, 2>",
-                 "expand_scatter": "k_expand_scatter_pair", "bucket_sort": "k_wave_sort<1, true>", "compact": "k_compact_flags<1>"}
+                 "expand_scatter": "k_expand_scatter_pair", "bucket_sort": "k_wave_sort<1, true>", "compact": "k_gather_counts<1>"}
         try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), only if they were taken on this exact workload
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload and kname.get(dom) in pt["kernels"]:
@@ -291,7 +397,6 @@ def main():
                 traffic = kt["hbm_bytes_per_step"] / max(1, ktime[dom][1] // max(1, args.steps)) if "hbm_bytes_per_step" in kt else kt["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-        launches_per_step = max(1, ktime[dom][1] // max(1, args.steps))
         out = {
             "metric": "distinct k-mers/s at k=%d" % k, "value": value, "unit": "distinct k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -341,7 +446,7 @@ def main():
         if exch is not None:
             out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push, "per_rank": exch}
         if world == 1 and not args.no_host_landed:
-            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct)
+            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=args.steps)
             if "abundance_min_2" in out["host_landed"]:
                 out["host_landed"]["abundance_min_2"]["vs_value"] = out["host_landed"]["abundance_min_2"]["value"] / value
         if world == 1 and k == 31 and not args.no_cpu_baseline:
@@ -362,6 +467,17 @@ def main():
                     torch.cuda.synchronize(); t0 = time.perf_counter(); bl.insert_solid(); torch.cuda.synchronize()
                     blk["bloom_%s_ms" % kind] = (time.perf_counter() - t0) * 1e3
                     bl.close()
+            # the query side (DebloomMinimizerAlgorithm.cpp:201: contains8 of every solid k-mer), on the device, neighbor kind
+            bl = gkc.Bloom(c, "neighbor", int(ns * 11.0), 7, k); bl.insert_solid()
+            for rep_ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); nq, npos = bl.query_solid(True); torch.cuda.synchronize()
+                blk["bloom_contains8_ms"] = (time.perf_counter() - t0) * 1e3
+            blk["bloom_contains8_kmers_per_s"] = nq / (blk["bloom_contains8_ms"] * 1e-3); blk["bloom_contains8_neighbours_per_s"] = 8 * blk["bloom_contains8_kmers_per_s"]
+            blk["bloom_contains8_set_bits"] = npos
+            torch.cuda.synchronize(); t0 = time.perf_counter(); nq1, npos1 = bl.query_solid(False); torch.cuda.synchronize()
+            blk["bloom_contains_ms"] = (time.perf_counter() - t0) * 1e3; blk["bloom_contains_kmers_per_s"] = nq1 / (blk["bloom_contains_ms"] * 1e-3)
+            assert npos1 == nq1 == ns                             # no false negatives
+            bl.close()
             mp_ = gkc.Mphf(c); mp_.close()                      # first build warms the allocator
             torch.cuda.synchronize(); t0 = time.perf_counter(); mp_ = gkc.Mphf(c); torch.cuda.synchronize(); t1 = time.perf_counter()
             amap, above = mp_.abundance_map(); t2 = time.perf_counter()
@@ -378,7 +494,7 @@ def main():
             for b_, o_, _, _ in chunks:
                 c.device_free(b_); c.device_free(o_)
             chunks.clear()
-            c.close()
+            c.close(); c = None
             c63 = gkc.Counter(local)
             p63 = int(min(65535, max(64, 2 ** int(np.ceil(np.log2(max(1, n_reads * (L - 63 + 1) / 3.0e6)))))))
             c63.configure(63, m, p63, repart_for_bench(m, p63))
@@ -386,21 +502,81 @@ def main():
             def step63():
                 c63.begin_pass(0); c63.push_reads_device(b63, o63, n_reads, n_bases); c63.finish_pass()
             step63(); torch.cuda.synchronize()
+            b63t = {nme: c63.timing(nme) for nme in names}
             t0 = time.perf_counter()
             for _ in range(2):
                 step63()
             torch.cuda.synchronize()
             dt63 = (time.perf_counter() - t0) / 2
             s63 = c63.stats()
+            kt63 = {nme: ((c63.timing(nme)[0] - b63t[nme][0]), (c63.timing(nme)[1] - b63t[nme][1])) for nme in names}
+            alg63, dom63, dom63_ms, ach63, ln63 = kernel_roofline(kt63, 2, n_bases, s63, 63, s63["kmers_nb_valid"], s63["kmers_nb_distinct"])
             out["config"]["k63"] = {"workload": "k=63, %d synthetic 150 bp reads, single-pass count, m=%d, %d partitions (BASELINE configs[3])" % (n_reads, m, p63),
                                     "steps": 2, "warmup": 1, "ms_per_step": dt63 * 1e3, "value": s63["kmers_nb_distinct"] / dt63, "unit": "distinct k-mers/s", "dtype": "u128",
-                                    "valid_kmers": s63["kmers_nb_valid"], "distinct_kmers": s63["kmers_nb_distinct"], "valid_kmers_per_s": s63["kmers_nb_valid"] / dt63}
+                                    "valid_kmers": s63["kmers_nb_valid"], "distinct_kmers": s63["kmers_nb_distinct"], "valid_kmers_per_s": s63["kmers_nb_valid"] / dt63,
+                                    "kernel_ms_per_step": {n_: round(kt63[n_][0] / 2, 3) for n_ in names},
+                                    "roofline": {"bound": "hbm", "kernel": dom63, "achieved": ach63, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach63 / HBM_PEAK_GBS,
+                                                 "traffic": None, "launches_per_step": int(ln63), "launch_ms": dom63_ms / ln63,
+                                                 "algorithmic_bytes_per_launch": alg63[dom63] / ln63, "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))}}
             c63.device_free(b63); c63.device_free(o63); c63.close()
-            c = None
+        if world == 1 and k == 31 and not args.no_share_of_8:
+            # BASELINE configs[2]'s per-GPU share on THIS GPU: 1.25e8 reads of the 10^9-read stream, the partition count the 8-GPU run uses (-> two-level Stage A),
+            # 4 pushes each followed by gkc_exchange through a one-rank RCCL communicator (the planning, narrowing and import code of the multi-GPU path; no peer,
+            # so no byte crosses xGMI). All 32768 partitions are counted here (8 ranks would each count 4096 partitions of 8x the k-mers: the same number of k-mers).
+            if c is not None:
+                for b_, o_, _, _ in chunks:
+                    c.device_free(b_); c.device_free(o_)
+                chunks.clear(); c.close(); c = None
+            from gatb_core_amd import dist as gdist          # noqa
+            W8 = 8
+            p8 = int(min(65535, 2 ** int(np.ceil(np.log2(SHARE_OF_8 * (L - k + 1) * W8 / 3.0e6)))))
+            c8 = gkc.Counter(local); c8.configure(k, m, p8, repart_for_bench(m, p8))
+            g8 = SHARE_OF_8 * W8 * L // 30
+            np8 = args.pushes; per8 = (SHARE_OF_8 + np8 - 1) // np8
+            ch8 = []
+            for i in range(np8):
+                nr = min(per8, SHARE_OF_8 - i * per8)
+                if nr > 0:
+                    b_, o_ = c8.synth_reads_device(2, nr, L, g8, 10000, first_read=i * per8)
+                    ch8.append((b_, o_, nr, nr * L))
+            r8 = gdist.DistributedCounter(c8, 0, 1, p8)
+            def step8():
+                c8.begin_pass(0)
+                for b_, o_, nr, nb_ in ch8:
+                    c8.push_reads_device(b_, o_, nr, nb_); r8.exchange()
+                c8.finish_pass()
+            step8(); torch.cuda.synchronize()
+            b8t = {nme: c8.timing(nme) for nme in names}
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step8()
+            torch.cuda.synchronize()
+            dt8 = (time.perf_counter() - t0) / 3
+            s8 = c8.stats(); cs8 = r8.stats()
+            out["config"]["share_of_8"] = {
+                "workload": "BASELINE configs[2] per-GPU share on one GPU: k=31, %d of 10^9 reads, %d partitions (two-level Stage A), %d pushes + gkc_exchange (one-rank RCCL communicator)" % (SHARE_OF_8, p8, len(ch8)),
+                "steps": 3, "warmup": 1, "ms_per_step": dt8 * 1e3, "value": s8["kmers_nb_distinct"] / dt8, "unit": "distinct k-mers/s (this GPU's share)",
+                "x8_if_the_exchange_were_free": 8 * s8["kmers_nb_distinct"] / dt8,
+                "valid_kmers": s8["kmers_nb_valid"], "distinct_kmers": s8["kmers_nb_distinct"],
+                "kernel_ms_per_step": {n_: round((c8.timing(n_)[0] - b8t[n_][0]) / 3, 3) for n_ in names},
+                "exchange": {"exchanges_per_step": cs8["n_exchanges"] / 4, "ms_host_per_step": cs8["ms_host"] / 4, "ms_transfer_per_step": cs8["ms_transfer"] / 4}}
+            for b_, o_, _, _ in ch8:
+                c8.device_free(b_); c8.device_free(o_)
+            c8.close()
         if not args.no_cpu_baseline and world == 1:
-            cp = int(min(parts, 4096))
             cb = c if c is not None else gkc.Counter(local)
-            out["cpu_baseline"] = cpu_baseline(cb, k, m, cp, repart_for_bench(m, cp))
+            ref_b = cpu_baseline_reference(cb, k)
+            cp = int(min(parts, 4096))
+            port_b = cpu_baseline(cb, k, m, cp, repart_for_bench(m, cp))
+            if ref_b is not None and "value" in ref_b:
+                ref_b["port"] = port_b                         # the C restatement (oracle) beside it, clearly labelled
+                out["cpu_baseline"] = ref_b
+            else:
+                if ref_b is not None:
+                    port_b["reference_attempt"] = ref_b
+                else:
+                    port_b["reference_attempt"] = "integration/_build/ref/dbgh5 absent (integration/build_reference.sh builds it from /root/reference)"
+                out["cpu_baseline"] = port_b
         elif world == 1:
             out["cpu_baseline"] = None
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -457,6 +457,59 @@ static int bloom_query(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stri
     if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "bloom query failed: %s", hipGetErrorString(e));
     return GKC_OK;
 }
+__global__ void k_sum_bits8(const uint8_t* __restrict__ a, uint64_t n, unsigned long long* __restrict__ out)
+{
+    unsigned long long s = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) s += (unsigned)__popc((unsigned)a[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+int gkc_bloom_query_solid(gkc_bloom* b, gkc_ctx* c, int neighbors8, uint8_t* d_out, uint64_t* n_queried, uint64_t* n_positive)
+{
+    if (!b || !c) return GKC_ERR_ARG;
+    if (c->k != b->k) GKC_FAIL(c, GKC_ERR_ARG, "bloom k (%u) differs from the context's k (%u)", b->k, c->k);
+    if (neighbors8 && b->kind != 2) GKC_FAIL(c, GKC_ERR_ARG, "contains8 is implemented by the neighbor kind only (Bloom.hpp:245-250 throws ExceptionNotImplemented)");
+    GKC_TRY(gkc_require_resident(c, "gkc_bloom_query_solid"));
+    const uint32_t stride = c->key_words == 1 ? 16 : 32;
+    uint64_t total = 0;
+    for (const Dataset& D : c->datasets) if (D.done) total += D.n_solid;
+    if (n_queried) *n_queried = total;
+    if (n_positive) *n_positive = 0;
+    if (!total) return GKC_OK;
+    DevBuf tmp, acc;
+    if (!d_out) { GKC_TRY(c->ensure(tmp, (size_t)total)); d_out = (uint8_t*)tmp.p; }
+    int rc = c->ensure(acc, 8);
+    if (rc != GKC_OK) { tmp.release(); return rc; }
+    hipError_t e = hipMemsetAsync(acc.p, 0, 8, c->stream);
+    {   ScopedTimer tm(c, neighbors8 ? "bloom_contains8" : "bloom_contains");
+        uint64_t done = 0;
+        const uint8_t* run_p = nullptr; uint64_t run_n = 0;                // consecutive datasets of one Stage-B batch form one array
+        auto flush = [&]() {
+            if (!run_n) return;
+            const unsigned grid = (unsigned)std::min<uint64_t>((run_n + 255) / 256, 256 * 16);
+            if (neighbors8) hipLaunchKernelGGL(k_bloom_contains8, dim3(grid), dim3(256), 0, c->stream, params_of(b), run_p, run_n, stride, d_out + done);
+            else            hipLaunchKernelGGL(k_bloom_contains, dim3(grid), dim3(256), 0, c->stream, params_of(b), run_p, run_n, stride, d_out + done);
+            done += run_n; run_n = 0;
+        };
+        for (const Dataset& D : c->datasets) {
+            if (!D.done || !D.n_solid) continue;
+            if (run_n && (const uint8_t*)D.d_counts == run_p + run_n * stride) { run_n += D.n_solid; continue; }
+            flush();
+            run_p = (const uint8_t*)D.d_counts; run_n = D.n_solid;
+        }
+        flush();
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_sum_bits8, dim3(1024), dim3(256), 0, c->stream, (const uint8_t*)d_out, total, (unsigned long long*)acc.p); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, acc.p, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    tmp.release(); acc.release();
+    if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "bloom query failed: %s", hipGetErrorString(e));
+    if (n_positive) *n_positive = h;
+    return GKC_OK;
+}
 int gkc_bloom_contains(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out) { return bloom_query(b, keys, n, stride, out, false); }
 int gkc_bloom_contains8(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out) { return bloom_query(b, keys, n, stride, out, true); }
 

@@ -20,7 +20,7 @@ SYMBOLS = [
     "gkc_partition_info", "gkc_partition_counts", "gkc_partition_counts_device", "gkc_histogram", "gkc_get_stats",
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
-    "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_contains",
+    "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_query_solid", "gkc_bloom_contains",
     "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free", "gkc_host_alloc", "gkc_host_free", "gkc_release_pass", "gkc_device_memory",
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
@@ -112,6 +112,7 @@ def lib():
         "gkc_bloom_insert": (C.c_int, [vp, vp, u64, u32]),
         "gkc_bloom_insert_device": (C.c_int, [vp, vp, u64, u32]),
         "gkc_bloom_insert_solid": (C.c_int, [vp, vp]),
+        "gkc_bloom_query_solid": (C.c_int, [vp, vp, C.c_int, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "gkc_bloom_contains": (C.c_int, [vp, vp, u64, u32, vp]),
         "gkc_bloom_contains8": (C.c_int, [vp, vp, u64, u32, vp]),
         "gkc_bloom_get_array": (C.c_int, [vp, vp, u64]),
@@ -640,6 +641,12 @@ class Bloom:
 
     def insert_solid(self):
         self.c._chk(self.L.gkc_bloom_insert_solid(self.h, self.c.h))
+
+    def query_solid(self, neighbors8=True, d_out=None):
+        """contains8 (or contains) of every solid k-mer of the counter, on the device (gkc_bloom_query_solid) -> (k-mers queried, set result bits)"""
+        nq = C.c_uint64(0); npos = C.c_uint64(0)
+        self.c._chk(self.L.gkc_bloom_query_solid(self.h, self.c.h, 1 if neighbors8 else 0, d_out, C.byref(nq), C.byref(npos)))
+        return nq.value, npos.value
 
     def contains(self, keys):
         a = self._keys(keys); out = np.zeros(len(a), np.uint8)

@@ -242,6 +242,11 @@ int gkc_bloom_insert_device(gkc_bloom* b, const void* d_keys, uint64_t n, uint32
 int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* ctx);
 int gkc_bloom_contains(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out);
 int gkc_bloom_contains8(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out);  /* neighbor kind */
+/* The query side at the reference's call site (DebloomMinimizerAlgorithm.cpp:201: contains8 of every solid k-mer; Bloom.hpp:645-811), on the device: every solid
+ * k-mer of every finished dataset of the context is queried where it lies (HBM), in dataset order. neighbors8 != 0: contains8 (neighbor kind), one result byte per
+ * k-mer (bit j: neighbour j is in the filter); else contains, 0/1 per k-mer. d_out: device buffer of *n_queried bytes or NULL (results discarded).
+ * n_positive: number of set result bits. */
+int gkc_bloom_query_solid(gkc_bloom* b, gkc_ctx* ctx, int neighbors8, uint8_t* d_out, uint64_t* n_queried, uint64_t* n_positive);
 int gkc_bloom_get_array(gkc_bloom* b, uint8_t* out, uint64_t cap_bytes);                               /* IBloom::getArray() */
 int gkc_bloom_set_array(gkc_bloom* b, const uint8_t* in, uint64_t n_bytes);                            /* StorageTools::loadBloom */
 /* the bit array where it lives (device memory, n_bytes = gkc_bloom_nbytes rounded up to 4): multi-GPU runs insert their own

@@ -281,6 +281,29 @@ def test_bloom_of_solid_kmers_and_cfp_known_answer(gkc, ref_vectors):
     assert {x for x, h in zip(cand, hits) if h} == set(v["cfp"])
 
 
+@pytest.mark.parametrize("k", [31, 41])
+def test_bloom_query_of_the_solid_set_on_the_device(gkc, k):
+    """gkc_bloom_query_solid (the reference's call site: DebloomMinimizerAlgorithm.cpp:201, contains8 of every solid k-mer; Bloom.hpp:645-811): queried where the
+    records lie, in dataset order; set result bits == the oracle's contains8 / contains over the same k-mers"""
+    reads = synth_reads(3000, 20000, 150, seed=21 + k)
+    bases, offs = gko.pack_reads(reads)
+    m, parts = 9, 5
+    c = gkc.Counter(0); c.configure(k, m, parts, simple_repart(m, parts)); c.set_solidity(2, 2147483647, 10000); c.count(bases, offs)
+    solid = c.all_counts()
+    keys = list(solid.keys()) if isinstance(solid, dict) else list(solid)
+    assert len(keys) > 1000
+    bits = len(keys) * 11
+    ob = gko.Bloom("neighbor", bits, 7, k); ob.insert(keys)
+    db = gkc.Bloom(c, "neighbor", bits, 7, k); db.insert_solid()
+    assert np.array_equal(db.array(), ob.array())
+    nq, npos = db.query_solid(neighbors8=True)
+    exp8 = ob.contains8(keys)
+    assert nq == len(keys) and npos == int(sum(bin(int(x)).count("1") for x in exp8))
+    nq1, npos1 = db.query_solid(neighbors8=False)
+    assert nq1 == len(keys) and npos1 == len(keys)                      # no false negatives
+    db.close()
+
+
 def test_synth_generator_and_checksum_property(gkc):
     """device generator == numpy twin; independent checksum kernel == checksum of the counted records; sums match"""
     c = gkc.Counter(0)
