@@ -123,7 +123,7 @@ def cpu_baseline_reference(c, k, n_reads=10_000_000):
         except (ValueError, OSError):
             mem_mb = 64000
         cmd = [dbgh5, "-in", fa, "-kmer-size", str(k), "-abundance-min", "1", "-nb-cores", str(cores), "-max-memory", str(mem_mb),
-               "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-out", os.path.join(work, "ref"), "-verbose", "0"]
+               "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf", "-out", os.path.join(work, "ref"), "-verbose", "0"]
         t0 = time.time()
         r = subprocess.run(cmd, cwd=work, capture_output=True, text=True, timeout=900)
         wall = time.time() - t0
@@ -149,7 +149,7 @@ def cpu_baseline_reference(c, k, n_reads=10_000_000):
                 "fillsolid_read_sort_dump_s": [f("1.read"), f("2.sort"), f("3.dump")],
                 "nb_partitions": f("nb_partitions"), "nb_passes": f("nb_passes"), "distinct_kmers": distinct,
                 "sample": "GATB-Core's own dbgh5 (unpatched, built from the reference sources by integration/build_reference.sh): -kmer-size %d -abundance-min 1 -nb-cores %d "
-                          "-max-memory %d -bloom none -debloom none -branching-nodes none, on %d synthetic 150 bp reads (same generator, seed 1, 30x) as FASTA in %s; "
+                          "-max-memory %d -bloom none -debloom none -branching-nodes none -no-mphf, on %d synthetic 150 bp reads (same generator, seed 1, 30x) as FASTA in %s; "
                           "value = kmers_nb_distinct / dsk.time (SortingCountAlgorithm::execute: fill_partitions + fill_solid_kmers)" % (k, cores, mem_mb, n_reads, shm)}
     except Exception as e:      # noqa
         return {"error": "reference baseline: %r" % (e,)}
@@ -290,7 +290,8 @@ def main():
     SHARE_OF_8 = 125_000_000                                  # BASELINE configs[2]: 10^9 reads on 8 GPUs
     n_reads = args.reads or (100_000_000 if world == 1 else SHARE_OF_8)
     n_kmers = n_reads * (L - k + 1)
-    parts = args.partitions or int(min(65535, max(64 * world, 2 ** int(np.ceil(np.log2(max(1, n_kmers * world / 3.0e6)))))))
+    # about 3e6 k-mers per partition (8192 sub-buckets of ~370 keys), a power of two: 4096 for configs[1], 32768 = 4096 per rank for configs[2] at 8 GPUs
+    parts = args.partitions or int(min(32768, max(64 * world, 2 ** int(np.floor(np.log2(max(1, n_kmers * world / 3.0e6)) + 0.5)))))
     parts = (parts + world - 1) // world * world
     rep = repart_for_bench(m, parts)
 
@@ -522,16 +523,18 @@ def main():
         if world == 1 and k == 31 and not args.no_share_of_8:
             # BASELINE configs[2]'s per-GPU share on THIS GPU: 1.25e8 reads of the 10^9-read stream, the partition count the 8-GPU run uses (-> two-level Stage A),
             # 4 pushes each followed by gkc_exchange through a one-rank RCCL communicator (the planning, narrowing and import code of the multi-GPU path; no peer,
-            # so no byte crosses xGMI). All 32768 partitions are counted here (8 ranks would each count 4096 partitions of 8x the k-mers: the same number of k-mers).
+            # so no byte crosses xGMI). All 32768 partitions are counted here (8 ranks would each count 4096 partitions of 8x the k-mers: the same number of k-mers);
+            # the reads are drawn at 30x over a genome of their own, so that the k-mer multiplicities are those an owner rank sees.
             if c is not None:
                 for b_, o_, _, _ in chunks:
                     c.device_free(b_); c.device_free(o_)
                 chunks.clear(); c.close(); c = None
             from gatb_core_amd import dist as gdist          # noqa
             W8 = 8
-            p8 = int(min(65535, 2 ** int(np.ceil(np.log2(SHARE_OF_8 * (L - k + 1) * W8 / 3.0e6)))))
+            p8 = int(min(32768, 2 ** int(np.floor(np.log2(SHARE_OF_8 * (L - k + 1) * W8 / 3.0e6) + 0.5))))
             c8 = gkc.Counter(local); c8.configure(k, m, p8, repart_for_bench(m, p8))
-            g8 = SHARE_OF_8 * W8 * L // 30
+            g8 = SHARE_OF_8 * L // 30                          # 30x over a genome of their own: Stage B sees the multiplicities an owner rank sees in the 8-GPU run
+                                                             # (this share of the global stream alone would cover the 5e9-base genome 3.75x: nearly every k-mer distinct)
             np8 = args.pushes; per8 = (SHARE_OF_8 + np8 - 1) // np8
             ch8 = []
             for i in range(np8):
