@@ -219,6 +219,14 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
     } else {
         c->default_key = (uint32_t)(nm - 1);
     }
+    {   // fingerprint of the model: gkc_exchange compares it across the ranks (different tables would silently split one k-mer over two owners)
+        uint64_t h = 0x9E3779B97F4A7C15ULL;
+        auto mixin = [&](uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2); h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 31; };
+        mixin(k); mixin(m); mixin(nb_partitions); mixin(nb_passes); mixin((uint64_t)minimizer_type);
+        for (uint64_t i = 0; i < nm; i++) mixin(repart[i]);
+        if (minimizer_type == GKC_MINIMIZER_FREQ) for (uint64_t i = 0; i < nm; i++) mixin(freq_order[i]);
+        c->model_hash = h;
+    }
     GKC_TRY(gkc_alloc_histo(c));
     c->configured = true;
     return GKC_OK;

@@ -145,6 +145,7 @@ struct gkc_ctx {
     int minimizer_type = 0;
     uint32_t maxs = 0;
     uint32_t key_words = 1, record_bytes = 16;
+    uint64_t model_hash = 0;               // of (k, m, partitions, passes, minimizer type, repartition table, frequency order): every rank of a communicator must hold the same
     int32_t amin = 1, amax = 2147483647; uint32_t histo_max = 10000;
     // device tables
     DevBuf d_mkey_lut;      // u32[4^m] : m-mer (forward strand) -> order key (freq mode only)

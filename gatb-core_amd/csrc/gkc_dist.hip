@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <chrono>
 #include <numeric>
+#include <string>
+#include <unistd.h>
+#include <sys/stat.h>
 
 namespace {
 constexpr uint64_t MSG_CHUNK = 1ull << 28;     // 256 MiB per message: through torch's all_to_all_single a 1 GiB transfer is intact, a 1.9 GiB one comes back corrupt from
@@ -25,6 +28,7 @@ struct gkc_comm {
     gkc_ctx* ctx = nullptr; int world = 1, rank = 0;
     bool rccl = false; ncclComm_t nccl = nullptr;
     gkc_transport t{};
+    void* owned_user = nullptr; void (*owned_free)(void*) = nullptr;   // transport state the library itself created (gkc_comm_create_files)
     hipStream_t xstream = nullptr;
     std::vector<uint32_t> first;               // owner ranges [world+1]; empty until known
     bool owners_pinned = false; uint32_t owners_pass = ~0u; uint32_t owners_P = 0;
@@ -158,6 +162,76 @@ void gkc_comm_settle_timers(gkc_comm* m)
     m->timed.clear();
 }
 
+// ------------------------------------------------------------------------------------------------ file-mailbox transport (gkc_comm_create_files)
+// Collective calls happen in the same order on every rank, so a per-communicator sequence number names the files of one call. A file becomes visible
+// atomically (written under a temporary name, then renamed); a reader polls for it. all-gather: rank r writes ag.<seq>.<r>, reads the others', and removes
+// its own file of call seq-1 when it enters call seq+1 (every rank has read call seq-1 before it wrote its file of call seq). send/recv: one file per
+// message, named by (seq, source, destination, index of the message between the two in this call), removed by the receiver.
+namespace {
+struct FileBox {
+    std::string dir; int world, rank; uint64_t seq_ag = 0, seq_p2p = 0;
+    std::vector<uint8_t> stage;
+    static bool write_file(const std::string& path, const void* data, size_t n) {
+        const std::string tmp = path + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb"); if (!f) return false;
+        const bool ok = n == 0 || fwrite(data, 1, n, f) == n;
+        if (fclose(f) != 0 || !ok) return false;
+        return rename(tmp.c_str(), path.c_str()) == 0;
+    }
+    static bool read_file(const std::string& path, void* data, size_t n, double timeout_s) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            struct stat st;
+            if (stat(path.c_str(), &st) == 0 && (size_t)st.st_size == n) {
+                FILE* f = fopen(path.c_str(), "rb");
+                if (f) { const bool ok = n == 0 || fread(data, 1, n, f) == n; fclose(f); if (ok) return true; }
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+            usleep(200);
+        }
+    }
+    std::string ag_name(uint64_t seq, int r) const { return dir + "/ag." + std::to_string(seq) + "." + std::to_string(r); }
+    static int allgather(void* user, const void* mine, uint64_t n, void* all) {
+        FileBox* b = (FileBox*)user;
+        const uint64_t seq = b->seq_ag++;
+        if (seq >= 2) (void)unlink(b->ag_name(seq - 2, b->rank).c_str());
+        if (!write_file(b->ag_name(seq, b->rank), mine, (size_t)n)) return 1;
+        for (int r = 0; r < b->world; r++) {
+            if (r == b->rank) { memcpy((uint8_t*)all + (size_t)r * n, mine, (size_t)n); continue; }
+            if (!read_file(b->ag_name(seq, r), (uint8_t*)all + (size_t)r * n, (size_t)n, 600.0)) return 1;
+        }
+        return 0;
+    }
+    static int sendrecv(void* user, const gkc_xfer* sends, uint32_t n_sends, const gkc_xfer* recvs, uint32_t n_recvs) {
+        FileBox* b = (FileBox*)user;
+        const uint64_t seq = b->seq_p2p++;
+        std::vector<uint32_t> idx(b->world, 0);
+        for (uint32_t i = 0; i < n_sends; i++) {
+            const gkc_xfer& x = sends[i];
+            b->stage.resize((size_t)x.n_bytes);
+            if (x.n_bytes && hipMemcpy(b->stage.data(), x.d_ptr, (size_t)x.n_bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+            const std::string name = b->dir + "/p2p." + std::to_string(seq) + "." + std::to_string(b->rank) + "." + std::to_string(x.peer) + "." + std::to_string(idx[x.peer]++);
+            if (!write_file(name, b->stage.data(), (size_t)x.n_bytes)) return 1;
+        }
+        std::fill(idx.begin(), idx.end(), 0u);
+        for (uint32_t i = 0; i < n_recvs; i++) {
+            const gkc_xfer& x = recvs[i];
+            b->stage.resize((size_t)x.n_bytes);
+            const std::string name = b->dir + "/p2p." + std::to_string(seq) + "." + std::to_string(x.peer) + "." + std::to_string(b->rank) + "." + std::to_string(idx[x.peer]++);
+            if (!read_file(name, b->stage.data(), (size_t)x.n_bytes, 600.0)) return 1;
+            (void)unlink(name.c_str());
+            if (x.n_bytes && hipMemcpy(x.d_ptr, b->stage.data(), (size_t)x.n_bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
+        }
+        return 0;
+    }
+    static void destroy(void* user) {
+        FileBox* b = (FileBox*)user;
+        for (uint64_t s = b->seq_ag >= 2 ? b->seq_ag - 2 : 0; s < b->seq_ag; s++) (void)unlink(b->ag_name(s, b->rank).c_str());
+        delete b;
+    }
+};
+}
+
 extern "C" {
 
 int gkc_balanced_owner_ranges(const uint64_t* weights, uint32_t P, int world, uint32_t* first)
@@ -248,6 +322,17 @@ int gkc_comm_create_transport(gkc_ctx* c, const gkc_transport* t, int world, int
     (*out)->t = *t;
     return GKC_OK;
 }
+int gkc_comm_create_files(gkc_ctx* c, const char* directory, int world, int rank, gkc_comm** out)
+{
+    if (!directory || !*directory) return GKC_ERR_ARG;
+    GKC_TRY(comm_new(c, world, rank, out));
+    FileBox* b = new FileBox();
+    b->dir = directory; b->world = world; b->rank = rank;
+    gkc_comm* m = *out;
+    m->t.user = b; m->t.allgather_host = &FileBox::allgather; m->t.sendrecv_device = &FileBox::sendrecv;
+    m->owned_user = b; m->owned_free = &FileBox::destroy;
+    return GKC_OK;
+}
 void gkc_comm_destroy(gkc_comm* m)
 {
     if (!m) return;
@@ -258,6 +343,7 @@ void gkc_comm_destroy(gkc_comm* m)
     if (m->nccl) (void)ncclCommDestroy(m->nccl);
     m->ag_send.release(); m->ag_recv.release();
     if (m->xstream) (void)hipStreamDestroy(m->xstream);
+    if (m->owned_user && m->owned_free) m->owned_free(m->owned_user);
     delete m;
     gkc_ctx_child_release(c);
 }
@@ -298,9 +384,17 @@ int gkc_exchange(gkc_ctx* c, gkc_comm* m)
     std::vector<size_t> mine;
     for (size_t i = c->n_exchanged_segments; i < c->segments.size(); i++) if (c->segments[i].owned && !c->segments[i].foreign) mine.push_back(i);
     // 1) how many segments does everybody bring (pushes per rank may differ)
-    uint64_t hdr = mine.size();
-    std::vector<uint64_t> Ls(W);
-    GKC_TRY(gkc_comm_allgather_host(m, &hdr, 8, Ls.data()));
+    //    ... and does everybody count with the same model? (ranks that derived their own Configuration / Repartitor from their own share of the reads would
+    //    differ: another partition count makes the tables below mismatch, another table silently splits one k-mer over two owners)
+    const uint64_t hdr[2] = { (uint64_t)mine.size(), c->model_hash };
+    std::vector<uint64_t> hdrs((size_t)2 * W), Ls(W);
+    GKC_TRY(gkc_comm_allgather_host(m, hdr, 16, hdrs.data()));
+    for (int r = 0; r < W; r++) {
+        Ls[r] = hdrs[2 * (size_t)r];
+        if (hdrs[2 * (size_t)r + 1] != c->model_hash)
+            GKC_FAIL(c, GKC_ERR_ARG, "rank %d counts with another model than rank %d (k, minimizer size / type, partitions, passes, repartition table or frequency order differ): "
+                                     "every rank of a communicator must be configured identically", r, me);
+    }
     const uint64_t Lmax = *std::max_element(Ls.begin(), Ls.end());
     if (Lmax == 0) { c->n_exchanged_segments = c->segments.size(); return GKC_OK; }
     // 2) everybody's per-partition record and k-mer counts: [W][Lmax][2][P]
@@ -382,6 +476,90 @@ int gkc_exchange(gkc_ctx* c, gkc_comm* m)
     c->n_exchanged_segments = c->segments.size();
     m->stats.n_exchanges++; m->stats.bytes_sent += sent_bytes; m->stats.bytes_received += recv_recs * rb;
     m->stats.ms_host += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    return GKC_OK;
+}
+
+int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
+{
+    if (!c || !m || m->ctx != c) return GKC_ERR_ARG;
+    const int W = m->world, me = m->rank;
+    if (root < 0 || root >= W) GKC_FAIL(c, GKC_ERR_ARG, "bad root rank %d", root);
+    if (c->stage_b_running || c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_gather_results before the pass has finished (gkc_finish_pass / gkc_finish_pass_wait first)");
+    GKC_HIP(c, hipSetDevice(c->device));
+    if (W == 1) return GKC_OK;
+    if (m->first.size() != (size_t)W + 1) GKC_FAIL(c, GKC_ERR_ARG, "owner ranges unknown: no gkc_exchange happened in this pass");
+    const uint32_t P = c->nb_partitions, pass = c->pass, rb = c->key_words == 1 ? 16 : 32;
+    Dataset* DS = c->datasets.data() + (size_t)pass * P;
+    // 1) what every owner holds: per partition (solid, distinct, k-mers, starts a new contiguous array on its owner)
+    std::vector<uint64_t> tab((size_t)P * 4, 0), all((size_t)W * P * 4);
+    const uint32_t lo = m->first[me], hi = m->first[me + 1];
+    for (uint32_t p = lo; p < hi; p++) {
+        const Dataset& D = DS[p];
+        if (!D.done) GKC_FAIL(c, GKC_ERR_ARG, "partition %u of pass %u has not been counted", p, pass);
+        tab[(size_t)p * 4 + 0] = D.n_solid; tab[(size_t)p * 4 + 1] = D.n_distinct; tab[(size_t)p * 4 + 2] = D.n_kmers;
+        const bool joins = p > lo && DS[p - 1].n_solid && D.n_solid && (const uint8_t*)D.d_counts == (const uint8_t*)DS[p - 1].d_counts + DS[p - 1].n_solid * rb;
+        tab[(size_t)p * 4 + 3] = joins ? 0 : 1;
+    }
+    GKC_TRY(gkc_comm_allgather_host(m, tab.data(), tab.size() * 8, all.data()));
+    // 2) the arrays travel, one message per contiguous array of the owner (a Stage-B batch), into one buffer per owner on the root
+    std::vector<gkc_xfer> sends, recvs;
+    if (me != root) {
+        for (uint32_t p = lo; p < hi; ) {
+            if (!DS[p].n_solid) { p++; continue; }
+            uint32_t q = p + 1; uint64_t n = DS[p].n_solid;
+            while (q < hi && (DS[q].n_solid == 0 || tab[(size_t)q * 4 + 3] == 0)) { n += DS[q].n_solid; q++; }
+            sends.push_back(gkc_xfer{ root, 0, (void*)DS[p].d_counts, n * rb });
+            p = q;
+        }
+    } else {
+        for (int r = 0; r < W; r++) {
+            if (r == root) continue;
+            const uint64_t* T = all.data() + (size_t)r * P * 4;
+            uint64_t total = 0;
+            for (uint32_t p = m->first[r]; p < m->first[r + 1]; p++) total += T[(size_t)p * 4];
+            uint8_t* buf = nullptr;
+            if (total) {
+                buf = (uint8_t*)c->dalloc((size_t)total * rb);
+                if (!buf) return GKC_ERR_NOMEM;
+                c->pass_outputs[pass].push_back(buf);
+            }
+            uint64_t off = 0;
+            for (uint32_t p = m->first[r]; p < m->first[r + 1]; ) {
+                if (!T[(size_t)p * 4]) { Dataset& D = DS[p]; D = Dataset(); D.n_distinct = T[(size_t)p * 4 + 1]; D.n_kmers = T[(size_t)p * 4 + 2]; D.done = true; p++; continue; }
+                uint32_t q = p; uint64_t n = 0;
+                do {
+                    Dataset& D = DS[q]; D = Dataset();
+                    D.n_solid = T[(size_t)q * 4]; D.n_distinct = T[(size_t)q * 4 + 1]; D.n_kmers = T[(size_t)q * 4 + 2]; D.done = true;
+                    D.d_counts = D.n_solid ? buf + (off + n) * rb : nullptr;
+                    n += D.n_solid; q++;
+                } while (q < m->first[r + 1] && (T[(size_t)q * 4] == 0 || T[(size_t)q * 4 + 3] == 0));
+                recvs.push_back(gkc_xfer{ r, 0, buf + off * rb, n * rb });
+                off += n; p = q;
+            }
+        }
+    }
+    GKC_HIP(c, hipStreamSynchronize(c->stream));
+    GKC_TRY(gkc_comm_sendrecv(m, sends, recvs, m->xstream));
+    GKC_HIP(c, hipStreamSynchronize(m->xstream));
+    // 3) the abundance histogram and the statistics of the pass: summed on the root
+    const size_t hn = (size_t)c->histo_max + 1;
+    std::vector<uint64_t> h(hn), hall(hn * W);
+    GKC_HIP(c, hipMemcpy(h.data(), c->histo_of(pass), hn * 8, hipMemcpyDeviceToHost));
+    GKC_TRY(gkc_comm_allgather_host(m, h.data(), hn * 8, hall.data()));
+    std::vector<gkc_stats> sall(W);
+    GKC_TRY(gkc_comm_allgather_host(m, &c->pass_stats[pass], sizeof(gkc_stats), sall.data()));
+    if (me == root) {
+        for (size_t i = 0; i < hn; i++) { uint64_t v = 0; for (int r = 0; r < W; r++) v += hall[(size_t)r * hn + i]; h[i] = v; }
+        GKC_HIP(c, hipMemcpy(c->histo_of(pass), h.data(), hn * 8, hipMemcpyHostToDevice));
+        gkc_stats& S = c->pass_stats[pass];
+        for (int r = 0; r < W; r++) {
+            if (r == root) continue;
+            const gkc_stats& o = sall[r];
+            S.kmers_nb_valid += o.kmers_nb_valid; S.kmers_nb_invalid += o.kmers_nb_invalid; S.kmers_nb_distinct += o.kmers_nb_distinct; S.kmers_nb_solid += o.kmers_nb_solid;
+            S.nb_superkmers += o.nb_superkmers; S.nb_sequences += o.nb_sequences; S.nb_bases += o.nb_bases; S.superkmer_bytes += o.superkmer_bytes;
+            S.oversize_buckets += o.oversize_buckets;
+        }
+    }
     return GKC_OK;
 }
 

@@ -193,6 +193,10 @@ typedef struct gkc_transport {
 int  gkc_comm_unique_id(uint8_t id[GKC_COMM_ID_BYTES]);
 int  gkc_comm_create_rccl(gkc_ctx* ctx, const uint8_t id[GKC_COMM_ID_BYTES], int world, int rank, gkc_comm** out);
 int  gkc_comm_create_transport(gkc_ctx* ctx, const gkc_transport* t, int world, int rank, gkc_comm** out);
+/* A transport that needs nothing but a directory all ranks can see (a mailbox of files: host all-gather = one file per rank, device send/recv = staged
+ * through host memory, one file per message). For ranks RCCL cannot connect — two processes sharing one GPU in the tests (RCCL refuses a duplicate device),
+ * hosts without xGMI — and for launchers that have nothing but a shared file system. Development / test transport: bandwidth is that of the file system. */
+int  gkc_comm_create_files(gkc_ctx* ctx, const char* directory, int world, int rank, gkc_comm** out);
 void gkc_comm_destroy(gkc_comm* comm);
 /* Owner ranges: rank r owns partitions [first[r], first[r+1]); first[0] = 0, first[world] = nb_partitions. By default the first
  * exchange of a pass balances them by the k-mers per partition all ranks report ("balanced by weight"); gkc_comm_set_owners
@@ -221,6 +225,12 @@ typedef struct gkc_comm_stats {
     uint64_t reserved[4];
 } gkc_comm_stats;
 int  gkc_comm_get_stats(gkc_comm* comm, gkc_comm_stats* out);
+/* Collective, after gkc_finish_pass of the current pass on every rank: the Count[] arrays of all partitions are gathered on `root` (each owner sends the arrays of
+ * its partitions, whole Stage-B batches at a time), and so are the abundance histogram and the pass statistics (summed). Afterwards gkc_wait_partition /
+ * gkc_partition_counts* / gkc_histogram / gkc_get_stats on `root` serve EVERY partition of the pass — what a single process would hold — so that one process
+ * writes the one result file the reference's consumers open (CountProcessorDump.hpp:85-95: all nb_partitions x nb_passes datasets live in one file;
+ * GraphUnitigs.cpp:921-931 opens that file). The other ranks keep what they had. The results must fit root's HBM (solid k-mers only travel). */
+int  gkc_gather_results(gkc_ctx* ctx, gkc_comm* comm, int root);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bloom filter of solid k-mers — replaces BloomBuilder::build / IBloom::insert (kmer/impl/BloomBuilder.hpp:102-128,

@@ -8,7 +8,8 @@
 #    PartitionsCommand) for spans 32 and 64 with -DGATB_WITH_DEVICE_COUNTING, plus explicit instantiations of PartitionsByDeviceCommand and
 #    of BloomDevice<LargeInt<1>>, <LargeInt<2>>;
 # 4. --link: compiles those units for the four spans and links a patched dbgh5 against libgatbcore.a, libhdf5.a and libgkc_hip.so
-#    (link only: running it needs a GPU).
+#    (link only: running it needs a GPU) -> integration/_build/dbgh5_device. Without a built reference in the given directory,
+#    integration/build_reference.sh builds it first (the reference's own cmake, ~10 minutes).
 # This is a compile check in the build container, not an oracle: nothing it produces is used by the tests of the hot path.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd); REPO=$(dirname "$HERE")
@@ -48,7 +49,8 @@ for f in ts2_32 ts2_64 bloom_device; do grep -E "error" "$SCRATCH/obj/$f.log" | 
 [ $rc -eq 0 ] || { echo "[check_integration] SYNTAX CHECK FAILED"; exit 1; }
 echo "[check_integration] syntax ok"
 if [ $LINK -eq 1 ]; then
-  test -f "$LIBDIR/lib/Release/libgatbcore.a" || { echo "no libgatbcore.a under $LIBDIR (build the reference with its own cmake first)"; exit 5; }
+  # no built reference yet: integration/build_reference.sh builds it with the reference's own cmake (~10 minutes), so the chain is reproducible from this repository
+  test -f "$LIBDIR/lib/Release/libgatbcore.a" || bash "$HERE/build_reference.sh" "$LIBDIR" || { echo "no libgatbcore.a under $LIBDIR and the reference build failed"; exit 5; }
   test -f "$REPO/gatb-core_amd/csrc/libgkc_hip.so" || { echo "libgkc_hip.so missing"; exit 6; }
   echo "[check_integration] compiling the patched instantiation units (4 spans) and dbgh5"
   pids=""
@@ -61,5 +63,6 @@ if [ $LINK -eq 1 ]; then
       -ldl -lpthread -lz -lm > "$SCRATCH/obj/link.log" 2>&1 || { head -30 "$SCRATCH/obj/link.log"; echo "[check_integration] LINK FAILED"; exit 1; }
   nm -C "$SCRATCH/dbgh5_device" | grep -c "PartitionsByDeviceCommand" | sed 's/^/[check_integration] PartitionsByDeviceCommand symbols in the patched dbgh5: /'
   nm -D "$SCRATCH/dbgh5_device" | grep -E " U gkc_" | sed 's/^/[check_integration] imports /'
-  echo "[check_integration] link ok: $SCRATCH/dbgh5_device"
+  mkdir -p "$HERE/_build" && cp -f "$SCRATCH/dbgh5_device" "$HERE/_build/dbgh5_device"      # git-ignored; travels to the GPU box with gpurun (tools/run_patched_dbgh5.py, tests/test_gpu_dropin.py)
+  echo "[check_integration] link ok: $SCRATCH/dbgh5_device (copied to integration/_build/)"
 fi

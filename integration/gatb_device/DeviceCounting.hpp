@@ -2,13 +2,15 @@
  * src/gatb/kmer/impl/ so that SortingCountAlgorithm<span> counts on an MI355X. Compiled against the reference's own headers by
  * integration/check_integration.sh (it is NOT part of libgkc_hip.so and includes nothing of this repository but include/gkc.h).
  *
- *   DeviceSession               one gkc_ctx per process (one GPU per process), configured from the reference's Configuration + Repartitor
+ *   DeviceSession               one gkc_ctx per process (one GPU per process), configured from the reference's Configuration + Repartitor;
+ *                               optionally one rank of a communicator (environment, see enableMultiGpuFromEnvironment)
  *   FillPartitionsDevice<span>  the functor fillPartitions() iterates the bank with (SortingCountAlgorithm.cpp:1081-1151 FillPartitions,
- *                               dispatched at :1266-1275): packs sequences into a flat ASCII buffer + CSR offsets and hands them to
- *                               gkc_push_reads (Stage A on the device) instead of cutting super-k-mers on the CPU
+ *                               dispatched at :1266-1275): every worker thread packs its sequences into its OWN flat ASCII buffer + CSR offsets
+ *                               (no lock per sequence) and hands a full buffer to gkc_push_reads (Stage A on the device)
  *   PartitionsByDeviceCommand   the ICommand fillSolidKmers_aux() dispatches per partition (SortingCountAlgorithm.cpp:1456-1587), beside
  *                               PartitionsByVectorCommand / PartitionsByHashCommand (PartitionsCommand.hpp:100-160): waits for the device's
- *                               Count[] of its partition and feeds the CountProcessor clone in ascending k-mer order
+ *                               Count[] of its partition and hands it to the count processor — as ONE block when the processor is the default
+ *                               chain (histogram -> solidity -> dump, SortingCountAlgorithm.cpp:376-400), record by record otherwise
  */
 #ifndef _GATB_CORE_KMER_IMPL_DEVICE_COUNTING_HPP_
 #define _GATB_CORE_KMER_IMPL_DEVICE_COUNTING_HPP_
@@ -17,6 +19,7 @@
 #include <gatb/kmer/impl/PartiInfo.hpp>
 #include <gatb/kmer/impl/BankKmers.hpp>
 #include <gatb/kmer/impl/Configuration.hpp>
+#include <gatb/kmer/impl/CountProcessor.hpp>
 #include <gatb/bank/api/Sequence.hpp>
 #include <gatb/system/api/Exception.hpp>
 #include <gatb/system/impl/System.hpp>
@@ -33,6 +36,17 @@
 namespace gatb { namespace core { namespace kmer { namespace impl {
 
 /********************************************************************************/
+/** How the Count records of a partition reach the count processor. */
+struct DeviceBulkPlan
+{
+    bool     on;           /**< the processor is the default chain with ONE abundance range: the device applies the solidity window and the histogram,
+                                the dump takes each partition's records as one block (BagHDF5Patch::insert(const Item*, size_t), CollectionHDF5Patch.hpp:262-308) */
+    int32_t  abundanceMin, abundanceMax;
+    uint32_t histoMax;
+    DeviceBulkPlan () : on(false), abundanceMin(1), abundanceMax(2147483647), histoMax(10000) {}
+};
+
+/********************************************************************************/
 /** One device context per process. */
 class DeviceSession
 {
@@ -42,36 +56,54 @@ public:
     gkc_ctx* ctx ()  {  open();  return _ctx;  }
 
     /** Configuration + Repartitor of the run -> gkc_configure (replaces `Model model(...)`, SortingCountAlgorithm.cpp:1251-1256, and
-     *  Repartitor::operator(), PartiInfo.hpp:323). The solidity window stays open: the reference's processor chain filters. */
-    void configure (const Configuration& config, Repartitor& repartitor)
+     *  Repartitor::operator(), PartiInfo.hpp:323). Without a bulk plan the solidity window stays open and the reference's processor chain filters. */
+    void configure (const Configuration& config, Repartitor& repartitor, const DeviceBulkPlan& plan, size_t pass)
     {
         open();
+        if (pass > 0)  { return; }                                   /* one configuration per run: the passes share the datasets and the histogram */
         enableMultiGpuFromEnvironment();
+        _plan = plan;  _nbPartitions = config._nb_partitions;
         const u_int64_t nbMinims = (u_int64_t)1 << (2 * config._minim_size);
         std::vector<uint16_t> table (nbMinims);
         for (u_int64_t m = 0; m < nbMinims; m++)  { table[m] = (uint16_t) repartitor (m); }
-        check (gkc_set_solidity (_ctx, 1, 2147483647, 10000));      /* the histogram is the CountProcessorHistogram's job */
+        if (plan.on)  { check (gkc_set_solidity (_ctx, plan.abundanceMin, plan.abundanceMax, plan.histoMax)); }
+        else          { check (gkc_set_solidity (_ctx, 1, 2147483647, 10000)); }      /* the histogram and the filter are the chain's job */
         check (gkc_configure (_ctx, (uint32_t) config._kmerSize, (uint32_t) config._minim_size, (uint32_t) config._nb_partitions, (uint32_t) config._nb_passes,
                               config._minimizerType == 1 ? GKC_MINIMIZER_FREQ : GKC_MINIMIZER_LEXI, table.data(),
                               config._minimizerType == 1 ? repartitor.getMinimizerFrequencies() : 0));
+        /* multi-rank: a fixed number of exchanges per pass, the same on every rank (derived from the bank estimate every rank computes from the same bank),
+         * so that the i-th gkc_exchange of one rank always meets the i-th of the others whatever the threads' timing */
+        _nbExchanges = 1;
+        if (_comm != 0)  { _nbExchanges = (uint32_t) std::max<u_int64_t> (1, std::min<u_int64_t> (64, config._estimateSeqNb / 4000000)); }
+        _readsPerExchange = std::max<u_int64_t> (1, config._estimateSeqNb / (u_int64_t)_ranks / _nbExchanges);
     }
+
+    const DeviceBulkPlan& plan () const  { return _plan; }
+    size_t nbPartitions () const  { return _nbPartitions; }
 
     void check (int rc)
     {
         if (rc != GKC_OK)  { throw system::Exception ("device counting: error %d: %s", rc, gkc_last_error(_ctx)); }
     }
 
-    /** Multi-GPU (one process per GPU): GATB_DEVICE_RANKS / GATB_DEVICE_RANK / GATB_DEVICE_COMM_ID (a file: rank 0 writes the 128-byte
-     *  ncclUniqueId, the other ranks wait for it) in the environment of each process turn the session into one rank of an RCCL communicator. Each
-     *  process reads ITS share of the reads; after every block pushed to Stage A the super-k-mers are routed to the rank owning their partition
-     *  (gkc_exchange), and each process counts — and writes into its own .h5 — the partitions it owns (the other datasets stay empty). */
+    /** Multi-GPU (one process per GPU). In the environment of each process:
+     *      GATB_DEVICE_RANKS, GATB_DEVICE_RANK          world size and rank
+     *      GATB_DEVICE_COMM_ID = <file>                 RCCL over xGMI: rank 0 writes the 128-byte ncclUniqueId there, the others wait for it
+     *   or GATB_DEVICE_TRANSPORT_DIR = <directory>      the library's file-mailbox transport (ranks RCCL cannot connect: two processes on one GPU, no xGMI)
+     *  Every process opens the SAME bank with the same options (so that Configuration and Repartitor are the same everywhere: gkc_exchange checks it) and
+     *  counts the sequences whose index is its rank modulo the world size; after every few million reads the super-k-mers are routed to the rank owning
+     *  their partition (gkc_exchange, overlapping the scan of the next reads); at the end of the pass the Count[] of all partitions, the histogram and the
+     *  statistics are gathered on rank 0 (gkc_gather_results), whose .h5 is THE result: every dataset of the single-process file, in one file. */
     void enableMultiGpuFromEnvironment ()
     {
-        const char* ranks = getenv ("GATB_DEVICE_RANKS");  const char* rank = getenv ("GATB_DEVICE_RANK");  const char* idFile = getenv ("GATB_DEVICE_COMM_ID");
-        if (_comm != 0  ||  ranks == 0  ||  rank == 0  ||  idFile == 0  ||  atoi(ranks) < 2)  { return; }
+        const char* ranks = getenv ("GATB_DEVICE_RANKS");  const char* rank = getenv ("GATB_DEVICE_RANK");
+        const char* idFile = getenv ("GATB_DEVICE_COMM_ID");  const char* boxDir = getenv ("GATB_DEVICE_TRANSPORT_DIR");
+        if (_comm != 0  ||  ranks == 0  ||  rank == 0  ||  (idFile == 0 && boxDir == 0)  ||  atoi(ranks) < 2)  { return; }
         open();
+        _ranks = atoi(ranks);  _rank = atoi(rank);
+        if (boxDir != 0)  { check (gkc_comm_create_files (_ctx, boxDir, _ranks, _rank, &_comm));  return; }
         uint8_t id [GKC_COMM_ID_BYTES];
-        if (atoi(rank) == 0)
+        if (_rank == 0)
         {
             check (gkc_comm_unique_id (id));
             std::string tmp = std::string(idFile) + ".tmp";
@@ -85,66 +117,108 @@ public:
             if (f == 0  ||  fread (id, 1, sizeof(id), f) != sizeof(id))  { throw system::Exception ("device counting: no communicator id in %s", idFile); }
             fclose (f);
         }
-        check (gkc_comm_create_rccl (_ctx, id, atoi(ranks), atoi(rank), &_comm));
+        check (gkc_comm_create_rccl (_ctx, id, _ranks, _rank, &_comm));
     }
-    gkc_comm* comm ()  { return _comm; }
-    /** collective, ONCE per pass on every rank, after the rank's last push: every block pushed so far goes to the owners of its partitions */
-    void exchange ()  { if (_comm != 0) { check (gkc_exchange (_ctx, _comm)); } }
+    gkc_comm* comm  ()  { return _comm; }
+    int       ranks () const { return _ranks; }
+    int       rank  () const { return _rank;  }
+
+    void beginPass (size_t pass)  { check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0; }
+
+    /** one block of reads to Stage A (the caller holds the packers' lock: one thread drives the context at a time); multi-rank: the exchanges that are due */
+    void push (const char* bases, const uint64_t* offsets, uint64_t nbReads)
+    {
+        check (gkc_push_reads (_ctx, bases, offsets, nbReads));
+        _pushedReads += nbReads;
+        while (_comm != 0  &&  _exchangesDone + 1 < _nbExchanges  &&  _pushedReads >= (u_int64_t)(_exchangesDone + 1) * _readsPerExchange)
+        {
+            check (gkc_exchange (_ctx, _comm));  _exchangesDone++;
+        }
+    }
+    /** after the last read of the pass: the remaining exchanges (every rank makes exactly _nbExchanges of them) */
+    void endOfReads ()
+    {
+        while (_comm != 0  &&  _exchangesDone < _nbExchanges)  { check (gkc_exchange (_ctx, _comm));  _exchangesDone++; }
+    }
+    /** Stage B. One rank: started in the background, the partition commands wait for their partition. Several ranks: counted, then gathered on rank 0. */
+    void finishPass ()
+    {
+        if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  return; }
+        check (gkc_finish_pass (_ctx));
+        check (gkc_gather_results (_ctx, _comm, 0));
+    }
+    void joinPass ()  { if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); } }
 
     ~DeviceSession ()  { if (_comm) { gkc_comm_destroy (_comm); }  if (_ctx) { gkc_destroy (_ctx); } }
 
 private:
-    DeviceSession () : _ctx(0), _comm(0) {}
+    DeviceSession () : _ctx(0), _comm(0), _ranks(1), _rank(0), _nbExchanges(1), _exchangesDone(0), _readsPerExchange(1), _pushedReads(0), _nbPartitions(0) {}
     void open ()
     {
         if (_ctx == 0  &&  gkc_create (0, &_ctx) != GKC_OK)  { throw system::Exception ("device counting: %s", gkc_last_error(0)); }
     }
-    gkc_ctx* _ctx;
+    gkc_ctx*  _ctx;
     gkc_comm* _comm;
+    int       _ranks, _rank;
+    uint32_t  _nbExchanges, _exchangesDone;
+    u_int64_t _readsPerExchange, _pushedReads;
+    DeviceBulkPlan _plan;
+    size_t    _nbPartitions;
 };
 
 /********************************************************************************/
-/** Functor for Dispatcher::iterate over the sequences of the bank (one instance per thread, copies share the packer). */
+/** Functor for Dispatcher::iterate over the sequences of the bank: one COPY per worker thread (ICommand.hpp:291-335 news a copy per thread and deletes it
+ *  when the thread is done), each with its own packing buffers; only a full buffer takes the lock (gkc_push_reads: one thread drives the context at a time). */
 template<size_t span>
 class FillPartitionsDevice
 {
 public:
-    struct Packer
+    struct Shared
     {
-        std::vector<char> bases;  std::vector<uint64_t> offsets;  std::mutex lock;
-        BankStats stats;
-        Packer ()  { offsets.push_back (0); }
-        /** hands what has been packed to Stage A; called with the lock held, or at the end */
-        void flush ()
-        {
-            if (offsets.size() > 1)
-            {
-                DeviceSession::singleton().check (gkc_push_reads (DeviceSession::singleton().ctx(), bases.data(), offsets.data(), offsets.size()-1));
-                bases.clear();  offsets.assign (1, 0);
-            }
-
-        }
+        std::mutex  lock;
+        BankStats   stats;
+        std::string error;          /**< first failure of a push (a destructor must not throw) */
     };
+    enum { BLOCK_BYTES = 1 << 26 };
 
-    FillPartitionsDevice (Packer& packer, gatb::core::tools::dp::IteratorListener* progress, size_t kmerSize)
-        : _packer(packer), _progress(progress), _kmerSize(kmerSize), _nbWritten(0)  {}
+    FillPartitionsDevice (Shared& shared, gatb::core::tools::dp::IteratorListener* progress, size_t kmerSize)
+        : _shared(shared), _progress(progress), _kmerSize(kmerSize), _nbWritten(0),
+          _ranks (DeviceSession::singleton().ranks()), _rank (DeviceSession::singleton().rank())  { _offsets.push_back (0); }
+
+    FillPartitionsDevice (const FillPartitionsDevice& o)
+        : _shared(o._shared), _progress(o._progress), _kmerSize(o._kmerSize), _nbWritten(0), _ranks(o._ranks), _rank(o._rank)  { _offsets.push_back (0); }
+
+    ~FillPartitionsDevice ()  { flush(); }
 
     void operator() (bank::Sequence& sequence)
     {
+        if (_ranks > 1  &&  (int)(sequence.getIndex() % (size_t)_ranks) != _rank)  { return; }      /* another rank's read */
         const size_t len = sequence.getDataSize();
-        std::lock_guard<std::mutex> guard (_packer.lock);
-        _packer.stats.update (sequence);
-        _packer.bases.insert (_packer.bases.end(), sequence.getDataBuffer(), sequence.getDataBuffer() + len);
-        _packer.offsets.push_back (_packer.bases.size());
-        if (_packer.bases.size() >= ((size_t)1 << 28))  { _packer.flush(); }
+        _stats.update (sequence);
+        _bases.insert (_bases.end(), sequence.getDataBuffer(), sequence.getDataBuffer() + len);
+        _offsets.push_back (_bases.size());
+        if (_bases.size() >= (size_t)BLOCK_BYTES)  { flush(); }
         if (_nbWritten++ > 500000)  { _progress->inc (_nbWritten);  _nbWritten = 0; }
     }
 
 private:
-    Packer& _packer;
+    /** hands what this thread has packed to Stage A */
+    void flush ()
+    {
+        if (_offsets.size() <= 1)  { return; }
+        std::lock_guard<std::mutex> guard (_shared.lock);
+        _shared.stats += _stats;  _stats = BankStats();
+        try  {  if (_shared.error.empty())  { DeviceSession::singleton().push (_bases.data(), _offsets.data(), _offsets.size()-1); }  }
+        catch (system::Exception& e)  { _shared.error = e.getMessage(); }
+        _bases.clear();  _offsets.assign (1, 0);
+    }
+
+    Shared& _shared;
     gatb::core::tools::dp::IteratorListener* _progress;
     size_t _kmerSize;
     size_t _nbWritten;
+    int    _ranks, _rank;
+    std::vector<char> _bases;  std::vector<uint64_t> _offsets;  BankStats _stats;
 };
 
 /********************************************************************************/
@@ -174,6 +248,41 @@ public:
 
     const char* getName() const { return "device"; }
 
+    /** The default chain (SortingCountAlgorithm.cpp:376-400) with one abundance range (one bank, sum solidity, no auto cut-off) is what the device itself
+     *  computes — histogram of every distinct k-mer, solidity window, ascending Count records — so the per-k-mer virtual process() calls
+     *  (CountProcessorChain.hpp:128-135 -> CountProcessorDump.hpp:148-152 -> BagCache) can be replaced by one block insert per partition. */
+    static DeviceBulkPlan bulkPlan (CountProcessor* processor, size_t nbProcessors, const Configuration& config)
+    {
+        DeviceBulkPlan plan;
+        if (processor == 0  ||  nbProcessors != 1  ||  config._abundance.size() != 1  ||  config._abundance[0].getBegin() < 1  ||  getenv ("GATB_DEVICE_NO_BULK") != 0)  { return plan; }
+        std::vector<CountProcessor*> items = processor->getInstances();
+        if (items.size() != 3)  { return plan; }
+        CountProcessorHistogram<span>*   histo = dynamic_cast<CountProcessorHistogram<span>*>   (items[0]);
+        CountProcessorSoliditySum<span>* solid = dynamic_cast<CountProcessorSoliditySum<span>*> (items[1]);
+        CountProcessorDump<span>*        dump  = dynamic_cast<CountProcessorDump<span>*>        (items[2]);
+        if (histo == 0  ||  solid == 0  ||  dump == 0  ||  histo->getHistogram() == 0)  { return plan; }
+        plan.on = true;
+        plan.abundanceMin = (int32_t) config._abundance[0].getBegin();
+        plan.abundanceMax = (int32_t) config._abundance[0].getEnd();
+        plan.histoMax     = (uint32_t) histo->getHistogram()->getLength();
+        return plan;
+    }
+
+    /** bulk mode, main thread, after the last pass: the device's abundance histogram into the prototype's (what the clones' HistogramCache instances
+     *  would have merged, Histogram.hpp:221-238: bins 1 .. length-1) */
+    static void mergeDeviceHistogram (CountProcessor* processor)
+    {
+        DeviceSession& dev = DeviceSession::singleton();
+        if (!dev.plan().on)  { return; }
+        std::vector<CountProcessor*> items = processor->getInstances();
+        CountProcessorHistogram<span>* histo = items.empty() ? 0 : dynamic_cast<CountProcessorHistogram<span>*> (items[0]);
+        if (histo == 0)  { return; }
+        tools::misc::IHistogram* h = histo->getHistogram();
+        std::vector<uint64_t> dh (dev.plan().histoMax + 1);
+        dev.check (gkc_histogram (dev.ctx(), dh.data(), (uint32_t) dh.size()));
+        for (size_t cc = 1; cc < h->getLength(); cc++)  { h->get (cc) += dh[cc]; }
+    }
+
     void execute ()
     {
         DeviceSession& dev = DeviceSession::singleton();
@@ -196,15 +305,39 @@ public:
             recs = fetched.data();
         }
 
-        CounterBuilder solidCounter;
-        for (uint64_t i = 0; i < nbSolid; i++)
+        CountProcessorDump<span>* dump = 0;
+        if (dev.plan().on)
         {
-            const unsigned char* r = recs + i * recBytes;
-            Type kmer;
-            if (recBytes == 16)  {  kmer.setVal (*(const u_int64_t*) r);  }
-            else                 {  setWide (kmer, ((const u_int64_t*) r)[0], ((const u_int64_t*) r)[1]);  }
-            solidCounter.set (*(const int32_t*) (r + (recBytes == 16 ? 8 : 16)));
-            this->insert (kmer, solidCounter);
+            std::vector<CountProcessor*> items = this->_processor->getInstances();
+            if (items.size() == 3)  { dump = dynamic_cast<CountProcessorDump<span>*> (items[2]); }
+        }
+
+        if (dump != 0  &&  dump->getSolidCounts() != 0)
+        {
+            /* one block per partition straight into the partition's collection (for HDF5 storage: one H5Dwrite, synchronized inside) */
+            const size_t actualPartId = this->_parti_num + this->_pass_num * dev.nbPartitions();      /* CountProcessorDump.hpp:131 */
+            tools::collections::Collection<Count>& coll = (*dump->getSolidCounts()) [actualPartId];
+            if (nbSolid > 0)
+            {
+                if (sizeof(Count) == recBytes)  { coll.insert ((const Count*) recs, (size_t) nbSolid); }     /* the device layout IS Abundance<Type,int32> (Abundance.hpp:68-129) */
+                else
+                {
+                    std::vector<Count> block (nbSolid);
+                    for (uint64_t i = 0; i < nbSolid; i++)  { decode (recs + i * recBytes, recBytes, block[i].value, block[i].abundance); }
+                    coll.insert (block.data(), block.size());
+                }
+            }
+        }
+        else
+        {
+            CounterBuilder solidCounter;
+            for (uint64_t i = 0; i < nbSolid; i++)
+            {
+                Type kmer;  CountNumber ab;
+                decode (recs + i * recBytes, recBytes, kmer, ab);
+                solidCounter.set (ab);
+                this->insert (kmer, solidCounter);
+            }
         }
 
         this->_progress->inc (this->_pInfo.getNbKmer (this->_parti_num));
@@ -212,6 +345,13 @@ public:
     }
 
 private:
+    static void decode (const unsigned char* r, size_t recBytes, Type& kmer, CountNumber& abundance)
+    {
+        if (recBytes == 16)  {  kmer.setVal (*(const u_int64_t*) r);  }
+        else                 {  setWide (kmer, ((const u_int64_t*) r)[0], ((const u_int64_t*) r)[1]);  }
+        abundance = *(const int32_t*) (r + (recBytes == 16 ? 8 : 16));
+    }
+
     /* 128-bit value into a Type of 2+ words (LargeInt<2..4>); spans of one word never get here (k <= 31) */
     template<typename T> static void setWide (T& kmer, u_int64_t lo, u_int64_t hi)
     {

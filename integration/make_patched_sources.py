@@ -23,21 +23,23 @@ HUNKS = [
 FILL_BEGIN = "\t\t\tgetDispatcher()->iterate(\n\t\t\t\titSeq,\n\t\t\t\tFillPartitions<span, true>("
 FILL_END = "\t\t\t\tgroupSize, deleteSynchro);\n\n\t\t\t// GR: close the input bank here with call to finalize\n\t\t\titSeq->finalize();\n"
 FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
-\t\t\t/** Stage A on the device: the sequences are packed and pushed (gkc_push_reads); Stage B starts right away (gkc_finish_pass_async)
-\t\t\t *  and the PartitionsByDeviceCommand instances of fillSolidKmers wait for their partition. */
+\t\t\t/** Stage A on the device: every worker thread packs its sequences and pushes full blocks (gkc_push_reads); Stage B starts right away
+\t\t\t *  (gkc_finish_pass_async) and the PartitionsByDeviceCommand instances of fillSolidKmers wait for their partition. Several ranks
+\t\t\t *  (GATB_DEVICE_RANKS ...): the super-k-mers are routed to the rank owning their partition as the reads go by, and the results are
+\t\t\t *  gathered on rank 0. */
 \t\t\tDeviceSession& device = DeviceSession::singleton();
-\t\t\tdevice.configure (_config, *_repartitor);
-\t\t\tdevice.check (gkc_begin_pass (device.ctx(), pass));
-\t\t\ttypename FillPartitionsDevice<span>::Packer packer;
-\t\t\tgetDispatcher()->iterate (itSeq, FillPartitionsDevice<span> (packer, _progress, _config._kmerSize), groupSize, deleteSynchro);
-\t\t\tpacker.flush();
-\t\t\tdevice.exchange();          /* multi-GPU (GATB_DEVICE_RANKS ...): the super-k-mers go to the rank owning their partition */
+\t\t\tdevice.configure (_config, *_repartitor, PartitionsByDeviceCommand<span>::bulkPlan (_processors.empty() ? 0 : _processors[0], _processors.size(), _config), pass);
+\t\t\tdevice.beginPass (pass);
+\t\t\ttypename FillPartitionsDevice<span>::Shared packed;
+\t\t\tgetDispatcher()->iterate (itSeq, FillPartitionsDevice<span> (packed, _progress, _config._kmerSize), groupSize, deleteSynchro);
+\t\t\tif (!packed.error.empty())  { throw system::Exception ("%s", packed.error.c_str()); }
+\t\t\tdevice.endOfReads();        /* multi-rank: the exchanges that are still due */
 \t\t\titSeq->finalize();
 \t\t\tif (pass == 0)
 \t\t\t{
 \t\t\t\tgkc_stats st;  device.check (gkc_get_stats (device.ctx(), &st));
-\t\t\t\tpacker.stats.kmersNbValid = st.kmers_nb_valid;  packer.stats.kmersNbInvalid = st.kmers_nb_invalid;
-\t\t\t\t_bankStats += packer.stats;
+\t\t\t\tpacked.stats.kmersNbValid = st.kmers_nb_valid;  packed.stats.kmersNbInvalid = st.kmers_nb_invalid;
+\t\t\t\t_bankStats += packed.stats;
 \t\t\t}
 \t\t\t/* per-partition sizes for fillSolidKmers (progress, getNbCoresList) */
 \t\t\t{
@@ -49,7 +51,7 @@ FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 \t\t\t\t\tfor (size_t p=0; p<_config._nb_partitions; p++)  { pInfo.incKmer (p, nbKmers[p]);  pInfo.incKxmer (p, recOff[p+1]-recOff[p]); }
 \t\t\t\t}
 \t\t\t}
-\t\t\tdevice.check (gkc_finish_pass_async (device.ctx()));
+\t\t\tdevice.finishPass();
 #else
 """
 
@@ -68,7 +70,8 @@ CMD_END = "            cmds.push_back (cmd);\n"
 # end of fillSolidKmers_aux (SortingCountAlgorithm.cpp:1596-1600): join Stage B
 TAIL = "\tif(_config._solidityKind == KMER_SOLIDITY_SUM)\n\t\t_superKstorage->closeFiles();\n"
 TAIL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
-\tDeviceSession::singleton().check (gkc_finish_pass_wait (DeviceSession::singleton().ctx()));
+\tDeviceSession::singleton().joinPass();
+\tif (pass + 1 == _config._nb_passes)  { PartitionsByDeviceCommand<span>::mergeDeviceHistogram (processor); }      /* bulk mode: the device counted the histogram */
 #endif
 """
 

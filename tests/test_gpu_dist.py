@@ -101,3 +101,74 @@ def test_two_ranks_one_gpu_end_to_end(k, parts, amin):
         assert np.array_equal(r[5], bl.array()), "OR-reduced Bloom filter differs from the single-GPU filter"
         assert r[9] == mp1.size and np.array_equal(r[6], mp1.save()), "multi-rank MPHF stream differs from gkc_mphf_save of the single-GPU run"
         assert np.array_equal(r[7], amap1) and r[8] == above1
+
+
+def _files_rank_main(rank, world, box, k, parts, amin, q, bad_model):
+    """one rank of a communicator over the library's file-mailbox transport (gkc_comm_create_files): no torch.distributed, nothing shared but a directory"""
+    try:
+        pkg = ge.load(); gkc = pkg.gkc
+        m = 8
+        reads = synth_reads(2600, 14000, 150, seed=43, n_rate=0.001, ragged=True)
+        rep = simple_repart(m, parts)
+        if bad_model and rank == 1:
+            rep = rep[::-1].copy()                                    # another repartition table on this rank
+        mine = reads[rank::world]                                     # the bank shared out read by read
+        c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
+        comm = gkc.Comm.files(c, box, world, rank)
+        c.begin_pass(0)
+        half = len(mine) // 2
+        for ch in (mine[:half], mine[half:]):
+            b, o = gko.pack_reads(ch); c.push_reads(b, o)
+            try:
+                c.exchange(comm)
+            except gkc.GkcError as e:
+                q.put((rank, "error", str(e))); return
+        c.finish_pass()
+        own_hist = c.histogram().copy()
+        comm.gather_results(0)
+        got = {p: c.partition(0, p) for p in range(parts)} if rank == 0 else None
+        q.put((rank, "ok", got, c.histogram(), c.stats(), own_hist))
+        comm.close()
+    except Exception as e:      # noqa
+        import traceback
+        q.put((rank, "exception", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("k,parts,amin", [(31, 9, 2), (41, 6, 1)])
+def test_results_gathered_on_one_rank_over_the_file_transport(tmp_path, k, parts, amin):
+    """gkc_gather_results: after the exchange and Stage B on two ranks (two processes on the one GPU, the library's own file-mailbox transport), rank 0 holds EVERY
+    partition's Count[] (== oracle over all reads), the summed histogram and the summed statistics: what one process would hold, i.e. what one .h5 needs
+    (CountProcessorDump.hpp:85-95 creates all datasets in one file; GraphUnitigs.cpp:921-931 opens that file)"""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    procs = [ctx.Process(target=_files_rank_main, args=(r, world, str(tmp_path), k, parts, amin, q, False)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(r[1] == "ok" for r in res), res
+    m = 8
+    reads = synth_reads(2600, 14000, 150, seed=43, n_rate=0.001, ragged=True)
+    bases, offs = gko.pack_reads(reads)
+    ref = gko.Dsk(bases, offs, k, m, parts, simple_repart(m, parts))
+    got = res[0][2]
+    for p in range(parts):
+        rlo, rhi, rab = ref.part(p); keep = rab >= amin
+        lo, hi, ab = got[p]
+        assert np.array_equal(lo, rlo[keep]) and np.array_equal(hi, rhi[keep]) and np.array_equal(ab, rab[keep]), "gathered partition %d differs from the oracle" % p
+    assert np.array_equal(res[0][3], ref.histogram())                                   # rank 0: the histogram of the whole run
+    assert np.array_equal(res[0][5] + res[1][5], ref.histogram()) and res[1][5].sum() > 0   # ... the sum of the two ranks' own
+    assert res[0][4]["kmers_nb_valid"] == ref.stats["kmers_nb_valid"] and res[0][4]["kmers_nb_distinct"] == ref.stats["kmers_nb_distinct"]
+
+
+def test_ranks_with_different_models_are_refused(tmp_path):
+    """ranks that hold different repartition tables must not exchange (one k-mer would be split over two owners): gkc_exchange compares a fingerprint
+    of the model and fails on every rank"""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    procs = [ctx.Process(target=_files_rank_main, args=(r, world, str(tmp_path), 31, 8, 1, q, True)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(r[1] == "error" and "another model" in r[2] for r in res), res

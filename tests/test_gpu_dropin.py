@@ -1,0 +1,86 @@
+"""The drop-in end to end on the GPU box: the reference's OWN dbgh5 (main(), Configuration, Repartitor, processor chain, HDF5 storage), patched with
+integration/SortingCountAlgorithm.device.patch + integration/gatb_device/DeviceCounting.hpp and linked against libgkc_hip.so
+(integration/check_integration.sh --link -> integration/_build/dbgh5_device, a build-container artefact that travels with the repository snapshot), must write
+.h5 files whose datasets are exactly what the UNPATCHED reference wrote for the same input (tests/golden/reference_run/*.npz): every /dsk/solid/<p> in order,
+the histogram, the repartition table. Three ways through the binding:
+  * bulk        the default chain: solidity window + histogram on the device, one block insert per partition (BagHDF5Patch::insert(const Item*, size_t));
+  * per record  GATB_DEVICE_NO_BULK=1: every record through the chain's virtual process();
+  * two ranks   two processes on the one GPU (the library's file-mailbox transport), reads shared out by index, super-k-mers exchanged, results gathered on
+                rank 0: ONE .h5 with every dataset of the single-process file (CountProcessorDump.hpp:85-95, GraphUnitigs.cpp:921-931).
+The files are read back with the reference's own gatb-h5dump (integration/_build/ref, built by integration/build_reference.sh). Skipped where the artefacts are absent."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.test_reference_run import load
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "integration", "_build", "dbgh5_device")
+H5DUMP = os.path.join(ROOT, "integration", "_build", "ref", "gatb-h5dump")
+needs_artefacts = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(H5DUMP)),
+                                     reason="integration/_build/dbgh5_device or ref/gatb-h5dump absent (built in the build container: integration/check_integration.sh --link)")
+
+CASES = {"k21_freq_4parts": (["-minimizer-type", "1", "-repartition-type", "1"], "1", "1"),
+         "k21_default_parts": ([], "1", "1"),
+         "k31_2parts_mphf": ([], "2000", "2")}
+
+
+def dump_dataset(h5, path, mode):
+    with tempfile.NamedTemporaryFile() as t:
+        subprocess.run([H5DUMP, "-d", path, "-b", mode, "-o", t.name, h5], capture_output=True)
+        return np.fromfile(t.name, dtype=np.uint8)
+
+
+def check_h5(h5, tag):
+    z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    rec = 12 if k <= 31 else 20
+    assert np.array_equal(dump_dataset(h5, "/minimizers/minimRepart", "LE"), z["minimRepart"]), "minimRepart differs"
+    for p in range(nbpart):
+        raw = dump_dataset(h5, "/dsk/solid/%d" % p, "FILE")
+        n = len(raw) // rec; raw = raw[:n * rec].reshape(n, rec)
+        vals = [int.from_bytes(bytes(r), "little") for r in raw[:, :rec - 4]]
+        ab = raw[:, rec - 4:].copy().view("<u4")[:, 0].tolist()
+        assert list(zip(vals, ab)) == parts[p], "/dsk/solid/%d differs from the unpatched reference's" % p
+    hist = dump_dataset(h5, "/histogram/histogram", "FILE"); hist = hist[:len(hist) // 12 * 12].reshape(-1, 12)
+    assert np.array_equal(hist[:, 4:].copy().view("<u8")[:, 0], z["histogram_abundance"]), "histogram differs"
+
+
+def run_dbgh5(tag, outdir, env_extra=None, out_name=None):
+    z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    extra, mem, cores = CASES[tag]
+    fa = os.path.join(outdir, tag + ".fa")
+    if not os.path.exists(fa):
+        open(fa, "wb").write(bytes(z["fasta"]))
+    out = os.path.join(outdir, out_name or (tag + "_dev"))
+    cmd = [EXE, "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", outdir, "-nb-cores", cores,
+           "-max-memory", mem, "-verbose", "0", "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"] + extra
+    env = dict(os.environ); env.update(env_extra or {})
+    return subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), out + ".h5"
+
+
+@needs_artefacts
+@pytest.mark.parametrize("tag", sorted(CASES))
+@pytest.mark.parametrize("mode", ["bulk", "per_record"])
+def test_patched_dbgh5_writes_the_reference_datasets(tmp_path, tag, mode):
+    p, h5 = run_dbgh5(tag, str(tmp_path), {"GATB_DEVICE_NO_BULK": "1"} if mode == "per_record" else None)
+    log = p.communicate(timeout=600)[0]
+    assert p.returncode == 0, log[-2000:]
+    check_h5(h5, tag)
+
+
+@needs_artefacts
+@pytest.mark.parametrize("tag", ["k21_freq_4parts", "k31_2parts_mphf"])
+def test_two_ranks_write_one_h5(tmp_path, tag):
+    box = tmp_path / "box"; box.mkdir()
+    procs = []
+    for r in range(2):
+        env = {"GATB_DEVICE_RANKS": "2", "GATB_DEVICE_RANK": str(r), "GATB_DEVICE_TRANSPORT_DIR": str(box)}
+        procs.append(run_dbgh5(tag, str(tmp_path), env, out_name="%s_rank%d" % (tag, r)))
+    logs = [p.communicate(timeout=900)[0] for p, _ in procs]
+    assert all(p.returncode == 0 for p, _ in procs), "\n".join(l[-1500:] for l in logs)
+    check_h5(procs[0][1], tag)                     # rank 0's file: every dataset of the single-process file
