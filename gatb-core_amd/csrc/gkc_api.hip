@@ -164,6 +164,7 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
                   int minimizer_type, const uint16_t* repart, const uint32_t* freq_order)
 {
     if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     GKC_HIP(c, hipSetDevice(c->device));
     if (k <= 2) GKC_FAIL(c, GKC_ERR_ARG, "kmer size %u too small (SortingCountAlgorithm.cpp:662-666 refuses k<=2)", k);
     if (k > 63) GKC_FAIL(c, GKC_ERR_ARG, "kmer size %u not supported (this build covers spans 32 and 64: k<=63)", k);
@@ -235,6 +236,7 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
 int gkc_set_solidity(gkc_ctx* c, int32_t amin, int32_t amax, uint32_t histo_max)
 {
     if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (amin > amax) GKC_FAIL(c, GKC_ERR_ARG, "abundance_min > abundance_max");
     if (histo_max < 1 || histo_max > (1u << 24)) GKC_FAIL(c, GKC_ERR_ARG, "histo_max out of range");
     c->amin = amin; c->amax = amax; c->d_hint = 0;
@@ -278,6 +280,7 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
 int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
 {
     if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
     if (((uintptr_t)d_bases & 15) != 0) GKC_FAIL(c, GKC_ERR_ARG, "d_bases must be 16-byte aligned");
     GKC_HIP(c, hipSetDevice(c->device));
@@ -293,6 +296,7 @@ static const uint64_t PUSH_CHUNK_BASES = getenv("GKC_PUSH_CHUNK") ? (uint64_t)st
 int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads)
 {
     if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
     if (!offsets) GKC_FAIL(c, GKC_ERR_ARG, "offsets is required");
     if (offsets[0] != 0) GKC_FAIL(c, GKC_ERR_ARG, "offsets[0] must be 0");
@@ -571,7 +575,12 @@ int gkc_segment_import(gkc_ctx* c, const void* d_records, const uint64_t* rec_of
     c->segments.push_back(std::move(s));
     return GKC_OK;
 }
-int gkc_segments_clear(gkc_ctx* c) { if (!c) return GKC_ERR_ARG; (void)hipStreamSynchronize(c->stream); clear_segments(c); return GKC_OK; }
+int gkc_segments_clear(gkc_ctx* c)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
+    (void)hipStreamSynchronize(c->stream); clear_segments(c); return GKC_OK;
+}
 
 int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len,
                            uint32_t sub_ppm, char** d_bases, uint64_t** d_offsets)
@@ -595,6 +604,7 @@ int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) GK
 int gkc_release_pass(gkc_ctx* c, uint32_t pass)
 {
     if (!c) return GKC_ERR_ARG;
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (!c->configured || pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "no such pass %u", pass);
     if (c->in_pass && c->pass == pass) GKC_FAIL(c, GKC_ERR_ARG, "pass %u is still open (gkc_finish_pass first)", pass);
     GKC_HIP(c, hipSetDevice(c->device));

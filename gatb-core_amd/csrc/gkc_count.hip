@@ -1753,6 +1753,10 @@ int gkc_count_pass(gkc_ctx* c)
         if (it != c->pass_outputs.end()) { for (void* p : it->second) c->dfree(p); it->second.clear(); }
         for (uint32_t p = 0; p < Pn; p++) c->datasets[(size_t)c->pass * Pn + p] = Dataset();
         gkc_stats& S = c->stats_now(); S.kmers_nb_distinct = 0; S.kmers_nb_solid = 0; S.oversize_buckets = 0;
+        // ... and the host sink starts over as well: the failed attempt's copies are drained, its records are overwritten
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+        c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;
         GKC_HIP(c, hipMemsetAsync(c->histo_of(c->pass), 0, ((size_t)c->histo_max + 1) * 8, c->stream));
     }
     std::vector<uint64_t> part_keys(Pn, 0);
@@ -1866,8 +1870,11 @@ int gkc_count_pass(gkc_ctx* c)
         while (next_p < Pn) {
             const uint32_t p = next_p;
             if (part_keys[p] == 0) {                           // nothing to count (e.g. a partition another rank owns): an empty, finished dataset
-                Dataset& D = c->datasets[(size_t)c->pass * Pn + p];
-                D.d_counts = nullptr; D.n_solid = 0; D.n_distinct = 0; D.n_kmers = 0; D.done = true;
+                {   std::lock_guard<std::mutex> lk2(c->mu);       // (c->mu guards the datasets gkc_wait_partition looks at; plan_mu only the batch plan)
+                    Dataset& D = c->datasets[(size_t)c->pass * Pn + p];
+                    D.d_counts = nullptr; D.n_solid = 0; D.n_distinct = 0; D.n_kmers = 0; D.done = true;
+                }
+                c->cv_done.notify_all();
                 next_p++; continue;
             }
             if (!batch.empty() && acc + part_keys[p] > budget) break;

@@ -376,6 +376,7 @@ int gkc_exchange(gkc_ctx* c, gkc_comm* m)
 {
     if (!c || !m || m->ctx != c) return GKC_ERR_ARG;
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_exchange outside a pass (gkc_begin_pass first)");
+    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_exchange while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)");
     GKC_HIP(c, hipSetDevice(c->device));
     const auto t_host0 = std::chrono::steady_clock::now();
     const int W = m->world, me = m->rank;
@@ -479,6 +480,42 @@ int gkc_exchange(gkc_ctx* c, gkc_comm* m)
     return GKC_OK;
 }
 
+__global__ void k_loop_fill(uint64_t* __restrict__ a, uint64_t n, uint64_t seed)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a[i] = (i + seed) * 0x9E3779B97F4A7C15ULL;
+}
+__global__ void k_loop_check(const uint64_t* __restrict__ a, uint64_t n, uint64_t seed, unsigned long long* __restrict__ bad)
+{
+    unsigned long long b = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) b += a[i] != (i + seed) * 0x9E3779B97F4A7C15ULL;
+    if (b) atomicAdd(bad, b);
+}
+int gkc_comm_loopback(gkc_ctx* c, gkc_comm* m, uint64_t n_bytes, uint64_t* mismatches, double* ms)
+{
+    if (!c || !m || m->ctx != c || !mismatches) return GKC_ERR_ARG;
+    GKC_HIP(c, hipSetDevice(c->device));
+    const uint64_t n = (n_bytes + 7) / 8;
+    DevBuf src, dst, bad;
+    GKC_TRY(c->ensure(src, (size_t)n * 8 + 8));
+    int rc = c->ensure(dst, (size_t)n * 8 + 8); if (rc == GKC_OK) rc = c->ensure(bad, 8);
+    if (rc != GKC_OK) { src.release(); dst.release(); return rc; }
+    (void)hipMemsetAsync(bad.p, 0, 8, m->xstream); (void)hipMemsetAsync(dst.p, 0, (size_t)n * 8, m->xstream);
+    hipLaunchKernelGGL(k_loop_fill, dim3(1024), dim3(256), 0, m->xstream, (uint64_t*)src.p, n, 12345ull);
+    (void)hipStreamSynchronize(m->xstream);
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<gkc_xfer> sends{ gkc_xfer{ m->rank, 0, src.p, n * 8 } }, recvs{ gkc_xfer{ m->rank, 0, dst.p, n * 8 } };
+    rc = gkc_comm_sendrecv(m, sends, recvs, m->xstream);
+    (void)hipStreamSynchronize(m->xstream);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    unsigned long long h = 0;
+    if (rc == GKC_OK) {
+        hipLaunchKernelGGL(k_loop_check, dim3(1024), dim3(256), 0, m->xstream, (const uint64_t*)dst.p, n, 12345ull, (unsigned long long*)bad.p);
+        if (hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, m->xstream) != hipSuccess || hipStreamSynchronize(m->xstream) != hipSuccess) { c->set_error(GKC_ERR_HIP, "loopback check failed"); rc = GKC_ERR_HIP; }
+    }
+    src.release(); dst.release(); bad.release();
+    *mismatches = h;
+    return rc;
+}
 int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
 {
     if (!c || !m || m->ctx != c) return GKC_ERR_ARG;

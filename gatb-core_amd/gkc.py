@@ -25,7 +25,7 @@ SYMBOLS = [
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
-    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_gather_results", "gkc_comm_destroy", "gkc_comm_set_owners",
+    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_gather_results", "gkc_comm_loopback", "gkc_comm_destroy", "gkc_comm_set_owners",
     "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
     "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
     "gkc_sample_exact", "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
@@ -141,6 +141,7 @@ def lib():
         "gkc_comm_create_transport": (C.c_int, [vp, P(Transport), C.c_int, C.c_int, P(vp)]),
         "gkc_comm_create_files": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, P(vp)]),
         "gkc_gather_results": (C.c_int, [vp, vp, C.c_int]),
+        "gkc_comm_loopback": (C.c_int, [vp, vp, u64, P(u64), P(C.c_double)]),
         "gkc_comm_destroy": (None, [vp]),
         "gkc_comm_set_owners": (C.c_int, [vp, vp]),
         "gkc_comm_get_owners": (C.c_int, [vp, vp]),
@@ -549,6 +550,12 @@ class Comm:
         h = C.c_void_p()
         counter._chk(counter.L.gkc_comm_create_files(counter.h, str(directory).encode(), world, rank, C.byref(h)))
         return cls(counter, h)
+
+    def loopback(self, n_bytes):
+        """this rank sends n_bytes to itself through the communicator's send / receive path (chunked like gkc_exchange) -> (mismatching words, ms)"""
+        bad = C.c_uint64(0); ms = C.c_double(0)
+        self.c._chk(self.L.gkc_comm_loopback(self.c.h, self.h, int(n_bytes), C.byref(bad), C.byref(ms)))
+        return bad.value, ms.value
 
     def gather_results(self, root=0):
         """collective after finish_pass: every partition's Count[], the histogram and the statistics on `root` (gkc_gather_results)"""

@@ -231,6 +231,10 @@ int  gkc_comm_get_stats(gkc_comm* comm, gkc_comm_stats* out);
  * writes the one result file the reference's consumers open (CountProcessorDump.hpp:85-95: all nb_partitions x nb_passes datasets live in one file;
  * GraphUnitigs.cpp:921-931 opens that file). The other ranks keep what they had. The results must fit root's HBM (solid k-mers only travel). */
 int  gkc_gather_results(gkc_ctx* ctx, gkc_comm* comm, int root);
+/* Diagnostic: this rank sends n_bytes of a pattern to ITSELF through the communicator's own grouped send / receive path (the message is cut into the same
+ * 256 MiB chunks as the messages of gkc_exchange) and compares what arrived. With one rank this is the only way to run ncclSend / ncclRecv and the chunking on
+ * hardware. mismatches: 8-byte words that differ; ms: wall time of the transfer. */
+int  gkc_comm_loopback(gkc_ctx* ctx, gkc_comm* comm, uint64_t n_bytes, uint64_t* mismatches, double* ms);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bloom filter of solid k-mers — replaces BloomBuilder::build / IBloom::insert (kmer/impl/BloomBuilder.hpp:102-128,

@@ -281,6 +281,20 @@ public:
         std::vector<uint64_t> dh (dev.plan().histoMax + 1);
         dev.check (gkc_histogram (dev.ctx(), dh.data(), (uint32_t) dh.size()));
         for (size_t cc = 1; cc < h->getLength(); cc++)  { h->get (cc) += dh[cc]; }
+        /* ... and the solidity processor's counters (kmers_nb_distinct / kmers_nb_solid of the run's properties): what its clones would have counted one
+         * process() at a time comes from the device's statistics, through the same finishClones() the clones go through (CountProcessorSolidity.hpp:118-131) */
+        CountProcessorSoliditySum<span>* solid = items.size() > 1 ? dynamic_cast<CountProcessorSoliditySum<span>*> (items[1]) : 0;
+        if (solid != 0)
+        {
+            struct Totals : public CountProcessorSoliditySum<span>
+            {
+                Totals (u_int64_t total, u_int64_t ok)  { this->_total = total;  this->_ok = ok; }
+            };
+            gkc_stats st;  dev.check (gkc_get_stats (dev.ctx(), &st));
+            Totals totals (st.kmers_nb_distinct, st.kmers_nb_solid);
+            std::vector<ICountProcessor<span>*> one (1, &totals);
+            solid->finishClones (one);
+        }
     }
 
     void execute ()

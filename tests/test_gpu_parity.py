@@ -514,6 +514,28 @@ def test_distributed_counter_world1_rccl(gkc):
         dist.destroy_process_group()
 
 
+def test_rccl_send_recv_and_chunking_on_hardware(gkc):
+    """VERDICT r2 (3d/3e): the library's OWN grouped ncclSend / ncclRecv path with its 256 MiB chunking, on the GPU: a one-rank RCCL communicator sends 600 MiB + 24 B
+    (three chunks, the last one ragged) to itself (gkc_comm_loopback) and every word arrives; then three pushes with an exchange each (three segments) count right"""
+    c = gkc.Counter(0)
+    comm = gkc.Comm.rccl(c, gkc.Comm.unique_id(), 1, 0)
+    for n in (1 << 20, (600 << 20) + 24):
+        bad, ms = comm.loopback(n)
+        assert bad == 0, "%d of %d words differ after the self send" % (bad, n // 8)
+    reads = synth_reads(3000, 20000, 150, seed=6)
+    k, m, parts = 31, 10, 16
+    rep = simple_repart(m, parts)
+    bases, offs = gko.pack_reads(reads)
+    ref = gko.Dsk(bases, offs, k, m, parts, rep)
+    c.configure(k, m, parts, rep)
+    c.begin_pass(0)
+    for part in (reads[:1000], reads[1000:2000], reads[2000:]):
+        b, o = gko.pack_reads(part); c.push_reads(b, o); c.exchange(comm)
+    c.finish_pass()
+    assert c.all_counts() == ref.all_counts() and comm.stats()["n_exchanges"] == 3
+    comm.close()
+
+
 def test_bloom_or_reduce_world1_rccl(gkc):
     """gkc_bloom_allreduce_or over a one-rank RCCL communicator (ncclCommInitRank inside the library) is the identity; the two-rank
     reduction runs in tests/test_gpu_dist.py"""
