@@ -1,11 +1,15 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
-for e in 2 1 0; do
-  GKC_SPLIT_EXTRA=$e python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed > gpurun_out/sw_$e.json 2>/dev/null
+run() { # name, env...
+  n=$1; shift
+  env "$@" python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed --no-share-of-8 > gpurun_out/sw_$n.json 2>/dev/null
   python - <<PY
 import json
-d = json.load(open("gpurun_out/sw_$e.json"))
-s = d["roofline"]["single_lane"]["kernel_ms_per_step"]
-print("extra=$e ms_per_step %.1f" % d["ms_per_step"], "single: split %.1f compact %.1f big %.1f wg %.1f sort %.1f B %.1f" % (s["split_levels"], s["compact"], s["bucket_sort_big"], s["bucket_sort_wg"], s["bucket_sort"], s["total_stage_b"]))
+d = json.load(open("gpurun_out/sw_$n.json"))
+s = d["roofline"]["single_lane"]["kernel_ms_per_step"]; t = d["config"]["kernel_ms_per_step"]
+print("$n: ms_per_step %.1f  B two-lane %.1f  single: sort %.1f scatter %.1f B %.1f | timed sort %.1f scatter %.1f" % (d["ms_per_step"], t["total_stage_b"], s["bucket_sort"], s["expand_scatter"], s["total_stage_b"], t["bucket_sort"], t["expand_scatter"]))
 PY
-done
+}
+run base A=1
+run permswap GKC_LIB=$GRAFT_REPO_ROOT/gatb-core_amd/csrc/variants/libgkc_hip_permswap.so
+run base2 A=1
+run lanes3 GKC_STAGEB_LANES=3
