@@ -223,13 +223,20 @@ template <int KW, int RW>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                   uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
                                                                   TierLists T,
-                                                                  const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
+                                                                  const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
+                                                                  uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
     __shared__ uint32_t s_wsum[EXPAND_THREADS / 64];
     __shared__ WgList s_big, s_wg, s_split;
-    const uint32_t bi = order ? order[blockIdx.x] : blockIdx.x;
+    __shared__ uint32_t s_item;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1u);
+    __syncthreads();
+    if (s_item >= nb) break;
+    const uint32_t bi = order ? order[s_item] : s_item;
     const PartDesc pd = parts[bi];
     const uint32_t nsub = 1u << pd.sub_bits;
     for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) s_hist[i] = 0;
@@ -278,6 +285,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     wglist_flush(&s_big, T.big_count, T.big_list);
     wglist_flush(&s_wg, T.wg_count, T.wg_list);
     wglist_flush(&s_split, T.split_count, T.split_list);
+  }
 }
 
 __device__ __forceinline__ uint32_t count_at(const uint8_t* cnt8, const uint32_t* cnt32, uint64_t slot, uint32_t b) { return b == 255u ? cnt32[slot] : b; }
@@ -296,10 +304,18 @@ constexpr int PAIR_THREADS = 1024;
 // that key instead and starts over. Keys are conserved by every exchange, nobody waits on anybody; 1.5 exchanges per key.
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
-                                                                       const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
+                                                                       const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
+                                                                       uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub] parked key or EMPTY
-    const PartDesc pd = parts[order ? order[blockIdx.x] : blockIdx.x];
+    __shared__ uint32_t s_item;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    if (item >= nb) break;
+    const PartDesc pd = parts[order ? order[item] : item];
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + nsub);                     // [nsub] next free slot of the sub-bucket
     constexpr unsigned long long EMPTY = ~0ULL;
@@ -336,6 +352,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[s_cur[i]] = v; }
+  }
 }
 
 // B1, 16-byte keys in PAIRS: a single 16-byte store to one of 8192 open sub-buckets costs a whole 32-byte HBM write atom (twice the bytes),
@@ -354,10 +371,19 @@ __device__ __forceinline__ void lds_xchg128(unsigned long long* slot, uint64_t i
 }
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                         const uint64_t* __restrict__ b_start, u128* __restrict__ keys,
-                                                                        const uint32_t* __restrict__ order /* workgroup -> partition of the batch (largest first), or nullptr */)
+                                                                        const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
+                                                                        uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub][2] parked key (low word, high word) or EMPTY
-    const PartDesc pd = parts[order ? order[blockIdx.x] : blockIdx.x];
+  for (;;) {
+    // the ticket travels through the first word of the parking table (dead between two partitions): the table + cursors take the CU's whole 160 KB of LDS
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t*>(s_pend) = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t item = *reinterpret_cast<volatile uint32_t*>(s_pend);
+    __syncthreads();
+    if (item >= nb) break;
+    const PartDesc pd = parts[order ? order[item] : item];
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + 2 * (size_t)nsub);        // [nsub] next free slot of the sub-bucket
     constexpr unsigned long long EMPTY = ~0ULL;
@@ -394,6 +420,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long lo = s_pend[2 * i], hi = s_pend[2 * i + 1]; if (hi != EMPTY) out[s_cur[i]] = make_ulonglong2(lo, hi); }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ B2/B3 wave sort + RLE
@@ -1562,21 +1589,26 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     T.giant_list = (uint32_t*)B.glist.p; T.giant_count = misc + 3;
 
     {   ScopedTimer tm(c, "expand_count");
-        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p);
+        static const uint32_t cwgs_env = getenv("GKC_COUNT_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_COUNT_WGS"))) : 0u;
+        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nb, cwgs_env) : nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nb, misc + 7);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
+        // The scatter is bound by the write requests the whole chip retires, not by its CUs (tools/scatter_bench: 63-127 workgroups write MORE than 254), and the
+        // other Stage-B lane's kernel wants CUs: the launch takes 11/16 of them (persistent workgroups, partitions handed out largest first by a ticket).
+        // Measured, two lanes, 1e8 reads: one workgroup per partition 266-273 ms per step, 160-192 workgroups 249-251, 128: 252, 96: 256.
+        static const uint32_t scatter_wgs = getenv("GKC_SCATTER_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCATTER_WGS"))) : 176u;
         if constexpr (KW == 1) {
             const size_t lds = (size_t)MAX_SUB * 12;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p);
+            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6);
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(nb), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
-                               (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p);
+            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+                               (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6);
         }
         CB_HIP(hipGetLastError());
     }
@@ -1592,7 +1624,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     key_t* const keysA = (key_t*)B.keysA.p; key_t* const keysB = (key_t*)B.keysB.p;
     const uint64_t* const bs = (const uint64_t*)B.b_start.p; const uint32_t* const bn = (const uint32_t*)B.b_n.p; const uint8_t* const bc = (const uint8_t*)B.b_cons.p;
     {   ScopedTimer tm(c, "bucket_sort");
-        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_sub + 3) / 4, 256 * 32));
+        static const uint64_t sgrid_env = getenv("GKC_SORT_WGS") ? (uint64_t)std::max(1, atoi(getenv("GKC_SORT_WGS"))) : 256 * 32;
+        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_sub + 3) / 4, sgrid_env));
         if (tag) hipLaunchKernelGGL((k_wave_sort<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysA, bs, bn, (uint32_t)n_sub, O);
         else hipLaunchKernelGGL((k_wave_sort<KW, false>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysA, bs, bn, (uint32_t)n_sub, O);
         CB_HIP(hipGetLastError());
