@@ -340,7 +340,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
 #ifdef GKC_EXP_NOSTORE
                         if (c == 0x123456789ULL)
 #endif
-                        *reinterpret_cast<ulonglong2*>(out + p) = make_ulonglong2(y, h);
+                        store16(out + p, y, h);
                         break;
                     }
                     const unsigned long long z = atomicExch(&s_pend[q], h);
@@ -1358,10 +1358,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
                 if (ok) {
                     const typename KeyT<KW>::type key = keys[slot[u]];
                     uint64_t* dst = out + (o + sk[u] + __popcll(bal & lt_mask)) * OW;
-                    if (KW == 1) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2((uint64_t)key, (uint64_t)c);
+                    if (KW == 1) store16(dst, (uint64_t)key, (uint64_t)c);
                     else {
-                        *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2((uint64_t)key, (uint64_t)((u128)key >> 64));
-                        *reinterpret_cast<ulonglong2*>(dst + 2) = make_ulonglong2((uint64_t)c, 0ULL);
+                        store16(dst, (uint64_t)key, (uint64_t)((u128)key >> 64));
+                        store16(dst + 2, (uint64_t)c, 0ULL);
                     }
                 }
                 o += __popcll(bal);
@@ -1472,10 +1472,10 @@ __global__ __launch_bounds__(256) void k_root_write(const typename KeyT<KW>::typ
             if (ok) {
                 const typename KeyT<KW>::type key = keys[start + j];
                 uint64_t* dst = out + (o + __popcll(bal & lt_mask)) * OW;
-                if (KW == 1) *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2((uint64_t)key, (uint64_t)cc);
+                if (KW == 1) store16(dst, (uint64_t)key, (uint64_t)cc);
                 else {
-                    *reinterpret_cast<ulonglong2*>(dst) = make_ulonglong2((uint64_t)key, (uint64_t)((u128)key >> 64));
-                    *reinterpret_cast<ulonglong2*>(dst + 2) = make_ulonglong2((uint64_t)cc, 0ULL);
+                    store16(dst, (uint64_t)key, (uint64_t)((u128)key >> 64));
+                    store16(dst + 2, (uint64_t)cc, 0ULL);
                 }
             }
             o += __popcll(bal);

@@ -85,3 +85,18 @@ template <int RW> struct RecT { uint64_t w[RW]; };
 
 // wave64 helpers
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// 16-byte store of data that is not read again soon (keys on their way to the sort, records, results). GKC_NT_STORES=1 (build flag): non-temporal
+#ifndef GKC_NT_STORES
+#define GKC_NT_STORES 0
+#endif
+typedef unsigned long long gkc_v2u64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16(void* dst, unsigned long long a, unsigned long long b)
+{
+    gkc_v2u64 v; v.x = a; v.y = b;
+#if GKC_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<gkc_v2u64*>(dst));
+#else
+    *reinterpret_cast<gkc_v2u64*>(dst) = v;
+#endif
+}

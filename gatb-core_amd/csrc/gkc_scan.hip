@@ -89,7 +89,7 @@ __device__ __forceinline__ void store_record(const uint32_t* s_be, int start, ui
     }
     uint64_t* dst = arena + slot * RW;
 #pragma unroll
-    for (int i = 0; i < RW; i += 2) *reinterpret_cast<ulonglong2*>(dst + i) = make_ulonglong2(R[i], R[i + 1]);
+    for (int i = 0; i < RW; i += 2) store16(dst + i, R[i], R[i + 1]);
 }
 
 // 16 ASCII bases (4 dwords) -> little-endian 2-bit word + invalid mask (A1), SWAR
@@ -650,30 +650,56 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
 template <int RW>
 __device__ __forceinline__ uint32_t record_partition(const uint64_t (&R)[RW], const ScanParams& P)
 {
+    // the first k-mer of the record and its reverse complement, once; m-mer j (j = 0 .. k-m) is then a window of each: forward at nucleotide j from the
+    // left, reverse complement at nucleotide j from the right (a revcomp per m-mer made this kernel VALU-bound: 22 of them per record)
     uint32_t best = P.default_key;
+    const uint32_t k = P.k, m = P.m;
     const uint64_t S0 = (R[0] << 8) | (R[1] >> 56);
-    uint64_t S1 = 0;
-    if (RW == 4) S1 = (R[1] << 8) | (R[RW > 2 ? 2 : 1] >> 56);
-    for (uint32_t j = 0; j < P.nb_mm; j++) {
-        const uint32_t e = 2 * (j + P.m);                              // bits of the string up to the end of m-mer j (<= 2k <= 126)
-        uint32_t fw;
-        if (RW == 2 || e <= 64) fw = (uint32_t)(S0 >> (64 - e)) & P.mmask;
-        else fw = (uint32_t)(((((u128)S0) << 64) | S1) >> (128 - e)) & P.mmask;
-        uint32_t key;
-        if (P.freq_mode) key = P.mkey_lut[fw];
-        else {
-            const uint32_t rc = (uint32_t)revcomp64(fw, P.m);
-            const uint32_t cn = fw < rc ? fw : rc;
-            uint32_t a = ~(cn | (cn >> 2));
-            a = (a >> 1) & a & P.mask_ma1;
-            key = a ? P.mmask : cn;
+    if (RW == 2 || k <= 32) {
+        const uint64_t F = k == 32 ? S0 : (S0 >> (64 - 2 * k));
+        const uint64_t RC = revcomp64(F, k);
+        for (uint32_t j = 0; j < P.nb_mm; j++) {
+            const uint32_t fw = (uint32_t)(F >> (2 * (k - m - j))) & P.mmask;
+            uint32_t key;
+            if (P.freq_mode) key = P.mkey_lut[fw];
+            else {
+                const uint32_t rc = (uint32_t)(RC >> (2 * j)) & P.mmask;
+                const uint32_t cn = fw < rc ? fw : rc;
+                uint32_t a = ~(cn | (cn >> 2));
+                a = (a >> 1) & a & P.mask_ma1;
+                key = a ? P.mmask : cn;
+            }
+            best = key < best ? key : best;
         }
-        best = key < best ? key : best;
+    } else {
+        const uint64_t S1 = (R[1] << 8) | (R[RW > 2 ? 2 : 1] >> 56);
+        const u128 F = ((((u128)S0) << 64) | S1) >> (128 - 2 * k);
+        const u128 RC = revcomp128(F, k);
+        for (uint32_t j = 0; j < P.nb_mm; j++) {
+            const uint32_t fw = (uint32_t)(F >> (2 * (k - m - j))) & P.mmask;
+            uint32_t key;
+            if (P.freq_mode) key = P.mkey_lut[fw];
+            else {
+                const uint32_t rc = (uint32_t)(RC >> (2 * j)) & P.mmask;
+                const uint32_t cn = fw < rc ? fw : rc;
+                uint32_t a = ~(cn | (cn >> 2));
+                a = (a >> 1) & a & P.mask_ma1;
+                key = a ? P.mmask : cn;
+            }
+            best = key < best ? key : best;
+        }
     }
     const uint32_t value = P.freq_mode ? P.key2val[best] : best;
     return P.repart[value];
 }
 constexpr int REFINE_THREADS = 256, REFINE_MAX_FINE = 64;
+// lanes of the wave that hold the same value b (< 2^bits) as this lane, among the lanes where `active` holds (all lanes of the wave must call this)
+__device__ __forceinline__ unsigned long long wave_peers(uint32_t b, uint32_t bits, bool active)
+{
+    unsigned long long peers = __ballot(active);
+    for (uint32_t i = 0; i < bits; i++) { const unsigned long long bal = __ballot((b >> i) & 1u); peers &= ((b >> i) & 1u) ? bal : ~bal; }
+    return peers;
+}
 // one workgroup per coarse group: records -> fine partition; counts per fine partition + the fine id of every record
 template <int RW>
 __global__ __launch_bounds__(REFINE_THREADS) void k_refine_count(ScanParams P, const uint64_t* __restrict__ arena, const unsigned long long* __restrict__ coarse_off,
@@ -685,16 +711,33 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_refine_count(ScanParams P, c
     if (threadIdx.x < nf) { s_rec[threadIdx.x] = 0; s_km[threadIdx.x] = 0; }
     __syncthreads();
     const unsigned long long r0 = coarse_off[g], r1 = coarse_off[g + 1];
-    for (unsigned long long r = r0 + threadIdx.x; r < r1; r += REFINE_THREADS) {
-        uint64_t R[RW];
-        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + r * RW);
+    const int lane = threadIdx.x & 63;
+    ulonglong2 nx[RW / 2];                                              // the next record of the thread is in flight while this one is worked on
+    if (r0 + threadIdx.x < r1) { const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + (r0 + threadIdx.x) * RW);
 #pragma unroll
-        for (int i = 0; i < RW; i += 2) { const ulonglong2 v = src[i / 2]; R[i] = v.x; R[i + 1] = v.y; }
-        const uint32_t part = record_partition<RW>(R, P);
-        const uint32_t b = part - (g << shift);
-        if (b >= nf) { *bad = 1u; continue; }                          // cannot happen: the coarse group of a record is its partition >> shift
-        fine_id[r] = (uint8_t)b;
-        atomicAdd(&s_rec[b], 1u); atomicAdd(&s_km[b], (unsigned long long)(R[0] >> 56));
+        for (int i = 0; i < RW / 2; i++) nx[i] = src[i]; }
+    for (unsigned long long rb = r0; rb < r1; rb += REFINE_THREADS) {     // (uniform trip count: the ballots see all lanes)
+        const unsigned long long r = rb + threadIdx.x;
+        const bool in = r < r1;
+        uint32_t b = 0, nk = 0;
+        uint64_t R[RW];
+#pragma unroll
+        for (int i = 0; i < RW; i += 2) { R[i] = nx[i / 2].x; R[i + 1] = nx[i / 2].y; }
+        if (r + REFINE_THREADS < r1) { const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + (r + REFINE_THREADS) * RW);
+#pragma unroll
+            for (int i = 0; i < RW / 2; i++) nx[i] = src[i]; }
+        if (in) {
+            const uint32_t part = record_partition<RW>(R, P);
+            b = part - (g << shift); nk = (uint32_t)(R[0] >> 56);
+            if (b >= nf) { *bad = 1u; b = 0; nk = 0; }                   // cannot happen: the coarse group of a record is its partition >> shift
+            fine_id[r] = (uint8_t)b;
+        }
+        // one LDS add per fine partition and wave, not per record: all lanes hitting the same 8 counters serialise
+        const unsigned long long peers = wave_peers(b, shift, in);
+        uint32_t km = 0;                                                // sum of nk (< 64) over the peers, bit by bit
+#pragma unroll
+        for (int i = 0; i < 6; i++) km += (uint32_t)__popcll(__ballot((nk >> i) & 1u) & peers) << i;
+        if (in && (peers & ((1ULL << lane) - 1ULL)) == 0) { atomicAdd(&s_rec[b], (uint32_t)__popcll(peers)); atomicAdd(&s_km[b], (unsigned long long)km); }
     }
     __syncthreads();
     if (threadIdx.x < nf && ((g << shift) + threadIdx.x) < P.n_parts) { cnt_rec[(g << shift) + threadIdx.x] = s_rec[threadIdx.x]; cnt_km[(g << shift) + threadIdx.x] = s_km[threadIdx.x]; }
@@ -709,12 +752,33 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_refine_scatter(const uint64_
     if (threadIdx.x < nf) s_cur[threadIdx.x] = ((g << shift) + threadIdx.x) < n_parts ? fine_off[(g << shift) + threadIdx.x] : 0;
     __syncthreads();
     const unsigned long long r0 = coarse_off[g], r1 = coarse_off[g + 1];
-    for (unsigned long long r = r0 + threadIdx.x; r < r1; r += REFINE_THREADS) {
-        const unsigned long long slot = atomicAdd(&s_cur[fine_id[r]], 1ULL);
-        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(arena + r * RW);
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + slot * RW);
+    const int lane = threadIdx.x & 63;
+    ulonglong2 nx[RW / 2]; uint32_t nb_ = 0;                            // the next record (and its fine id) of the thread is in flight while this one is placed
+    if (r0 + threadIdx.x < r1) { const ulonglong2* src0 = reinterpret_cast<const ulonglong2*>(arena + (r0 + threadIdx.x) * RW); nb_ = fine_id[r0 + threadIdx.x];
 #pragma unroll
-        for (int i = 0; i < RW / 2; i++) dst[i] = src[i];
+        for (int i = 0; i < RW / 2; i++) nx[i] = src0[i]; }
+    for (unsigned long long rb = r0; rb < r1; rb += REFINE_THREADS) {     // (uniform trip count: the ballots see all lanes)
+        const unsigned long long r = rb + threadIdx.x;
+        const bool in = r < r1;
+        const uint32_t b = in ? nb_ : 0u;
+        ulonglong2 cur[RW / 2];
+#pragma unroll
+        for (int i = 0; i < RW / 2; i++) cur[i] = nx[i];
+        if (r + REFINE_THREADS < r1) { const ulonglong2* src1 = reinterpret_cast<const ulonglong2*>(arena + (r + REFINE_THREADS) * RW); nb_ = fine_id[r + REFINE_THREADS];
+#pragma unroll
+            for (int i = 0; i < RW / 2; i++) nx[i] = src1[i]; }
+        // one returning LDS add per fine partition and wave (the lowest peer reserves for all, the others take their rank)
+        const unsigned long long peers = wave_peers(b, shift, in);
+        const int leader = peers ? __ffsll((long long)peers) - 1 : 0;
+        unsigned long long base = 0;
+        if (in && lane == leader) base = atomicAdd(&s_cur[b], (unsigned long long)__popcll(peers));
+        base = __shfl(base, leader, 64);
+        if (in) {
+            const unsigned long long slot = base + (unsigned long long)__popcll(peers & ((1ULL << lane) - 1ULL));
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>(out + slot * RW);
+#pragma unroll
+            for (int i = 0; i < RW / 2; i++) dst[i] = cur[i];
+        }
     }
 }
 
