@@ -184,6 +184,9 @@ template <int KW> __device__ __forceinline__ uint32_t sub_index(typename KeyT<KW
 }
 
 constexpr int EXPAND_THREADS = 512;
+// A key on its way through the sort is the canonical k-mer shifted left by WEIGHT_BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
+// of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. 2k + WEIGHT_BITS <= 64 / 128 for k <= 31 / 63.
+constexpr int WEIGHT_BITS = 2;
 
 
 // ------------------------------------------------------------------------------------------------ B1 expand_count
@@ -330,9 +333,10 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         for (; r < r1; r += PAIR_THREADS) {
             const uint64_t R[2] = {nx.x, nx.y};
             if (r + PAIR_THREADS < r1) nx = recs[r + PAIR_THREADS];                  // next record in flight while this one is expanded
+            const unsigned long long wq = R[1] & 3ull;                              // the record's weight - 1 (WEIGHT_BITS below the nucleotides; 0 unless the records were deduplicated)
             for_each_kmer16(R, k, [&](uint64_t c) {
                 const uint32_t q = (uint32_t)(c >> pd.shift);
-                unsigned long long h = c;
+                unsigned long long h = (c << WEIGHT_BITS) | wq;                      // never all ones: the all-G k-mer is not canonical
                 for (;;) {
                     const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
                     if (y != EMPTY) {
@@ -399,27 +403,29 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
         for (; r < r1; r += PAIR_THREADS) {
             const uint64_t R[4] = {nx0.x, nx0.y, nx1.x, nx1.y};
             if (r + PAIR_THREADS < r1) { nx0 = recs[2 * (r + PAIR_THREADS)]; nx1 = recs[2 * (r + PAIR_THREADS) + 1]; }   // next record in flight
+            const uint64_t wq = R[3] & 3ull;                                          // the record's weight - 1
             for_each_kmer32(R, k, [&](u128 c) {
                 const uint32_t q = sub_index<2>(c, pd.shift);
-                uint64_t h_lo = (uint64_t)c, h_hi = (uint64_t)(c >> 64);
+                const u128 st = (c << WEIGHT_BITS) | (u128)wq;                           // never all ones: the all-G k-mer is not canonical
+                uint64_t h_lo = (uint64_t)st, h_hi = (uint64_t)(st >> 64);
                 for (;;) {
                     uint64_t y_lo, y_hi;
                     lds_xchg128(&s_pend[2 * (size_t)q], EMPTY, EMPTY, y_lo, y_hi);
-                    if (y_hi != EMPTY) {
+                    if (y_hi != EMPTY || y_lo != EMPTY) {
                         const uint32_t p = atomicAdd(&s_cur[q], 2u);
                         out[p] = make_ulonglong2(y_lo, y_hi); out[p + 1] = make_ulonglong2(h_lo, h_hi);
                         break;
                     }
                     uint64_t z_lo, z_hi;
                     lds_xchg128(&s_pend[2 * (size_t)q], h_lo, h_hi, z_lo, z_hi);
-                    if (z_hi == EMPTY) break;
+                    if (z_hi == EMPTY && z_lo == EMPTY) break;
                     h_lo = z_lo; h_hi = z_hi;
                 }
             });
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long lo = s_pend[2 * i], hi = s_pend[2 * i + 1]; if (hi != EMPTY) out[s_cur[i]] = make_ulonglong2(lo, hi); }
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long lo = s_pend[2 * i], hi = s_pend[2 * i + 1]; if (hi != EMPTY || lo != EMPTY) out[s_cur[i]] = make_ulonglong2(lo, hi); }
   }
 }
 
@@ -624,37 +630,53 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
 #ifndef GKC_EXP_NOSORT
     bitonic_wave<KW, KPL, F>(v, lane);
 #endif
-    // run-length count (B3). e = lane*KPL + r is the sorted rank
+    // run-length count (B3), weighted: e = lane*KPL + r is the sorted rank; a key is the k-mer above WEIGHT_BITS bits of (multiplicity - 1): equal k-mers are
+    // adjacent whatever their weights, the abundance of a run is the sum of its weights
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
     const key_t next_first = Shfl<KW>::down(v[0]);
-    // whole-lane bit masks (bit r = rank lane*KPL + r): one compare per key, the head / tail logic on the masks
-    uint32_t neq = (lane == 0 || v[0] != prev_last) ? 1u : 0u;                    // key differs from the one before it (rank 0: always)
+    constexpr uint32_t WMASK = (1u << WEIGHT_BITS) - 1u;
+    auto differs = [](key_t a, key_t b) -> uint32_t { return ((a ^ b) > (key_t)WMASK) ? 1u : 0u; };
+    // whole-lane bit masks (bit r = rank lane*KPL + r): one compare per key, the tail logic on the masks
+    uint32_t neq = lane == 0 ? 1u : differs(v[0], prev_last);                      // k-mer differs from the one before it (rank 0: always)
 #pragma unroll
-    for (int r = 1; r < KPL; r++) neq |= (v[r] != v[r - 1] ? 1u : 0u) << r;
+    for (int r = 1; r < KPL; r++) neq |= differs(v[r], v[r - 1]) << r;
     const uint32_t lane0 = (uint32_t)lane * KPL;
     const uint32_t have = n > lane0 ? (n - lane0 < (uint32_t)KPL ? n - lane0 : (uint32_t)KPL) : 0u;     // ranks of this lane below n
     const uint32_t inm = have >= 32u ? 0xFFFFFFFFu : ((1u << have) - 1u);
-    const uint32_t nxt_differs = (v[KPL - 1] != next_first) ? 1u : 0u;
+    const uint32_t nxt_differs = differs(v[KPL - 1], next_first);
     const uint32_t lastm = (have && lane0 + have == n) ? (1u << (have - 1u)) : 0u;                    // rank n-1 closes its run
-    const uint32_t headm = neq & inm;
     const uint32_t tailm = inm & ((neq >> 1) | (nxt_differs << (KPL - 1)) | lastm);
     const uint32_t nt = __popc(tailm);
-    int lh = headm ? (int)(lane * KPL + 31 - __clz((int)headm)) : -1;
-    uint32_t x = nt; int hx = lh;
+    // weights of the lane's ranks: total, and the part up to its last run end
+    uint32_t wtot = 0, wlast = 0;
+    {   const uint32_t lastbit = tailm ? (uint32_t)(31 - __clz((int)tailm)) : 0u;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); const int hy = __shfl_up(hx, d, 64); if (lane >= d) { x += y; hx = hy > hx ? hy : hx; } }
+        for (int r = 0; r < KPL; r++) {
+            const uint32_t w = ((inm >> r) & 1u) ? ((uint32_t)v[r] & WMASK) + 1u : 0u;
+            wtot += w;
+            if ((uint32_t)r <= lastbit) wlast += w;
+        }
+    }
+    uint32_t x = nt, t = wtot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64), u = __shfl_up(t, d, 64); if (lane >= d) { x += y; t += u; } }
     uint32_t idx = x - nt;
     nd_out = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-    int cur = __shfl_up(hx, 1, 64); if (lane == 0) cur = -1;
-    uint32_t nsol = 0;
+    const uint32_t wbase = t - wtot;                                              // weight of all ranks before this lane
+    // weight up to the last run end before this lane (0: none): the weights are monotone along the ranks, so a max-scan carries it
+    uint32_t lt = tailm ? wbase + wlast : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(lt, d, 64); if (lane >= d) lt = y > lt ? y : lt; }
+    uint32_t prevw = __shfl_up(lt, 1, 64); if (lane == 0) prevw = 0;
+    uint32_t nsol = 0, run = wbase;
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
+        run += ((inm >> r) & 1u) ? ((uint32_t)v[r] & WMASK) + 1u : 0u;
         if ((tailm >> r) & 1) {
-            // the run that ends here started at the last head at or before r in this lane, else at the carried-in head of an earlier lane
-            const uint32_t hb_ = headm & ((2u << r) - 1u);
-            const uint32_t c = hb_ ? (uint32_t)(r - (31 - __clz((int)hb_)) + 1) : (uint32_t)((int)(lane * KPL + r) - cur + 1);
+            const uint32_t c = run - prevw;                                       // the run that ends here: every weight since the previous run end
+            prevw = run;
 #ifndef GKC_EXP_NORLESTORE
-            if constexpr (F && KW == 1) outk[start + idx] = (v[r] & TAG64_MANT) | top; else outk[start + idx] = v[r];
+            if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WEIGHT_BITS; else outk[start + idx] = v[r] >> WEIGHT_BITS;
             put_count(O, start + idx, c);
 #else
             if (c == 0x7fffffffu) outk[start + idx] = v[r];
@@ -767,7 +789,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     key_t* s_x = reinterpret_cast<key_t*>(s_raw);                 // [NW][KPL][64] exchange buffer
     __shared__ key_t s_first[NW], s_last[NW];
-    __shared__ uint32_t s_tails[NW]; __shared__ int s_head[NW];
+    __shared__ uint32_t s_tails[NW], s_wsum[NW], s_lt[NW];
     __shared__ uint32_t s_hc[HIST_LDS];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     __shared__ uint32_t s_sol[NW];
@@ -822,33 +844,50 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
         if (lane == 0 && w > 0) prev_last = s_last[w - 1];
         if (lane == 63 && w < NW - 1) next_first = s_first[w + 1];
         const uint32_t E0 = w * CAPW + lane * KPL;
-        uint32_t headm = 0, tailm = 0;
+        constexpr uint32_t WMASK = (1u << WEIGHT_BITS) - 1u;
+        auto differs = [](key_t a, key_t b) -> bool { return (a ^ b) > (key_t)WMASK; };     // the k-mers above the weight bits differ
+        uint32_t tailm = 0, inm = 0;
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
             const uint32_t e = E0 + r;
-            const key_t pv = r ? v[r - 1] : prev_last;
             const key_t nx = (r < KPL - 1) ? v[r + 1] : next_first;
             const bool in = e < n;
-            headm |= (uint32_t)(in && (e == 0 || v[r] != pv)) << r;
-            tailm |= (uint32_t)(in && (e == n - 1 || v[r] != nx)) << r;
+            inm |= (uint32_t)in << r;
+            tailm |= (uint32_t)(in && (e == n - 1 || differs(v[r], nx))) << r;
         }
+        (void)prev_last;
         const uint32_t nt = __popc(tailm);
-        int lh = headm ? (int)(E0 + 31 - __clz((int)headm)) : -1;
-        uint32_t x = nt; int hx = lh;
+        uint32_t wtot = 0, wlast = 0;                              // weights of the lane's ranks: total, and the part up to its last run end
+        {   const uint32_t lastbit = tailm ? (uint32_t)(31 - __clz((int)tailm)) : 0u;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); const int hy = __shfl_up(hx, d, 64); if (lane >= d) { x += y; hx = hy > hx ? hy : hx; } }
-        if (lane == 63) { s_tails[w] = x; s_head[w] = hx; }
+            for (int r = 0; r < KPL; r++) {
+                const uint32_t wgt = ((inm >> r) & 1u) ? ((uint32_t)v[r] & WMASK) + 1u : 0u;
+                wtot += wgt;
+                if ((uint32_t)r <= lastbit) wlast += wgt;
+            }
+        }
+        uint32_t x = nt, tw = wtot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64), u = __shfl_up(tw, d, 64); if (lane >= d) { x += y; tw += u; } }
+        if (lane == 63) { s_tails[w] = x; s_wsum[w] = tw; }
         __syncthreads();
-        uint32_t idx = x - nt; int cur = __shfl_up(hx, 1, 64); if (lane == 0) cur = -1;
-        for (int ww = 0; ww < w; ww++) { idx += s_tails[ww]; cur = s_head[ww] > cur ? s_head[ww] : cur; }
-        uint32_t nsol = 0;
+        uint32_t idx = x - nt, wbase = tw - wtot;
+        for (int ww = 0; ww < w; ww++) { idx += s_tails[ww]; wbase += s_wsum[ww]; }
+        uint32_t lt = tailm ? wbase + wlast : 0u;                  // weight up to the lane's last run end; carried by a max-scan (monotone along the ranks)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(lt, d, 64); if (lane >= d) lt = y > lt ? y : lt; }
+        if (lane == 63) s_lt[w] = lt;
+        __syncthreads();
+        uint32_t prevw = __shfl_up(lt, 1, 64); if (lane == 0) prevw = 0;
+        for (int ww = 0; ww < w; ww++) prevw = s_lt[ww] > prevw ? s_lt[ww] : prevw;
+        uint32_t nsol = 0, run = wbase;
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
-            const int e = (int)E0 + r;
-            if ((headm >> r) & 1) cur = e;
+            run += ((inm >> r) & 1u) ? ((uint32_t)v[r] & WMASK) + 1u : 0u;
             if ((tailm >> r) & 1) {
-                const uint32_t c = (uint32_t)(e - cur + 1);
-                if constexpr (F && KW == 1) outk[start + idx] = (v[r] & TAG64_MANT) | top; else outk[start + idx] = v[r];
+                const uint32_t c = run - prevw;
+                prevw = run;
+                if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WEIGHT_BITS; else outk[start + idx] = v[r] >> WEIGHT_BITS;
                 put_count(O, start + idx, c); idx++;
                 nsol += ((int32_t)c >= O.amin && (int32_t)c <= O.amax) ? 1u : 0u;
                 const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
@@ -881,15 +920,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
 // at once (round 2 fetched the lists to the host between the levels: ~1 ms of latency per level and batch for 1.3 % of the keys). Results land in the
 // primary key buffer at the piece's own slots; the root's nd / ns counters collect them.
 struct SplitPlan { uint32_t left, bits, shift; };
-__device__ __forceinline__ SplitPlan split_plan(unsigned long long or_lo, unsigned long long or_hi, uint32_t consumed, uint32_t two_k, uint32_t max_bits)
+__device__ __forceinline__ SplitPlan split_plan(unsigned long long or_lo, unsigned long long or_hi, uint32_t consumed, uint32_t key_bits /* 2k + WEIGHT_BITS */, uint32_t max_bits)
 {
     const uint32_t diff_bits = or_hi ? 128 - __clzll((long long)or_hi) : (or_lo ? 64 - __clzll((long long)or_lo) : 0);   // number of low bits that may differ between keys
-    const uint32_t have = two_k - consumed;
-    SplitPlan p; p.left = diff_bits < have ? diff_bits : have; p.bits = 0; p.shift = 0;       // informative bits still unused
+    const uint32_t have = key_bits - consumed;
+    const uint32_t span = diff_bits < have ? diff_bits : have;              // low bits still unused and not shared by all keys; the lowest WEIGHT_BITS are not k-mer bits
+    SplitPlan p; p.left = span > (uint32_t)WEIGHT_BITS ? span - WEIGHT_BITS : 0u; p.bits = 0; p.shift = 0;   // informative k-mer bits (0: all keys are one k-mer)
     if (p.left == 0) return p;
     // always as many bits as the tables hold: the pieces that come out small are listed in runs (see k_deep_split), and a cluster under a longer shared prefix spreads
     p.bits = min(max_bits, p.left);
-    p.shift = p.left - p.bits;
+    p.shift = span - p.bits;                                                // >= WEIGHT_BITS: equal k-mers stay together whatever their weights
     return p;
 }
 struct DeepItem { uint64_t start; uint32_t n; uint32_t root; uint32_t consumed; uint32_t buf; };      // buf: 0 = keys are in the primary buffer, 1 = in the ping-pong buffer
@@ -915,14 +955,14 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
     uint32_t* s_cur = s_dyn + (1u << max_bits);             // [1 << max_bits] first slot of the piece, then its scatter cursor (relative to the item)
     __shared__ uint32_t s_gs[DEEP_WINDOWS], s_ge[DEEP_WINDOWS];    // runs of small pieces by window of their first slot: first slot, one past the last
     __shared__ uint32_t s_wsum[DEEP_THREADS / 64];
-    __shared__ unsigned long long s_or[2];
+    __shared__ unsigned long long s_or[3];                  // OR of (key ^ first key), low / high word; sum of the weights
     __shared__ uint32_t s_item, s_base_sort, s_base_q;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t n_items = *n_in_p;
     for (;;) {
         __syncthreads();                                      // LDS of the previous item fully consumed
         if (t == 0) s_item = atomicAdd(ticket, 1u);           // items differ by orders of magnitude: dynamic hand-out
-        if (t < 2) s_or[t] = 0;
+        if (t < 3) s_or[t] = 0;
         __syncthreads();
         const uint32_t it = s_item;
         if (it >= n_items) break;
@@ -945,27 +985,28 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
         {
             const key_t k0 = src[0];
             key_t acc = 0;
+            unsigned long long wsum = 0;                           // the item's total weight (its abundance if it turns out to be one k-mer)
             uint32_t i = t;
             for (; i + (DEEP_MLP - 1) * DEEP_THREADS < d.n; i += DEEP_MLP * DEEP_THREADS) {       // a root of 10^6 keys is walked by ONE workgroup: keep DEEP_MLP loads in flight
                 key_t v[DEEP_MLP];
 #pragma unroll
                 for (int u = 0; u < DEEP_MLP; u++) v[u] = src[i + u * DEEP_THREADS];
 #pragma unroll
-                for (int u = 0; u < DEEP_MLP; u++) acc |= v[u] ^ k0;
+                for (int u = 0; u < DEEP_MLP; u++) { acc |= v[u] ^ k0; wsum += ((uint32_t)v[u] & ((1u << WEIGHT_BITS) - 1u)) + 1u; }
             }
-            for (; i < d.n; i += DEEP_THREADS) acc |= src[i] ^ k0;
+            for (; i < d.n; i += DEEP_THREADS) { const key_t v1 = src[i]; acc |= v1 ^ k0; wsum += ((uint32_t)v1 & ((1u << WEIGHT_BITS) - 1u)) + 1u; }
             unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
 #pragma unroll
-            for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); }
-            if (lane == 0) { if (lo) atomicOr(&s_or[0], lo); if (KW == 2 && hi) atomicOr(&s_or[1], hi); }
+            for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); wsum += __shfl_down(wsum, dd, 64); }
+            if (lane == 0) { if (lo) atomicOr(&s_or[0], lo); if (KW == 2 && hi) atomicOr(&s_or[1], hi); atomicAdd(&s_or[2], wsum); }
         }
         __syncthreads();
         const SplitPlan P = split_plan(s_or[0], s_or[1], d.consumed, two_k, max_bits);
         const uint32_t left = P.left;
         if (left == 0) {                                       // one k-mer, abundance n (CountNumber is int32)
             if (t == 0) {
-                keysA[d.start] = src[0];
-                const uint32_t c = d.n > 0x7FFFFFFFu ? 0x7FFFFFFFu : d.n;
+                keysA[d.start] = src[0] >> WEIGHT_BITS;
+                const uint32_t c = s_or[2] > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)s_or[2];
                 put_count(O, d.start, c);
                 atomicAdd(&O.histo[c >= O.histo_max ? O.histo_max : c], 1ULL);
                 atomicAdd(&O.nd[d.root], 1u);
@@ -1061,7 +1102,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
 // OR of the keys (informative bits) -> histogram of the chunk in LDS, added to the giant's global histogram -> one workgroup scans it into piece offsets and lists
 // the pieces -> every key takes its slot from the piece's global cursor. The pieces then go the way of all pieces (sort list / next level's queue).
 constexpr int GIANT_THREADS = 1024, GIANT_MLP = GIANT_CHUNK / GIANT_THREADS;
-struct GiantTables { unsigned long long* gor; uint32_t* ghist; uint32_t* gcur; const uint32_t* list; const uint32_t* count; };   // [MAX][2], [MAX][MAX_SUB], [MAX][MAX_SUB]
+struct GiantTables { unsigned long long* gor; uint32_t* ghist; uint32_t* gcur; const uint32_t* list; const uint32_t* count; };   // [MAX][4] (OR low, OR high, total weight), [MAX][MAX_SUB], [MAX][MAX_SUB]
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                              uint8_t* __restrict__ cnt8)
@@ -1074,12 +1115,13 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<
     const key_t* src = keysA + start;
     const key_t k0 = src[0];
     key_t acc = 0;
+    unsigned long long wsum = 0;
     for (uint32_t c0 = blockIdx.x * GIANT_CHUNK; c0 < n; c0 += gridDim.x * GIANT_CHUNK) {
         key_t v[GIANT_MLP];
 #pragma unroll
         for (int u = 0; u < GIANT_MLP; u++) { const uint32_t i = c0 + u * GIANT_THREADS + threadIdx.x; v[u] = i < n ? src[i] : k0; }
 #pragma unroll
-        for (int u = 0; u < GIANT_MLP; u++) acc |= v[u] ^ k0;
+        for (int u = 0; u < GIANT_MLP; u++) { acc |= v[u] ^ k0; if (c0 + u * GIANT_THREADS + threadIdx.x < n) wsum += ((uint32_t)v[u] & ((1u << WEIGHT_BITS) - 1u)) + 1u; }
         // the root's abundance plane is read slot by slot by the gather: clear it (start is a multiple of 4)
         for (uint32_t i = threadIdx.x; i < GIANT_CHUNK / 4; i += GIANT_THREADS) if (c0 + 4 * i < n) {
             if (c0 + 4 * i + 4 <= n) reinterpret_cast<uint32_t*>(cnt8 + start + c0)[i] = 0u;
@@ -1088,8 +1130,8 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<
     }
     unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
 #pragma unroll
-    for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); }
-    if ((threadIdx.x & 63) == 0) { if (lo) atomicOr(&G.gor[2 * y], lo); if (KW == 2 && hi) atomicOr(&G.gor[2 * y + 1], hi); }
+    for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); wsum += __shfl_down(wsum, dd, 64); }
+    if ((threadIdx.x & 63) == 0) { if (lo) atomicOr(&G.gor[4 * y], lo); if (KW == 2 && hi) atomicOr(&G.gor[4 * y + 1], hi); if (wsum) atomicAdd(&G.gor[4 * y + 2], wsum); }
 }
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
@@ -1102,7 +1144,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename Key
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     if ((uint64_t)blockIdx.x * GIANT_CHUNK >= n) return;
-    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
+    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
     if (P.left == 0) return;
     const uint32_t nsub = 1u << P.bits, mask = nsub - 1u;
     for (uint32_t i = threadIdx.x; i < nsub; i += GIANT_THREADS) s_cnt[i] = 0;
@@ -1120,7 +1162,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename Key
 }
 // one workgroup per giant: histogram -> piece offsets (the scatter's cursors) and the piece lists
 template <int KW>
-__global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
+__global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                                const uint8_t* __restrict__ b_cons, DeepItem* __restrict__ q_out, uint32_t* __restrict__ n_out_p,
                                                                SortItem* __restrict__ sort_list, uint32_t* __restrict__ n_sort_p,
                                                                uint32_t two_k, uint32_t max_bits, uint32_t cap1, SortOut O)
@@ -1130,13 +1172,15 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(const typename Key
     const uint32_t y = blockIdx.x;
     if (y >= min(*G.count, GIANT_MAX)) return;
     const uint32_t g = G.list[y];
-    const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
+    const uint64_t start = b_start[g];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
-    if (P.left == 0) {                                         // one k-mer, abundance n (CountNumber is int32)
+    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
+    if (P.left == 0) {                                         // one k-mer, abundance = the total weight (CountNumber is int32)
         if (t == 0) {
-            const uint32_t c = n > 0x7FFFFFFFu ? 0x7FFFFFFFu : n;
-            put_count(O, start, c);                            // (the key is where it is: keysA[start])
+            const unsigned long long wsum = G.gor[4 * y + 2];
+            const uint32_t c = wsum > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)wsum;
+            keysA[start] = keysA[start] >> WEIGHT_BITS;         // the k-mer without its weight bits, where the gather expects it
+            put_count(O, start, c);
             atomicAdd(&O.histo[c >= O.histo_max ? O.histo_max : c], 1ULL);
             atomicAdd(&O.nd[g], 1u);
             if (!O.all_solid && (int32_t)c >= O.amin && (int32_t)c <= O.amax) atomicAdd(&O.ns[g], 1u);
@@ -1206,7 +1250,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_scatter(const typename 
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     if ((uint64_t)blockIdx.x * GIANT_CHUNK >= n) return;
-    const SplitPlan P = split_plan(G.gor[2 * y], G.gor[2 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
+    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
     if (P.left == 0) return;
     const uint32_t mask = (1u << P.bits) - 1u;
     const key_t* src = keysA + start; key_t* dst = keysB + start;
@@ -1535,6 +1579,9 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
         uint32_t bits = 0;
         while (bits < max_bits1 && bits < 2 * k && (np >> bits) > target) bits++;
+        // 8-byte keys: a small partition still gets enough sub-buckets for what is left of a key below the sub-bucket index (k-mer + weight bits) to fit a double's
+        // mantissa, so that the whole batch sorts with the f64-tagged network (one partition with fewer would switch the batch to the integer network: +30 %)
+        if (KW == 1 && getenv("GKC_MAX_SUB_BITS") == nullptr) while (bits < max_bits1 && 2 * k + WEIGHT_BITS - bits > 52) bits++;
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pidx[i] = n_sub;
@@ -1619,7 +1666,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     // --- the sort tiers, back to back: which sub-bucket goes where was decided by k_expand_count; no host round trip until the totals below
     uint32_t min_bits1 = 64; for (uint32_t i = 0; i < nb; i++) min_bits1 = std::min(min_bits1, pd[i].sub_bits);
     // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
-    const bool tag = KW == 1 && 2 * k - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
+    const bool tag = KW == 1 && 2 * k + WEIGHT_BITS - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
     constexpr bool FT = KW == 1;
     key_t* const keysA = (key_t*)B.keysA.p; key_t* const keysB = (key_t*)B.keysB.p;
     const uint64_t* const bs = (const uint64_t*)B.b_start.p; const uint32_t* const bn = (const uint32_t*)B.b_n.p; const uint8_t* const bc = (const uint8_t*)B.b_cons.p;
@@ -1664,9 +1711,9 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         const uint32_t bits_small = std::min<uint32_t>(deep_bits, DEEP_SMALL_BITS), bits_large = std::min<uint32_t>(deep_bits, (uint32_t)MAX_SUB_BITS);
         static std::once_flag once_deep; std::call_once(once_deep, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_deep_split<KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)8 << MAX_SUB_BITS)); });
         hipLaunchKernelGGL((k_deep_split<KW>), dim3(deep_grid), dim3(DEEP_THREADS), (size_t)8 << bits_small, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 2, q_out, cn + 0,
-                           (SortItem*)B.sitems.p, cn + 1, 2 * k, bits_small, 0u, DEEP_SMALL_N, CAP1, O);
+                           (SortItem*)B.sitems.p, cn + 1, 2 * k + WEIGHT_BITS, bits_small, 0u, DEEP_SMALL_N, CAP1, O);
         hipLaunchKernelGGL((k_deep_split<KW>), dim3(std::min(deep_grid, 512u)), dim3(DEEP_THREADS), (size_t)8 << bits_large, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 3, q_out, cn + 0,
-                           (SortItem*)B.sitems.p, cn + 1, 2 * k, bits_large, DEEP_SMALL_N, 0xFFFFFFFFu, CAP1, O);
+                           (SortItem*)B.sitems.p, cn + 1, 2 * k + WEIGHT_BITS, bits_large, DEEP_SMALL_N, 0xFFFFFFFFu, CAP1, O);
         const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((sort_cap + 3) / 4, 256 * 8));
         if (tag) hipLaunchKernelGGL((k_sort_items<KW, FT>), dim3(sgrid), dim3(SORT_THREADS), 0, cur_stream(c), keysA, (const key_t*)keysB, (const SortItem*)B.sitems.p, (const uint32_t*)(cn + 1), 0u, O);
         else hipLaunchKernelGGL((k_sort_items<KW, false>), dim3(sgrid), dim3(SORT_THREADS), 0, cur_stream(c), keysA, (const key_t*)keysB, (const SortItem*)B.sitems.p, (const uint32_t*)(cn + 1), 0u, O);
@@ -1675,17 +1722,17 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     };
     {   ScopedTimer tm(c, "split_levels");
         {   // giants first: their pieces join level 1's sort list / queue
-            const size_t gor_bytes = (size_t)GIANT_MAX * 16, tab_bytes = (size_t)GIANT_MAX * MAX_SUB * 4;
+            const size_t gor_bytes = (size_t)GIANT_MAX * 32, tab_bytes = (size_t)GIANT_MAX * MAX_SUB * 4;
             CB_TRY(c->ensure(B.giant, gor_bytes + 2 * tab_bytes));
             CB_HIP(hipMemsetAsync(B.giant.p, 0, gor_bytes + tab_bytes, cur_stream(c)));                    // OR words + histograms (the cursors are written by k_giant_plan)
             GiantTables G{ (unsigned long long*)B.giant.p, (uint32_t*)((uint8_t*)B.giant.p + gor_bytes), (uint32_t*)((uint8_t*)B.giant.p + gor_bytes + tab_bytes),
                            (const uint32_t*)T.giant_list, (const uint32_t*)T.giant_count };
             uint32_t* cn = counters_of(1);
             hipLaunchKernelGGL((k_giant_or<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, (uint8_t*)B.cnt8.p);
-            hipLaunchKernelGGL((k_giant_hist<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, 2 * k, deep_bits);
-            hipLaunchKernelGGL((k_giant_plan<KW>), dim3(GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, (DeepItem*)B.q[1].p, cn + 0,
-                               (SortItem*)B.sitems.p, cn + 1, 2 * k, deep_bits, CAP1, O);
-            hipLaunchKernelGGL((k_giant_scatter<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysB, G, bs, bn, bc, 2 * k, deep_bits);
+            hipLaunchKernelGGL((k_giant_hist<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, 2 * k + WEIGHT_BITS, deep_bits);
+            hipLaunchKernelGGL((k_giant_plan<KW>), dim3(GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), keysA, G, bs, bn, bc, (DeepItem*)B.q[1].p, cn + 0,
+                               (SortItem*)B.sitems.p, cn + 1, 2 * k + WEIGHT_BITS, deep_bits, CAP1, O);
+            hipLaunchKernelGGL((k_giant_scatter<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysB, G, bs, bn, bc, 2 * k + WEIGHT_BITS, deep_bits);
             CB_HIP(hipGetLastError());
         }
         for (int level = 1; level <= DEEP_FIXED; level++) CB_TRY(launch_deep(level));
