@@ -334,7 +334,7 @@ def main():
         step()
     sync()
     # per-kernel timers are HIP events on the context's own stream, accumulated inside the library
-    names = ["scan_count", "scan_emit", "scan_refine", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "split_levels", "compact",
+    names = ["scan_count", "scan_emit", "scan_refine", "dedupe", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "split_levels", "compact",
              "total_stage_a", "total_stage_b"]
     base = {nme: c.timing(nme) for nme in names}
     t0 = time.perf_counter()

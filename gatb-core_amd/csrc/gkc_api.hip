@@ -180,7 +180,7 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
     (void)hipStreamSynchronize(c->stream);
     clear_segments(c);
     { std::vector<uint32_t> passes; for (auto& kv : c->pass_outputs) passes.push_back(kv.first); for (uint32_t p : passes) free_pass_outputs(c, p); }
-    c->d_hint = 0;
+    c->d_hint = 0; c->dedupe_off = false; c->dedupe_in = 0; c->dedupe_out = 0;
     c->k = k; c->m = m; c->nb_partitions = nb_partitions; c->nb_passes = nb_passes; c->minimizer_type = minimizer_type;
     c->key_words = k <= 31 ? 1 : 2; c->record_bytes = k <= 31 ? 16 : 32;
     const uint32_t def = k <= 31 ? 28 : 60;                      // min((8*sizeof(Type)-8)/2, 255), Sequence2SuperKmer.hpp:147

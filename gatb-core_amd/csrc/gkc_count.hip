@@ -44,6 +44,7 @@ struct SegTable {          // device copy of the segment list
     const uint8_t* const* rec;      // [n_seg] arena pointers
     const uint64_t* rec_off;        // [n_seg][P+1]
     uint32_t n_seg, P;
+    const uint64_t* rec_end;        // nullptr, or (one segment only) [P]: one past the last record of the partition when its range is not full (deduplicated copy)
 };
 
 // nucleotide i of a device record (see RecT in gkc_device.hpp)
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     if (threadIdx.x == 0) { s_big.n = 0; s_wg.n = 0; s_split.n = 0; }
     __syncthreads();
     for (uint32_t s = 0; s < segs.n_seg; s++) {
-        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         const uint8_t* base = segs.rec[s];
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     __syncthreads();
     uint64_t* out = keys + pd.key_base;
     for (uint32_t s = 0; s < segs.n_seg; s++) {
-        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
         uint64_t r = r0 + threadIdx.x;
         ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
     __syncthreads();
     ulonglong2* out = reinterpret_cast<ulonglong2*>(keys + pd.key_base);              // one 16-byte key per element (x = low word, y = high word)
     for (uint32_t s = 0; s < segs.n_seg; s++) {
-        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);     // 32-byte records: two elements each
         uint64_t r = r0 + threadIdx.x;
         ulonglong2 nx0 = make_ulonglong2(0, 0), nx1 = nx0;
@@ -1551,13 +1552,232 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], (unsigned long long)cs); atomicAdd(&out[1], (unsigned long long)sa); }
 }
 
+// ------------------------------------------------------------------------------------------------ super-k-mer deduplication (k <= 31)
+// With sequencing coverage c a genomic super-k-mer is read ~c times, and every copy that lies whole and error-free inside its read is the SAME record (same
+// minimizer, same extent) up to the strand. Expanding, scattering and sorting its k-mers once with a weight instead of c times is less work for every later
+// kernel of Stage B (30x synthetic reads, 1 % substitutions: 1.66x fewer keys with weights up to 4; the copies cut by a read end or changed by an error stay
+// single). The reference has no such step (it counts k-mer by k-mer: PartitionsCommand.cpp:944-1128); the result is the same multiset of k-mers.
+//   k_dedupe_bin   one workgroup per partition (persistent, ticket): every record in its strand-canonical form (the smaller of the nucleotide string and its
+//                  reverse complement: the same canonical k-mers either way) is dropped into one of <= 4096 bins of the partition by a hash of its content
+//                  (LDS histogram -> scan -> LDS cursors), in a scratch arena laid out like the partition's records;
+//   k_dedupe_sort  one wave per bin (~64 records): 128-bit register sort, run lengths, and the bin is rewritten in place as one record per run and per
+//                  2^WEIGHT_BITS copies — (copies - 1) in the record's WEIGHT_BITS spare bits below its nucleotides — followed by empty records (nbK = 0: the
+//                  expansion kernels skip them). A bin beyond the wave's registers is left as it is (weights 1).
+constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = 48, DD_KPL_MAX = 4;     // <= 256 records per bin are deduplicated
+struct DedupeTables { uint32_t* bin_start; /* [nb][DD_BINS_MAX + 1] first record of the bin, relative to the partition's first record */ uint32_t* bin_log2; /* [nb] */ };
+
+__device__ __forceinline__ void dd_canonical(uint64_t& R0, uint64_t& R1, uint32_t k)
+{
+    const uint32_t nbk = (uint32_t)(R0 >> 56);
+    if (nbk == 0) return;
+    const uint32_t L = k + nbk - 1;                                   // nucleotides of the record (<= 58)
+    const uint64_t s_hi = (R0 << 8) | (R1 >> 56), s_lo = R1 << 8;     // the string, left-aligned in 128 bits
+    // reverse complement of all 64 positions, then the L real ones moved back to the left (the complemented padding falls off)
+    const u128 rc = (((u128)revcomp64(s_lo, 32)) << 64) | revcomp64(s_hi, 32);
+    const u128 rv = rc << (128 - 2 * L);
+    const u128 fw = (((u128)s_hi) << 64) | s_lo;
+    if (rv < fw) {
+        const uint64_t h = (uint64_t)(rv >> 64), l = (uint64_t)rv;
+        R0 = ((uint64_t)nbk << 56) | (h >> 8); R1 = (h << 56) | (l >> 8);
+    }
+}
+__device__ __forceinline__ uint32_t dd_hash(uint64_t R0, uint64_t R1) { return (uint32_t)(mix64(R0 ^ mix64(R1)) >> 32); }
+
+__global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k, const uint64_t* __restrict__ rec_base /* [nb + 1] */,
+                                                            ulonglong2* __restrict__ arena, DedupeTables D, uint32_t nb, uint32_t* __restrict__ ticket)
+{
+    __shared__ uint32_t s_cnt[DD_BINS_MAX];
+    __shared__ uint32_t s_wsum[DD_THREADS / 64];
+    __shared__ uint32_t s_item;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (;;) {
+        __syncthreads();
+        if (t == 0) s_item = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t bi = s_item;
+        if (bi >= nb) break;
+        const PartDesc pd = parts[bi];
+        const uint64_t base = rec_base[bi]; const uint32_t nrec = (uint32_t)(rec_base[bi + 1] - base);
+        uint32_t lg = 0; while (lg < 12 && (nrec >> lg) > (uint32_t)DD_BIN_TARGET) lg++;
+        const uint32_t nbin = 1u << lg, hsh = 32 - lg;
+        for (uint32_t i = t; i < nbin; i += DD_THREADS) s_cnt[i] = 0;
+        __syncthreads();
+        for (uint32_t s = 0; s < segs.n_seg; s++) {
+            const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+            const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+            for (uint64_t r = r0 + t; r < r1; r += DD_THREADS) {
+                ulonglong2 v = recs[r]; uint64_t R0 = v.x, R1 = v.y;
+                dd_canonical(R0, R1, k);
+                atomicAdd(&s_cnt[lg ? dd_hash(R0, R1) >> hsh : 0u], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan -> first record of every bin; the cursors replace the counts
+        const uint32_t per = (nbin + DD_THREADS - 1) / DD_THREADS, b = t * per;
+        uint32_t loc = 0;
+        for (uint32_t i = 0; i < per; i++) if (b + i < nbin) loc += s_cnt[b + i];
+        uint32_t x = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        uint32_t run = x - loc;
+        for (int w = 0; w < wave; w++) run += s_wsum[w];
+        uint32_t* bs = D.bin_start + (size_t)bi * (DD_BINS_MAX + 1);
+        for (uint32_t i = 0; i < per; i++) if (b + i < nbin) { const uint32_t c = s_cnt[b + i]; s_cnt[b + i] = run; bs[b + i] = run; run += c; }
+        if (t == 0) { bs[nbin] = nrec; D.bin_log2[bi] = lg; }
+        __syncthreads();
+        ulonglong2* out = arena + base;
+        for (uint32_t s = 0; s < segs.n_seg; s++) {
+            const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+            const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+            for (uint64_t r = r0 + t; r < r1; r += DD_THREADS) {
+                ulonglong2 v = recs[r]; uint64_t R0 = v.x, R1 = v.y;
+                dd_canonical(R0, R1, k);
+                const uint32_t slot = atomicAdd(&s_cnt[lg ? dd_hash(R0, R1) >> hsh : 0u], 1u);
+                out[slot] = make_ulonglong2(R0, R1);
+            }
+        }
+    }
+}
+
+// One bin: the records are brought into hash order by sorting 64-bit words [hash : 43][slot : 8] in the f64-tagged register network of k_wave_sort (equal records have
+// equal hashes and end up adjacent; two different records under one 43-bit hash merely stay unmerged), then fetched in that order through the wave's LDS window.
+// Returns the records the bin is rewritten as (run by run, weight in the spare bits) in out[]: the o-th output record of the lane's r-th run end is produced by emit().
+constexpr int DDS_THREADS = 1024, DDS_WAVES = DDS_THREADS / 64, DDS_SLOTS = 64 * DD_KPL_MAX;
+template <int KPL>
+__device__ __forceinline__ uint32_t dd_sort_bin(const ulonglong2 (&in)[DD_KPL_MAX] /* record r * 64 + lane of the bin */, const uint32_t n, const int lane,
+                                                ulonglong2* __restrict__ s_win /* [DDS_SLOTS] of this wave */,
+                                                ulonglong2 (&rec)[DD_KPL_MAX], uint32_t (&cnt)[DD_KPL_MAX], unsigned long long& in_keys)
+{
+    uint64_t key[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t i = r * 64 + lane;
+        if (i < n) { const ulonglong2 q = in[r]; s_win[i] = q; key[r] = TAG64 | ((((q.x ^ (q.y * 0x9E3779B97F4A7C15ULL)) * 0xBF58476D1CE4E5B9ULL) >> 21) << 8) | (uint64_t)i; }   // 43 hash bits, 8 slot bits
+        else key[r] = TAG64 | TAG64_MANT;
+    }
+    bitonic_wave<1, KPL, true>(key, lane);
+    // the records in sorted order (rank e = lane * KPL + r), run ends by full comparison with the next record
+    u128 v[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; r++) { const uint32_t e = (uint32_t)lane * KPL + r; rec[r] = make_ulonglong2(0, 0); if (e < n) rec[r] = s_win[(uint32_t)key[r] & 255u]; v[r] = (((u128)rec[r].x) << 64) | rec[r].y; }
+    const u128 next_first = Shfl<2>::down(v[0]);
+    const uint32_t lane0 = (uint32_t)lane * KPL;
+    uint32_t tailm = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) {
+        const uint32_t e = lane0 + r;
+        const u128 nx = r < KPL - 1 ? v[r + 1] : next_first;
+        tailm |= (uint32_t)(e < n && (e == n - 1 || v[r] != nx)) << r;
+    }
+    int lt = tailm ? (int)(lane0 + 31 - __clz((int)tailm)) : -1;          // rank of the lane's last run end; carried by a max-scan
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(lt, d, 64); if (lane >= d) lt = y > lt ? y : lt; }
+    int prev = __shfl_up(lt, 1, 64); if (lane == 0) prev = -1;
+    constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
+    uint32_t nout = 0;
+#pragma unroll
+    for (int r = 0; r < DD_KPL_MAX; r++) cnt[r] = 0;
+#pragma unroll
+    for (int r = 0; r < KPL; r++) if ((tailm >> r) & 1) {
+        const int e = (int)lane0 + r; cnt[r] = (uint32_t)(e - prev); prev = e; nout += (cnt[r] + WCAP - 1) / WCAP;
+        in_keys += (unsigned long long)cnt[r] * (uint32_t)(rec[r].x >> 56);
+    }
+    return nout;
+}
+// one workgroup per partition (persistent, ticket): its waves take the bins in order; what a bin is rewritten as goes right behind the output of the bin before it
+// (a chain through LDS: the wave waits for its predecessor's end, never for more), so the partition's deduplicated records end up contiguous at the front of its
+// range — the expansion kernels then walk 0.6x the records instead of stepping over holes. In place: everything left of a bin's output has been read already.
+__global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(ulonglong2* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
+                                                             uint64_t* __restrict__ rec_end /* [P] */, uint32_t nb, uint32_t* __restrict__ ticket,
+                                                             unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */)
+{
+    __shared__ ulonglong2 s_win[DDS_WAVES][DDS_SLOTS];      // 64 KB
+    __shared__ volatile uint32_t s_next, s_pos;             // bin whose output may be placed now; where
+    __shared__ uint32_t s_item;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long ik = 0, ok = 0;
+    for (;;) {
+        __syncthreads();
+        if (t == 0) { s_item = atomicAdd(ticket, 1u); s_next = 0; s_pos = 0; }
+        __syncthreads();
+        const uint32_t bi = s_item;
+        if (bi >= nb) break;
+        const uint32_t nbin = 1u << D.bin_log2[bi];
+        const uint32_t* bs = D.bin_start + (size_t)bi * (DD_BINS_MAX + 1);
+        ulonglong2* part = arena + rec_base[bi];
+        // the next bin of the wave is in flight (registers) while this one is sorted: one bin at a time would expose the load latency 256 times per partition
+        ulonglong2 nx[DD_KPL_MAX]; uint32_t nx_s0 = 0, nx_n = 0;
+        auto fetch = [&](uint32_t bin_) {
+            nx_s0 = 0; nx_n = 0;
+            if (bin_ < nbin) {
+                nx_s0 = bs[bin_]; nx_n = bs[bin_ + 1] - nx_s0;
+                if (nx_n >= 2 && nx_n <= (uint32_t)DDS_SLOTS) {
+#pragma unroll
+                    for (int r = 0; r < DD_KPL_MAX; r++) { const uint32_t i = r * 64 + lane; nx[r] = i < nx_n ? part[nx_s0 + i] : make_ulonglong2(0, 0); }
+                }
+            }
+        };
+        fetch(wave);
+        for (uint32_t bin = wave; bin < nbin; bin += DDS_WAVES) {
+            const uint32_t s0 = nx_s0, n = nx_n;
+            ulonglong2 in[DD_KPL_MAX];
+#pragma unroll
+            for (int r = 0; r < DD_KPL_MAX; r++) in[r] = nx[r];
+            fetch(bin + DDS_WAVES);
+            ulonglong2 rec[DD_KPL_MAX]; uint32_t cnt[DD_KPL_MAX];
+            uint32_t nout = 0; int kpl = 0;                                   // kpl 0: the bin is moved as it is
+            if (n >= 2 && n <= 64) { nout = dd_sort_bin<1>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 1; }
+            else if (n > 64 && n <= 128) { nout = dd_sort_bin<2>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 2; }
+            else if (n > 128 && n <= (uint32_t)DDS_SLOTS) { nout = dd_sort_bin<DD_KPL_MAX>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = DD_KPL_MAX; }
+            uint32_t x = nout;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+            const uint32_t total = kpl ? (uint32_t)__builtin_amdgcn_readlane((int)x, 63) : n;
+            // my turn? (the bins of a partition are handed to the waves in order: the wave of bin - 1 is another wave of this workgroup)
+            while (s_next != bin) __builtin_amdgcn_s_sleep(1);
+            const uint32_t pos0 = s_pos;
+            if (!kpl && n) {
+                // one record, or more than the wave's registers hold (one record copied thousands of times: low-complexity reads): moved left, chunk by chunk,
+                // BEFORE the next bin may place its output (which may reach into this bin's old range)
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                    ulonglong2 q = make_ulonglong2(0, 0);
+                    if (i0 + lane < n) q = part[s0 + i0 + lane];
+                    if (i0 + lane < n) part[pos0 + i0 + lane] = q;
+                }
+            }
+            __threadfence_block();
+            if (lane == 0) { s_pos = pos0 + total; __threadfence_block(); s_next = bin + 1; }
+            if (kpl) {
+                constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
+                uint32_t pos = pos0 + x - nout;
+#pragma unroll
+                for (int r = 0; r < DD_KPL_MAX; r++) if (cnt[r]) {
+                    const uint32_t nbk = (uint32_t)(rec[r].x >> 56);
+                    for (uint32_t c = cnt[r]; c; ) {
+                        const uint32_t w = c < WCAP ? c : WCAP;
+                        part[pos++] = make_ulonglong2(rec[r].x, rec[r].y | (unsigned long long)(w - 1));
+                        ok += nbk; c -= w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 0) rec_end[parts[bi].part] = rec_base[bi] + s_pos;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ik += __shfl_down(ik, d, 64); ok += __shfl_down(ok, d, 64); }
+    if (lane == 0 && ik) { atomicAdd(&totals[0], ik); atomicAdd(&totals[1], ok); }
+}
+
 // ------------------------------------------------------------------------------------------------ host orchestration
 constexpr uint32_t PART_ALIGN = 256;            // a partition's slot range starts on a multiple of this many slots
 constexpr int DEEP_FIXED = 4;                   // split levels launched unconditionally (a level with an empty queue returns at once); more only if the last one left work
 constexpr int DEEP_COUNTERS = 8;                // per-level counter triples (next level's queue length, sort list length, item ticket), used cyclically
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, cnt8, b_start, b_n, b_cons, l_big, l_wg, l_split, misc, nd, ns, off_d, off_s, chunk, q[2], sitems, giant, glist, rbase, rroot, rcnt, pidx, ptot, order;
-    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start, &b_n, &b_cons, &l_big, &l_wg, &l_split, &misc, &nd, &ns, &off_d, &off_s, &chunk, &q[0], &q[1], &sitems, &giant, &glist, &rbase, &rroot, &rcnt, &pidx, &ptot, &order };
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start, b_n, b_cons, l_big, l_wg, l_split, misc, nd, ns, off_d, off_s, chunk, q[2], sitems, giant, glist, rbase, rroot, rcnt, dd_arena, dd_base, dd_bins, dd_lg, dd_off, dd_ptr, dd_end, pidx, ptot, order;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start, &b_n, &b_cons, &l_big, &l_wg, &l_split, &misc, &nd, &ns, &off_d, &off_s, &chunk, &q[0], &q[1], &sitems, &giant, &glist, &rbase, &rroot, &rcnt, &dd_arena, &dd_base, &dd_bins, &dd_lg, &dd_off, &dd_ptr, &dd_end, &pidx, &ptot, &order };
                      for (DevBuf* d : all) d->release(); }
 };
 
@@ -1635,9 +1855,47 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     CB_TRY(c->ensure(B.glist, GIANT_MAX * 4));
     T.giant_list = (uint32_t*)B.glist.p; T.giant_count = misc + 3;
 
+    // Identical super-k-mer records of a partition are merged first (8-byte keys; see k_dedupe_*): the expansion then reads the batch's own deduplicated copy
+    SegTable segs_b = segs;
+    static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
+    const bool dedupe = KW == 1 && RW == 2 && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
+    if constexpr (KW == 1 && RW == 2) if (dedupe) {
+        ScopedTimer tm(c, "dedupe");
+        unsigned long long* const dd_totals = reinterpret_cast<unsigned long long*>(misc + 40);     // k-mers into / out of the deduplication of this batch
+        const uint32_t Pn = segs.P, p_first = batch_parts.front(), p_last = batch_parts.back();
+        std::vector<uint64_t> base(nb + 1, 0), off((size_t)Pn + 1, 0);
+        {   uint64_t run = 0; uint32_t i = 0;
+            for (uint32_t p = 0; p <= Pn; p++) {
+                off[p] = run;
+                if (p >= p_first && p <= p_last && i < nb && batch_parts[i] == p) {
+                    uint64_t n = 0; for (const Segment& sg : c->segments) n += sg.rec_off[p + 1] - sg.rec_off[p];
+                    base[i] = run; run += n; i++; base[i] = run;
+                }
+            }
+        }
+        const uint64_t total_recs = base[nb];
+        bool fits = total_recs > 0; for (uint32_t i = 0; i < nb; i++) fits = fits && (base[i + 1] - base[i]) < (1ULL << 31);
+        if (fits) {
+            CB_TRY(c->ensure(B.dd_arena, (size_t)total_recs * 16)); CB_TRY(c->ensure(B.dd_base, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.dd_bins, (size_t)nb * (DD_BINS_MAX + 1) * 4));
+            CB_TRY(c->ensure(B.dd_lg, (size_t)nb * 4)); CB_TRY(c->ensure(B.dd_off, ((size_t)Pn + 1) * 8)); CB_TRY(c->ensure(B.dd_ptr, 8));
+            const void* arena_p = B.dd_arena.p;
+            CB_HIP(hipMemcpyAsync(B.dd_base.p, base.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
+            CB_HIP(hipMemcpyAsync(B.dd_off.p, off.data(), ((size_t)Pn + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
+            CB_HIP(hipMemcpyAsync(B.dd_ptr.p, &arena_p, 8, hipMemcpyHostToDevice, cur_stream(c)));
+            DedupeTables DT{ (uint32_t*)B.dd_bins.p, (uint32_t*)B.dd_lg.p };
+            hipLaunchKernelGGL(k_dedupe_bin, dim3(std::min(nb, 512u)), dim3(DD_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k, (const uint64_t*)B.dd_base.p,
+                               (ulonglong2*)B.dd_arena.p, DT, nb, misc + 5);
+            CB_TRY(c->ensure(B.dd_end, (size_t)Pn * 8));
+            hipLaunchKernelGGL(k_dedupe_sort, dim3(std::min(nb, 512u)), dim3(DDS_THREADS), 0, cur_stream(c), (ulonglong2*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
+                               (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals);
+            CB_HIP(hipGetLastError());
+            CB_HIP(hipStreamSynchronize(cur_stream(c)));               // (the host vectors above are the sources of the copies)
+            segs_b.rec = (const uint8_t* const*)B.dd_ptr.p; segs_b.rec_off = (const uint64_t*)B.dd_off.p; segs_b.n_seg = 1; segs_b.rec_end = (const uint64_t*)B.dd_end.p;
+        }
+    }
     {   ScopedTimer tm(c, "expand_count");
         static const uint32_t cwgs_env = getenv("GKC_COUNT_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_COUNT_WGS"))) : 0u;
-        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nb, cwgs_env) : nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nb, cwgs_env) : nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
                            (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nb, misc + 7);
         CB_HIP(hipGetLastError());
     }
@@ -1649,7 +1907,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         if constexpr (KW == 1) {
             const size_t lds = (size_t)MAX_SUB * 12;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
                                (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6);
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
@@ -1764,6 +2022,13 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             CB_TRY(launch_deep(level));
         }
         { std::lock_guard<std::mutex> lk(c->mu); c->stats_now().oversize_buckets += h_misc[2]; }
+        if (dedupe) {                                                    // does merging identical records pay on this input? (it costs ~13 % of Stage B)
+            unsigned long long dd[2]; memcpy(dd, h_misc + 40, 16);
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->dedupe_in += dd[0]; c->dedupe_out += dd[1];
+            if (dedupe_env != 1 && c->dedupe_in > 100000000ULL && (double)c->dedupe_out > 0.85 * (double)c->dedupe_in) c->dedupe_off = true;
+            if (getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc] dedupe: %llu k-mers in the deduplicated bins -> %llu weighted keys (%.2fx)\n", dd[0], dd[1], dd[1] ? (double)dd[0] / (double)dd[1] : 0.0);
+        }
         if (getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc] batch of %u partitions, %llu sub-buckets: %u in the double-size tier, %u in the workgroup tier, %u split (%d levels)\n",
                                            nb, (unsigned long long)n_sub, h_misc[0], h_misc[1], h_misc[2], level);
         total_solid = ptot[2 * nb + 1];

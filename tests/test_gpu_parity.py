@@ -677,7 +677,7 @@ def test_exact_repartitor_sample(gkc, k, m, freq):
         assert used == eused and np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(d, ed), (thr, used, eused)
 
 
-@pytest.mark.parametrize("switch", ["GKC_NO_F64", "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0", "GKC_DEEP_BITS=2", "GKC_WG_MAX=1024", "GKC_MAX_SUB_BITS=1", "GKC_MAX_SUB_BITS=6"])
+@pytest.mark.parametrize("switch", ["GKC_NO_F64", "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0", "GKC_DEEP_BITS=2", "GKC_WG_MAX=1024", "GKC_DEDUPE=0", "GKC_DEDUPE=1", "GKC_MAX_SUB_BITS=1", "GKC_MAX_SUB_BITS=6"])
 def test_alternative_kernel_paths_stay_bit_exact(gkc, switch):
     """A/B switches that select another HIP code path of the same library (integer instead of f64-tagged compare-exchange; the Stage A fallbacks: emit pass
     that recomputes instead of reading descriptors, global-atomic cursors instead of LDS ones; partitions in batch order; split levels of 2 bits each, which
