@@ -73,7 +73,7 @@ def cpu_baseline(c, k, m, parts, rep, n_reads=10_000_000):
             "single_thread": single}
 
 
-def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct):
+def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct, keys_moved=None):
     """algorithmic bytes of every timed kernel group (SURVEY §8d per-unit figures x the units of one step) -> the dominant one's roofline entry.
     ktime: {name: (ms, launches)} over `steps` steps; keys / distinct: this rank's share."""
     rec_bytes = 16 if k <= 31 else 32; key_bytes = 8 if k <= 31 else 16
@@ -85,6 +85,8 @@ def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct):
         "bucket_sort": keys * key_bytes + distinct * (key_bytes + 1),
         "compact": distinct * (key_bytes + 1 + rec_bytes),             # gather: key + abundance byte in, Count record out
     }
+    if "dedupe" in ktime and ktime["dedupe"][0] > 0:
+        alg["dedupe"] = st["nb_superkmers"] * rec_bytes * 3.0                # records read twice (bin count, bin scatter), written once, re-read and rewritten <= once by the sort
     dom = max(alg, key=lambda n_: ktime[n_][0])
     dom_ms = ktime[dom][0] / max(1, steps)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -417,7 +419,22 @@ def main():
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
                          "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))},
         }
+        # Stage B merges identical super-k-mer records before the expansion: every k-mer is still counted (the algorithmic bytes above are per k-mer of the
+        # input), but the kernels after it move fewer keys. Both figures are reported: `frac` on the algorithmic bytes, `frac_on_moved_bytes` on what
+        # the dominant kernel really reads and writes
+        dd_in, dd_out = st.get("dedupe_kmers_in", 0), st.get("dedupe_keys_out", 0)          # of the last step (the statistics are per pass)
+        keys_written = max(0.0, keys_per_rank - (dd_in - dd_out) / world) if dd_in else keys_per_rank
+        out["roofline"]["dedupe"] = {"kmers_in": dd_in, "weighted_keys_out": dd_out, "keys_per_step_after": keys_written, "ratio": keys_per_rank / keys_written if keys_written else None}
+        if dom in ("expand_scatter", "bucket_sort") and dd_in:
+            shrink = keys_written / keys_per_rank
+            moved = {"expand_scatter": (st["nb_superkmers"] * 16 if k <= 31 else st["nb_superkmers"] * 32) * shrink + keys_written * key_bytes,
+                     "bucket_sort": keys_written * key_bytes + (distinct / world) * (key_bytes + 1)}[dom]
+            out["roofline"]["moved_bytes_per_launch"] = moved / launches_per_step
+            out["roofline"]["frac_on_moved_bytes"] = moved / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_ms > 0 else None
+        else:
+            keys_written = keys_per_rank
         if dom == "expand_scatter" and k <= 31:
+            keys_per_rank = keys_written                       # the 16-byte-store ceiling below is about the keys that are really written
             # what actually bounds this kernel: the rate of scattered 16-byte stores with 8192 open cursors per workgroup measured on this chip
             # (tools/scatter_bench -> profiles/r02_scatter_store_calibration.txt: 984 GB/s of useful bytes; requests, not bytes, are the limit)
             key_gbs = keys_per_rank * key_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

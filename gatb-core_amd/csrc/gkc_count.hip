@@ -2026,6 +2026,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             unsigned long long dd[2]; memcpy(dd, h_misc + 40, 16);
             std::lock_guard<std::mutex> lk(c->mu);
             c->dedupe_in += dd[0]; c->dedupe_out += dd[1];
+            c->stats_now().dedupe_kmers_in += dd[0]; c->stats_now().dedupe_keys_out += dd[1];
             if (dedupe_env != 1 && c->dedupe_in > 100000000ULL && (double)c->dedupe_out > 0.85 * (double)c->dedupe_in) c->dedupe_off = true;
             if (getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc] dedupe: %llu k-mers in the deduplicated bins -> %llu weighted keys (%.2fx)\n", dd[0], dd[1], dd[1] ? (double)dd[0] / (double)dd[1] : 0.0);
         }
@@ -2097,7 +2098,7 @@ int gkc_count_pass(gkc_ctx* c)
         auto it = c->pass_outputs.find(c->pass);
         if (it != c->pass_outputs.end()) { for (void* p : it->second) c->dfree(p); it->second.clear(); }
         for (uint32_t p = 0; p < Pn; p++) c->datasets[(size_t)c->pass * Pn + p] = Dataset();
-        gkc_stats& S = c->stats_now(); S.kmers_nb_distinct = 0; S.kmers_nb_solid = 0; S.oversize_buckets = 0;
+        gkc_stats& S = c->stats_now(); S.kmers_nb_distinct = 0; S.kmers_nb_solid = 0; S.oversize_buckets = 0; S.dedupe_kmers_in = 0; S.dedupe_keys_out = 0;
         // ... and the host sink starts over as well: the failed attempt's copies are drained, its records are overwritten
         if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);

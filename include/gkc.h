@@ -139,7 +139,9 @@ typedef struct gkc_stats {
     uint64_t nb_bases;            /* pass 0 only                                          */
     uint64_t superkmer_bytes;     /* bytes of the device record buckets                   */
     uint64_t oversize_buckets;    /* sub-buckets that took the global-memory sort path    */
-    uint64_t reserved[7];
+    uint64_t dedupe_kmers_in;     /* k-mers of the record bins that were deduplicated before the expansion (Stage B, k <= 31) ... */
+    uint64_t dedupe_keys_out;     /* ... and the weighted keys they became (0 / 0: the step did not run)                          */
+    uint64_t reserved[5];
 } gkc_stats;
 int gkc_get_stats(gkc_ctx* ctx, gkc_stats* out);
 
