@@ -1563,28 +1563,64 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 //   k_dedupe_sort  one wave per bin (~64 records): 128-bit register sort, run lengths, and the bin is rewritten in place as one record per run and per
 //                  2^WEIGHT_BITS copies — (copies - 1) in the record's WEIGHT_BITS spare bits below its nucleotides — followed by empty records (nbK = 0: the
 //                  expansion kernels skip them). A bin beyond the wave's registers is left as it is (weights 1).
-constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = 48, DD_KPL_MAX = 4;     // <= 256 records per bin are deduplicated
+constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = 48;
+template <int RW> struct DDCap { static constexpr int KPL_MAX = RW == 2 ? 4 : 2; static constexpr int SLOTS = 64 * KPL_MAX; };   // <= 256 (16-byte) / 128 (32-byte) records per bin are deduplicated
 struct DedupeTables { uint32_t* bin_start; /* [nb][DD_BINS_MAX + 1] first record of the bin, relative to the partition's first record */ uint32_t* bin_log2; /* [nb] */ };
+template <int RW> struct DRec { uint64_t w[RW]; };
+template <int RW> __device__ __forceinline__ DRec<RW> dd_load(const uint64_t* p) { DRec<RW> r;
+#pragma unroll
+    for (int i = 0; i < RW; i += 2) { const ulonglong2 q = *reinterpret_cast<const ulonglong2*>(p + i); r.w[i] = q.x; r.w[i + 1] = q.y; } return r; }
+template <int RW> __device__ __forceinline__ void dd_store(uint64_t* p, const DRec<RW>& r) {
+#pragma unroll
+    for (int i = 0; i < RW; i += 2) *reinterpret_cast<ulonglong2*>(p + i) = make_ulonglong2(r.w[i], r.w[i + 1]); }
+template <int RW> __device__ __forceinline__ bool dd_equal(const DRec<RW>& a, const DRec<RW>& b) { bool e = true;
+#pragma unroll
+    for (int i = 0; i < RW; i++) e = e && a.w[i] == b.w[i]; return e; }
 
-__device__ __forceinline__ void dd_canonical(uint64_t& R0, uint64_t& R1, uint32_t k)
+// strand-canonical form: the smaller of the record's nucleotide string and its reverse complement (same nbK)
+__device__ __forceinline__ void dd_canonical(DRec<2>& R, uint32_t k)
 {
-    const uint32_t nbk = (uint32_t)(R0 >> 56);
+    const uint32_t nbk = (uint32_t)(R.w[0] >> 56);
     if (nbk == 0) return;
     const uint32_t L = k + nbk - 1;                                   // nucleotides of the record (<= 58)
-    const uint64_t s_hi = (R0 << 8) | (R1 >> 56), s_lo = R1 << 8;     // the string, left-aligned in 128 bits
+    const uint64_t s_hi = (R.w[0] << 8) | (R.w[1] >> 56), s_lo = R.w[1] << 8;     // the string, left-aligned in 128 bits
     // reverse complement of all 64 positions, then the L real ones moved back to the left (the complemented padding falls off)
     const u128 rc = (((u128)revcomp64(s_lo, 32)) << 64) | revcomp64(s_hi, 32);
     const u128 rv = rc << (128 - 2 * L);
     const u128 fw = (((u128)s_hi) << 64) | s_lo;
     if (rv < fw) {
         const uint64_t h = (uint64_t)(rv >> 64), l = (uint64_t)rv;
-        R0 = ((uint64_t)nbk << 56) | (h >> 8); R1 = (h << 56) | (l >> 8);
+        R.w[0] = ((uint64_t)nbk << 56) | (h >> 8); R.w[1] = (h << 56) | (l >> 8);
     }
 }
-__device__ __forceinline__ uint32_t dd_hash(uint64_t R0, uint64_t R1) { return (uint32_t)(mix64(R0 ^ mix64(R1)) >> 32); }
+__device__ __forceinline__ void dd_canonical(DRec<4>& R, uint32_t k)
+{
+    const uint32_t nbk = (uint32_t)(R.w[0] >> 56);
+    if (nbk == 0) return;
+    const uint32_t L = k + nbk - 1;                                   // nucleotides of the record (<= 122)
+    const uint64_t S0 = (R.w[0] << 8) | (R.w[1] >> 56), S1 = (R.w[1] << 8) | (R.w[2] >> 56), S2 = (R.w[2] << 8) | (R.w[3] >> 56), S3 = R.w[3] << 8;
+    const u128 fh = (((u128)S0) << 64) | S1, fl = (((u128)S2) << 64) | S3;                     // the string, left-aligned in 256 bits
+    const u128 rh = (((u128)revcomp64(S3, 32)) << 64) | revcomp64(S2, 32), rl = (((u128)revcomp64(S1, 32)) << 64) | revcomp64(S0, 32);   // all 128 positions reversed
+    const uint32_t sh = 256 - 2 * L;                                  // in [12, 192]
+    u128 vh, vl;
+    if (sh >= 128) { vh = sh == 128 ? rl : (rl << (sh - 128)); vl = 0; }
+    else { vh = (rh << sh) | (rl >> (128 - sh)); vl = rl << sh; }
+    if (vh < fh || (vh == fh && vl < fl)) {
+        const uint64_t a0 = (uint64_t)(vh >> 64), a1 = (uint64_t)vh, a2 = (uint64_t)(vl >> 64), a3 = (uint64_t)vl;
+        R.w[0] = ((uint64_t)nbk << 56) | (a0 >> 8); R.w[1] = (a0 << 56) | (a1 >> 8); R.w[2] = (a1 << 56) | (a2 >> 8); R.w[3] = (a2 << 56) | (a3 >> 8);
+    }
+}
+template <int RW> __device__ __forceinline__ uint64_t dd_hash64(const DRec<RW>& R)
+{
+    uint64_t h = R.w[0];
+#pragma unroll
+    for (int i = 1; i < RW; i++) h = (h ^ (R.w[i] * 0x9E3779B97F4A7C15ULL)) * 0xBF58476D1CE4E5B9ULL;
+    return h ^ (h >> 29);
+}
 
+template <int RW>
 __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k, const uint64_t* __restrict__ rec_base /* [nb + 1] */,
-                                                            ulonglong2* __restrict__ arena, DedupeTables D, uint32_t nb, uint32_t* __restrict__ ticket)
+                                                            uint64_t* __restrict__ arena, DedupeTables D, uint32_t nb, uint32_t* __restrict__ ticket)
 {
     __shared__ uint32_t s_cnt[DD_BINS_MAX];
     __shared__ uint32_t s_wsum[DD_THREADS / 64];
@@ -1599,16 +1635,16 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
         const PartDesc pd = parts[bi];
         const uint64_t base = rec_base[bi]; const uint32_t nrec = (uint32_t)(rec_base[bi + 1] - base);
         uint32_t lg = 0; while (lg < 12 && (nrec >> lg) > (uint32_t)DD_BIN_TARGET) lg++;
-        const uint32_t nbin = 1u << lg, hsh = 32 - lg;
+        const uint32_t nbin = 1u << lg, hsh = 64 - lg;
         for (uint32_t i = t; i < nbin; i += DD_THREADS) s_cnt[i] = 0;
         __syncthreads();
         for (uint32_t s = 0; s < segs.n_seg; s++) {
-            const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
-            const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+            const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+            const uint64_t* recs = reinterpret_cast<const uint64_t*>(segs.rec[s]);
             for (uint64_t r = r0 + t; r < r1; r += DD_THREADS) {
-                ulonglong2 v = recs[r]; uint64_t R0 = v.x, R1 = v.y;
-                dd_canonical(R0, R1, k);
-                atomicAdd(&s_cnt[lg ? dd_hash(R0, R1) >> hsh : 0u], 1u);
+                DRec<RW> R = dd_load<RW>(recs + r * RW);
+                dd_canonical(R, k);
+                atomicAdd(&s_cnt[lg ? (uint32_t)(dd_hash64<RW>(R) >> hsh) : 0u], 1u);
             }
         }
         __syncthreads();
@@ -1627,15 +1663,15 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
         for (uint32_t i = 0; i < per; i++) if (b + i < nbin) { const uint32_t c = s_cnt[b + i]; s_cnt[b + i] = run; bs[b + i] = run; run += c; }
         if (t == 0) { bs[nbin] = nrec; D.bin_log2[bi] = lg; }
         __syncthreads();
-        ulonglong2* out = arena + base;
+        uint64_t* out = arena + base * RW;
         for (uint32_t s = 0; s < segs.n_seg; s++) {
-            const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
-            const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+            const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+            const uint64_t* recs = reinterpret_cast<const uint64_t*>(segs.rec[s]);
             for (uint64_t r = r0 + t; r < r1; r += DD_THREADS) {
-                ulonglong2 v = recs[r]; uint64_t R0 = v.x, R1 = v.y;
-                dd_canonical(R0, R1, k);
-                const uint32_t slot = atomicAdd(&s_cnt[lg ? dd_hash(R0, R1) >> hsh : 0u], 1u);
-                out[slot] = make_ulonglong2(R0, R1);
+                DRec<RW> R = dd_load<RW>(recs + r * RW);
+                dd_canonical(R, k);
+                const uint32_t slot = atomicAdd(&s_cnt[lg ? (uint32_t)(dd_hash64<RW>(R) >> hsh) : 0u], 1u);
+                dd_store<RW>(out + (uint64_t)slot * RW, R);
             }
         }
     }
@@ -1643,33 +1679,38 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
 
 // One bin: the records are brought into hash order by sorting 64-bit words [hash : 43][slot : 8] in the f64-tagged register network of k_wave_sort (equal records have
 // equal hashes and end up adjacent; two different records under one 43-bit hash merely stay unmerged), then fetched in that order through the wave's LDS window.
-// Returns the records the bin is rewritten as (run by run, weight in the spare bits) in out[]: the o-th output record of the lane's r-th run end is produced by emit().
-constexpr int DDS_THREADS = 1024, DDS_WAVES = DDS_THREADS / 64, DDS_SLOTS = 64 * DD_KPL_MAX;
-template <int KPL>
-__device__ __forceinline__ uint32_t dd_sort_bin(const ulonglong2 (&in)[DD_KPL_MAX] /* record r * 64 + lane of the bin */, const uint32_t n, const int lane,
-                                                ulonglong2* __restrict__ s_win /* [DDS_SLOTS] of this wave */,
-                                                ulonglong2 (&rec)[DD_KPL_MAX], uint32_t (&cnt)[DD_KPL_MAX], unsigned long long& in_keys)
+constexpr int DDS_THREADS = 1024, DDS_WAVES = DDS_THREADS / 64;
+template <int RW, int KPL>
+__device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::KPL_MAX] /* record r * 64 + lane of the bin */, const uint32_t n, const int lane,
+                                                uint64_t* __restrict__ s_win /* [SLOTS][RW] of this wave */,
+                                                DRec<RW> (&rec)[DDCap<RW>::KPL_MAX], uint32_t (&cnt)[DDCap<RW>::KPL_MAX], unsigned long long& in_keys)
 {
+    constexpr int KM = DDCap<RW>::KPL_MAX;
     uint64_t key[KPL];
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const uint32_t i = r * 64 + lane;
-        if (i < n) { const ulonglong2 q = in[r]; s_win[i] = q; key[r] = TAG64 | ((((q.x ^ (q.y * 0x9E3779B97F4A7C15ULL)) * 0xBF58476D1CE4E5B9ULL) >> 21) << 8) | (uint64_t)i; }   // 43 hash bits, 8 slot bits
+        if (i < n) { dd_store<RW>(s_win + (size_t)i * RW, in[r]); key[r] = TAG64 | ((dd_hash64<RW>(in[r]) >> 21) << 8) | (uint64_t)i; }   // 43 hash bits, 8 slot bits
         else key[r] = TAG64 | TAG64_MANT;
     }
     bitonic_wave<1, KPL, true>(key, lane);
     // the records in sorted order (rank e = lane * KPL + r), run ends by full comparison with the next record
-    u128 v[KPL];
 #pragma unroll
-    for (int r = 0; r < KPL; r++) { const uint32_t e = (uint32_t)lane * KPL + r; rec[r] = make_ulonglong2(0, 0); if (e < n) rec[r] = s_win[(uint32_t)key[r] & 255u]; v[r] = (((u128)rec[r].x) << 64) | rec[r].y; }
-    const u128 next_first = Shfl<2>::down(v[0]);
+    for (int r = 0; r < KM; r++) { cnt[r] = 0;
+#pragma unroll
+        for (int i = 0; i < RW; i++) rec[r].w[i] = 0; }
+#pragma unroll
+    for (int r = 0; r < KPL; r++) { const uint32_t e = (uint32_t)lane * KPL + r; if (e < n) rec[r] = dd_load<RW>(s_win + (size_t)((uint32_t)key[r] & 255u) * RW); }
+    DRec<RW> next_first;
+#pragma unroll
+    for (int i = 0; i < RW; i++) next_first.w[i] = (uint64_t)__shfl_down((unsigned long long)rec[0].w[i], 1, 64);
     const uint32_t lane0 = (uint32_t)lane * KPL;
     uint32_t tailm = 0;
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const uint32_t e = lane0 + r;
-        const u128 nx = r < KPL - 1 ? v[r + 1] : next_first;
-        tailm |= (uint32_t)(e < n && (e == n - 1 || v[r] != nx)) << r;
+        const bool same = r < KPL - 1 ? dd_equal<RW>(rec[r], rec[r + 1 < KM ? r + 1 : r]) : dd_equal<RW>(rec[r], next_first);
+        tailm |= (uint32_t)(e < n && (e == n - 1 || !same)) << r;
     }
     int lt = tailm ? (int)(lane0 + 31 - __clz((int)tailm)) : -1;          // rank of the lane's last run end; carried by a max-scan
 #pragma unroll
@@ -1678,22 +1719,22 @@ __device__ __forceinline__ uint32_t dd_sort_bin(const ulonglong2 (&in)[DD_KPL_MA
     constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
     uint32_t nout = 0;
 #pragma unroll
-    for (int r = 0; r < DD_KPL_MAX; r++) cnt[r] = 0;
-#pragma unroll
     for (int r = 0; r < KPL; r++) if ((tailm >> r) & 1) {
         const int e = (int)lane0 + r; cnt[r] = (uint32_t)(e - prev); prev = e; nout += (cnt[r] + WCAP - 1) / WCAP;
-        in_keys += (unsigned long long)cnt[r] * (uint32_t)(rec[r].x >> 56);
+        in_keys += (unsigned long long)cnt[r] * (uint32_t)(rec[r].w[0] >> 56);
     }
     return nout;
 }
 // one workgroup per partition (persistent, ticket): its waves take the bins in order; what a bin is rewritten as goes right behind the output of the bin before it
 // (a chain through LDS: the wave waits for its predecessor's end, never for more), so the partition's deduplicated records end up contiguous at the front of its
 // range — the expansion kernels then walk 0.6x the records instead of stepping over holes. In place: everything left of a bin's output has been read already.
-__global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(ulonglong2* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
+template <int RW>
+__global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(uint64_t* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
                                                              uint64_t* __restrict__ rec_end /* [P] */, uint32_t nb, uint32_t* __restrict__ ticket,
                                                              unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */)
 {
-    __shared__ ulonglong2 s_win[DDS_WAVES][DDS_SLOTS];      // 64 KB
+    constexpr int KM = DDCap<RW>::KPL_MAX, SLOTS = DDCap<RW>::SLOTS;
+    __shared__ __attribute__((aligned(16))) uint64_t s_win[DDS_WAVES][SLOTS * RW];      // 64 KB
     __shared__ volatile uint32_t s_next, s_pos;             // bin whose output may be placed now; where
     __shared__ uint32_t s_item;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1706,31 +1747,33 @@ __global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(ulonglong2* __restr
         if (bi >= nb) break;
         const uint32_t nbin = 1u << D.bin_log2[bi];
         const uint32_t* bs = D.bin_start + (size_t)bi * (DD_BINS_MAX + 1);
-        ulonglong2* part = arena + rec_base[bi];
-        // the next bin of the wave is in flight (registers) while this one is sorted: one bin at a time would expose the load latency 256 times per partition
-        ulonglong2 nx[DD_KPL_MAX]; uint32_t nx_s0 = 0, nx_n = 0;
+        uint64_t* part = arena + rec_base[bi] * RW;
+        // the next bin of the wave is in flight (registers) while this one is sorted
+        DRec<RW> nx[KM]; uint32_t nx_s0 = 0, nx_n = 0;
         auto fetch = [&](uint32_t bin_) {
             nx_s0 = 0; nx_n = 0;
             if (bin_ < nbin) {
                 nx_s0 = bs[bin_]; nx_n = bs[bin_ + 1] - nx_s0;
-                if (nx_n >= 2 && nx_n <= (uint32_t)DDS_SLOTS) {
+                if (nx_n >= 2 && nx_n <= (uint32_t)SLOTS) {
 #pragma unroll
-                    for (int r = 0; r < DD_KPL_MAX; r++) { const uint32_t i = r * 64 + lane; nx[r] = i < nx_n ? part[nx_s0 + i] : make_ulonglong2(0, 0); }
+                    for (int r = 0; r < KM; r++) { const uint32_t i = r * 64 + lane; if (i < nx_n) nx[r] = dd_load<RW>(part + (size_t)(nx_s0 + i) * RW); }
                 }
             }
         };
         fetch(wave);
         for (uint32_t bin = wave; bin < nbin; bin += DDS_WAVES) {
             const uint32_t s0 = nx_s0, n = nx_n;
-            ulonglong2 in[DD_KPL_MAX];
+            DRec<RW> in[KM];
 #pragma unroll
-            for (int r = 0; r < DD_KPL_MAX; r++) in[r] = nx[r];
+            for (int r = 0; r < KM; r++) in[r] = nx[r];
             fetch(bin + DDS_WAVES);
-            ulonglong2 rec[DD_KPL_MAX]; uint32_t cnt[DD_KPL_MAX];
+            DRec<RW> rec[KM]; uint32_t cnt[KM];
+#pragma unroll
+            for (int r = 0; r < KM; r++) cnt[r] = 0;
             uint32_t nout = 0; int kpl = 0;                                   // kpl 0: the bin is moved as it is
-            if (n >= 2 && n <= 64) { nout = dd_sort_bin<1>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 1; }
-            else if (n > 64 && n <= 128) { nout = dd_sort_bin<2>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 2; }
-            else if (n > 128 && n <= (uint32_t)DDS_SLOTS) { nout = dd_sort_bin<DD_KPL_MAX>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = DD_KPL_MAX; }
+            if (n >= 2 && n <= 64) { nout = dd_sort_bin<RW, 1>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 1; }
+            else if (n > 64 && n <= 128) { nout = dd_sort_bin<RW, 2>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 2; }
+            else if (KM > 2 && n > 128 && n <= (uint32_t)SLOTS) { nout = dd_sort_bin<RW, KM>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = KM; }
             uint32_t x = nout;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -1742,9 +1785,9 @@ __global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(ulonglong2* __restr
                 // one record, or more than the wave's registers hold (one record copied thousands of times: low-complexity reads): moved left, chunk by chunk,
                 // BEFORE the next bin may place its output (which may reach into this bin's old range)
                 for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    ulonglong2 q = make_ulonglong2(0, 0);
-                    if (i0 + lane < n) q = part[s0 + i0 + lane];
-                    if (i0 + lane < n) part[pos0 + i0 + lane] = q;
+                    DRec<RW> q;
+                    if (i0 + lane < n) q = dd_load<RW>(part + (size_t)(s0 + i0 + lane) * RW);
+                    if (i0 + lane < n) dd_store<RW>(part + (size_t)(pos0 + i0 + lane) * RW, q);
                 }
             }
             __threadfence_block();
@@ -1753,11 +1796,12 @@ __global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(ulonglong2* __restr
                 constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
                 uint32_t pos = pos0 + x - nout;
 #pragma unroll
-                for (int r = 0; r < DD_KPL_MAX; r++) if (cnt[r]) {
-                    const uint32_t nbk = (uint32_t)(rec[r].x >> 56);
+                for (int r = 0; r < KM; r++) if (cnt[r]) {
+                    const uint32_t nbk = (uint32_t)(rec[r].w[0] >> 56);
                     for (uint32_t c = cnt[r]; c; ) {
                         const uint32_t w = c < WCAP ? c : WCAP;
-                        part[pos++] = make_ulonglong2(rec[r].x, rec[r].y | (unsigned long long)(w - 1));
+                        DRec<RW> o = rec[r]; o.w[RW - 1] |= (uint64_t)(w - 1);
+                        dd_store<RW>(part + (size_t)pos * RW, o); pos++;
                         ok += nbk; c -= w;
                     }
                 }
@@ -1858,8 +1902,8 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     // Identical super-k-mer records of a partition are merged first (8-byte keys; see k_dedupe_*): the expansion then reads the batch's own deduplicated copy
     SegTable segs_b = segs;
     static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
-    const bool dedupe = KW == 1 && RW == 2 && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
-    if constexpr (KW == 1 && RW == 2) if (dedupe) {
+    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
+    if (dedupe) {
         ScopedTimer tm(c, "dedupe");
         unsigned long long* const dd_totals = reinterpret_cast<unsigned long long*>(misc + 40);     // k-mers into / out of the deduplication of this batch
         const uint32_t Pn = segs.P, p_first = batch_parts.front(), p_last = batch_parts.back();
@@ -1876,17 +1920,17 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         const uint64_t total_recs = base[nb];
         bool fits = total_recs > 0; for (uint32_t i = 0; i < nb; i++) fits = fits && (base[i + 1] - base[i]) < (1ULL << 31);
         if (fits) {
-            CB_TRY(c->ensure(B.dd_arena, (size_t)total_recs * 16)); CB_TRY(c->ensure(B.dd_base, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.dd_bins, (size_t)nb * (DD_BINS_MAX + 1) * 4));
+            CB_TRY(c->ensure(B.dd_arena, (size_t)total_recs * RW * 8)); CB_TRY(c->ensure(B.dd_base, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.dd_bins, (size_t)nb * (DD_BINS_MAX + 1) * 4));
             CB_TRY(c->ensure(B.dd_lg, (size_t)nb * 4)); CB_TRY(c->ensure(B.dd_off, ((size_t)Pn + 1) * 8)); CB_TRY(c->ensure(B.dd_ptr, 8));
             const void* arena_p = B.dd_arena.p;
             CB_HIP(hipMemcpyAsync(B.dd_base.p, base.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
             CB_HIP(hipMemcpyAsync(B.dd_off.p, off.data(), ((size_t)Pn + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
             CB_HIP(hipMemcpyAsync(B.dd_ptr.p, &arena_p, 8, hipMemcpyHostToDevice, cur_stream(c)));
             DedupeTables DT{ (uint32_t*)B.dd_bins.p, (uint32_t*)B.dd_lg.p };
-            hipLaunchKernelGGL(k_dedupe_bin, dim3(std::min(nb, 512u)), dim3(DD_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k, (const uint64_t*)B.dd_base.p,
-                               (ulonglong2*)B.dd_arena.p, DT, nb, misc + 5);
+            hipLaunchKernelGGL((k_dedupe_bin<RW>), dim3(std::min(nb, 512u)), dim3(DD_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k, (const uint64_t*)B.dd_base.p,
+                               (uint64_t*)B.dd_arena.p, DT, nb, misc + 5);
             CB_TRY(c->ensure(B.dd_end, (size_t)Pn * 8));
-            hipLaunchKernelGGL(k_dedupe_sort, dim3(std::min(nb, 512u)), dim3(DDS_THREADS), 0, cur_stream(c), (ulonglong2*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
+            hipLaunchKernelGGL((k_dedupe_sort<RW>), dim3(std::min(nb, 512u)), dim3(DDS_THREADS), 0, cur_stream(c), (uint64_t*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
                                (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals);
             CB_HIP(hipGetLastError());
             CB_HIP(hipStreamSynchronize(cur_stream(c)));               // (the host vectors above are the sources of the copies)
@@ -1912,7 +1956,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs, k,
+            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
                                (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6);
         }
         CB_HIP(hipGetLastError());
