@@ -246,6 +246,7 @@ struct gkc_comm;                              // gkc_dist.hip
 int gkc_comm_world(gkc_comm* m);
 int gkc_comm_rank(gkc_comm* m);
 int gkc_comm_allgather_host(gkc_comm* m, const void* mine, size_t n, void* all);
+int gkc_comm_agree(gkc_comm* m, int local_rc, const char* where);          // all ranks return an error if one of them has one (gkc_dist.hip)
 int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st);
 int gkc_comm_allreduce_or_words(gkc_comm* m, uint64_t* d_words, uint64_t n_words, hipStream_t st);
 int gkc_comm_combine_seen_coll(gkc_comm* m, uint64_t* d_seen, uint64_t* d_coll, uint64_t n_words, hipStream_t st);

@@ -1380,10 +1380,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
         // (the wave's own LDS writes are visible to its later reads: same wave, in order)
         for (uint32_t s0 = 0; s0 < total; s0 += 64 * GATHER_UNROLL) {
             uint64_t slot[GATHER_UNROLL]; uint32_t b8[GATHER_UNROLL], sk[GATHER_UNROLL];
+            typename KeyT<KW>::type kk[GATHER_UNROLL];                                  // the keys are fetched with the abundance bytes, not behind them: all loads of a step in flight at once
 #pragma unroll
             for (int u = 0; u < GATHER_UNROLL; u++) {
                 const uint32_t s = s0 + u * 64 + lane;
-                b8[u] = 0; slot[u] = 0; sk[u] = 0;
+                b8[u] = 0; slot[u] = 0; sk[u] = 0; kk[u] = 0;
                 if (s < total) {
                     uint32_t lo = 0;
 #pragma unroll
@@ -1391,6 +1392,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
                     slot[u] = sta[lo] + (s - pre[lo]);
                     sk[u] = skp[lo];
                     b8[u] = cnt8[slot[u]];
+                    kk[u] = keys[slot[u]];
                 }
             }
 #pragma unroll
@@ -1401,7 +1403,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
                 const bool ok = c != 0 && (all_solid || ((int32_t)c >= amin && (int32_t)c <= amax));      // CountRange::includes (closed interval)
                 const unsigned long long bal = __ballot(ok);
                 if (ok) {
-                    const typename KeyT<KW>::type key = keys[slot[u]];
+                    const typename KeyT<KW>::type key = kk[u];
                     uint64_t* dst = out + (o + sk[u] + __popcll(bal & lt_mask)) * OW;
                     if (KW == 1) store16(dst, (uint64_t)key, (uint64_t)c);
                     else {

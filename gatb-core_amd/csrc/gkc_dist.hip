@@ -12,6 +12,7 @@
 // segment, so nothing is packed. Owner ranges are balanced by the k-mers per partition the ranks report in the first exchange of a pass.
 #include "gkc_common.hpp"
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
 #include <numeric>
@@ -37,8 +38,38 @@ struct gkc_comm {
     DevBuf ag_send, ag_recv;                   // staging of the host all-gather (RCCL)
 };
 
+// RCCL is bound at run time, when the first RCCL communicator is asked for: a single-GPU host without librccl loads libgkc_hip.so all the same
+// (ADVICE r2). Inside a PyTorch process the library of that name is already mapped (torch/lib/librccl.so) and dlopen returns it.
+struct RcclApi {
+    void* lib = nullptr; bool tried = false; std::string why;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        static std::mutex mu; std::lock_guard<std::mutex> lk(mu);
+        if (tried) return lib != nullptr;
+        tried = true;
+        for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) { lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+        if (!lib) { const char* e = dlerror(); why = e ? e : "librccl.so not found"; return false; }
+        bool ok = true;
+        auto sym = [&](const char* n) -> void* { void* p = dlsym(lib, n); if (!p) { ok = false; why = std::string("symbol ") + n + " missing in librccl"; } return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId"); CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        AllGather = (decltype(AllGather))sym("ncclAllGather"); Send = (decltype(Send))sym("ncclSend"); Recv = (decltype(Recv))sym("ncclRecv");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(lib); lib = nullptr; }
+        return ok;
+    }
+};
+static RcclApi g_rccl;
+
 static int comm_fail(gkc_comm* m, int code, const char* what, const char* detail) { m->ctx->set_error(code, "%s: %s", what, detail); return code; }
-#define NCCL_TRY(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail((m), GKC_ERR_HIP, #call, ncclGetErrorString(r_)); } while (0)
+#define NCCL_TRY(m, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return comm_fail((m), GKC_ERR_HIP, #call, g_rccl.GetErrorString(r_)); } while (0)
 
 int gkc_comm_world(gkc_comm* m) { return m->world; }
 int gkc_comm_rank(gkc_comm* m) { return m->rank; }
@@ -54,13 +85,31 @@ int gkc_comm_allgather_host(gkc_comm* m, const void* mine, size_t n, void* all)
     }
     GKC_TRY(c->ensure(m->ag_send, n + 16)); GKC_TRY(c->ensure(m->ag_recv, n * m->world + 16));
     GKC_HIP(c, hipMemcpyAsync(m->ag_send.p, mine, n, hipMemcpyHostToDevice, m->xstream));
-    NCCL_TRY(m, ncclAllGather(m->ag_send.p, m->ag_recv.p, n, ncclUint8, m->nccl, m->xstream));
+    NCCL_TRY(m, g_rccl.AllGather(m->ag_send.p, m->ag_recv.p, n, ncclUint8, m->nccl, m->xstream));
     GKC_HIP(c, hipMemcpyAsync(all, m->ag_recv.p, n * m->world, hipMemcpyDeviceToHost, m->xstream));
     GKC_HIP(c, hipStreamSynchronize(m->xstream));
     return GKC_OK;
 }
 
 // one grouped exchange, ordered on stream st (RCCL: enqueued, not waited for; transport: st is drained first, the callback blocks)
+// A rank that fails on its own just before a collective would leave the others blocked in it: the ranks exchange their local status first and
+// fail TOGETHER (every rank returns an error, the first failing rank's code; the failing rank keeps its own message).
+int gkc_comm_agree(gkc_comm* m, int local_rc, const char* where)
+{
+    if (m->world == 1) return local_rc;
+    int32_t mine = local_rc; std::vector<int32_t> all((size_t)m->world, 0);
+    const std::string kept = local_rc != GKC_OK ? m->ctx->err.msg : std::string();
+    const int rc = gkc_comm_allgather_host(m, &mine, sizeof(mine), all.data());
+    if (rc != GKC_OK) return rc;
+    for (int r = 0; r < m->world; r++)
+        if (all[r] != GKC_OK) {
+            if (local_rc != GKC_OK) { m->ctx->set_error(local_rc, "%s", kept.c_str()); return local_rc; }
+            m->ctx->set_error(all[r], "rank %d failed in %s (error %d): every rank gives up together", r, where, all[r]);
+            return all[r];
+        }
+    return GKC_OK;
+}
+
 int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st)
 {
     gkc_ctx* c = m->ctx;
@@ -73,10 +122,10 @@ int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std
     };
     split(sends, s2); split(recvs, r2);
     if (m->rccl) {
-        NCCL_TRY(m, ncclGroupStart());
-        for (const gkc_xfer& x : s2) NCCL_TRY(m, ncclSend(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
-        for (const gkc_xfer& x : r2) NCCL_TRY(m, ncclRecv(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
-        NCCL_TRY(m, ncclGroupEnd());
+        NCCL_TRY(m, g_rccl.GroupStart());
+        for (const gkc_xfer& x : s2) NCCL_TRY(m, g_rccl.Send(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
+        for (const gkc_xfer& x : r2) NCCL_TRY(m, g_rccl.Recv(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
+        NCCL_TRY(m, g_rccl.GroupEnd());
         return GKC_OK;
     }
     GKC_HIP(c, hipStreamSynchronize(st));
@@ -285,7 +334,7 @@ int gkc_comm_unique_id(uint8_t id[GKC_COMM_ID_BYTES])
     static_assert(sizeof(ncclUniqueId) == GKC_COMM_ID_BYTES, "ncclUniqueId size");
     if (!id) return GKC_ERR_ARG;
     ncclUniqueId u;
-    if (ncclGetUniqueId(&u) != ncclSuccess) return GKC_ERR_HIP;
+    if (!g_rccl.load() || g_rccl.GetUniqueId(&u) != ncclSuccess) return GKC_ERR_HIP;
     memcpy(id, &u, sizeof(u));
     return GKC_OK;
 }
@@ -310,8 +359,9 @@ int gkc_comm_create_rccl(gkc_ctx* c, const uint8_t id[GKC_COMM_ID_BYTES], int wo
     GKC_TRY(comm_new(c, world, rank, out));
     gkc_comm* m = *out;
     ncclUniqueId u; memcpy(&u, id, sizeof(u));
-    const ncclResult_t r = ncclCommInitRank(&m->nccl, world, u, rank);
-    if (r != ncclSuccess) { c->set_error(GKC_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
+    if (!g_rccl.load()) { c->set_error(GKC_ERR_HIP, "RCCL is not available on this host (%s): a communicator over several GPUs needs librccl", g_rccl.why.c_str()); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
+    const ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, u, rank);
+    if (r != ncclSuccess) { c->set_error(GKC_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
     m->rccl = true;
     return GKC_OK;
 }
@@ -340,7 +390,7 @@ void gkc_comm_destroy(gkc_comm* m)
     (void)hipSetDevice(c->device);
     if (m->xstream) (void)hipStreamSynchronize(m->xstream);
     gkc_comm_settle_timers(m);
-    if (m->nccl) (void)ncclCommDestroy(m->nccl);
+    if (m->nccl) (void)g_rccl.CommDestroy(m->nccl);
     m->ag_send.release(); m->ag_recv.release();
     if (m->xstream) (void)hipStreamDestroy(m->xstream);
     if (m->owned_user && m->owned_free) m->owned_free(m->owned_user);
@@ -420,21 +470,28 @@ int gkc_exchange(gkc_ctx* c, gkc_comm* m)
     //    per (source, segment) the records of my partitions, back to back in one receive arena
     std::vector<gkc_plan_msg> ps((size_t)W * Lmax + 1), pr((size_t)W * Lmax + 1);
     uint32_t n_ps = 0, n_pr = 0; uint64_t recv_recs = 0;
-    if (gkc_exchange_plan(W, me, P, m->first.data(), Ls.data(), Lmax, all.data(), ps.data(), &n_ps, pr.data(), &n_pr, &recv_recs) != GKC_OK)
-        GKC_FAIL(c, GKC_ERR_ARG, "internal error: exchange plan");
     uint8_t* rarena = nullptr;
-    if (recv_recs) {
-        rarena = (uint8_t*)c->dalloc((size_t)recv_recs * rb);
-        if (!rarena) return GKC_ERR_NOMEM;
-        c->owned_arenas.push_back(rarena);
-    }
     std::vector<gkc_xfer> sends, recvs;
     uint64_t sent_bytes = 0;
-    for (uint32_t i = 0; i < n_ps; i++) {
-        const Segment& sg = c->segments[mine[ps[i].seg]];
-        if (sg.rec_off[m->first[ps[i].peer]] != ps[i].rec_begin) GKC_FAIL(c, GKC_ERR_ARG, "internal error: segment offsets and counts disagree");
-        sends.push_back(gkc_xfer{ ps[i].peer, 0, (uint8_t*)sg.d_records + ps[i].rec_begin * rb, ps[i].n_recs * rb }); sent_bytes += ps[i].n_recs * rb;
-    }
+    // (what can fail on this rank alone — the receive arena does not fit, an inconsistency — is agreed on before the transfer: a rank that
+    //  simply returned here would leave the others waiting in their send / recv)
+    const int local_rc = [&]() -> int {
+        if (getenv("GKC_FAULT") && !strcmp(getenv("GKC_FAULT"), "exchange_local")) GKC_FAIL(c, GKC_ERR_NOMEM, "injected fault (GKC_FAULT=exchange_local)");
+        if (gkc_exchange_plan(W, me, P, m->first.data(), Ls.data(), Lmax, all.data(), ps.data(), &n_ps, pr.data(), &n_pr, &recv_recs) != GKC_OK)
+            GKC_FAIL(c, GKC_ERR_ARG, "internal error: exchange plan");
+        if (recv_recs) {
+            rarena = (uint8_t*)c->dalloc((size_t)recv_recs * rb);
+            if (!rarena) return GKC_ERR_NOMEM;
+            c->owned_arenas.push_back(rarena);
+        }
+        for (uint32_t i = 0; i < n_ps; i++) {
+            const Segment& sg = c->segments[mine[ps[i].seg]];
+            if (sg.rec_off[m->first[ps[i].peer]] != ps[i].rec_begin) GKC_FAIL(c, GKC_ERR_ARG, "internal error: segment offsets and counts disagree");
+            sends.push_back(gkc_xfer{ ps[i].peer, 0, (uint8_t*)sg.d_records + ps[i].rec_begin * rb, ps[i].n_recs * rb }); sent_bytes += ps[i].n_recs * rb;
+        }
+        return GKC_OK;
+    }();
+    GKC_TRY(gkc_comm_agree(m, local_rc, "gkc_exchange"));
     std::vector<Segment> imported;
     for (uint32_t i = 0; i < n_pr; i++) {
         const int r = pr[i].peer; const uint64_t j = pr[i].seg;
@@ -530,9 +587,12 @@ int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
     // 1) what every owner holds: per partition (solid, distinct, k-mers, starts a new contiguous array on its owner)
     std::vector<uint64_t> tab((size_t)P * 4, 0), all((size_t)W * P * 4);
     const uint32_t lo = m->first[me], hi = m->first[me + 1];
+    {   int rc0 = GKC_OK;
+        for (uint32_t p = lo; p < hi && rc0 == GKC_OK; p++) if (!DS[p].done) { c->set_error(GKC_ERR_ARG, "partition %u of pass %u has not been counted", p, pass); rc0 = GKC_ERR_ARG; }
+        GKC_TRY(gkc_comm_agree(m, rc0, "gkc_gather_results"));
+    }
     for (uint32_t p = lo; p < hi; p++) {
         const Dataset& D = DS[p];
-        if (!D.done) GKC_FAIL(c, GKC_ERR_ARG, "partition %u of pass %u has not been counted", p, pass);
         tab[(size_t)p * 4 + 0] = D.n_solid; tab[(size_t)p * 4 + 1] = D.n_distinct; tab[(size_t)p * 4 + 2] = D.n_kmers;
         const bool joins = p > lo && DS[p - 1].n_solid && D.n_solid && (const uint8_t*)D.d_counts == (const uint8_t*)DS[p - 1].d_counts + DS[p - 1].n_solid * rb;
         tab[(size_t)p * 4 + 3] = joins ? 0 : 1;
@@ -540,6 +600,7 @@ int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
     GKC_TRY(gkc_comm_allgather_host(m, tab.data(), tab.size() * 8, all.data()));
     // 2) the arrays travel, one message per contiguous array of the owner (a Stage-B batch), into one buffer per owner on the root
     std::vector<gkc_xfer> sends, recvs;
+    int root_rc = GKC_OK;                                          // the root's buffers may not fit: agreed on before anybody sends
     if (me != root) {
         for (uint32_t p = lo; p < hi; ) {
             if (!DS[p].n_solid) { p++; continue; }
@@ -557,7 +618,7 @@ int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
             uint8_t* buf = nullptr;
             if (total) {
                 buf = (uint8_t*)c->dalloc((size_t)total * rb);
-                if (!buf) return GKC_ERR_NOMEM;
+                if (!buf) { root_rc = GKC_ERR_NOMEM; break; }
                 c->pass_outputs[pass].push_back(buf);
             }
             uint64_t off = 0;
@@ -575,6 +636,7 @@ int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
             }
         }
     }
+    GKC_TRY(gkc_comm_agree(m, root_rc, "gkc_gather_results"));
     GKC_HIP(c, hipStreamSynchronize(c->stream));
     GKC_TRY(gkc_comm_sendrecv(m, sends, recvs, m->xstream));
     GKC_HIP(c, hipStreamSynchronize(m->xstream));

@@ -530,8 +530,8 @@ static int abundance_map_impl(gkc_mphf* m, gkc_ctx* c, gkc_comm* comm, uint8_t* 
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dmap.release(); dst.release();
     if (e != hipSuccess) GKC_FAIL(c, GKC_ERR_HIP, "abundance map failed: %s", hipGetErrorString(e));
-    if (st[1]) GKC_FAIL(c, GKC_ERR_ARG, "MPHF check: value out of bounds (%llu k-mers are not keys of this MPHF)", st[1]);      // MPHFAlgorithm.cpp:247
-    if (comm) {                                                    // counters over all ranks
+    if (!comm && st[1]) GKC_FAIL(c, GKC_ERR_ARG, "MPHF check: value out of bounds (%llu k-mers are not keys of this MPHF)", st[1]);      // MPHFAlgorithm.cpp:247
+    if (comm) {                                                    // (several ranks: the counters are summed first, so that all ranks fail together)                                                    // counters over all ranks
         std::vector<unsigned long long> alls((size_t)2 * gkc_comm_world(comm));
         GKC_TRY(gkc_comm_allgather_host(comm, st, 16, alls.data()));
         st[0] = st[1] = 0; for (size_t i = 0; i < alls.size(); i += 2) { st[0] += alls[i]; st[1] += alls[i + 1]; }

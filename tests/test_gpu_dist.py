@@ -110,7 +110,9 @@ def _files_rank_main(rank, world, box, k, parts, amin, q, bad_model):
         m = 8
         reads = synth_reads(2600, 14000, 150, seed=43, n_rate=0.001, ragged=True)
         rep = simple_repart(m, parts)
-        if bad_model and rank == 1:
+        if bad_model == "fault" and rank == 1:
+            os.environ["GKC_FAULT"] = "exchange_local"                # this rank fails on its own inside gkc_exchange, after the tables were gathered
+        elif bad_model and rank == 1:
             rep = rep[::-1].copy()                                    # another repartition table on this rank
         mine = reads[rank::world]                                     # the bank shared out read by read
         c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
@@ -172,3 +174,18 @@ def test_ranks_with_different_models_are_refused(tmp_path):
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     [p.join(timeout=120) for p in procs]
     assert all(r[1] == "error" and "another model" in r[2] for r in res), res
+
+
+def test_a_rank_failing_alone_takes_the_others_with_it(tmp_path):
+    """a rank that fails by itself between the table all-gather and the transfer of gkc_exchange (its receive arena does not fit, say) must not leave the
+    other ranks blocked in their send / recv: the ranks agree on a status word first (gkc_comm_agree) and every rank returns an error — the failing one its own,
+    the others one that names it"""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue()
+    procs = [ctx.Process(target=_files_rank_main, args=(r, world, str(tmp_path), 31, 8, 1, q, "fault")) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(r[1] == "error" for r in res), res
+    assert "rank 1 failed in gkc_exchange" in res[0][2] and "injected fault" in res[1][2], res

@@ -10,5 +10,5 @@ for f in gkc_api gkc_scan gkc_count gkc_bloom gkc_fastx gkc_mphf gkc_dist; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c $f.hip -o variants/$name/$f.o &
 done
 wait; for f in gkc_api gkc_scan gkc_count gkc_bloom gkc_fastx gkc_mphf gkc_dist; do test -f variants/$name/$f.o || { echo "compile of $f failed"; exit 1; }; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libgkc_hip_$name.so variants/$name/*.o -L/opt/rocm/lib -lrccl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libgkc_hip_$name.so variants/$name/*.o -ldl
 echo built variants/libgkc_hip_$name.so
