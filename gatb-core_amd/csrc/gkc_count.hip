@@ -1565,7 +1565,10 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 //   k_dedupe_sort  one wave per bin (~64 records): 128-bit register sort, run lengths, and the bin is rewritten in place as one record per run and per
 //                  2^WEIGHT_BITS copies — (copies - 1) in the record's WEIGHT_BITS spare bits below its nucleotides — followed by empty records (nbK = 0: the
 //                  expansion kernels skip them). A bin beyond the wave's registers is left as it is (weights 1).
-constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = 48;
+#ifndef GKC_DD_BIN_TARGET
+#define GKC_DD_BIN_TARGET 48
+#endif
+constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = GKC_DD_BIN_TARGET;
 template <int RW> struct DDCap { static constexpr int KPL_MAX = RW == 2 ? 4 : 2; static constexpr int SLOTS = 64 * KPL_MAX; };   // <= 256 (16-byte) / 128 (32-byte) records per bin are deduplicated
 struct DedupeTables { uint32_t* bin_start; /* [nb][DD_BINS_MAX + 1] first record of the bin, relative to the partition's first record */ uint32_t* bin_log2; /* [nb] */ };
 template <int RW> struct DRec { uint64_t w[RW]; };
