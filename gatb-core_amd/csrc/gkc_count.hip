@@ -1565,11 +1565,17 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 //   k_dedupe_sort  one wave per bin (~64 records): 128-bit register sort, run lengths, and the bin is rewritten in place as one record per run and per
 //                  2^WEIGHT_BITS copies — (copies - 1) in the record's WEIGHT_BITS spare bits below its nucleotides — followed by empty records (nbK = 0: the
 //                  expansion kernels skip them). A bin beyond the wave's registers is left as it is (weights 1).
-#ifndef GKC_DD_BIN_TARGET
-#define GKC_DD_BIN_TARGET 48
-#endif
-constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = GKC_DD_BIN_TARGET;
-template <int RW> struct DDCap { static constexpr int KPL_MAX = RW == 2 ? 4 : 2; static constexpr int SLOTS = 64 * KPL_MAX; };   // <= 256 (16-byte) / 128 (32-byte) records per bin are deduplicated
+// bins of 100..200 records (measured, 1e8 reads, one lane, k_dedupe_bin + k_dedupe_sort per step: mean <= 24: 46.6 ms, 48: 45.8, 96: 45.1, 160: 41.1, 200: 40.3; with 512-record
+// bins and a double-size network, mean <= 320: 44.4, 440: 41.9): fewer bins are fewer open 32-byte sectors per workgroup in the binning scatter — 1024 instead of 4096,
+// which two workgroups per CU keep inside the XCD's L2 — at the price of a longer sorting network per record
+constexpr int DD_THREADS = 1024, DD_BINS_MAX = 4096, DD_BIN_TARGET = 200;
+constexpr int DD_KPL_MAX = 4;
+// records per lane / per bin that are deduplicated (16-byte records; half for 32-byte ones), slot bits inside the sorted words, waves of a sorting workgroup (64 KB of LDS windows)
+template <int RW> struct DDCap {
+    static constexpr int KPL_MAX = RW == 2 ? DD_KPL_MAX : DD_KPL_MAX / 2; static constexpr int SLOTS = 64 * KPL_MAX;
+    static constexpr int SLOT_BITS = SLOTS <= 128 ? 7 : SLOTS <= 256 ? 8 : 9;
+    static constexpr int WAVES = 65536 / (SLOTS * RW * 8) > 16 ? 16 : 65536 / (SLOTS * RW * 8);
+};
 struct DedupeTables { uint32_t* bin_start; /* [nb][DD_BINS_MAX + 1] first record of the bin, relative to the partition's first record */ uint32_t* bin_log2; /* [nb] */ };
 template <int RW> struct DRec { uint64_t w[RW]; };
 template <int RW> __device__ __forceinline__ DRec<RW> dd_load(const uint64_t* p) { DRec<RW> r;
@@ -1684,18 +1690,17 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
 
 // One bin: the records are brought into hash order by sorting 64-bit words [hash : 43][slot : 8] in the f64-tagged register network of k_wave_sort (equal records have
 // equal hashes and end up adjacent; two different records under one 43-bit hash merely stay unmerged), then fetched in that order through the wave's LDS window.
-constexpr int DDS_THREADS = 1024, DDS_WAVES = DDS_THREADS / 64;
 template <int RW, int KPL>
 __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::KPL_MAX] /* record r * 64 + lane of the bin */, const uint32_t n, const int lane,
                                                 uint64_t* __restrict__ s_win /* [SLOTS][RW] of this wave */,
                                                 DRec<RW> (&rec)[DDCap<RW>::KPL_MAX], uint32_t (&cnt)[DDCap<RW>::KPL_MAX], unsigned long long& in_keys)
 {
-    constexpr int KM = DDCap<RW>::KPL_MAX;
+    constexpr int KM = DDCap<RW>::KPL_MAX, SB = DDCap<RW>::SLOT_BITS;
     uint64_t key[KPL];
 #pragma unroll
     for (int r = 0; r < KPL; r++) {
         const uint32_t i = r * 64 + lane;
-        if (i < n) { dd_store<RW>(s_win + (size_t)i * RW, in[r]); key[r] = TAG64 | ((dd_hash64<RW>(in[r]) >> 21) << 8) | (uint64_t)i; }   // 43 hash bits, 8 slot bits
+        if (i < n) { dd_store<RW>(s_win + (size_t)i * RW, in[r]); key[r] = TAG64 | ((dd_hash64<RW>(in[r]) >> (13 + SB)) << SB) | (uint64_t)i; }   // 51 - SB hash bits, SB slot bits
         else key[r] = TAG64 | TAG64_MANT;
     }
     bitonic_wave<1, KPL, true>(key, lane);
@@ -1705,7 +1710,7 @@ __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::
 #pragma unroll
         for (int i = 0; i < RW; i++) rec[r].w[i] = 0; }
 #pragma unroll
-    for (int r = 0; r < KPL; r++) { const uint32_t e = (uint32_t)lane * KPL + r; if (e < n) rec[r] = dd_load<RW>(s_win + (size_t)((uint32_t)key[r] & 255u) * RW); }
+    for (int r = 0; r < KPL; r++) { const uint32_t e = (uint32_t)lane * KPL + r; if (e < n) rec[r] = dd_load<RW>(s_win + (size_t)((uint32_t)key[r] & ((1u << SB) - 1u)) * RW); }
     DRec<RW> next_first;
 #pragma unroll
     for (int i = 0; i < RW; i++) next_first.w[i] = (uint64_t)__shfl_down((unsigned long long)rec[0].w[i], 1, 64);
@@ -1734,11 +1739,11 @@ __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::
 // (a chain through LDS: the wave waits for its predecessor's end, never for more), so the partition's deduplicated records end up contiguous at the front of its
 // range — the expansion kernels then walk 0.6x the records instead of stepping over holes. In place: everything left of a bin's output has been read already.
 template <int RW>
-__global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(uint64_t* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
+__global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
                                                              uint64_t* __restrict__ rec_end /* [P] */, uint32_t nb, uint32_t* __restrict__ ticket,
                                                              unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */)
 {
-    constexpr int KM = DDCap<RW>::KPL_MAX, SLOTS = DDCap<RW>::SLOTS;
+    constexpr int KM = DDCap<RW>::KPL_MAX, SLOTS = DDCap<RW>::SLOTS, DDS_WAVES = DDCap<RW>::WAVES;
     __shared__ __attribute__((aligned(16))) uint64_t s_win[DDS_WAVES][SLOTS * RW];      // 64 KB
     __shared__ volatile uint32_t s_next, s_pos;             // bin whose output may be placed now; where
     __shared__ uint32_t s_item;
@@ -1778,7 +1783,8 @@ __global__ __launch_bounds__(DDS_THREADS) void k_dedupe_sort(uint64_t* __restric
             uint32_t nout = 0; int kpl = 0;                                   // kpl 0: the bin is moved as it is
             if (n >= 2 && n <= 64) { nout = dd_sort_bin<RW, 1>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 1; }
             else if (n > 64 && n <= 128) { nout = dd_sort_bin<RW, 2>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 2; }
-            else if (KM > 2 && n > 128 && n <= (uint32_t)SLOTS) { nout = dd_sort_bin<RW, KM>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = KM; }
+            else if (KM >= 4 && n > 128 && n <= 256) { nout = dd_sort_bin<RW, (KM >= 4 ? 4 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 4; }
+            else if (KM >= 8 && n > 256 && n <= 512) { nout = dd_sort_bin<RW, (KM >= 8 ? 8 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 8; }
             uint32_t x = nout;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -1935,7 +1941,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             hipLaunchKernelGGL((k_dedupe_bin<RW>), dim3(std::min(nb, 512u)), dim3(DD_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k, (const uint64_t*)B.dd_base.p,
                                (uint64_t*)B.dd_arena.p, DT, nb, misc + 5);
             CB_TRY(c->ensure(B.dd_end, (size_t)Pn * 8));
-            hipLaunchKernelGGL((k_dedupe_sort<RW>), dim3(std::min(nb, 512u)), dim3(DDS_THREADS), 0, cur_stream(c), (uint64_t*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
+            hipLaunchKernelGGL((k_dedupe_sort<RW>), dim3(std::min(nb, 512u)), dim3(DDCap<RW>::WAVES * 64), 0, cur_stream(c), (uint64_t*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
                                (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals);
             CB_HIP(hipGetLastError());
             CB_HIP(hipStreamSynchronize(cur_stream(c)));               // (the host vectors above are the sources of the copies)
