@@ -85,8 +85,9 @@ def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct, keys_moved=Non
         "bucket_sort": keys * key_bytes + distinct * (key_bytes + 1),
         "compact": distinct * (key_bytes + 1 + rec_bytes),             # gather: key + abundance byte in, Count record out
     }
-    if "dedupe" in ktime and ktime["dedupe"][0] > 0:
-        alg["dedupe"] = st["nb_superkmers"] * rec_bytes * 3.0                # records read twice (bin count, bin scatter), written once, re-read and rewritten <= once by the sort
+    if "dedupe_bin" in ktime and ktime["dedupe_bin"][0] > 0:
+        alg["dedupe_bin"] = st["nb_superkmers"] * rec_bytes * 3.0            # records read twice (bin count, bin scatter), written once
+        alg["dedupe_sort"] = st["nb_superkmers"] * rec_bytes * 2.0           # ... read once and rewritten (at most once) by the sort
     dom = max(alg, key=lambda n_: ktime[n_][0])
     dom_ms = ktime[dom][0] / max(1, steps)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -336,7 +337,7 @@ def main():
         step()
     sync()
     # per-kernel timers are HIP events on the context's own stream, accumulated inside the library
-    names = ["scan_count", "scan_emit", "scan_refine", "dedupe", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "split_levels", "compact",
+    names = ["scan_count", "scan_emit", "scan_refine", "dedupe_bin", "dedupe_sort", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "split_levels", "compact",
              "total_stage_a", "total_stage_b"]
     base = {nme: c.timing(nme) for nme in names}
     t0 = time.perf_counter()

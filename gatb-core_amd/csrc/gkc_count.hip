@@ -1443,17 +1443,13 @@ __global__ __launch_bounds__(ROOT_THREADS) void k_root_chunks(const uint32_t* __
         const uint32_t i = i0 + threadIdx.x;
         const uint32_t nch = i < n_roots ? (b_n[root_list[i]] + ROOT_CHUNK - 1) / ROOT_CHUNK : 0u;
         uint32_t tot; const uint32_t pre = wg_excl_scan_1024(nch, s_w, tot);
-        if (i < n_roots) R.base[i] = carry + pre;
+        if (i < n_roots) {
+            R.base[i] = carry + pre;
+            for (uint32_t c = 0; c < nch; c++) R.root_of[carry + pre + c] = i;          // chunk -> root (1-2 chunks per root; a giant: a few hundred stores, nobody waits for them)
+        }
         carry += tot;
     }
     if (threadIdx.x == 0) { R.base[n_roots] = carry; *R.n_chunks = carry; }
-    __syncthreads();
-    // chunk -> root: one wave per root fills its entries
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t i = wave; i < n_roots; i += ROOT_THREADS / 64) {
-        const uint32_t c0 = R.base[i], c1 = R.base[i + 1];
-        for (uint32_t c = c0 + lane; c < c1; c += 64) R.root_of[c] = i;
-    }
 }
 __global__ __launch_bounds__(256) void k_root_count(const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ cnt32, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
                                                     const uint32_t* __restrict__ root_list, RootTables R, int32_t amin, int32_t amax, uint32_t all_solid)
@@ -1912,13 +1908,13 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
 
     // Identical super-k-mer records of a partition are merged first (8-byte keys; see k_dedupe_*): the expansion then reads the batch's own deduplicated copy
     SegTable segs_b = segs;
+    std::vector<uint64_t> dd_base_h, dd_off_h; const void* dd_arena_h = nullptr;      // sources of asynchronous copies: alive until the batch is through
     static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
     const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
     if (dedupe) {
-        ScopedTimer tm(c, "dedupe");
         unsigned long long* const dd_totals = reinterpret_cast<unsigned long long*>(misc + 40);     // k-mers into / out of the deduplication of this batch
         const uint32_t Pn = segs.P, p_first = batch_parts.front(), p_last = batch_parts.back();
-        std::vector<uint64_t> base(nb + 1, 0), off((size_t)Pn + 1, 0);
+        std::vector<uint64_t>& base = dd_base_h; std::vector<uint64_t>& off = dd_off_h; base.assign(nb + 1, 0); off.assign((size_t)Pn + 1, 0);
         {   uint64_t run = 0; uint32_t i = 0;
             for (uint32_t p = 0; p <= Pn; p++) {
                 off[p] = run;
@@ -1933,18 +1929,20 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         if (fits) {
             CB_TRY(c->ensure(B.dd_arena, (size_t)total_recs * RW * 8)); CB_TRY(c->ensure(B.dd_base, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.dd_bins, (size_t)nb * (DD_BINS_MAX + 1) * 4));
             CB_TRY(c->ensure(B.dd_lg, (size_t)nb * 4)); CB_TRY(c->ensure(B.dd_off, ((size_t)Pn + 1) * 8)); CB_TRY(c->ensure(B.dd_ptr, 8));
-            const void* arena_p = B.dd_arena.p;
+            const void*& arena_p = dd_arena_h; arena_p = B.dd_arena.p;
             CB_HIP(hipMemcpyAsync(B.dd_base.p, base.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
             CB_HIP(hipMemcpyAsync(B.dd_off.p, off.data(), ((size_t)Pn + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
             CB_HIP(hipMemcpyAsync(B.dd_ptr.p, &arena_p, 8, hipMemcpyHostToDevice, cur_stream(c)));
             DedupeTables DT{ (uint32_t*)B.dd_bins.p, (uint32_t*)B.dd_lg.p };
-            hipLaunchKernelGGL((k_dedupe_bin<RW>), dim3(std::min(nb, 512u)), dim3(DD_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k, (const uint64_t*)B.dd_base.p,
-                               (uint64_t*)B.dd_arena.p, DT, nb, misc + 5);
+            {   ScopedTimer tm(c, "dedupe_bin");
+                hipLaunchKernelGGL((k_dedupe_bin<RW>), dim3(std::min(nb, 512u)), dim3(DD_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs, k, (const uint64_t*)B.dd_base.p,
+                                   (uint64_t*)B.dd_arena.p, DT, nb, misc + 5);
+            }
             CB_TRY(c->ensure(B.dd_end, (size_t)Pn * 8));
+            ScopedTimer tm(c, "dedupe_sort");
             hipLaunchKernelGGL((k_dedupe_sort<RW>), dim3(std::min(nb, 512u)), dim3(DDCap<RW>::WAVES * 64), 0, cur_stream(c), (uint64_t*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
                                (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals);
             CB_HIP(hipGetLastError());
-            CB_HIP(hipStreamSynchronize(cur_stream(c)));               // (the host vectors above are the sources of the copies)
             segs_b.rec = (const uint8_t* const*)B.dd_ptr.p; segs_b.rec_off = (const uint64_t*)B.dd_off.p; segs_b.n_seg = 1; segs_b.rec_end = (const uint64_t*)B.dd_end.p;
         }
     }

@@ -5,7 +5,7 @@ run() { n=$1; shift; env "$@" python bench.py --steps 4 --warmup 1 --no-cpu-base
 python - <<PY
 import json
 d=json.load(open("gpurun_out/sw/$n.json")); t=d["config"]["kernel_ms_per_step"]; s=d["roofline"]["single_lane"]["kernel_ms_per_step"]
-print("$n: ms_per_step %.1f A %.1f B %.1f | single dedupe %.1f count %.1f scatter %.1f sort %.1f big %.1f wg %.1f split %.1f gather %.1f B %.1f" % (d["ms_per_step"], t["total_stage_a"], t["total_stage_b"], s["dedupe"], s["expand_count"], s["expand_scatter"], s["bucket_sort"], s["bucket_sort_big"], s["bucket_sort_wg"], s["split_levels"], s["compact"], s["total_stage_b"]))
+print("$n: ms_per_step %.1f A %.1f B %.1f | single dedupe %.1f count %.1f scatter %.1f sort %.1f big %.1f wg %.1f split %.1f gather %.1f B %.1f" % (d["ms_per_step"], t["total_stage_a"], t["total_stage_b"], s["dedupe_bin"] + s["dedupe_sort"], s["expand_count"], s["expand_scatter"], s["bucket_sort"], s["bucket_sort_big"], s["bucket_sort_wg"], s["split_levels"], s["compact"], s["total_stage_b"]))
 PY
 }
 V=$R/gatb-core_amd/csrc/variants
