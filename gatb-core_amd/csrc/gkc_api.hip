@@ -525,7 +525,8 @@ int gkc_get_stats(gkc_ctx* c, gkc_stats* out)
     gkc_stats t{};
     for (size_t p = 0; p < c->pass_stats.size(); p++) {
         const gkc_stats& S = c->pass_stats[p];
-        if (p == 0) { t.kmers_nb_valid = S.kmers_nb_valid; t.kmers_nb_invalid = S.kmers_nb_invalid; t.nb_sequences = S.nb_sequences; t.nb_bases = S.nb_bases; }
+        if (p == 0) { t.kmers_nb_valid = S.kmers_nb_valid; t.kmers_nb_invalid = S.kmers_nb_invalid; t.nb_sequences = S.nb_sequences; t.nb_bases = S.nb_bases;
+                      t.seq_len_min = S.seq_len_min; t.seq_len_max = S.seq_len_max; t.seq_len_sq_sum = S.seq_len_sq_sum; }
         t.kmers_nb_distinct += S.kmers_nb_distinct; t.kmers_nb_solid += S.kmers_nb_solid; t.nb_superkmers += S.nb_superkmers;
         t.superkmer_bytes += S.superkmer_bytes; t.oversize_buckets += S.oversize_buckets; t.dedupe_kmers_in += S.dedupe_kmers_in; t.dedupe_keys_out += S.dedupe_keys_out;
     }

@@ -47,14 +47,26 @@ struct ScanParams {
 // ------------------------------------------------------------------------------------------------
 // The offsets come from the caller: an offset beyond n_bases, a decreasing pair, offsets[0] != 0 or offsets[n_reads] != n_bases sets *bad
 // (the push then fails with GKC_ERR_ARG) and never touches memory outside the mask.
-__global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_t n_entries, uint64_t n_bases, uint32_t* __restrict__ bits, uint32_t* __restrict__ bad)
+// also the read-length statistics of BankStats::update (BankKmers.hpp:176-186) when len_stats != nullptr: [0] max of ~length (= ~shortest), [1] longest, [2] sum of squares
+__global__ void k_mark_read_starts(const uint64_t* __restrict__ offsets, uint64_t n_entries, uint64_t n_bases, uint32_t* __restrict__ bits, uint32_t* __restrict__ bad,
+                                   unsigned long long* __restrict__ len_stats)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_entries) return;
-    uint64_t g = offsets[i];
-    const bool wrong = g > n_bases || (i + 1 < n_entries && offsets[i + 1] < g) || (i == 0 && g != 0) || (i + 1 == n_entries && g != n_bases);
-    if (wrong) { if (bad) *bad = 1u; if (g > n_bases) return; }
-    atomicOr(&bits[g >> 5], 1u << (g & 31));
+    const bool in = i < n_entries;
+    uint64_t g = in ? offsets[i] : 0, nxt = (in && i + 1 < n_entries) ? offsets[i + 1] : 0;
+    const bool wrong = in && (g > n_bases || (i + 1 < n_entries && nxt < g) || (i == 0 && g != 0) || (i + 1 == n_entries && g != n_bases));
+    if (wrong && bad) *bad = 1u;
+    if (in && g <= n_bases) atomicOr(&bits[g >> 5], 1u << (g & 31));
+    if (len_stats) {
+        const bool read = in && i + 1 < n_entries && !wrong && nxt >= g;
+        unsigned long long len = read ? nxt - g : 0ull, inv = read ? ~len : 0ull, mx = len, sq = len * len;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long a = __shfl_xor(inv, d, 64), b = __shfl_xor(mx, d, 64);
+            inv = a > inv ? a : inv; mx = b > mx ? b : mx; sq += __shfl_xor(sq, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && mx) { atomicMax(&len_stats[0], inv); atomicMax(&len_stats[1], mx); atomicAdd(&len_stats[2], sq); }
+    }
 }
 
 // LDS index of per-position arrays: thread t owns positions 16t..16t+15; one pad word per 16 entries makes the lane
@@ -806,7 +818,8 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         uint64_t n_entries = n_reads + 1;
         dim3 g((unsigned)((n_entries + 255) / 256)), b(256);
         // the validity flag lives in the last word of the (zeroed) mask allocation's slack and is read back with the counters below
-        hipLaunchKernelGGL(k_mark_read_starts, g, b, 0, c->stream, d_offsets, n_entries, n_bases, (uint32_t*)c->d_rsbits.p, (uint32_t*)c->d_rsbits.p + rs_words - 1);
+        hipLaunchKernelGGL(k_mark_read_starts, g, b, 0, c->stream, d_offsets, n_entries, n_bases, (uint32_t*)c->d_rsbits.p, (uint32_t*)c->d_rsbits.p + rs_words - 1,
+                           (unsigned long long*)((uint32_t*)c->d_rsbits.p + rs_words - 8));      // (... and the read-length statistics in the six words before it)
         GKC_HIP(c, hipGetLastError());
     }
     // geometry: persistent workgroups when the partition cursors fit in LDS
@@ -870,6 +883,8 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     uint32_t bad_offsets = 0;
     GKC_HIP(c, hipMemcpyAsync(h.data(), cnt, n_cnt * 8, hipMemcpyDeviceToHost, c->stream));
     GKC_HIP(c, hipMemcpyAsync(&bad_offsets, (uint32_t*)c->d_rsbits.p + rs_words - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long len_stats[3] = {0, 0, 0};
+    GKC_HIP(c, hipMemcpyAsync(len_stats, (uint32_t*)c->d_rsbits.p + rs_words - 8, sizeof(len_stats), hipMemcpyDeviceToHost, c->stream));
     GKC_HIP(c, hipStreamSynchronize(c->stream));
     if (bad_offsets) GKC_FAIL(c, GKC_ERR_ARG, "read offsets are not a CSR table of the bases (need offsets[0] == 0, non-decreasing, offsets[n_reads] == n_bases = %llu)", (unsigned long long)n_bases);
     uint64_t total = 0;
@@ -878,6 +893,11 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     {   gkc_stats& S = c->stats_now();
         S.kmers_nb_valid += h[3 * (size_t)Pn + 0]; S.kmers_nb_invalid += h[3 * (size_t)Pn + 1];
         S.nb_sequences += n_reads; S.nb_bases += n_bases;
+        if (len_stats[1]) {                                             // BankStats::update (BankKmers.hpp:176-186)
+            const uint64_t mn = ~len_stats[0];
+            S.seq_len_min = S.seq_len_min == 0 || mn < S.seq_len_min ? mn : S.seq_len_min;      // (0 = no read yet; an empty read does not count, like an empty line in the reference's reader)
+            S.seq_len_max = std::max<uint64_t>(S.seq_len_max, len_stats[1]); S.seq_len_sq_sum += len_stats[2];
+        }
         S.nb_superkmers += total; S.superkmer_bytes += total * c->record_bytes;
     }
 
@@ -977,7 +997,7 @@ int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, 
     const size_t rs_words = (size_t)(n_tiles * SCAN_TILE / 32 + 64);
     GKC_TRY(c->ensure(c->d_rsbits, rs_words * 4));
     GKC_HIP(c, hipMemsetAsync(c->d_rsbits.p, 0, rs_words * 4, c->stream));
-    hipLaunchKernelGGL(k_mark_read_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, c->stream, d_offsets, n_reads + 1, n_bases, (uint32_t*)c->d_rsbits.p, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_mark_read_starts, dim3((unsigned)((n_reads + 1 + 255) / 256)), dim3(256), 0, c->stream, d_offsets, n_reads + 1, n_bases, (uint32_t*)c->d_rsbits.p, (uint32_t*)nullptr, (unsigned long long*)nullptr);
     DevBuf cnt; GKC_TRY(c->ensure(cnt, (size_t)(2 * nm + 4) * 8));
     hipError_t e = hipMemsetAsync(cnt.p, 0, (size_t)(2 * nm + 4) * 8, c->stream);
     ScanParams P{};

@@ -60,7 +60,7 @@ class CommStats(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "kmers_nb_valid", "kmers_nb_invalid", "kmers_nb_distinct", "kmers_nb_solid", "nb_superkmers", "nb_sequences",
-        "nb_bases", "superkmer_bytes", "oversize_buckets", "dedupe_kmers_in", "dedupe_keys_out")] + [("reserved", C.c_uint64 * 5)]
+        "nb_bases", "superkmer_bytes", "oversize_buckets", "dedupe_kmers_in", "dedupe_keys_out", "seq_len_min", "seq_len_max", "seq_len_sq_sum")] + [("reserved", C.c_uint64 * 2)]
 
 
 def build(force=False):

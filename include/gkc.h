@@ -141,7 +141,10 @@ typedef struct gkc_stats {
     uint64_t oversize_buckets;    /* sub-buckets that took the global-memory sort path    */
     uint64_t dedupe_kmers_in;     /* k-mers of the record bins that were deduplicated before the expansion (Stage B, k <= 31) ... */
     uint64_t dedupe_keys_out;     /* ... and the weighted keys they became (0 / 0: the step did not run)                          */
-    uint64_t reserved[5];
+    uint64_t seq_len_min;         /* pass 0 only: shortest / longest read and the sum of the squared read lengths — what BankStats::update keeps   */
+    uint64_t seq_len_max;         /* (BankKmers.hpp:164-200: seq_size_min / max / deviation of getInfo(), SortingCountAlgorithm.cpp:735-739);       */
+    uint64_t seq_len_sq_sum;      /* seq_len_min is 0 when no read was pushed                                                                       */
+    uint64_t reserved[2];
 } gkc_stats;
 int gkc_get_stats(gkc_ctx* ctx, gkc_stats* out);
 

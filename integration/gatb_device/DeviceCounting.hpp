@@ -28,6 +28,12 @@
 
 #include <vector>
 #include <mutex>
+#include <thread>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <gatb/bank/impl/BankFasta.hpp>
+#include <gatb/bank/impl/BankComposite.hpp>
 #include <string>
 #include <stdio.h>
 #include <stdlib.h>
@@ -140,6 +146,80 @@ public:
     {
         while (_comm != 0  &&  _exchangesDone < _nbExchanges)  { check (gkc_exchange (_ctx, _comm));  _exchangesDone++; }
     }
+    /** The plain-text FASTA / FASTQ files behind a bank, in iteration order (a BankFasta holds one file, BankFasta.cpp:109-116; an album / a list of banks is a
+     *  BankComposite of them, BankComposite.hpp:56-160). False when the bank is anything else, or a file is gzipped or cannot be opened: the bank is iterated then. */
+    static bool plainTextFiles (bank::IBank* bank, std::vector<std::string>& files)
+    {
+        if (bank == 0)  { return false; }
+        if (bank::impl::BankFasta* fasta = dynamic_cast<bank::impl::BankFasta*> (bank))
+        {
+            const std::string name = fasta->getId();
+            FILE* f = fopen (name.c_str(), "rb");  if (f == 0)  { return false; }
+            unsigned char magic[2] = {0, 0};  const size_t got = fread (magic, 1, 2, f);  fclose (f);
+            if (got == 2  &&  magic[0] == 0x1f  &&  magic[1] == 0x8b)  { return false; }      /* gzip: the reference's reader inflates it (BankFasta.cpp:425-483) */
+            files.push_back (name);
+            return true;
+        }
+        if (bank::impl::BankComposite* composite = dynamic_cast<bank::impl::BankComposite*> (bank))
+        {
+            const std::vector<bank::IBank*> subs = composite->getBanks();
+            if (subs.empty())  { return false; }
+            for (size_t i = 0; i < subs.size(); i++)  { if (subs[i] == bank  ||  !plainTextFiles (subs[i], files))  { return false; } }
+            return true;
+        }
+        return false;
+    }
+
+    /** The whole text of the files to the device: parsed there (gkc_push_fastx: gkc_fastx_parse_device + Stage A) instead of sequence by sequence through
+     *  BankFasta::Iterator (BankFasta.cpp:488-571) and the locked group reader of Dispatcher::iterate (ICommand.hpp:291-335). One rank only. Chunks of
+     *  CHUNK bytes are read by several threads (pread) into page-locked memory; the bytes behind the last complete record of a chunk open the next one.
+     *  Returns false when the text is not what the device parser takes (GKC_ERR_FORMAT: e.g. a multi-line FASTQ) — the caller starts the pass again and
+     *  iterates the bank. */
+    bool pushTextFiles (const std::vector<std::string>& files, gatb::core::tools::dp::IteratorListener* progress)
+    {
+        enum { CHUNK = 1 << 28, READERS = 8 };
+        if (_text == 0)  { void* p = 0;  check (gkc_host_alloc (&p, (uint64_t)CHUNK + 64));  _text = (char*) p; }
+        uint64_t seenReads = 0;
+        for (size_t fi = 0; fi < files.size(); fi++)
+        {
+            const int fd = ::open (files[fi].c_str(), O_RDONLY);
+            if (fd < 0)  { throw system::Exception ("device counting: cannot open %s", files[fi].c_str()); }
+            struct stat sb;  if (fstat (fd, &sb) != 0)  { ::close (fd);  throw system::Exception ("device counting: cannot stat %s", files[fi].c_str()); }
+            const uint64_t size = (uint64_t) sb.st_size;
+            uint64_t off = 0, have = 0;
+            bool ok = true;
+            while (ok  &&  (off < size  ||  have > 0))
+            {
+                const uint64_t n = std::min<uint64_t> ((uint64_t)CHUNK - have, size - off);
+                {   /* n bytes from `off` behind the `have` bytes that are left over */
+                    std::vector<std::thread> readers;  bool failed = false;
+                    const uint64_t share = (n + READERS - 1) / READERS;
+                    for (int r = 0; r < READERS; r++)
+                    {
+                        const uint64_t b = std::min<uint64_t> (n, (uint64_t)r * share), e = std::min<uint64_t> (n, b + share);
+                        if (b < e)  { readers.emplace_back ([=, &failed] { uint64_t done = b;  while (done < e) { const ssize_t g = pread (fd, _text + have + done, e - done, (off_t)(off + done));  if (g <= 0) { failed = true; break; }  done += (uint64_t)g; } }); }
+                    }
+                    for (size_t r = 0; r < readers.size(); r++)  { readers[r].join(); }
+                    if (failed)  { ::close (fd);  throw system::Exception ("device counting: read error in %s", files[fi].c_str()); }
+                }
+                off += n;  have += n;
+                const int final = off == size ? 1 : 0;
+                uint64_t consumed = 0;
+                const int rc = gkc_push_fastx (_ctx, _text, have, final, &consumed);
+                if (rc == GKC_ERR_FORMAT  ||  (rc == GKC_OK  &&  !final  &&  consumed == 0  &&  have == (uint64_t)CHUNK))  { ok = false;  break; }      /* (or one record larger than a chunk) */
+                check (rc);
+                if (consumed < have)  { memmove (_text, _text + consumed, have - consumed); }
+                have -= consumed;
+                if (final)  { have = 0; }
+                gkc_stats st;  check (gkc_get_stats (_ctx, &st));
+                if (progress != 0  &&  st.nb_sequences > seenReads)  { progress->inc (st.nb_sequences - seenReads);  seenReads = st.nb_sequences; }
+            }
+            ::close (fd);
+            if (!ok)  { return false; }
+        }
+        return true;
+    }
+
     /** Stage B. One rank: started in the background, the partition commands wait for their partition. Several ranks: counted, then gathered on rank 0. */
     void finishPass ()
     {
@@ -149,14 +229,15 @@ public:
     }
     void joinPass ()  { if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); } }
 
-    ~DeviceSession ()  { if (_comm) { gkc_comm_destroy (_comm); }  if (_ctx) { gkc_destroy (_ctx); } }
+    ~DeviceSession ()  { if (_text) { gkc_host_free (_text); }  if (_comm) { gkc_comm_destroy (_comm); }  if (_ctx) { gkc_destroy (_ctx); } }
 
 private:
-    DeviceSession () : _ctx(0), _comm(0), _ranks(1), _rank(0), _nbExchanges(1), _exchangesDone(0), _readsPerExchange(1), _pushedReads(0), _nbPartitions(0) {}
+    DeviceSession () : _text(0), _ctx(0), _comm(0), _ranks(1), _rank(0), _nbExchanges(1), _exchangesDone(0), _readsPerExchange(1), _pushedReads(0), _nbPartitions(0) {}
     void open ()
     {
         if (_ctx == 0  &&  gkc_create (0, &_ctx) != GKC_OK)  { throw system::Exception ("device counting: %s", gkc_last_error(0)); }
     }
+    char*     _text;        /**< page-locked buffer of pushTextFiles */
     gkc_ctx*  _ctx;
     gkc_comm* _comm;
     int       _ranks, _rank;

@@ -31,13 +31,25 @@ FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 \t\t\tdevice.configure (_config, *_repartitor, PartitionsByDeviceCommand<span>::bulkPlan (_processors.empty() ? 0 : _processors[0], _processors.size(), _config), pass);
 \t\t\tdevice.beginPass (pass);
 \t\t\ttypename FillPartitionsDevice<span>::Shared packed;
-\t\t\tgetDispatcher()->iterate (itSeq, FillPartitionsDevice<span> (packed, _progress, _config._kmerSize), groupSize, deleteSynchro);
-\t\t\tif (!packed.error.empty())  { throw system::Exception ("%s", packed.error.c_str()); }
+\t\t\t/* a bank of plain FASTA / FASTQ files (one rank): the text itself goes to the device and is parsed there; anything else is iterated */
+\t\t\tstd::vector<std::string> textFiles;
+\t\t\tbool direct = device.ranks() == 1  &&  getenv ("GATB_DEVICE_NO_TEXT") == 0  &&  DeviceSession::plainTextFiles (_bank, textFiles);
+\t\t\tif (direct  &&  !device.pushTextFiles (textFiles, _progress))  { direct = false;  device.beginPass (pass); }      /* not the device parser's subset: the pass again, iterated */
+\t\t\tif (!direct)
+\t\t\t{
+\t\t\t\tgetDispatcher()->iterate (itSeq, FillPartitionsDevice<span> (packed, _progress, _config._kmerSize), groupSize, deleteSynchro);
+\t\t\t\tif (!packed.error.empty())  { throw system::Exception ("%s", packed.error.c_str()); }
+\t\t\t}
 \t\t\tdevice.endOfReads();        /* multi-rank: the exchanges that are still due */
 \t\t\titSeq->finalize();
 \t\t\tif (pass == 0)
 \t\t\t{
 \t\t\t\tgkc_stats st;  device.check (gkc_get_stats (device.ctx(), &st));
+\t\t\t\tif (direct)      /* BankStats::update (BankKmers.hpp:176-186) from the device's counters */
+\t\t\t\t{
+\t\t\t\t\tpacked.stats.sequencesNb = st.nb_sequences;  packed.stats.sequencesTotalLength = st.nb_bases;  packed.stats.sequencesTotalLengthSquare = st.seq_len_sq_sum;
+\t\t\t\t\tpacked.stats.sequencesMinLength = st.seq_len_min;  packed.stats.sequencesMaxLength = st.seq_len_max;
+\t\t\t\t}
 \t\t\t\tpacked.stats.kmersNbValid = st.kmers_nb_valid;  packed.stats.kmersNbInvalid = st.kmers_nb_invalid;
 \t\t\t\t_bankStats += packed.stats;
 \t\t\t}

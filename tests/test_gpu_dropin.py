@@ -5,6 +5,8 @@ integration/SortingCountAlgorithm.device.patch + integration/gatb_device/DeviceC
 the histogram, the repartition table. Three ways through the binding:
   * bulk        the default chain: solidity window + histogram on the device, one block insert per partition (BagHDF5Patch::insert(const Item*, size_t));
   * per record  GATB_DEVICE_NO_BULK=1: every record through the chain's virtual process();
+  * iterated    GATB_DEVICE_NO_TEXT=1: the bank is iterated sequence by sequence and packed by the worker threads (what happens for a gzipped or non-FASTA bank);
+                by default the text of a plain FASTA / FASTQ bank goes to the device as it is and is parsed there (gkc_push_fastx);
   * two ranks   two processes on the one GPU (the library's file-mailbox transport), reads shared out by index, super-k-mers exchanged, results gathered on
                 rank 0: ONE .h5 with every dataset of the single-process file (CountProcessorDump.hpp:85-95, GraphUnitigs.cpp:921-931).
 The files are read back with the reference's own gatb-h5dump (integration/_build/ref, built by integration/build_reference.sh). Skipped where the artefacts are absent."""
@@ -65,9 +67,9 @@ def run_dbgh5(tag, outdir, env_extra=None, out_name=None):
 
 @needs_artefacts
 @pytest.mark.parametrize("tag", sorted(CASES))
-@pytest.mark.parametrize("mode", ["bulk", "per_record"])
+@pytest.mark.parametrize("mode", ["bulk", "per_record", "iterated"])
 def test_patched_dbgh5_writes_the_reference_datasets(tmp_path, tag, mode):
-    p, h5 = run_dbgh5(tag, str(tmp_path), {"GATB_DEVICE_NO_BULK": "1"} if mode == "per_record" else None)
+    p, h5 = run_dbgh5(tag, str(tmp_path), {"per_record": {"GATB_DEVICE_NO_BULK": "1"}, "iterated": {"GATB_DEVICE_NO_TEXT": "1"}}.get(mode))
     log = p.communicate(timeout=600)[0]
     assert p.returncode == 0, log[-2000:]
     check_h5(h5, tag)
@@ -84,3 +86,29 @@ def test_two_ranks_write_one_h5(tmp_path, tag):
     logs = [p.communicate(timeout=900)[0] for p, _ in procs]
     assert all(p.returncode == 0 for p, _ in procs), "\n".join(l[-1500:] for l in logs)
     check_h5(procs[0][1], tag)                     # rank 0's file: every dataset of the single-process file
+
+
+DBGINFO = os.path.join(ROOT, "integration", "_build", "ref", "dbginfo")
+
+
+@needs_artefacts
+@pytest.mark.skipif(not os.path.exists(DBGINFO), reason="integration/_build/ref/dbginfo absent")
+def test_bank_statistics_of_the_text_path(tmp_path):
+    """the device-parsed text path fills BankStats from the device's counters (gkc_stats.seq_len_*): getInfo() must report the same sequence statistics as the
+    iterated path, whose BankStats::update sees every Sequence (SortingCountAlgorithm.cpp:728-742, BankKmers.hpp:164-200)"""
+    keys = ("bank_total_nt", "seq_number", "seq_size_min", "seq_size_max", "seq_size_mean", "seq_size_deviation", "kmers_nb_valid", "kmers_nb_invalid",
+            "kmers_nb_distinct", "kmers_nb_solid")
+    seen = {}
+    for mode, env in (("text", None), ("iterated", {"GATB_DEVICE_NO_TEXT": "1"})):
+        p, h5 = run_dbgh5("k21_default_parts", str(tmp_path), env, out_name="stats_" + mode)
+        log = p.communicate(timeout=600)[0]
+        assert p.returncode == 0, log[-2000:]
+        info = subprocess.run([DBGINFO, "-in", h5], capture_output=True, text=True).stdout
+        vals = {}
+        for line in info.splitlines():
+            parts = line.split(":")
+            if len(parts) >= 2 and parts[0].strip() in keys and parts[0].strip() not in vals:
+                vals[parts[0].strip()] = parts[1].strip()
+        assert set(keys) <= set(vals), (mode, vals, info[-1500:])
+        seen[mode] = vals
+    assert seen["text"] == seen["iterated"], seen

@@ -710,3 +710,18 @@ print(json.dumps(res))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert json.loads(out.stdout.strip().splitlines()[-1]) == {"31": True, "41": True}
+
+
+def test_read_length_statistics(gkc):
+    """gkc_stats.seq_len_min / max / sq_sum: BankStats::update (BankKmers.hpp:176-186) over every pushed read, several pushes"""
+    reads = synth_reads(3000, 9000, 150, seed=5, n_rate=0.001, ragged=True) + [b"ACGT" * 3, b"A" * 700]
+    lens = np.array([len(r) for r in reads], dtype=np.uint64)
+    c = gkc.Counter(0); c.configure(21, 8, 4, simple_repart(8, 4))
+    c.begin_pass(0)
+    half = len(reads) // 2
+    for ch in (reads[:half], reads[half:]):
+        b, o = gko.pack_reads(ch); c.push_reads(b, o)
+    c.finish_pass()
+    st = c.stats()
+    assert st["nb_sequences"] == len(reads) and st["nb_bases"] == int(lens.sum())
+    assert st["seq_len_min"] == int(lens.min()) and st["seq_len_max"] == int(lens.max()) and st["seq_len_sq_sum"] == int((lens * lens).sum())

@@ -1,5 +1,6 @@
 """(GPU box) Wall of the DSK step inside the reference's own dbgh5, three ways, on the same FASTA of synthetic 150 bp reads in /dev/shm:
-   unpatched reference (integration/_build/ref/dbgh5)  |  patched, per-record hand-over (GATB_DEVICE_NO_BULK=1)  |  patched, bulk hand-over (default)
+   unpatched reference (integration/_build/ref/dbgh5)  |  patched: the bank iterated, per-record hand-over (GATB_DEVICE_NO_TEXT=1 GATB_DEVICE_NO_BULK=1)  |
+   patched: the bank iterated, bulk hand-over  |  patched: the FASTA text parsed on the device, bulk hand-over (default)
 `dsk.time`, fill_partitions, fill_solid_kmers as the reference's own dbginfo prints them (SortingCountAlgorithm.cpp:770-781), plus the process wall.
     python tools/dropin_timing.py [n_reads=10000000] [abundance_min=2]        -> stdout (kept under profiles/)"""
 import os, shutil, subprocess, sys, tempfile, time
@@ -37,16 +38,15 @@ def main():
         fa = os.path.join(work, "reads.fa"); rec.tofile(fa); del rec, bases
         cores = os.cpu_count() or 1
         print("# %d synthetic 150 bp reads (30x, 1%% substitutions) as FASTA in %s, k=31, abundance-min %s, -nb-cores %d, -bloom none -debloom none -branching-nodes none -no-mphf" % (n, work, amin, cores))
-        print("# %-34s %9s %9s %9s %9s %12s %12s   %s" % ("run", "wall s", "dsk s", "fill_part", "fill_solid", "distinct", "solid", "kind of partition commands"))
+        print("# %-62s %9s %9s %9s %9s %12s %12s   %s" % ("run", "wall s", "dsk s", "fill_part", "fill_solid", "distinct", "solid", "kind of partition commands"))
         ref_solid = None
         for name, exe, env in (("reference (unpatched dbgh5)", os.path.join(REF, "dbgh5"), {}),
-                               ("patched, per-record hand-over", DEV, {"GATB_DEVICE_NO_BULK": "1"}),
-                               ("patched, bulk hand-over", DEV, {})):
+                               ("patched, iterated bank, per-record hand-over", DEV, {"GATB_DEVICE_NO_BULK": "1", "GATB_DEVICE_NO_TEXT": "1"}),
+                               ("patched, iterated bank, bulk hand-over", DEV, {"GATB_DEVICE_NO_TEXT": "1"}),
+                               ("patched, text parsed on the device, bulk hand-over (default)", DEV, {})):
             if not os.path.exists(exe):
                 print("# %s: %s absent" % (name, exe)); continue
-            out = os.path.join(work, "out_" + name.split()[0].strip(","))
-            if name.endswith("bulk hand-over"):
-                out += "_bulk"
+            out = os.path.join(work, "out_%d" % abs(hash(name)))
             e = dict(os.environ); e.update(env)
             cmd = [exe, "-in", fa, "-kmer-size", "31", "-abundance-min", amin, "-nb-cores", str(cores), "-max-memory", "200000", "-bloom", "none", "-debloom", "none",
                    "-branching-nodes", "none", "-no-mphf", "-out", out, "-verbose", "0"]
@@ -55,7 +55,7 @@ def main():
                 print("# %s FAILED rc %d: %s" % (name, r.returncode, (r.stdout + r.stderr)[-400:])); continue
             v = info(out + ".h5")
             kinds = ", ".join("%s %s" % (k_, v[k_]) for k_ in ("vector", "hash", "device") if k_ in v)
-            print("  %-34s %9.2f %9s %9s %9s %12s %12s   %s" % (name, wall, v.get("time", "?"), v.get("fill_partitions", "?"), v.get("fill_solid_kmers", "?"),
+            print("  %-62s %9.2f %9s %9s %9s %12s %12s   %s" % (name, wall, v.get("time", "?"), v.get("fill_partitions", "?"), v.get("fill_solid_kmers", "?"),
                                                              v.get("kmers_nb_distinct", "?"), v.get("kmers_nb_solid", "?"), kinds), flush=True)
             if ref_solid is None:
                 ref_solid = (v.get("kmers_nb_distinct"), v.get("kmers_nb_solid"))
