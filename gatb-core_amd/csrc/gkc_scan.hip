@@ -39,6 +39,8 @@ struct ScanParams {
     const unsigned long long* wg_base;   // LDSPART emit : [grid][P] first arena slot of this workgroup in the partition
     const unsigned long long* rec_off;   // LDSPART emit : [P] first record of the partition in the arena
     uint32_t* desc; uint32_t desc_cap_wg; uint2* desc_tile; uint32_t* desc_overflow;   // record descriptors written by the count pass
+    uint8_t* desc_fine; uint32_t fine_shift;     // two-level scan, <= 16 partitions per group: `repart` is the FINE table, the group is partition >> fine_shift, and the
+                                                 // partition's low bits travel beside the descriptor into the record's 4 spare bits (k_refine_* read them back)
     unsigned long long* gstats;   // [0] valid k-mers [1] invalid k-mers [2] records emitted/counted
 };
 
@@ -83,7 +85,7 @@ constexpr int BE_PAD = 12;   // zero words after the tile planes so record extra
 // builds the 16/32-byte record of the super-k-mer that starts at tile-local position `start` (nbk k-mers) from the
 // big-endian 2-bit plane in LDS and stores it at arena slot `slot`
 template <int RW>
-__device__ __forceinline__ void store_record(const uint32_t* s_be, int start, uint32_t nbk, uint32_t k, uint64_t* arena, unsigned long long slot)
+__device__ __forceinline__ void store_record(const uint32_t* s_be, int start, uint32_t nbk, uint32_t k, uint64_t* arena, unsigned long long slot, const uint64_t spare = 0 /* the 4 bits below the nucleotides */)
 {
     const int w0 = start >> 4, sh = 2 * (start & 15);
     uint64_t A[RW + 1];
@@ -105,6 +107,7 @@ __device__ __forceinline__ void store_record(const uint32_t* s_be, int start, ui
         if (have <= 0) R[i] = 0;
         else if (have < 32) R[i] &= ~((1ULL << (64 - 2 * have)) - 1);
     }
+    R[RW - 1] |= spare;
     uint64_t* dst = arena + slot * RW;
 #pragma unroll
     for (int i = 0; i < RW; i += 2) store16(dst + i, R[i], R[i + 1]);
@@ -505,8 +508,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                     if (dlow[u] == 0xFFFFFFFFu) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }      // filtered out: a hole in the descriptor stream
                     n_rec++;
                     if (P.dbg_noatomic) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }
-                    atomicAdd(&s_part[dpart[u]], 1u);
-                    if (dstore) dst[e0 + u] = (dpart[u] << (DESC_START_BITS + DESC_NBK_BITS)) | dlow[u];
+                    const uint32_t grp = dpart[u] >> P.fine_shift;
+                    atomicAdd(&s_part[grp], 1u);
+                    if (dstore) {
+                        dst[e0 + u] = (grp << (DESC_START_BITS + DESC_NBK_BITS)) | dlow[u];
+                        if (P.fine_shift) P.desc_fine[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e0 + u] = (uint8_t)(dpart[u] & ((1u << P.fine_shift) - 1u));
+                    }
                 }
             }
         } else
@@ -516,7 +523,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             next_end(e, nbk, key, start);
             const uint32_t value = P.freq_mode ? P.key2val[key] : key;
             if (P.nb_passes > 1 && (value % P.nb_passes) != P.pass) continue;          // SortingCountAlgorithm.cpp:1083
-            const uint32_t part = P.identity_part ? value : P.repart[value];
+            const uint32_t full = P.identity_part ? value : P.repart[value];
+            const uint32_t part = full >> P.fine_shift;
             n_rec++;
             if (!EMIT) {
                 if (P.dbg_noatomic) continue;
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             } else {
                 const unsigned long long slot = LDSPART ? (P.wg_base[(uint64_t)blockIdx.x * P.n_parts + part] + atomicAdd(&s_part[part], 1u))
                                                         : atomicAdd(&P.cursor[part], 1ULL);
-                store_record<RW>(s_be, start, nbk, k, P.arena, slot);
+                store_record<RW>(s_be, start, nbk, k, P.arena, slot, (uint64_t)(full & ((1u << P.fine_shift) - 1u)));
             }
         }
     }
@@ -572,6 +580,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_emit_desc(ScanParams P)
     uint32_t* s_km = reinterpret_cast<uint32_t*>(s_cur + P.n_parts);              // k-mers per partition of this workgroup
     for (uint32_t p = threadIdx.x; p < P.n_parts; p += SCAN_THREADS) { s_cur[p] = P.wg_base[(uint64_t)blockIdx.x * P.n_parts + p]; s_km[p] = 0u; }
     const uint32_t* desc = P.desc + (uint64_t)blockIdx.x * P.desc_cap_wg;
+    const uint8_t* dfine = P.fine_shift ? P.desc_fine + (uint64_t)blockIdx.x * P.desc_cap_wg : nullptr;
     for (uint64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         int t = threadIdx.x;
         asm volatile("" : "+v"(t));
@@ -587,11 +596,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_emit_desc(ScanParams P)
         const uint2 td = P.desc_tile[tile];
         for (uint32_t i = t; i < td.y; i += SCAN_THREADS) {
             const uint32_t d = desc[td.x + i];
+            const uint64_t spare = dfine ? (uint64_t)dfine[td.x + i] : 0ULL;          // (both loads in flight together)
             if (d == 0xFFFFFFFFu) continue;
             const uint32_t part = d >> (DESC_START_BITS + DESC_NBK_BITS), nbk = ((d >> DESC_START_BITS) & ((1u << DESC_NBK_BITS) - 1)) + 1u; const int start = (int)(d & (uint32_t)(SCAN_TILE - 1));
             const unsigned long long slot = atomicAdd(&s_cur[part], 1ULL);
             atomicAdd(&s_km[part], nbk);
-            store_record<RW>(s_be, start, nbk, P.k, P.arena, slot);
+            store_record<RW>(s_be, start, nbk, P.k, P.arena, slot, spare);
         }
     }
     __syncthreads();
@@ -745,10 +755,11 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_refine_count(ScanParams P, c
 #pragma unroll
             for (int i = 0; i < RW / 2; i++) nx[i] = src[i]; }
         if (in) {
-            const uint32_t part = record_partition<RW>(R, P);
-            b = part - (g << shift); nk = (uint32_t)(R[0] >> 56);
+            if (fine_id == nullptr) b = (uint32_t)R[RW - 1] & 15u;      // the scan left the partition's low bits in the record's spare bits
+            else { b = record_partition<RW>(R, P) - (g << shift); }
+            nk = (uint32_t)(R[0] >> 56);
             if (b >= nf) { *bad = 1u; b = 0; nk = 0; }                   // cannot happen: the coarse group of a record is its partition >> shift
-            fine_id[r] = (uint8_t)b;
+            if (fine_id) fine_id[r] = (uint8_t)b;
         }
         // one LDS add per fine partition and wave, not per record: all lanes hitting the same 8 counters serialise
         const unsigned long long peers = wave_peers(b, shift, in);
@@ -772,17 +783,18 @@ __global__ __launch_bounds__(REFINE_THREADS) void k_refine_scatter(const uint64_
     const unsigned long long r0 = coarse_off[g], r1 = coarse_off[g + 1];
     const int lane = threadIdx.x & 63;
     ulonglong2 nx[RW / 2]; uint32_t nb_ = 0;                            // the next record (and its fine id) of the thread is in flight while this one is placed
-    if (r0 + threadIdx.x < r1) { const ulonglong2* src0 = reinterpret_cast<const ulonglong2*>(arena + (r0 + threadIdx.x) * RW); nb_ = fine_id[r0 + threadIdx.x];
+    if (r0 + threadIdx.x < r1) { const ulonglong2* src0 = reinterpret_cast<const ulonglong2*>(arena + (r0 + threadIdx.x) * RW); if (fine_id) nb_ = fine_id[r0 + threadIdx.x];
 #pragma unroll
         for (int i = 0; i < RW / 2; i++) nx[i] = src0[i]; }
     for (unsigned long long rb = r0; rb < r1; rb += REFINE_THREADS) {     // (uniform trip count: the ballots see all lanes)
         const unsigned long long r = rb + threadIdx.x;
         const bool in = r < r1;
-        const uint32_t b = in ? nb_ : 0u;
         ulonglong2 cur[RW / 2];
 #pragma unroll
         for (int i = 0; i < RW / 2; i++) cur[i] = nx[i];
-        if (r + REFINE_THREADS < r1) { const ulonglong2* src1 = reinterpret_cast<const ulonglong2*>(arena + (r + REFINE_THREADS) * RW); nb_ = fine_id[r + REFINE_THREADS];
+        if (fine_id == nullptr) { nb_ = (uint32_t)cur[RW / 2 - 1].y & 15u; cur[RW / 2 - 1].y &= ~15ull; }      // the spare bits go back to zero (Stage B keeps weights there)
+        const uint32_t b = in ? nb_ : 0u;
+        if (r + REFINE_THREADS < r1) { const ulonglong2* src1 = reinterpret_cast<const ulonglong2*>(arena + (r + REFINE_THREADS) * RW); if (fine_id) nb_ = fine_id[r + REFINE_THREADS];
 #pragma unroll
             for (int i = 0; i < RW / 2; i++) nx[i] = src1[i]; }
         // one returning LDS add per fine partition and wave (the lowest peer reserves for all, the others take their rank)
@@ -856,7 +868,11 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     P.mask_ma1 = (uint32_t)(0x5555555555555555ULL & ((1ULL << ((c->m - 2) * 2)) - 1));
     P.freq_mode = c->minimizer_type == GKC_MINIMIZER_FREQ;
     P.mkey_lut = (const uint32_t*)c->d_mkey_lut.p; P.key2val = (const uint32_t*)c->d_key2val.p; P.default_key = c->default_key;
-    P.repart = cshift ? (const uint16_t*)c->d_repart_coarse.p : (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
+    // two-level scan with <= 16 partitions per group: the scan looks the FINE partition up and leaves its low bits in the record (4 spare bits below the nucleotides),
+    // so the refine level does not recompute minimizers; more partitions per group: the group table, and k_refine_count recomputes
+    const bool stash = cshift > 0 && cshift <= 4 && getenv("GKC_REFINE_RECOMPUTE") == nullptr;
+    P.fine_shift = stash ? cshift : 0u; P.desc_fine = nullptr;
+    P.repart = (cshift && !stash) ? (const uint16_t*)c->d_repart_coarse.p : (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
     P.cnt_rec = cnt; P.cnt_kmers = cnt + Pn; P.cursor = cnt + 2 * (size_t)Pn; P.gstats = cnt + 3 * (size_t)Pn;
     P.arena = nullptr;
     P.dbg_noatomic = getenv("GKC_DEBUG_NOATOMIC") != nullptr;
@@ -870,7 +886,8 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         const uint64_t tiles_per_wg = (n_tiles + grid_n - 1) / grid_n;
         const uint64_t cap = tiles_per_wg * (SCAN_TILE * 5 / 32);
         if (cap < (1ULL << 32)) {
-            GKC_TRY(c->ensure(c->d_desc, (size_t)grid_n * cap * 4));
+            GKC_TRY(c->ensure(c->d_desc, (size_t)grid_n * cap * (stash ? 5 : 4)));
+            if (stash) P.desc_fine = (uint8_t*)c->d_desc.p + (size_t)grid_n * cap * 4;
             GKC_TRY(c->ensure(c->d_desc_tile, (size_t)n_tiles * 8));
             P.desc = (uint32_t*)c->d_desc.p; P.desc_cap_wg = (uint32_t)cap; P.desc_tile = (uint2*)c->d_desc_tile.p;
             P.desc_overflow = (uint32_t*)(cnt + 3 * (size_t)Pn + 3);
@@ -951,15 +968,16 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         if (total) {
             DevBuf d_fid, d_cnt, d_coff;
             struct Guard { DevBuf *a, *b, *cc; ~Guard() { a->release(); b->release(); cc->release(); } } guard{&d_fid, &d_cnt, &d_coff};
-            GKC_TRY(c->ensure(d_fid, (size_t)total)); GKC_TRY(c->ensure(d_cnt, ((size_t)2 * Pfine + 2) * 8)); GKC_TRY(c->ensure(d_coff, ((size_t)Pn + 1) * 8));
+            if (!stash) GKC_TRY(c->ensure(d_fid, (size_t)total));
+            GKC_TRY(c->ensure(d_cnt, ((size_t)2 * Pfine + 2) * 8)); GKC_TRY(c->ensure(d_coff, ((size_t)Pn + 1) * 8));
             GKC_HIP(c, hipMemsetAsync(d_cnt.p, 0, ((size_t)2 * Pfine + 2) * 8, c->stream));
             GKC_HIP(c, hipMemcpyAsync(d_coff.p, seg.rec_off.data(), ((size_t)Pn + 1) * 8, hipMemcpyHostToDevice, c->stream));
             ScanParams Q = P; Q.repart = (const uint16_t*)c->d_repart.p; Q.n_parts = Pfine;
             unsigned long long* fc = (unsigned long long*)d_cnt.p;
             if (c->record_bytes == 16) hipLaunchKernelGGL((k_refine_count<2>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, Q, (const uint64_t*)arena, (const unsigned long long*)d_coff.p,
-                                                          cshift, (uint8_t*)d_fid.p, fc, fc + Pfine, (uint32_t*)(fc + 2 * (size_t)Pfine));
+                                                          cshift, stash ? (uint8_t*)nullptr : (uint8_t*)d_fid.p, fc, fc + Pfine, (uint32_t*)(fc + 2 * (size_t)Pfine));
             else                       hipLaunchKernelGGL((k_refine_count<4>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, Q, (const uint64_t*)arena, (const unsigned long long*)d_coff.p,
-                                                          cshift, (uint8_t*)d_fid.p, fc, fc + Pfine, (uint32_t*)(fc + 2 * (size_t)Pfine));
+                                                          cshift, stash ? (uint8_t*)nullptr : (uint8_t*)d_fid.p, fc, fc + Pfine, (uint32_t*)(fc + 2 * (size_t)Pfine));
             GKC_HIP(c, hipGetLastError());
             std::vector<unsigned long long> hc((size_t)2 * Pfine + 1);
             GKC_HIP(c, hipMemcpyAsync(hc.data(), fc, hc.size() * 8, hipMemcpyDeviceToHost, c->stream));
@@ -973,9 +991,9 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
             if (!arena2) return GKC_ERR_NOMEM;
             GKC_HIP(c, hipMemcpyAsync(fc, fine.rec_off.data(), (size_t)Pfine * 8, hipMemcpyHostToDevice, c->stream));
             if (c->record_bytes == 16) hipLaunchKernelGGL((k_refine_scatter<2>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, (const uint64_t*)arena, (const unsigned long long*)d_coff.p, cshift,
-                                                          (const uint8_t*)d_fid.p, (const unsigned long long*)fc, Pfine, (uint64_t*)arena2);
+                                                          stash ? (const uint8_t*)nullptr : (const uint8_t*)d_fid.p, (const unsigned long long*)fc, Pfine, (uint64_t*)arena2);
             else                       hipLaunchKernelGGL((k_refine_scatter<4>), dim3(Pn), dim3(REFINE_THREADS), 0, c->stream, (const uint64_t*)arena, (const unsigned long long*)d_coff.p, cshift,
-                                                          (const uint8_t*)d_fid.p, (const unsigned long long*)fc, Pfine, (uint64_t*)arena2);
+                                                          stash ? (const uint8_t*)nullptr : (const uint8_t*)d_fid.p, (const unsigned long long*)fc, Pfine, (uint64_t*)arena2);
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->dfree(arena2); GKC_FAIL(c, GKC_ERR_HIP, "refine scatter failed: %s", hipGetErrorString(e)); }

@@ -138,6 +138,12 @@ def test_two_level_scan_many_partitions(gkc, monkeypatch, cmax):
     L.gko_freq_order_from_counts(m, counts, freq)
     device_vs_oracle(gkc, reads[:1500], 31, m, 50, freq=freq)
     device_vs_oracle(gkc, reads[:800], 45, m, 50, freq=freq)
+    # up to 16 partitions per group the scan leaves the partition's low bits in the record's spare bits (no recomputation); beyond, and with the switch, k_refine_count
+    # recomputes the minimizer: 200 partitions in <= 4 groups are 64 per group
+    device_vs_oracle(gkc, reads[:1500], 31, 10, 200)
+    monkeypatch.setenv("GKC_REFINE_RECOMPUTE", "1")
+    device_vs_oracle(gkc, reads[:1500], 31, 10, 64)
+    device_vs_oracle(gkc, reads[:800], 63, 9, 37, batches=2)
 
 
 def test_reference_known_answers_through_the_device(gkc, ref_vectors):
