@@ -170,11 +170,36 @@ public:
         return false;
     }
 
+    /** First byte of a record at or behind `pos` (a FASTA record starts with a '>' line; a FASTQ record with an '@' line whose second next line starts with '+':
+     *  a quality line may start with '@' too, but the line two below it is then a sequence). `size` when there is none. */
+    static uint64_t recordStart (int fd, uint64_t pos, uint64_t size, bool fastq)
+    {
+        if (pos == 0  ||  pos >= size)  { return std::min (pos, size); }
+        std::vector<char> win;
+        for (uint64_t len = 1 << 20;  ;  len *= 4)
+        {
+            const uint64_t from = pos - 1, n = std::min<uint64_t> (len, size - from);       /* from the byte before: is `pos` itself a line start? */
+            win.resize (n);
+            uint64_t done = 0;  while (done < n) { const ssize_t g = pread (fd, win.data() + done, n - done, (off_t)(from + done));  if (g <= 0) { return size; }  done += (uint64_t)g; }
+            std::vector<uint64_t> lines;                                                    /* line starts inside the window (window offsets) */
+            for (uint64_t i = 1; i < n; i++)  { if (win[i-1] == '\n')  { lines.push_back (i); } }
+            for (size_t l = 0; l < lines.size(); l++)
+            {
+                const char c0 = win[lines[l]];
+                if (!fastq)  { if (c0 == '>')  { return from + lines[l]; }  continue; }
+                if (c0 == '@'  &&  l + 2 < lines.size()  &&  win[lines[l+2]] == '+')  { return from + lines[l]; }
+            }
+            if (from + n >= size)  { return size; }
+        }
+    }
+
     /** The whole text of the files to the device: parsed there (gkc_push_fastx: gkc_fastx_parse_device + Stage A) instead of sequence by sequence through
-     *  BankFasta::Iterator (BankFasta.cpp:488-571) and the locked group reader of Dispatcher::iterate (ICommand.hpp:291-335). One rank only. Chunks of
-     *  CHUNK bytes are read by several threads (pread) into page-locked memory; the bytes behind the last complete record of a chunk open the next one.
-     *  Returns false when the text is not what the device parser takes (GKC_ERR_FORMAT: e.g. a multi-line FASTQ) — the caller starts the pass again and
-     *  iterates the bank. */
+     *  BankFasta::Iterator (BankFasta.cpp:488-571) and the locked group reader of Dispatcher::iterate (ICommand.hpp:291-335). Chunks of CHUNK bytes are read
+     *  by several threads (pread) into page-locked memory; the bytes behind the last complete record of a chunk open the next one. Several ranks: every rank
+     *  takes its own byte range of every file, cut at record starts (which rank scans which read does not matter: the super-k-mers go to the owner of their
+     *  partition), and makes the exchanges that are due as its reads go by.
+     *  Returns false when the text is not what the device parser takes (GKC_ERR_FORMAT: e.g. a multi-line FASTQ) — one rank: the caller starts the pass again
+     *  and iterates the bank; several ranks: an error (the other ranks cannot be called back). */
     bool pushTextFiles (const std::vector<std::string>& files, gatb::core::tools::dp::IteratorListener* progress)
     {
         enum { CHUNK = 1 << 28, READERS = 8 };
@@ -185,8 +210,16 @@ public:
             const int fd = ::open (files[fi].c_str(), O_RDONLY);
             if (fd < 0)  { throw system::Exception ("device counting: cannot open %s", files[fi].c_str()); }
             struct stat sb;  if (fstat (fd, &sb) != 0)  { ::close (fd);  throw system::Exception ("device counting: cannot stat %s", files[fi].c_str()); }
-            const uint64_t size = (uint64_t) sb.st_size;
-            uint64_t off = 0, have = 0;
+            const uint64_t fileSize = (uint64_t) sb.st_size;
+            uint64_t off = 0, size = fileSize;
+            if (_ranks > 1  &&  fileSize > 0)
+            {
+                char first = 0;  if (pread (fd, &first, 1, 0) != 1)  { ::close (fd);  throw system::Exception ("device counting: read error in %s", files[fi].c_str()); }
+                const bool fastq = first == '@';
+                off  = recordStart (fd, fileSize / (uint64_t)_ranks * (uint64_t)_rank, fileSize, fastq);
+                size = _rank + 1 == _ranks ? fileSize : recordStart (fd, fileSize / (uint64_t)_ranks * (uint64_t)(_rank + 1), fileSize, fastq);
+            }
+            uint64_t have = 0;
             bool ok = true;
             while (ok  &&  (off < size  ||  have > 0))
             {
@@ -212,10 +245,22 @@ public:
                 have -= consumed;
                 if (final)  { have = 0; }
                 gkc_stats st;  check (gkc_get_stats (_ctx, &st));
-                if (progress != 0  &&  st.nb_sequences > seenReads)  { progress->inc (st.nb_sequences - seenReads);  seenReads = st.nb_sequences; }
+                if (st.nb_sequences > seenReads)
+                {
+                    if (progress != 0)  { progress->inc (st.nb_sequences - seenReads); }
+                    _pushedReads += st.nb_sequences - seenReads;  seenReads = st.nb_sequences;
+                }
+                while (_comm != 0  &&  _exchangesDone + 1 < _nbExchanges  &&  _pushedReads >= (u_int64_t)(_exchangesDone + 1) * _readsPerExchange)
+                {
+                    check (gkc_exchange (_ctx, _comm));  _exchangesDone++;
+                }
             }
             ::close (fd);
-            if (!ok)  { return false; }
+            if (!ok)
+            {
+                if (_ranks > 1)  { throw system::Exception ("device counting: %s is not FASTA / FASTQ text the device parser takes; with several ranks set GATB_DEVICE_NO_TEXT=1", files[fi].c_str()); }
+                return false;
+            }
         }
         return true;
     }

@@ -31,9 +31,9 @@ FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 \t\t\tdevice.configure (_config, *_repartitor, PartitionsByDeviceCommand<span>::bulkPlan (_processors.empty() ? 0 : _processors[0], _processors.size(), _config), pass);
 \t\t\tdevice.beginPass (pass);
 \t\t\ttypename FillPartitionsDevice<span>::Shared packed;
-\t\t\t/* a bank of plain FASTA / FASTQ files (one rank): the text itself goes to the device and is parsed there; anything else is iterated */
+\t\t\t/* a bank of plain FASTA / FASTQ files: the text itself goes to the device and is parsed there (several ranks: a byte range of every file each); anything else is iterated */
 \t\t\tstd::vector<std::string> textFiles;
-\t\t\tbool direct = device.ranks() == 1  &&  getenv ("GATB_DEVICE_NO_TEXT") == 0  &&  DeviceSession::plainTextFiles (_bank, textFiles);
+\t\t\tbool direct = getenv ("GATB_DEVICE_NO_TEXT") == 0  &&  DeviceSession::plainTextFiles (_bank, textFiles);
 \t\t\tif (direct  &&  !device.pushTextFiles (textFiles, _progress))  { direct = false;  device.beginPass (pass); }      /* not the device parser's subset: the pass again, iterated */
 \t\t\tif (!direct)
 \t\t\t{

@@ -52,12 +52,29 @@ def check_h5(h5, tag):
     assert np.array_equal(hist[:, 4:].copy().view("<u8")[:, 0], z["histogram_abundance"]), "histogram differs"
 
 
-def run_dbgh5(tag, outdir, env_extra=None, out_name=None):
+def fasta_to_fastq(text):
+    """the same reads as FASTQ; every third quality line starts with '@' (a record start must not be taken for one: DeviceSession::recordStart)"""
+    out, name, seq, n = [], None, [], 0
+    def flush():
+        nonlocal n
+        if name is not None:
+            sq = b"".join(seq)
+            out.append(b"@" + name + b"\n" + sq + b"\n+\n" + ((b"@" + b"I" * (len(sq) - 1)) if n % 3 == 0 and sq else b"I" * len(sq)) + b"\n"); n += 1
+    for line in text.split(b"\n"):
+        if line.startswith(b">"):
+            flush(); name = line[1:]; seq = []
+        elif line:
+            seq.append(line.strip())
+    flush()
+    return b"".join(out)
+
+
+def run_dbgh5(tag, outdir, env_extra=None, out_name=None, fastq=False):
     z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
     extra, mem, cores = CASES[tag]
-    fa = os.path.join(outdir, tag + ".fa")
+    fa = os.path.join(outdir, tag + (".fq" if fastq else ".fa"))
     if not os.path.exists(fa):
-        open(fa, "wb").write(bytes(z["fasta"]))
+        open(fa, "wb").write(fasta_to_fastq(bytes(z["fasta"])) if fastq else bytes(z["fasta"]))
     out = os.path.join(outdir, out_name or (tag + "_dev"))
     cmd = [EXE, "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", outdir, "-nb-cores", cores,
            "-max-memory", mem, "-verbose", "0", "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"] + extra
@@ -67,22 +84,26 @@ def run_dbgh5(tag, outdir, env_extra=None, out_name=None):
 
 @needs_artefacts
 @pytest.mark.parametrize("tag", sorted(CASES))
-@pytest.mark.parametrize("mode", ["bulk", "per_record", "iterated"])
+@pytest.mark.parametrize("mode", ["bulk", "per_record", "iterated", "fastq"])
 def test_patched_dbgh5_writes_the_reference_datasets(tmp_path, tag, mode):
-    p, h5 = run_dbgh5(tag, str(tmp_path), {"per_record": {"GATB_DEVICE_NO_BULK": "1"}, "iterated": {"GATB_DEVICE_NO_TEXT": "1"}}.get(mode))
+    p, h5 = run_dbgh5(tag, str(tmp_path), {"per_record": {"GATB_DEVICE_NO_BULK": "1"}, "iterated": {"GATB_DEVICE_NO_TEXT": "1"}}.get(mode), fastq=mode == "fastq")
     log = p.communicate(timeout=600)[0]
     assert p.returncode == 0, log[-2000:]
     check_h5(h5, tag)
 
 
 @needs_artefacts
-@pytest.mark.parametrize("tag", ["k21_freq_4parts", "k31_2parts_mphf"])
-def test_two_ranks_write_one_h5(tmp_path, tag):
+@pytest.mark.parametrize("tag,how", [("k21_freq_4parts", "text"), ("k31_2parts_mphf", "text"), ("k21_default_parts", "fastq"), ("k31_2parts_mphf", "iterated")])
+def test_two_ranks_write_one_h5(tmp_path, tag, how):
+    """how: text = every rank parses its own byte range of the FASTA file on the device; fastq = the same on a FASTQ version of the reads (record starts found among
+    quality lines that begin with '@'); iterated = every rank iterates the bank and keeps the reads whose index is its rank modulo 2"""
     box = tmp_path / "box"; box.mkdir()
     procs = []
     for r in range(2):
         env = {"GATB_DEVICE_RANKS": "2", "GATB_DEVICE_RANK": str(r), "GATB_DEVICE_TRANSPORT_DIR": str(box)}
-        procs.append(run_dbgh5(tag, str(tmp_path), env, out_name="%s_rank%d" % (tag, r)))
+        if how == "iterated":
+            env["GATB_DEVICE_NO_TEXT"] = "1"
+        procs.append(run_dbgh5(tag, str(tmp_path), env, out_name="%s_rank%d" % (tag, r), fastq=how == "fastq"))
     logs = [p.communicate(timeout=900)[0] for p, _ in procs]
     assert all(p.returncode == 0 for p, _ in procs), "\n".join(l[-1500:] for l in logs)
     check_h5(procs[0][1], tag)                     # rank 0's file: every dataset of the single-process file
