@@ -601,7 +601,7 @@ int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint6
     *d_bases = (char*)b; *d_offsets = (uint64_t*)o;
     return GKC_OK;
 }
-int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) GKC_HIP(c, hipFree(p)); return GKC_OK; }
+int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) { GKC_HIP(c, hipSetDevice(c->device)); c->dfree(p); } return GKC_OK; }      // back to the context's allocator (a foreign pointer: hipFree)
 int gkc_release_pass(gkc_ctx* c, uint32_t pass)
 {
     if (!c) return GKC_ERR_ARG;

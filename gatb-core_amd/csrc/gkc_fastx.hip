@@ -311,8 +311,8 @@ int gkc_fastx_parse_device(gkc_ctx* c, const char* d_text, uint64_t n, int final
     if (n >= (1ULL << 36)) GKC_FAIL(c, GKC_ERR_ARG, "a text chunk is limited to 2^36 bytes");
     const uint8_t* text = (const uint8_t*)d_text;
     auto finish_empty = [&]() -> int {
-        void* o = nullptr; void* b = nullptr;
-        if (hipMalloc(&o, 8) != hipSuccess || hipMalloc(&b, 64) != hipSuccess) { if (o) (void)hipFree(o); GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc failed"); }
+        void* o = c->dalloc(8); void* b = o ? c->dalloc(64) : nullptr;           // (the context's caching allocator: a chunk per call would otherwise cost a hipMalloc + hipFree of ~10 ms)
+        if (!o || !b) { if (o) c->dfree(o); return GKC_ERR_NOMEM; }
         GKC_HIP(c, hipMemsetAsync(o, 0, 8, c->stream)); GKC_HIP(c, hipStreamSynchronize(c->stream));
         *d_bases = (char*)b; *d_offsets = (uint64_t*)o; *consumed = final_chunk ? n : 0;
         return GKC_OK;
@@ -385,15 +385,16 @@ int gkc_fastx_parse_device(gkc_ctx* c, const char* d_text, uint64_t n, int final
     if (info.error) GKC_FAIL(c, GKC_ERR_FORMAT, "FASTA/FASTQ text not parseable on the device, line %llu: %s", (unsigned long long)info.error_line + 1, fx_error_text(info.error));
     const uint64_t nr = tots[0], nb = tots[1];
     // 5 compaction
-    void *b = nullptr, *o = nullptr;
-    if (hipMalloc(&b, (size_t)nb + 64) != hipSuccess) GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of %llu bases failed", (unsigned long long)nb);
-    if (hipMalloc(&o, (size_t)(nr + 1) * 8) != hipSuccess) { (void)hipFree(b); GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of offsets failed"); }
+    void* b = c->dalloc((size_t)nb + 64);
+    if (!b) return GKC_ERR_NOMEM;
+    void* o = c->dalloc((size_t)(nr + 1) * 8);
+    if (!o) { c->dfree(b); return GKC_ERR_NOMEM; }
     hipLaunchKernelGGL((k_fx_keep<true>), dim3((unsigned)n_tiles), dim3(FX_THREADS), 0, c->stream, text, n, (const uint64_t*)tile_line0.p, (const uint64_t*)line_start.p,
                        (const uint8_t*)kind.p, n_lines, (uint64_t*)tile_keep.p, (const uint64_t*)rec_id.p, (uint8_t*)b, (uint64_t*)o);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync((uint64_t*)o + nr, &nb, 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { (void)hipFree(b); (void)hipFree(o); GKC_FAIL(c, GKC_ERR_HIP, "fastx compaction failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { c->dfree(b); c->dfree(o); GKC_FAIL(c, GKC_ERR_HIP, "fastx compaction failed: %s", hipGetErrorString(e)); }
     *d_bases = (char*)b; *d_offsets = (uint64_t*)o; *n_reads = nr; *n_bases = nb; *consumed = cons;
     return GKC_OK;
 }
@@ -410,8 +411,8 @@ int gkc_push_fastx(gkc_ctx* c, const char* text, uint64_t n, int final_chunk, ui
     int rc = gkc_fastx_parse_device(c, (const char*)dt.p, n, final_chunk, &db, &dof, &nr, &nb, consumed);
     if (rc == GKC_OK && nr) rc = gkc_push_reads_device(c, db, dof, nr, nb);
     (void)hipStreamSynchronize(c->stream);
-    if (db) (void)hipFree(db);
-    if (dof) (void)hipFree(dof);
+    if (db) c->dfree(db);
+    if (dof) c->dfree(dof);
     dt.release();
     return rc;
 }
