@@ -203,7 +203,7 @@ public:
      *  and iterates the bank; several ranks: an error (the other ranks cannot be called back). */
     bool pushTextFiles (const std::vector<std::string>& files, gatb::core::tools::dp::IteratorListener* progress)
     {
-        enum { CHUNK = 1 << 26, PAD = 1 << 24, READERS = 16 };
+        enum { CHUNK = 1 << 28, PAD = 1 << 24, READERS = 16 };      /* (large chunks: every chunk is one segment of super-k-mer records, and Stage B walks a partition segment by segment) */
         /* (ordinary memory: page-locking 2 x 272 MB costs more than the staged copy of 1.5 GB loses — measured 0.31 s against 0.26 s of fill_partitions at 10^7 reads) */
         for (int i = 0; i < 2; i++)  { if (_text[i] == 0)  { _text[i] = (char*) malloc ((size_t)CHUNK + PAD + 64);  if (_text[i] == 0) { throw system::Exception ("device counting: out of host memory"); } } }
         uint64_t seenReads = 0;
