@@ -166,7 +166,7 @@ __device__ unsigned long long g_scan_prof[16];
 // and the emit launch). Per-partition counters / record cursors live in LDS (64-bit LDS atomics): the count launch
 // leaves a [workgroup][partition] matrix, a tiny prefix kernel turns it into private record ranges, and the emit launch
 // needs no global atomic at all. !LDSPART (nb_partitions too large for LDS): global atomics per record.
-template <bool EMIT, int RW, bool LDSPART>
+template <bool EMIT, int RW, bool LDSPART, bool FINE = false /* count pass of the two-level scan with the fine bits kept beside the descriptors */>
 __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_part[];       // per-partition record counter of this workgroup (4 B)
@@ -508,11 +508,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                     if (dlow[u] == 0xFFFFFFFFu) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }      // filtered out: a hole in the descriptor stream
                     n_rec++;
                     if (P.dbg_noatomic) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }
-                    const uint32_t grp = dpart[u] >> P.fine_shift;
+                    const uint32_t grp = FINE ? dpart[u] >> P.fine_shift : dpart[u];
                     atomicAdd(&s_part[grp], 1u);
                     if (dstore) {
                         dst[e0 + u] = (grp << (DESC_START_BITS + DESC_NBK_BITS)) | dlow[u];
-                        if (P.fine_shift) P.desc_fine[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e0 + u] = (uint8_t)(dpart[u] & ((1u << P.fine_shift) - 1u));
+                        if constexpr (FINE) P.desc_fine[(uint64_t)blockIdx.x * P.desc_cap_wg + dbase + e0 + u] = (uint8_t)(dpart[u] & ((1u << P.fine_shift) - 1u));
                     }
                 }
             }
@@ -650,10 +650,10 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
     dim3 grid(grid_n), block(SCAN_THREADS);
 #define GKC_LAUNCH(E, R, L) hipLaunchKernelGGL((k_scan_tile<E, R, L>), grid, block, dyn_lds, c->stream, P)
     if (c->record_bytes == 16) {
-        if (ldspart) { if (emit) GKC_LAUNCH(true, 2, true); else GKC_LAUNCH(false, 2, true); }
+        if (ldspart) { if (emit) GKC_LAUNCH(true, 2, true); else if (P.fine_shift) hipLaunchKernelGGL((k_scan_tile<false, 2, true, true>), grid, block, dyn_lds, c->stream, P); else GKC_LAUNCH(false, 2, true); }
         else         { if (emit) GKC_LAUNCH(true, 2, false); else GKC_LAUNCH(false, 2, false); }
     } else {
-        if (ldspart) { if (emit) GKC_LAUNCH(true, 4, true); else GKC_LAUNCH(false, 4, true); }
+        if (ldspart) { if (emit) GKC_LAUNCH(true, 4, true); else if (P.fine_shift) hipLaunchKernelGGL((k_scan_tile<false, 4, true, true>), grid, block, dyn_lds, c->stream, P); else GKC_LAUNCH(false, 4, true); }
         else         { if (emit) GKC_LAUNCH(true, 4, false); else GKC_LAUNCH(false, 4, false); }
     }
 #undef GKC_LAUNCH
