@@ -29,6 +29,8 @@
 #include <vector>
 #include <mutex>
 #include <thread>
+#include <memory>
+#include <time.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
@@ -283,11 +285,23 @@ public:
     /** Stage B. One rank: started in the background, the partition commands wait for their partition. Several ranks: counted, then gathered on rank 0. */
     void finishPass ()
     {
+        _finishWall = wallNow();
         if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  return; }
         check (gkc_finish_pass (_ctx));
         check (gkc_gather_results (_ctx, _comm, 0));
     }
-    void joinPass ()  { if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); } }
+    void joinPass ()
+    {
+        if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); }
+        if (getenv ("GATB_DEVICE_VERBOSE") != 0)
+        {
+            double a = 0, b = 0;  uint64_t n = 0;
+            gkc_get_timing (_ctx, "total_stage_a", &a, &n);  gkc_get_timing (_ctx, "total_stage_b", &b, &n);
+            fprintf (stderr, "[device counting] Stage A %.0f ms, Stage B %.0f ms on the device (summed over the passes so far); %.2f s of wall between the start of Stage B and the last partition handed over\n",
+                     a, b, wallNow() - _finishWall);
+        }
+    }
+    static double wallNow ()  { struct timespec ts;  clock_gettime (CLOCK_MONOTONIC, &ts);  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
     ~DeviceSession ()  { for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); }  if (_ctx) { gkc_destroy (_ctx); } }
 
@@ -305,6 +319,7 @@ private:
     u_int64_t _readsPerExchange, _pushedReads;
     DeviceBulkPlan _plan;
     size_t    _nbPartitions;
+    double    _finishWall = 0;
 };
 
 /********************************************************************************/
@@ -446,19 +461,22 @@ public:
 
         /* the device's Count records of this partition (ascending), as soon as Stage B has produced them */
         const void* landed = 0;  uint64_t nbSolid = 0;
+        const double t0 = now();
         dev.check (gkc_wait_partition (dev.ctx(), this->_pass_num, this->_parti_num, &landed, &nbSolid));
+        const double t1 = now();
 
         /* the device record width follows k (16 bytes for k <= 31, 32 bytes above) */
         const size_t recBytes = this->_kmerSize <= 31 ? 16 : 32;
-        std::vector<unsigned char> fetched;
+        std::unique_ptr<unsigned char[]> fetched;                 /* (not a vector: no zero-fill of a block that is overwritten at once) */
         const unsigned char* recs = (const unsigned char*) landed;
         if (recs == 0  &&  nbSolid > 0)
         {
-            fetched.resize (nbSolid * recBytes);
+            fetched.reset (new unsigned char [nbSolid * recBytes]);
             uint64_t got = 0;
-            dev.check (gkc_partition_counts (dev.ctx(), this->_pass_num, this->_parti_num, fetched.data(), nbSolid, &got));
-            recs = fetched.data();
+            dev.check (gkc_partition_counts (dev.ctx(), this->_pass_num, this->_parti_num, fetched.get(), nbSolid, &got));
+            recs = fetched.get();
         }
+        const double t2 = now();
 
         CountProcessorDump<span>* dump = 0;
         if (dev.plan().on)
@@ -497,9 +515,22 @@ public:
 
         this->_progress->inc (this->_pInfo.getNbKmer (this->_parti_num));
         this->_processor->endPart (this->_pass_num, this->_parti_num);
+        if (getenv ("GATB_DEVICE_VERBOSE") != 0)
+        {
+            static std::mutex mu;  static double waited = 0, fetchedS = 0, handed = 0;  static size_t done = 0;
+            std::lock_guard<std::mutex> guard (mu);
+            waited += t1 - t0;  fetchedS += t2 - t1;  handed += now() - t2;  done++;
+            if (done % dev.nbPartitions() == 0)
+            {
+                fprintf (stderr, "[device counting] pass %d, summed over the partition commands: waiting for Stage B %.2f s, Count[] to the host %.2f s, hand-over to the processors %.2f s\n",
+                         (int)this->_pass_num, waited, fetchedS, handed);
+                waited = fetchedS = handed = 0;
+            }
+        }
     }
 
 private:
+    static double now ()  { struct timespec ts;  clock_gettime (CLOCK_MONOTONIC, &ts);  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     static void decode (const unsigned char* r, size_t recBytes, Type& kmer, CountNumber& abundance)
     {
         if (recBytes == 16)  {  kmer.setVal (*(const u_int64_t*) r);  }

@@ -44,6 +44,8 @@ def main():
                                ("patched, iterated bank, per-record hand-over", DEV, {"GATB_DEVICE_NO_BULK": "1", "GATB_DEVICE_NO_TEXT": "1"}),
                                ("patched, iterated bank, bulk hand-over", DEV, {"GATB_DEVICE_NO_TEXT": "1"}),
                                ("patched, text parsed on the device, bulk hand-over (default)", DEV, {})):
+            if os.environ.get("DROPIN_ONLY") and os.environ["DROPIN_ONLY"] not in name:
+                continue
             if not os.path.exists(exe):
                 print("# %s: %s absent" % (name, exe)); continue
             out = os.path.join(work, "out_%d" % abs(hash(name)))
@@ -51,6 +53,8 @@ def main():
             cmd = [exe, "-in", fa, "-kmer-size", "31", "-abundance-min", amin, "-nb-cores", str(cores), "-max-memory", "200000", "-bloom", "none", "-debloom", "none",
                    "-branching-nodes", "none", "-no-mphf", "-out", out, "-verbose", "0"]
             t0 = time.time(); r = subprocess.run(cmd, cwd=work, env=e, capture_output=True, text=True); wall = time.time() - t0
+            if os.environ.get("GATB_DEVICE_VERBOSE"):
+                print("#   " + "\n#   ".join(l for l in (r.stdout + r.stderr).splitlines() if "device counting" in l or "[gkc]" in l)[:3000])
             if r.returncode != 0:
                 print("# %s FAILED rc %d: %s" % (name, r.returncode, (r.stdout + r.stderr)[-400:])); continue
             v = info(out + ".h5")
