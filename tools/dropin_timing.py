@@ -37,20 +37,21 @@ def main():
         rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 2] = 10; rec[:, 3:3 + L] = bases.reshape(n, L); rec[:, 3 + L] = 10
         fa = os.path.join(work, "reads.fa"); rec.tofile(fa); del rec, bases
         cores = os.cpu_count() or 1
-        print("# %d synthetic 150 bp reads (30x, 1%% substitutions) as FASTA in %s, k=31, abundance-min %s, -nb-cores %d, -bloom none -debloom none -branching-nodes none -no-mphf" % (n, work, amin, cores))
-        print("# %-62s %9s %9s %9s %9s %12s %12s   %s" % ("run", "wall s", "dsk s", "fill_part", "fill_solid", "distinct", "solid", "kind of partition commands"))
+        print("# %d synthetic 150 bp reads (30x, 1%% substitutions) as FASTA in %s, k=31, abundance-min %s, -nb-cores %d, -max-memory 200000 unless stated, -bloom none -debloom none -branching-nodes none -no-mphf" % (n, work, amin, cores))
+        print("# %-78s %9s %9s %9s %9s %12s %12s   %s" % ("run", "wall s", "dsk s", "fill_part", "fill_solid", "distinct", "solid", "kind of partition commands"))
         ref_solid = None
         for name, exe, env in (("reference (unpatched dbgh5)", os.path.join(REF, "dbgh5"), {}),
                                ("patched, iterated bank, per-record hand-over", DEV, {"GATB_DEVICE_NO_BULK": "1", "GATB_DEVICE_NO_TEXT": "1"}),
                                ("patched, iterated bank, bulk hand-over", DEV, {"GATB_DEVICE_NO_TEXT": "1"}),
-                               ("patched, text parsed on the device, bulk hand-over (default)", DEV, {})):
+                               ("patched, text parsed on the device, bulk hand-over (default)", DEV, {}),
+                               ("patched (default), -max-memory 5000 = dbgh5's own default: 2816 partitions", DEV, {"_maxmem": "5000"})):
             if os.environ.get("DROPIN_ONLY") and os.environ["DROPIN_ONLY"] not in name:
                 continue
             if not os.path.exists(exe):
                 print("# %s: %s absent" % (name, exe)); continue
             out = os.path.join(work, "out_%d" % abs(hash(name)))
-            e = dict(os.environ); e.update(env)
-            cmd = [exe, "-in", fa, "-kmer-size", "31", "-abundance-min", amin, "-nb-cores", str(cores), "-max-memory", "200000", "-bloom", "none", "-debloom", "none",
+            e = dict(os.environ); e.update({k_: v_ for k_, v_ in env.items() if not k_.startswith("_")})
+            cmd = [exe, "-in", fa, "-kmer-size", "31", "-abundance-min", amin, "-nb-cores", str(cores), "-max-memory", env.get("_maxmem", "200000"), "-bloom", "none", "-debloom", "none",
                    "-branching-nodes", "none", "-no-mphf", "-out", out, "-verbose", "0"]
             t0 = time.time(); r = subprocess.run(cmd, cwd=work, env=e, capture_output=True, text=True); wall = time.time() - t0
             if os.environ.get("GATB_DEVICE_VERBOSE"):
@@ -59,7 +60,7 @@ def main():
                 print("# %s FAILED rc %d: %s" % (name, r.returncode, (r.stdout + r.stderr)[-400:])); continue
             v = info(out + ".h5")
             kinds = ", ".join("%s %s" % (k_, v[k_]) for k_ in ("vector", "hash", "device") if k_ in v)
-            print("  %-62s %9.2f %9s %9s %9s %12s %12s   %s" % (name, wall, v.get("time", "?"), v.get("fill_partitions", "?"), v.get("fill_solid_kmers", "?"),
+            print("  %-78s %9.2f %9s %9s %9s %12s %12s   %s" % (name, wall, v.get("time", "?"), v.get("fill_partitions", "?"), v.get("fill_solid_kmers", "?"),
                                                              v.get("kmers_nb_distinct", "?"), v.get("kmers_nb_solid", "?"), kinds), flush=True)
             if ref_solid is None:
                 ref_solid = (v.get("kmers_nb_distinct"), v.get("kmers_nb_solid"))
