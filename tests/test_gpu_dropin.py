@@ -133,3 +133,22 @@ def test_bank_statistics_of_the_text_path(tmp_path):
         assert set(keys) <= set(vals), (mode, vals, info[-1500:])
         seen[mode] = vals
     assert seen["text"] == seen["iterated"], seen
+
+
+@needs_artefacts
+def test_a_bank_of_two_files_goes_to_the_device_as_text(tmp_path):
+    """-in a.fa,b.fa is a BankComposite of two BankFasta (Bank::open): DeviceSession::plainTextFiles walks it and both files are parsed on the device, one after
+    the other; the datasets are those of the one-file run (the reads are the same, cut at a record start)"""
+    tag = "k21_default_parts"
+    z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    text = bytes(z["fasta"])
+    cut = text.index(b"\n>", len(text) // 2) + 1
+    a, b = str(tmp_path / "a.fa"), str(tmp_path / "b.fa")
+    open(a, "wb").write(text[:cut]); open(b, "wb").write(text[cut:])
+    extra, mem, cores = CASES[tag]
+    out = str(tmp_path / "two_files")
+    cmd = [EXE, "-in", a + "," + b, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", str(tmp_path), "-nb-cores", cores,
+           "-max-memory", mem, "-verbose", "0", "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"] + extra
+    r = subprocess.run(cmd, env=dict(os.environ, GATB_DEVICE_VERBOSE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    check_h5(out + ".h5", tag)

@@ -689,7 +689,8 @@ def test_alternative_kernel_paths_stay_bit_exact(gkc, switch):
     that recomputes instead of reading descriptors, global-atomic cursors instead of LDS ones; partitions in batch order; split levels of 2 bits each, which
     forces more of them than the fixed launches; no workgroup tier; 2 / 64 sub-buckets per partition, which makes every sub-bucket a root of the split levels —
     with 2 they are "giants" split by many workgroups together): each must give the oracle's records on an input with N's, ragged reads,
-    low-complexity reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31 and k = 41.
+    low-complexity reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31, k = 41 and k = 63 (the longest records the
+    256-bit canonical form of the deduplication sees).
     (The measured-slower round-2 kernels left the product: branch experiments-r02, logs in profiles/r02_*_experiment.txt.)"""
     import json, os, subprocess, sys
     code = r'''
@@ -703,7 +704,7 @@ reads = synth_reads(30000, 60000, 150, seed=97, n_rate=0.001, ragged=True)
 reads += [b"A" * 150] * 300 + [b"ACACACACAC" * 15] * 300 + [(b"ACGTTGCA" * 19)[:150]] * 200
 bases, offs = gko.pack_reads(reads)
 res = {}
-for k, m, parts in ((31, 8, 3), (41, 9, 2)):
+for k, m, parts in ((31, 8, 3), (41, 9, 2), (63, 10, 2)):
     rep = simple_repart(m, parts)
     c = gkc.Counter(0); c.configure(k, m, parts, rep); c.count(bases, offs)
     ref = gko.Dsk(bases, offs, k, m, parts, rep, threads=4)
@@ -715,7 +716,7 @@ print(json.dumps(res))
         name, _, val = kv.partition("="); env[name] = val or "1"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"31": True, "41": True}
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"31": True, "41": True, "63": True}
 
 
 def test_read_length_statistics(gkc):
