@@ -515,7 +515,9 @@ def main():
             chunks.clear()
             c.close(); c = None
             c63 = gkc.Counter(local)
-            p63 = int(min(65535, max(64, 2 ** int(np.ceil(np.log2(max(1, n_reads * (L - 63 + 1) / 3.0e6)))))))
+            # 16-byte keys: a wave's registers hold half as many, so the partitions are half the size (about 1.5e6 k-mers: 8192 sub-buckets of ~180 keys);
+            # measured at 10^8 reads: 4096 partitions 410-434 ms, 8192: 403, 16384: 395 (Stage A +8 ms for the second level, the sort tiers -40)
+            p63 = int(min(32768, max(64, 2 ** int(np.ceil(np.log2(max(1, n_reads * (L - 63 + 1) / 1.5e6)))))))
             c63.configure(63, m, p63, repart_for_bench(m, p63))
             b63, o63 = c63.synth_reads_device(2, n_reads, L, genome, 10000)
             def step63():
