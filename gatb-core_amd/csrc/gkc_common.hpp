@@ -145,6 +145,7 @@ struct gkc_ctx {
     int minimizer_type = 0;
     uint32_t maxs = 0;
     uint32_t key_words = 1, record_bytes = 16;
+    size_t last_plan_budget = 0;                // Stage B batch budget of the last pass (see gkc_count_pass)
     bool dedupe_off = false; unsigned long long dedupe_in = 0, dedupe_out = 0;   // super-k-mer deduplication in Stage B: switched off for the rest of a run when it gives < 1.18x fewer keys
     uint64_t model_hash = 0;               // of (k, m, partitions, passes, minimizer type, repartition table, frequency order): every rank of a communicator must hold the same
     int32_t amin = 1, amax = 2147483647; uint32_t histo_max = 10000;

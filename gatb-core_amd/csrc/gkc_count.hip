@@ -2319,6 +2319,10 @@ int gkc_count_pass(gkc_ctx* c)
     }
     fixed_budget = c->d_hint > 0 ? plan_budget(c->d_hint) : plan_budget(1.0);   // without a ratio the memory does not bind even at d = 1
     if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc plan] avail %.1f GB, keys %.3e, d_hint %.4f, lanes %d, budget %.3e\n", avail0 / 1e9, (double)total_keys, c->d_hint, lanes, (double)fixed_budget);
+    // another batch size than the last pass planned (another input, a host sink set or dropped, another solidity ratio): the blocks parked in the allocator have the
+    // wrong sizes — keeping them would make every new block a failed hipMalloc followed by frees, one parked block at a time (seen: 1.5 s for a 0.26 s pass)
+    if (c->last_plan_budget && (fixed_budget > c->last_plan_budget + c->last_plan_budget / 10 || fixed_budget + fixed_budget / 10 < c->last_plan_budget)) c->pool.trim();      // (the allocator reuses a block up to 25 % larger than asked)
+    c->last_plan_budget = fixed_budget;
     if (!c->key_budget && fixed_budget < 250000000ULL) {                       // ... unless there is little room: one lane, larger batches
         lanes = 1; plan_lanes = 1; fixed_budget = c->d_hint > 0 ? plan_budget(c->d_hint) : plan_budget(1.0);
     }
