@@ -1,8 +1,9 @@
-"""Golden vectors from the reference ITSELF: runs the reference's dbgh5 / gatb-h5dump binaries that the survey phase of this project had
-built in this container (/tmp/gatb_build, the reference's own cmake build — not rebuilt or modified here) on small generated inputs and
-stores what they wrote as fixtures under tests/golden/reference_run/. The tests only read the committed fixtures.
+"""Golden vectors from the reference ITSELF: runs the reference's dbgh5 / gatb-h5dump binaries — integration/_build/ref/, built from /root/reference by
+integration/build_reference.sh (the reference's own cmake; reproducible from this repository) — on small generated inputs and stores what they wrote as
+fixtures under tests/golden/reference_run/. The tests only read the committed fixtures.
 
-    python tools/make_reference_run_vectors.py [/tmp/gatb_build/bin/Release]
+    python tools/make_reference_run_vectors.py [directory with dbgh5 and gatb-h5dump] [--out DIR]
+    python tools/make_reference_run_vectors.py --check        regenerates into a scratch directory and compares with the committed fixtures
 
 What is kept per run: the input FASTA, the (k-mer, abundance) records of every /dsk/solid/<p> dataset in dataset order, the histogram
 datasets, and — where the run produced them — the byte arrays /bloom/bloom (with its size / nb_hash / type attributes) and /dsk/mphf."""
@@ -18,8 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests.util import synth_reads  # noqa: E402
 
-BIN = sys.argv[1] if len(sys.argv) > 1 else "/tmp/gatb_build/bin/Release"
-OUT = os.path.join(ROOT, "tests", "golden", "reference_run")
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+_default_bin = os.path.join(ROOT, "integration", "_build", "ref")
+BIN = _args[0] if _args else (_default_bin if os.path.exists(os.path.join(_default_bin, "dbgh5")) else "/tmp/gatb_build/bin/Release")
+COMMITTED = os.path.join(ROOT, "tests", "golden", "reference_run")
+CHECK = "--check" in sys.argv
+OUT = tempfile.mkdtemp(prefix="gkc_refrun_") if CHECK else (sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else COMMITTED)
 
 
 def h5dump(args):
@@ -93,3 +98,24 @@ if __name__ == "__main__":
     run("k21_default_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only, max_memory=1)
     run("k31_2parts_mphf", synth_reads(2000, 10000, 150, seed=3), 31, ["-bloom", "none", "-debloom", "none", "-branching-nodes", "none"], want_mphf=True, cores=2)
     run("k63_neighbor_mphf", reads[:300], 63, ["-bloom", "neighbor", "-debloom", "none", "-branching-nodes", "none"], want_bloom=True, want_mphf=True)
+    if CHECK:
+        # every array of every regenerated fixture against the committed one
+        bad = []
+        for f in sorted(os.listdir(OUT)):
+            if not f.endswith(".npz"):
+                continue
+            new = np.load(os.path.join(OUT, f), allow_pickle=True)
+            if not os.path.exists(os.path.join(COMMITTED, f)):
+                bad.append(f + ": not committed"); continue
+            old = np.load(os.path.join(COMMITTED, f), allow_pickle=True)
+            if sorted(new.files) != sorted(old.files):
+                bad.append("%s: arrays %s != %s" % (f, sorted(new.files), sorted(old.files))); continue
+            for name in new.files:
+                a, b = new[name], old[name]
+                if a.shape != b.shape or not np.array_equal(a, b):
+                    bad.append("%s: %s differs" % (f, name))
+        print("reference binaries: %s" % BIN)
+        print("check of tests/golden/reference_run against a fresh run of the reference: %s" % ("IDENTICAL (%d fixtures)" % len([f for f in os.listdir(OUT) if f.endswith(".npz")]) if not bad else "\n".join(bad)))
+        import shutil
+        shutil.rmtree(OUT, ignore_errors=True)
+        sys.exit(1 if bad else 0)
