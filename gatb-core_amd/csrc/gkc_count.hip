@@ -2216,7 +2216,7 @@ int gkc_count_pass(gkc_ctx* c)
     // budget for a given solid-per-key ratio d. Deterministic in (free memory rounded to GB, total keys, d rounded up to 0.05): every
     // pass of a context plans the same sizes, so from the second pass on all blocks are parked already.
     const double avail_q = std::floor(avail0 / 1e9) * 1e9;
-    int plan_lanes = (c->key_budget || total_keys < 50000000ULL) ? 1 : 2;                                  // one lane gets the same batches as two would (same blocks whichever way a pass runs) ...
+    int plan_lanes = (c->key_budget || total_keys < 50000000ULL) ? 1 : std::max(2, lanes);                 // (more than two lanes: planned for what will really run)                                  // one lane gets the same batches as two would (same blocks whichever way a pass runs) ...
     auto plan_budget = [&](double d) -> size_t {
         const double work = (double)plan_lanes * (double)work_per_key;
         const double dq = std::min(1.0, std::ceil(1.05 * d / 0.05) * 0.05);
