@@ -303,7 +303,9 @@ def main():
     genome = max(L, n_reads * world * L // 30)               # 30x coverage over the whole job
     # rank r draws reads [r*n, (r+1)*n) of ONE global read stream over the SAME genome (seed 2). Multi-GPU: the rank's reads are pushed in
     # n_push chunks, each followed by gkc_exchange — the exchange of chunk i (RCCL, the communicator's own stream) overlaps Stage A of chunk i+1
-    n_push = args.pushes if use_dist else 1
+    # one rank: one push per 1.25e8 reads at most (the size Stage A's per-push buffers — 0.8 bytes of descriptors per base, the record arena and, above 4096 partitions,
+    # its refined copy — are meant for; a single push of 2e8 reads works but spends seconds in hipMalloc on a GPU that also holds the previous step's results)
+    n_push = args.pushes if use_dist else max(1, -(-n_reads // 125_000_000))
     per_push = (n_reads + n_push - 1) // n_push
     chunks = []
     for i in range(n_push):

@@ -92,7 +92,9 @@ int gkc_sample_exact(gkc_ctx* ctx, const char* bases, const uint64_t* offsets, u
  * ------------------------------------------------------------------------------------------------------------- */
 int gkc_begin_pass(gkc_ctx* ctx, uint32_t pass);
 int gkc_push_reads(gkc_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads);
-/* same, inputs already resident in HBM (d_bases 16-byte aligned). The buffers may be released after the call returns. */
+/* same, inputs already resident in HBM (d_bases 16-byte aligned). The buffers may be released after the call returns.
+ * A push is one segment of super-k-mer records with its own per-push buffers (about 0.8 bytes of descriptors per base besides the records): pushes of up to ~10^8 reads
+ * (1.5*10^10 bases) are what those are sized for; a larger input is pushed in several calls (any number per pass). */
 int gkc_push_reads_device(gkc_ctx* ctx, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases);
 
 /* Stage B — replaces SortingCountAlgorithm::fillSolidKmers (:1384-1602) = PartitionsByVectorCommand read/sort/dump
