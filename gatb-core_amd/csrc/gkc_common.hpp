@@ -28,6 +28,7 @@ struct gkc_error { int code; std::string msg; };
 // Stage A tile: one 512-thread workgroup scans TILE k-mer start positions (16 per thread) plus a halo. 512 threads share one set of
 // per-partition LDS counters (16 KB at 4096 partitions): 2 workgroups = 16 waves per CU fit in LDS, with 256 threads only 12 did
 // (measured: scan 64 -> 54 ms).
+constexpr uint64_t GKC_PASS_GATHERED = 0x6761746865726564ull;   // pass_stats[pass].reserved[1] once gkc_gather_results has run for the pass
 constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_PER_THREAD = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_PER_THREAD;      // 8192 positions
@@ -172,7 +173,7 @@ struct gkc_ctx {
     // marks the context closed; the last child to be destroyed frees it (gkc_ctx_child_release)
     int children = 0; bool closed = false;
     int comm_world = 1;                    // world size of the communicator built on this context (multi-GPU): Stage A then leaves a few CUs to the exchange kernels
-    std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them
+    std::vector<gkc_stats> pass_stats;               // one per pass; gkc_get_stats sums them (reserved[1] == GKC_PASS_GATHERED: gkc_gather_results has run for the pass)
     gkc_stats& stats_now() { return pass_stats[pass]; }
     // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted
     void* sink = nullptr; uint64_t sink_cap = 0, sink_used = 0; bool sink_overflow = false;

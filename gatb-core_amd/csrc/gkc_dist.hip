@@ -583,6 +583,9 @@ int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
     if (W == 1) return GKC_OK;
     if (m->first.size() != (size_t)W + 1) GKC_FAIL(c, GKC_ERR_ARG, "owner ranges unknown: no gkc_exchange happened in this pass");
     const uint32_t P = c->nb_partitions, pass = c->pass, rb = c->key_words == 1 ? 16 : 32;
+    // a pass is gathered once: a second call would add the other ranks' histograms and counters to the root's again (every rank keeps the mark for itself,
+    // so the ranks agree without talking; gkc_begin_pass of the pass clears it with the pass's statistics)
+    if (c->pass_stats[pass].reserved[1] == GKC_PASS_GATHERED) return GKC_OK;
     Dataset* DS = c->datasets.data() + (size_t)pass * P;
     // 1) what every owner holds: per partition (solid, distinct, k-mers, starts a new contiguous array on its owner)
     std::vector<uint64_t> tab((size_t)P * 4, 0), all((size_t)W * P * 4);
@@ -656,9 +659,13 @@ int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
             const gkc_stats& o = sall[r];
             S.kmers_nb_valid += o.kmers_nb_valid; S.kmers_nb_invalid += o.kmers_nb_invalid; S.kmers_nb_distinct += o.kmers_nb_distinct; S.kmers_nb_solid += o.kmers_nb_solid;
             S.nb_superkmers += o.nb_superkmers; S.nb_sequences += o.nb_sequences; S.nb_bases += o.nb_bases; S.superkmer_bytes += o.superkmer_bytes;
-            S.oversize_buckets += o.oversize_buckets;
+            S.oversize_buckets += o.oversize_buckets; S.dedupe_kmers_in += o.dedupe_kmers_in; S.dedupe_keys_out += o.dedupe_keys_out;
+            // what BankStats::update keeps per sequence (BankKmers.hpp:176-186): shortest (0 = that rank saw no read) / longest read, sum of the squared lengths
+            if (o.seq_len_min != 0 && (S.seq_len_min == 0 || o.seq_len_min < S.seq_len_min)) S.seq_len_min = o.seq_len_min;
+            S.seq_len_max = std::max(S.seq_len_max, o.seq_len_max); S.seq_len_sq_sum += o.seq_len_sq_sum;
         }
     }
+    c->pass_stats[pass].reserved[1] = GKC_PASS_GATHERED;
     return GKC_OK;
 }
 

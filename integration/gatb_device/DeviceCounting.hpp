@@ -25,9 +25,11 @@
 #include <gatb/system/impl/System.hpp>
 
 #include <gkc.h>
+#include <gatb_device/DeviceContext.hpp>
 
 #include <vector>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <memory>
 #include <time.h>
@@ -70,7 +72,9 @@ public:
         open();
         if (pass > 0)  { return; }                                   /* one configuration per run: the passes share the datasets and the histogram */
         enableMultiGpuFromEnvironment();
-        _plan = plan;  _nbPartitions = config._nb_partitions;
+        device::DeviceContext::singleton().setResident (device::DeviceContext::Resident());      /* a new count: what an earlier one left in HBM is going away */
+        _plan = plan;  _nbPartitions = config._nb_partitions;  _kmerSize = config._kmerSize;
+        _waitS = _handOverS = 0;
         const u_int64_t nbMinims = (u_int64_t)1 << (2 * config._minim_size);
         std::vector<uint16_t> table (nbMinims);
         for (u_int64_t m = 0; m < nbMinims; m++)  { table[m] = (uint16_t) repartitor (m); }
@@ -131,7 +135,7 @@ public:
     int       ranks () const { return _ranks; }
     int       rank  () const { return _rank;  }
 
-    void beginPass (size_t pass)  { check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0; }
+    void beginPass (size_t pass)  { check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0;  _progressReported = 0; }
 
     /** one block of reads to Stage A (the caller holds the packers' lock: one thread drives the context at a time); multi-rank: the exchanges that are due */
     void push (const char* bases, const uint64_t* offsets, uint64_t nbReads)
@@ -182,7 +186,13 @@ public:
         {
             const uint64_t from = pos - 1, n = std::min<uint64_t> (len, size - from);       /* from the byte before: is `pos` itself a line start? */
             win.resize (n);
-            uint64_t done = 0;  while (done < n) { const ssize_t g = pread (fd, win.data() + done, n - done, (off_t)(from + done));  if (g <= 0) { return size; }  done += (uint64_t)g; }
+            uint64_t done = 0;
+            while (done < n)
+            {
+                const ssize_t g = pread (fd, win.data() + done, n - done, (off_t)(from + done));
+                if (g <= 0)  { throw system::Exception ("device counting: read error while looking for a record start (offset %llu)", (unsigned long long)(from + done)); }   /* never a silently shortened byte range */
+                done += (uint64_t)g;
+            }
             std::vector<uint64_t> lines;                                                    /* line starts inside the window (window offsets) */
             for (uint64_t i = 1; i < n; i++)  { if (win[i-1] == '\n')  { lines.push_back (i); } }
             for (size_t l = 0; l < lines.size(); l++)
@@ -226,7 +236,7 @@ public:
             /* n bytes of the file from `from` to dst, by READERS threads; false on a read error */
             auto fill = [fd] (char* dst, uint64_t from, uint64_t n) -> bool
             {
-                std::vector<std::thread> readers;  bool failed = false;
+                std::vector<std::thread> readers;  std::atomic<bool> failed (false);
                 const uint64_t share = (n + READERS - 1) / READERS;
                 for (int r = 0; r < READERS; r++)
                 {
@@ -234,7 +244,7 @@ public:
                     if (b < e)  { readers.emplace_back ([=, &failed] { uint64_t done = b;  while (done < e) { const ssize_t g = pread (fd, dst + done, e - done, (off_t)(from + done));  if (g <= 0) { failed = true; break; }  done += (uint64_t)g; } }); }
                 }
                 for (size_t r = 0; r < readers.size(); r++)  { readers[r].join(); }
-                return !failed;
+                return !failed.load();
             };
             /* two buffers: the next chunk is read (behind PAD bytes of room for what the parser leaves of this one) while this one is parsed and scanned */
             int cur = 0;
@@ -245,22 +255,25 @@ public:
             while (ok  &&  !readError  &&  have > 0)
             {
                 const uint64_t next = std::min<uint64_t> ((uint64_t)CHUNK, size - off);
-                bool nextFailed = false;
+                std::atomic<bool> nextFailed (false);
                 std::thread prefetch;
                 if (next > 0)  { char* dst = _text[cur ^ 1] + PAD;  const uint64_t from = off;  prefetch = std::thread ([&fill, &nextFailed, dst, from, next] { nextFailed = !fill (dst, from, next); }); }
                 const int final = next == 0 ? 1 : 0;
                 uint64_t consumed = 0;
                 const int rc = gkc_push_fastx (_ctx, ptr, have, final, &consumed);
                 if (prefetch.joinable())  { prefetch.join(); }
-                readError = nextFailed;
+                readError = nextFailed.load();
                 const uint64_t left = final ? 0 : have - consumed;
                 if (rc == GKC_ERR_FORMAT  ||  (rc == GKC_OK  &&  left > (uint64_t)PAD))  { ok = false;  break; }      /* (or a record larger than the room: a genome, not reads) */
                 if (rc != GKC_OK)  { ::close (fd);  check (rc); }
+                /* reads of THIS pass so far (gkc_stats.nb_sequences is pass 0's only: on later passes it would add the whole bank at the first chunk and
+                 * nothing afterwards — progress, and with several ranks the pacing of the exchanges, need the pass's own count) */
                 gkc_stats st;  check (gkc_get_stats (_ctx, &st));
-                if (st.nb_sequences > seenReads)
+                const uint64_t passReads = st.reserved[0];
+                if (passReads > seenReads)
                 {
-                    if (progress != 0)  { progress->inc (st.nb_sequences - seenReads); }
-                    _pushedReads += st.nb_sequences - seenReads;  seenReads = st.nb_sequences;
+                    if (progress != 0)  { progress->inc (passReads - seenReads);  _progressReported += passReads - seenReads; }
+                    _pushedReads += passReads - seenReads;  seenReads = passReads;
                 }
                 while (_comm != 0  &&  _exchangesDone + 1 < _nbExchanges  &&  _pushedReads >= (u_int64_t)(_exchangesDone + 1) * _readsPerExchange)
                 {
@@ -276,6 +289,7 @@ public:
             if (!ok)
             {
                 if (_ranks > 1)  { throw system::Exception ("device counting: %s is not FASTA / FASTQ text the device parser takes; with several ranks set GATB_DEVICE_NO_TEXT=1", files[fi].c_str()); }
+                if (progress != 0  &&  _progressReported > 0)  { progress->inc ((u_int64_t)0 - _progressReported);  _progressReported = 0; }      /* the pass starts again, iterated: what was reported is taken back */
                 return false;
             }
         }
@@ -283,16 +297,25 @@ public:
     }
 
     /** Stage B. One rank: started in the background, the partition commands wait for their partition. Several ranks: counted, then gathered on rank 0. */
-    void finishPass ()
+    void finishPass (size_t pass)
     {
         _finishWall = wallNow();
         if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  return; }
         check (gkc_finish_pass (_ctx));
         check (gkc_gather_results (_ctx, _comm, 0));
     }
-    void joinPass ()
+    /** after the partition commands of the pass; after the last pass of a bulk-mode count the device's datasets ARE /dsk/solid (the window was applied on the
+     *  device) and they stay in HBM: BloomAlgorithm / MPHFAlgorithm find them there (DeviceContext::residentMatches) */
+    void joinPass (size_t pass, size_t nbPasses)
     {
         if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); }
+        if (pass + 1 == nbPasses  &&  _plan.on  &&  (_comm == 0  ||  _rank == 0))
+        {
+            gkc_stats st;  check (gkc_get_stats (_ctx, &st));
+            device::DeviceContext::Resident r;
+            r.on = true;  r.nbSolid = st.kmers_nb_solid;  r.kmerSize = (uint32_t) _kmerSize;  r.keyBytes = _kmerSize <= 31 ? 8 : 16;
+            device::DeviceContext::singleton().setResident (r);
+        }
         if (getenv ("GATB_DEVICE_VERBOSE") != 0)
         {
             double a = 0, b = 0;  uint64_t n = 0;
@@ -303,13 +326,41 @@ public:
     }
     static double wallNow ()  { struct timespec ts;  clock_gettime (CLOCK_MONOTONIC, &ts);  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
-    ~DeviceSession ()  { for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); }  if (_ctx) { gkc_destroy (_ctx); } }
+    /** The device's figures where the reference's commands put "1.read / 2.sort / 3.dump" (SortingCountAlgorithm.cpp:777-780, PartitionsCommand.cpp TIME_INFO):
+     *  device_stage_a / device_stage_b = HIP-event time of the two stages on the MI355X summed over the passes, device_wait / device_hand_over = host wall the
+     *  partition commands spent waiting for Stage B and handing Count[] to the processors, divided by the dispatcher's units like the
+     *  reference's entries (:777). TimeInfo only counts between start() and stop() of its clock (TimeInfo.hpp:86-92): a clock set by hand carries the values in. */
+    void addTimes (tools::misc::impl::TimeInfo& into, size_t nbUnits)
+    {
+        struct Clock : public system::ITime
+        {
+            u_int32_t now;  Clock () : now(0) {}
+            Value getTimeStamp ()  { return now; }
+            Unit getUnit ()  { return MSEC; }
+            std::string getDateString ()  { return ""; }
+        } clock;
+        tools::misc::impl::TimeInfo mine (clock);
+        double a = 0, b = 0;  uint64_t n = 0;
+        if (_ctx != 0)  { gkc_get_timing (_ctx, "total_stage_a", &a, &n);  gkc_get_timing (_ctx, "total_stage_b", &b, &n); }
+        const char* names[4] = { "device_stage_a", "device_stage_b", "device_wait", "device_hand_over" };
+        const double ms[4] = { a, b, 1000.0 * _waitS / (double) std::max<size_t> (1, nbUnits), 1000.0 * _handOverS / (double) std::max<size_t> (1, nbUnits) };
+        for (int i = 0; i < 4; i++)  { clock.now = 0;  mine.start (names[i]);  clock.now = (u_int32_t) (ms[i] + 0.5);  mine.stop (names[i]); }
+        into += mine;
+    }
+    /** called by every partition command: seconds it waited for Stage B / spent handing its records over */
+    void addCommandTimes (double waitS, double handOverS)  { std::lock_guard<std::mutex> guard (_timesLock);  _waitS += waitS;  _handOverS += handOverS; }
+
+    ~DeviceSession ()  { for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); } }      /* (the context is the process's: DeviceContext) */
 
 private:
     DeviceSession () : _ctx(0), _comm(0), _ranks(1), _rank(0), _nbExchanges(1), _exchangesDone(0), _readsPerExchange(1), _pushedReads(0), _nbPartitions(0) {}
     void open ()
     {
-        if (_ctx == 0  &&  gkc_create (0, &_ctx) != GKC_OK)  { throw system::Exception ("device counting: %s", gkc_last_error(0)); }
+        if (_ctx == 0)
+        {
+            _ctx = device::DeviceContext::singleton().ctx();
+            if (_ctx == 0)  { throw system::Exception ("device counting: %s", device::DeviceContext::singleton().error().c_str()); }
+        }
     }
     char*     _text[2] = {0, 0};        /**< text buffers of pushTextFiles */
     gkc_ctx*  _ctx;
@@ -319,7 +370,11 @@ private:
     u_int64_t _readsPerExchange, _pushedReads;
     DeviceBulkPlan _plan;
     size_t    _nbPartitions;
+    size_t    _kmerSize = 0;
     double    _finishWall = 0;
+    u_int64_t _progressReported = 0;
+    std::mutex _timesLock;
+    double    _waitS = 0, _handOverS = 0;
 };
 
 /********************************************************************************/
@@ -515,6 +570,7 @@ public:
 
         this->_progress->inc (this->_pInfo.getNbKmer (this->_parti_num));
         this->_processor->endPart (this->_pass_num, this->_parti_num);
+        dev.addCommandTimes (t1 - t0, now() - t1);
         if (getenv ("GATB_DEVICE_VERBOSE") != 0)
         {
             static std::mutex mu;  static double waited = 0, fetchedS = 0, handed = 0;  static size_t done = 0;

@@ -1,23 +1,28 @@
 #!/usr/bin/env python
-"""Applies the device-counting patch to a scratch COPY of the reference's SortingCountAlgorithm.cpp (the reference tree is never written)
-and emits the unified diff a maintainer would apply (integration/SortingCountAlgorithm.device.patch).
+"""Applies the device patch to scratch COPIES of the reference's sources (the reference tree is never written) and emits the unified diff a maintainer
+would apply (integration/gatb-core.device.patch).
 
     python integration/make_patched_sources.py <reference gatb-core dir> <scratch include dir> [--write-patch]
 
-The edits are anchored on lines of the reference file (file:line cited per hunk); every anchor must be found exactly once. Everything new is
-guarded by GATB_WITH_DEVICE_COUNTING, so the patched file still builds the CPU path without the macro."""
+Six files are touched (file:line cited per hunk below); every edit is anchored on text of the reference file that must be found exactly once, and everything
+new is guarded by GATB_WITH_DEVICE_COUNTING, so the patched files still build the CPU path without the macro:
+  kmer/impl/SortingCountAlgorithm.cpp       fillPartitions -> Stage A on the device, the partition command, the join, device time keys in getInfo()
+  tools/collections/impl/Bloom.hpp          BloomFactory::createBloom returns BloomDevice<T> for the item types / kinds the device knows
+  kmer/impl/BloomAlgorithm.cpp              execute(): the solid k-mers are inserted where the counting step left them in HBM
+  kmer/impl/MPHFAlgorithm.cpp               execute(): BooPHF built on the device, stored, loaded by the reference's own MapMPHF::load; populate() on the device
+  kmer/impl/DebloomMinimizerAlgorithm.cpp   contains8 of a partition's solid k-mers as ONE batched device query instead of one call per k-mer
+The scratch copies land under <scratch include dir>/gatb/..., which check_integration.sh puts in front of the reference's src/ on the include path."""
 import difflib
 import os
 import sys
 
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# kmer/impl/SortingCountAlgorithm.cpp
+# ------------------------------------------------------------------------------------------------------------------------------------------
 REL = "src/gatb/kmer/impl/SortingCountAlgorithm.cpp"
 
-HUNKS = [
-    # (anchor line, mode, text)   mode: "after" inserts after the anchor line, "wrap" guards [anchor .. end anchor] with #ifndef/#else
-    # --- include (after the last include of the file head, SortingCountAlgorithm.cpp:20-40)
-    ("#include <gatb/kmer/impl/SortingCountAlgorithm.hpp>", "after",
-     "#ifdef GATB_WITH_DEVICE_COUNTING\n#include <gatb_device/DeviceCounting.hpp>   /* MI355X back-end: libgkc_hip.so */\n#endif\n"),
-]
+SCA_INCLUDE_ANCHOR = "#include <gatb/kmer/impl/SortingCountAlgorithm.hpp>"
+SCA_INCLUDE = "#ifdef GATB_WITH_DEVICE_COUNTING\n#include <gatb_device/DeviceCounting.hpp>   /* MI355X back-end: libgkc_hip.so */\n#endif\n"
 
 # fillPartitions (SortingCountAlgorithm.cpp:1266-1282): the CPU functor is replaced by the packer + Stage A on the device
 FILL_BEGIN = "\t\t\tgetDispatcher()->iterate(\n\t\t\t\titSeq,\n\t\t\t\tFillPartitions<span, true>("
@@ -42,17 +47,6 @@ FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 \t\t\t}
 \t\t\tdevice.endOfReads();        /* multi-rank: the exchanges that are still due */
 \t\t\titSeq->finalize();
-\t\t\tif (pass == 0)
-\t\t\t{
-\t\t\t\tgkc_stats st;  device.check (gkc_get_stats (device.ctx(), &st));
-\t\t\t\tif (direct)      /* BankStats::update (BankKmers.hpp:176-186) from the device's counters */
-\t\t\t\t{
-\t\t\t\t\tpacked.stats.sequencesNb = st.nb_sequences;  packed.stats.sequencesTotalLength = st.nb_bases;  packed.stats.sequencesTotalLengthSquare = st.seq_len_sq_sum;
-\t\t\t\t\tpacked.stats.sequencesMinLength = st.seq_len_min;  packed.stats.sequencesMaxLength = st.seq_len_max;
-\t\t\t\t}
-\t\t\t\tpacked.stats.kmersNbValid = st.kmers_nb_valid;  packed.stats.kmersNbInvalid = st.kmers_nb_invalid;
-\t\t\t\t_bankStats += packed.stats;
-\t\t\t}
 \t\t\t/* per-partition sizes for fillSolidKmers (progress, getNbCoresList) */
 \t\t\t{
 \t\t\t\tuint32_t nbSegments = 0;  device.check (gkc_segment_count (device.ctx(), &nbSegments));
@@ -63,7 +57,21 @@ FILL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 \t\t\t\t\tfor (size_t p=0; p<_config._nb_partitions; p++)  { pInfo.incKmer (p, nbKmers[p]);  pInfo.incKxmer (p, recOff[p+1]-recOff[p]); }
 \t\t\t\t}
 \t\t\t}
-\t\t\tdevice.finishPass();
+\t\t\tdevice.finishPass (pass);
+\t\t\t/* the bank statistics of pass 0, read AFTER finishPass: with several ranks that is after gkc_gather_results, which sums / combines the ranks' counters on
+\t\t\t * rank 0 (every rank scanned only its share of the reads) — rank 0's .h5 then reports what a single process reports */
+\t\t\tif (pass == 0)
+\t\t\t{
+\t\t\t\tgkc_stats st;  device.check (gkc_get_stats (device.ctx(), &st));
+\t\t\t\tif (direct  ||  device.ranks() > 1)      /* BankStats::update (BankKmers.hpp:176-186) from the device's counters */
+\t\t\t\t{
+\t\t\t\t\tpacked.stats = BankStats();
+\t\t\t\t\tpacked.stats.sequencesNb = st.nb_sequences;  packed.stats.sequencesTotalLength = st.nb_bases;  packed.stats.sequencesTotalLengthSquare = st.seq_len_sq_sum;
+\t\t\t\t\tpacked.stats.sequencesMinLength = st.seq_len_min;  packed.stats.sequencesMaxLength = st.seq_len_max;
+\t\t\t\t}
+\t\t\t\tpacked.stats.kmersNbValid = st.kmers_nb_valid;  packed.stats.kmersNbInvalid = st.kmers_nb_invalid;
+\t\t\t\t_bankStats += packed.stats;
+\t\t\t}
 #else
 """
 
@@ -82,8 +90,16 @@ CMD_END = "            cmds.push_back (cmd);\n"
 # end of fillSolidKmers_aux (SortingCountAlgorithm.cpp:1596-1600): join Stage B
 TAIL = "\tif(_config._solidityKind == KMER_SOLIDITY_SUM)\n\t\t_superKstorage->closeFiles();\n"
 TAIL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
-\tDeviceSession::singleton().joinPass();
+\tDeviceSession::singleton().joinPass (pass, _config._nb_passes);
 \tif (pass + 1 == _config._nb_passes)  { PartitionsByDeviceCommand<span>::mergeDeviceHistogram (processor); }      /* bulk mode: the device counted the histogram */
+#endif
+"""
+
+# getInfo() (SortingCountAlgorithm.cpp:777-778): the reference's commands time "1.read / 2.sort / 3.dump" into _fillTimeInfo; the device command has none of these
+# phases, so the device's own figures go where consumers look for them
+TIME_ANCHOR = "    _fillTimeInfo /= getDispatcher()->getExecutionUnitsNumber();\n"
+TIME_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+    DeviceSession::singleton().addTimes (_fillTimeInfo, getDispatcher()->getExecutionUnitsNumber());      /* device_stage_a / device_stage_b (HIP-event time on the MI355X), device_wait / device_hand_over (host wall) */
 #endif
 """
 
@@ -91,37 +107,210 @@ TAIL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
 def once(text, anchor):
     n = text.count(anchor)
     if n != 1:
-        raise SystemExit("anchor found %d times (expected once): %r" % (n, anchor[:60]))
+        raise SystemExit("anchor found %d times (expected once): %r" % (n, anchor[:70]))
     return text.index(anchor)
 
 
+def insert_after_line(text, anchor, new):
+    i = once(text, anchor) + len(anchor)
+    i = text.index("\n", i) + 1 if not anchor.endswith("\n") else i
+    return text[:i] + new + text[i:]
+
+
+def insert_before(text, anchor, new):
+    i = once(text, anchor)
+    return text[:i] + new + text[i:]
+
+
 def patch(src):
-    out = src
-    for anchor, mode, text in HUNKS:
-        i = once(out, anchor) + len(anchor)
-        i = out.index("\n", i) + 1
-        out = out[:i] + text + out[i:]
+    """kmer/impl/SortingCountAlgorithm.cpp"""
+    out = insert_after_line(src, SCA_INCLUDE_ANCHOR, SCA_INCLUDE)
     a = once(out, FILL_BEGIN); b = out.index(FILL_END, a) + len(FILL_END)
     out = out[:a] + FILL_DEVICE + out[a:b] + "#endif\n" + out[b:]
     a = once(out, CMD_BEGIN) + len(CMD_BEGIN); b = once(out, CMD_END)
     out = out[:a] + CMD_DEVICE + out[a:b] + "#endif\n" + out[b:]
-    a = once(out, TAIL)
-    out = out[:a] + TAIL_DEVICE + out[a:]
+    out = insert_before(out, TAIL, TAIL_DEVICE)
+    out = insert_after_line(out, TIME_ANCHOR, TIME_DEVICE)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# tools/collections/impl/Bloom.hpp — BloomFactory::createBloom (Bloom.hpp:1254-1266)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+BLOOM_HPP = "src/gatb/tools/collections/impl/Bloom.hpp"
+FACTORY_ANCHOR = "/** \\brief Factory that creates IBloom instances\n"
+FACTORY_INCLUDE = """#ifdef GATB_WITH_DEVICE_COUNTING
+template <typename Item> class BloomDevice;
+} } } } }
+#include <gatb_device/BloomDevice.hpp>   /* BloomDevice<Item>: the CPU class of the kind + a device copy of its array (libgkc_hip.so) */
+namespace gatb { namespace core { namespace tools { namespace collections { namespace impl {
+#endif
+
+"""
+CREATE_ANCHOR = "        switch (kind)\n        {\n            case tools::misc::BLOOM_NONE:      return new BloomNull<T>             ();\n"
+CREATE_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+        /* a k-mer type the device knows, a kind it implements and an MI355X in the process: same bit array, bulk inserts and batched queries on the device */
+        if (BloomDevice<T>::usable (kind, kmersize))  { return new BloomDevice<T> (kind, tai_bloom, nbHash, kmersize); }
+#endif
+"""
+
+
+def patch_bloom_hpp(src):
+    out = insert_before(src, FACTORY_ANCHOR, FACTORY_INCLUDE)
+    out = insert_before(out, CREATE_ANCHOR, CREATE_DEVICE)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# kmer/impl/BloomAlgorithm.cpp — execute() (BloomAlgorithm.cpp:155-199)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+BLOOM_ALGO = "src/gatb/kmer/impl/BloomAlgorithm.cpp"
+BA_INCLUDE_ANCHOR = "#include <gatb/kmer/impl/BloomAlgorithm.hpp>"
+BA_INCLUDE = "#ifdef GATB_WITH_DEVICE_COUNTING\n#include <gatb_device/DeviceContext.hpp>\n#endif\n"
+BA_BUILD = "        bloom = builder.build (itKmers);\n"
+BA_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+        /* the solid k-mers of the counting step are still in HBM (DeviceSession, bulk mode) and they are the Iterable we were given: they are inserted where
+         * they lie (gkc_bloom_insert_solid) instead of being read back from /dsk/solid and inserted one by one (BloomBuilder.hpp:117, :178) */
+        if (gatb::core::device::DeviceContext::singleton().residentMatches (solidKmersNb, sizeof(Type)))
+        {
+            IBloom<Type>* candidate = BloomFactory::singleton().createBloom<Type> (_bloomKind, estimatedBloomSize, nbHash, _kmerSize);
+            BloomDevice<Type>* onDevice = dynamic_cast<BloomDevice<Type>*> (candidate);
+            if (onDevice != 0)  { onDevice->insertSolid ();  bloom = candidate; }
+            else                { candidate->use();  candidate->forget(); }
+        }
+        if (bloom == 0)
+#endif
+"""
+
+
+def patch_bloom_algo(src):
+    out = insert_after_line(src, BA_INCLUDE_ANCHOR, BA_INCLUDE)
+    out = insert_before(out, BA_BUILD, BA_DEVICE)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# kmer/impl/MPHFAlgorithm.cpp — execute() (:150-187), populate() (:216-275)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+MPHF_ALGO = "src/gatb/kmer/impl/MPHFAlgorithm.cpp"
+MA_INCLUDE_ANCHOR = "#include <gatb/kmer/impl/MPHFAlgorithm.hpp>"
+MA_INCLUDE = "#ifdef GATB_WITH_DEVICE_COUNTING\n#include <gatb_device/MphfDevice.hpp>   /* BooPHF build + abundance map on the MI355X (libgkc_hip.so) */\n#endif\n"
+MA_BUILD_BEGIN = "        /** We build the hash. */\n        {   TIME_INFO (getTimeInfo(), \"build\");\n"
+MA_BUILD_END = "            _dataSize = _abundanceMap->save (_group, _name);\n        }\n"
+MA_BUILD_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+        /* BooPHF on the device: built (from the solid k-mers in HBM when they are still there), its stream stored as <group>/<name> — what save() writes — and
+         * LOADED by the reference's own MapMPHF::load, so the object the consumers get is the reference's BooPHF read from those bytes */
+        bool builtOnDevice = false;
+        if (sizeof(Abundance_t) == 1)
+        {
+            {   TIME_INFO (getTimeInfo(), "build");
+                builtOnDevice = MphfDevice::build<Type> (this, _group, _name, _solidKmers, _dataSize);
+            }
+            if (builtOnDevice)
+            {   TIME_INFO (getTimeInfo(), "save");       /* (the stream is in the storage already: this is the read-back) */
+                _abundanceMap->load (_group, _name);
+            }
+        }
+        if (!builtOnDevice)
+        {
+#endif
+"""
+MA_BUILD_TAIL = """#ifdef GATB_WITH_DEVICE_COUNTING
+        }
+#endif
+"""
+MA_POP_ANCHOR = "    // set counts and at the same time, test the mphf\n"
+MA_POP_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+    /* the same cells from the device: cell[code(kmer)] = abundance index, for the solid k-mers in HBM (gkc_mphf_abundance_map) */
+    bool populatedOnDevice = false;
+    if (sizeof(Abundance_t) == 1  &&  n > 0)
+    {
+        size_t above = 0;
+        populatedOnDevice = MphfDevice::populate (this, (u_int8_t*) & _abundanceMap->at ((typename AbundanceMap::Hash::Code) 0), n, above);
+        if (populatedOnDevice)  { _nb_abundances_above_precision = above;  nb_iterated = n; }
+    }
+    MphfDevice::release (this);
+    if (!populatedOnDevice)
+#endif
+"""
+
+
+def patch_mphf_algo(src):
+    out = insert_after_line(src, MA_INCLUDE_ANCHOR, MA_INCLUDE)
+    a = once(out, MA_BUILD_BEGIN); b = out.index(MA_BUILD_END, a) + len(MA_BUILD_END)
+    out = out[:a] + MA_BUILD_DEVICE + out[a:b] + MA_BUILD_TAIL + out[b:]
+    out = insert_after_line(out, MA_POP_ANCHOR, MA_POP_DEVICE)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# kmer/impl/DebloomMinimizerAlgorithm.cpp — the contains8 call site (:201) and the partition loop (:352-372)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+DEBLOOM_ALGO = "src/gatb/kmer/impl/DebloomMinimizerAlgorithm.cpp"
+DB_MEMBER_ANCHOR = "    Model&        model;\n    IBloom<Type>* bloom;\n"
+DB_MEMBER = """#ifdef GATB_WITH_DEVICE_COUNTING
+    const u_int8_t* deviceMasks = 0;      /**< contains8 of every solid k-mer of the partition, in the order of the (sorted) solids vector: ONE batched device query */
+#endif
+"""
+DB_CALL = "        bitset<8> mask =  bloom->contains8 (kmer.value);\n"
+DB_CALL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+        bitset<8> mask = deviceMasks != 0
+            ? bitset<8> (deviceMasks [std::lower_bound (functorNeighbors._solids.begin(), functorNeighbors._solids.end(), kmer.value) - functorNeighbors._solids.begin()])
+            : bloom->contains8 (kmer.value);
+#else
+"""
+DB_LOOP_ANCHOR = "            /** We iterate the solid kmers. */\n            this->getDispatcher()->iterate (itKmers, functorKmers);\n"
+DB_LOOP_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+            /* the filter is a BloomDevice: the 8 neighbour tests of every solid k-mer of the partition in one device query (gkc_bloom_contains8) */
+            std::vector<u_int8_t> deviceMasks;
+            if (BloomDevice<Type>* onDevice = dynamic_cast<BloomDevice<Type>*> (bloom))
+            {
+                if (!solids.empty()  &&  getenv ("GATB_DEVICE_NO_BATCHED_QUERIES") == 0)
+                {
+                    deviceMasks.resize (solids.size());
+                    onDevice->contains8Batch (solids.data(), solids.size(), deviceMasks.data());
+                    functorKmers.deviceMasks = deviceMasks.data();
+                }
+            }
+#endif
+"""
+
+
+def patch_debloom_algo(src):
+    out = insert_after_line(src, DB_MEMBER_ANCHOR, DB_MEMBER)
+    a = once(out, DB_CALL)
+    out = out[:a] + DB_CALL_DEVICE + DB_CALL + "#endif\n" + out[a + len(DB_CALL):]
+    out = insert_before(out, DB_LOOP_ANCHOR, DB_LOOP_DEVICE)
+    return out
+
+
+FILES = [(REL, patch), (BLOOM_HPP, patch_bloom_hpp), (BLOOM_ALGO, patch_bloom_algo), (MPHF_ALGO, patch_mphf_algo), (DEBLOOM_ALGO, patch_debloom_algo)]
+PATCH_NAME = "gatb-core.device.patch"
+
+
+def make_diff(ref):
+    """the unified diff of all patched files against the reference tree at `ref`"""
+    parts = []
+    for rel, fn in FILES:
+        src = open(os.path.join(ref, rel)).read()
+        new = fn(src)
+        parts.append("".join(difflib.unified_diff(src.splitlines(True), new.splitlines(True), "a/" + rel, "b/" + rel, n=1)))
+    return "".join(parts)
 
 
 def main():
     ref, scratch = sys.argv[1], sys.argv[2]
-    src = open(os.path.join(ref, REL)).read()
-    new = patch(src)
-    dst = os.path.join(scratch, "gatb/kmer/impl/SortingCountAlgorithm.cpp")
-    os.makedirs(os.path.dirname(dst), exist_ok=True)
-    open(dst, "w").write(new)
+    for rel, fn in FILES:
+        src = open(os.path.join(ref, rel)).read()
+        dst = os.path.join(scratch, rel[len("src/"):])
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        new = fn(src)
+        if not (os.path.exists(dst) and open(dst).read() == new):      # (untouched copies keep their time stamp: make-style rebuilds stay cheap)
+            open(dst, "w").write(new)
+        print(dst)
     if "--write-patch" in sys.argv:
-        diff = difflib.unified_diff(src.splitlines(True), new.splitlines(True), "a/" + REL, "b/" + REL, n=1)
         here = os.path.dirname(os.path.abspath(__file__))
-        open(os.path.join(here, "SortingCountAlgorithm.device.patch"), "w").write("".join(diff))
-    print(dst)
+        open(os.path.join(here, PATCH_NAME), "w").write(make_diff(ref))
 
 
 if __name__ == "__main__":

@@ -42,7 +42,7 @@ def attr(h5, path):
     return m.group(1) if m else None
 
 
-def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1, max_memory=2000, want_freq=False):
+def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1, max_memory=2000, want_freq=False, want_graph=False):
     with tempfile.TemporaryDirectory() as td:
         fa = os.path.join(td, "in.fa")
         text = "".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads))
@@ -75,10 +75,46 @@ def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1, max_me
                 fx["bloom_" + a] = np.frombuffer((v or "").encode(), dtype=np.uint8)
         if want_mphf:
             fx["mphf"] = dataset_bytes(h5, "/dsk/mphf", "LE")
+        if want_graph:                                             # what the steps behind the Bloom filter leave (dbgh5's DEFAULT flags: debloom cascading, branching nodes stored):
+            for name in ("debloom/bloom2", "debloom/bloom3", "debloom/bloom4", "debloom/cfp", "branching/nodes"):      # they depend on every query the debloom step made
+                fx[name.replace("/", "_")] = dataset_bytes(h5, "/" + name, "FILE")
         if want_freq:                                              # u32 freq_order[4^m] + u32 magic (RepartitionAlgorithm.cpp:352-380, PartiInfo.cpp:271-295)
             fx["minimFrequency"] = dataset_bytes(h5, "/minimizers/minimFrequency", "LE")
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
-        print(tag, "partitions", nparts, "solid", int(fx["nb_solid_kmers"]), {k_: (v.shape if hasattr(v, "shape") else v) for k_, v in fx.items() if k_ in ("bloom", "mphf")})
+        print(tag, "partitions", nparts, "solid", int(fx["nb_solid_kmers"]), {k_: (v.shape if hasattr(v, "shape") else v) for k_, v in fx.items() if k_ in ("bloom", "mphf") or k_.startswith(("debloom", "branching"))})
+
+
+def canonical_unitigs(fa):
+    """(count, total length, sha256) of the unitigs of a .unitigs.fa as a SET of canonical sequences"""
+    import hashlib
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs = []
+    for line in open(fa, "rb"):
+        if not line.startswith(b">"):
+            s_ = line.strip(); seqs.append(min(s_, s_.translate(comp)[::-1]))
+    seqs.sort()
+    return [len(seqs), sum(len(x) for x in seqs), hashlib.sha256(b"\n".join(seqs)).hexdigest()]
+
+
+def run_unitigs(tag, reads, k):
+    """the reference's GraphUnitigs (integration/unitigs_check.cpp linked against the UNPATCHED library: integration/_build/ref/unitigs_check) on the .h5 the reference's
+    dbgh5 counted in the mode GraphUnitigs forces (-minimizer-type 1 -repartition-type 1, GraphUnitigs.cpp:861-870), and straight from the FASTA: the unitig set"""
+    import json
+    exe = os.path.join(BIN, "unitigs_check")
+    if not os.path.exists(exe):
+        print(tag, "skipped: no", exe); return
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "in.fa")
+        open(fa, "w").write("".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads)))
+        subprocess.run([os.path.join(BIN, "dbgh5"), "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", os.path.join(td, "ref"), "-out-tmp", td, "-nb-cores", "1",
+                        "-max-memory", "1", "-verbose", "0", "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf", "-minimizer-type", "1", "-repartition-type", "1"],
+                       check=True, capture_output=True)
+        subprocess.run([exe, os.path.join(td, "ref.h5"), os.path.join(td, "from_h5"), "1"], check=True, capture_output=True, cwd=td)
+        subprocess.run([exe, fa, os.path.join(td, "from_fa"), "1", "-kmer-size", str(k), "-abundance-min", "2", "-out-tmp", td], check=True, capture_output=True, cwd=td)
+        a, b = canonical_unitigs(os.path.join(td, "from_h5.unitigs.fa")), canonical_unitigs(os.path.join(td, "from_fa.unitigs.fa"))
+        assert a == b, (a, b)
+        json.dump({"k": k, "abundance_min": 2, "unitigs": a[0], "total_length": a[1], "sha256_sorted_canonical": a[2]}, open(os.path.join(OUT, tag + ".json"), "w"))
+        print(tag, a)
 
 
 if __name__ == "__main__":
@@ -98,7 +134,15 @@ if __name__ == "__main__":
     run("k21_default_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, count_only, max_memory=1)
     run("k31_2parts_mphf", synth_reads(2000, 10000, 150, seed=3), 31, ["-bloom", "none", "-debloom", "none", "-branching-nodes", "none"], want_mphf=True, cores=2)
     run("k63_neighbor_mphf", reads[:300], 63, ["-bloom", "neighbor", "-debloom", "none", "-branching-nodes", "none"], want_bloom=True, want_mphf=True)
+    # dbgh5 with its DEFAULT flags (MPHF, neighbor Bloom, cascading debloom, branching nodes): BASELINE configs[4]'s pipeline behind the counting step
+    run("k31_defaults", reads, 31, [], want_bloom=True, want_mphf=True, want_graph=True)
+    run("k63_defaults", reads[:300], 63, [], want_bloom=True, want_mphf=True, want_graph=True)
+    run("k21_defaults_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, [], want_bloom=True, want_mphf=True, want_graph=True, max_memory=1)
+    run_unitigs("k21_freq_4parts_unitigs", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21)
     if CHECK:
+        for f in sorted(os.listdir(OUT)):
+            if f.endswith(".json") and open(os.path.join(OUT, f)).read() != (open(os.path.join(COMMITTED, f)).read() if os.path.exists(os.path.join(COMMITTED, f)) else None):
+                print("%s differs from the committed one" % f); sys.exit(1)
         # every array of every regenerated fixture against the committed one
         bad = []
         for f in sorted(os.listdir(OUT)):
