@@ -95,6 +95,42 @@ def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct, keys_moved=Non
     return alg, dom, dom_ms, achieved, launches
 
 
+M64 = (1 << 64) - 1
+
+
+def input_checksum(c, chunks):
+    """order-independent checksum of the canonical k-mer multiset of the device-resident reads (an independent one-thread-per-position kernel: no minimizers,
+    no buckets): sum of mix(canonical) over the valid k-mers mod 2^64, and their number"""
+    cs, nv = 0, 0
+    for b_, o_, nr, nb_ in chunks:
+        s_, n_ = c.kmer_checksum_device(b_, o_, nr, nb_)
+        cs = (cs + int(s_)) & M64; nv += int(n_)
+    return cs, nv
+
+
+def verify_block(c, expect, amin=1):
+    """OUTSIDE the clock: is what the timed block left on the device the count of its input? `expect` = input_checksum of the reads it counted.
+    abundance-min 1 (every distinct k-mer is a record): sum abundance * mix(value) over the records == the input's checksum, sum abundance == valid k-mers.
+    abundance-min > 1 (only solid records are kept): the records' sum of abundances == sum i * h[i] over the window of the device's histogram, which itself must
+    account for every valid k-mer and every distinct one. Returns {"verified": bool, ...}."""
+    cs_in, nv = expect
+    cs_out, sa = c.result_checksum()
+    st = c.stats()
+    out = {"valid_kmers_in": nv, "sum_abundance_of_records": int(sa)}
+    if amin <= 1:
+        out["method"] = "sum abundance * mix(value) over the Count records == checksum of the input's canonical k-mers (independent kernel); sum abundance == valid k-mers"
+        out["verified"] = bool(int(cs_out) == cs_in and int(sa) == nv and st["kmers_nb_valid"] == nv)
+    else:
+        h = c.histogram().astype(np.int64)
+        idx = np.arange(len(h), dtype=np.int64)
+        clamped = int(h[-1]) != 0                                  # abundances beyond histo_max share the last bin: the weighted sums are lower bounds then
+        tot = int((idx * h).sum()); solid_w = int((idx[amin:] * h[amin:]).sum())
+        out["method"] = "device histogram: sum i*h[i] == valid k-mers, sum h == distinct, sum h[i >= %d] == solid records, their sum of abundances == sum i*h[i >= %d]" % (amin, amin)
+        out["verified"] = bool((tot == nv or clamped) and int(h[1:].sum()) == st["kmers_nb_distinct"] and int(h[amin:].sum()) == st["kmers_nb_solid"]
+                               and (int(sa) == solid_w or clamped) and st["kmers_nb_valid"] == nv)
+    return out
+
+
 REF_DIR = os.path.join(ROOT, "integration", "_build", "ref")      # unpatched reference tools built by integration/build_reference.sh (git-ignored, shipped by gpurun)
 
 
@@ -188,7 +224,7 @@ def fastq_parse_leg(c, n_reads=1_000_000, L=150):
             "text_GBps": t.numel() / best / 1e9, "gbases_per_s": n_reads * L / best / 1e9, "ms": best * 1e3}
 
 
-def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2):
+def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, expect=None, parts=0):
     """SURVEY §8(d) wall: from the first push to the last partition's Count[] in (page-locked) host memory. Every Stage-B batch is copied into
     the host sink on a copy stream while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns when everything has landed.
     Reported beside `value` (which stops with the results in HBM), at abundance-min 1 (every distinct k-mer travels: PCIe-bound) and 2."""
@@ -225,6 +261,19 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2):
                                           "ms_per_step": dt * 1e3, "steps": ns_, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
                                           "landed_GBps_over_the_step": landed / dt / 1e9, "frac_of_pcie": landed / dt / 1e9 / pcie,
                                           "sink_overflow": "sink" in err}
+        if expect is not None:                                 # outside the clock: the device's records are the count of the input, and what landed is those records
+            v = verify_block(c, expect, amin)
+            try:
+                same = True
+                for p_ in sorted({0, parts // 2, parts - 1}) if parts else []:
+                    host, n_ = c.wait_partition(0, p_)
+                    if n_:
+                        same = same and host is not None and bool(np.array_equal(host, c.partition_records(0, p_)))
+                v["sink_spot_check"] = "first / middle / last partition: bytes in the sink == bytes on the device: %s" % same
+                v["verified"] = bool(v["verified"] and same)
+            except Exception as e:      # noqa
+                v["sink_spot_check"] = "skipped: %r" % (e,)
+            out["abundance_min_%d" % amin]["verified"] = v["verified"]; out["abundance_min_%d" % amin]["verification"] = v
     # PCIe at BOTH ends (never `value`): bases in page-locked host memory in (gkc_push_reads: H2D of chunk j+1 under the scan of chunk j), every solid Count[]
     # into the page-locked sink out; 5e7 reads of the same generator (30x over their own genome)
     try:
@@ -317,7 +366,21 @@ def main():
 
     if use_dist:
         from gatb_core_amd import dist as gdist          # noqa
+        t_c0 = time.perf_counter()
         runner = gdist.DistributedCounter(c, rank, world, parts)
+        comm_create_s = time.perf_counter() - t_c0
+        # Start-up self-test over the REAL peers, before anything is timed (default on with several ranks; GKC_COMM_SELFTEST=0 skips it): every pair of GPUs exchanges
+        # 64 MiB and 300 MiB (two chunks of the 256 MiB chunking) of a keyed pattern through the communicator's grouped ncclSend / ncclRecv path — the first thing
+        # an 8-GPU run does with RCCL is a checked transfer, not the job. A mismatch or an RCCL error fails every rank loudly here.
+        selftest = None
+        if os.environ.get("GKC_COMM_SELFTEST", "1" if world > 1 else "0") != "0":
+            selftest = {}
+            for nb_ in (64 << 20, 300 << 20):
+                bad_, ms_ = runner.comm.selftest(nb_)
+                selftest["%d_MiB" % (nb_ >> 20)] = {"mismatching_words": int(bad_), "ms": ms_, "GBps_per_peer": (nb_ / (ms_ * 1e-3) / 1e9) if ms_ > 0 else None}
+                sys.stderr.write("[bench rank %d] comm self-test %d MiB to each of %d peer(s): %d mismatching words, %.1f ms\n" % (rank, nb_ >> 20, max(world - 1, 1), bad_, ms_))
+                if bad_:
+                    raise SystemExit("rank %d: the communicator self-test received %d wrong words" % (rank, bad_))
     else:
         runner = None
 
@@ -354,12 +417,33 @@ def main():
     if world > 1:
         t = torch.tensor([distinct, valid], device="cuda", dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
     ktime = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
+    # OUTSIDE the clock: the records the last timed step left on the device are the count of the reads it was given (every rank: its reads in, the partitions it
+    # owns out; over all ranks the two sides must meet)
+    expect = input_checksum(c, chunks)
+    if world > 1:
+        cs_out, sa = c.result_checksum()
+        mine_v = (expect[0], expect[1], int(cs_out), int(sa))
+        all_v = [None] * world
+        dist.all_gather_object(all_v, mine_v)
+        verification = {"method": "over all ranks: sum abundance * mix(value) of the owned partitions' records == checksum of every rank's input k-mers; sum abundance == valid k-mers",
+                        "valid_kmers_in": sum(v[1] for v in all_v), "sum_abundance_of_records": sum(v[3] for v in all_v)}
+        verification["verified"] = bool(sum(v[0] for v in all_v) & M64 == sum(v[2] for v in all_v) & M64 and verification["valid_kmers_in"] == verification["sum_abundance_of_records"] == valid)
+    else:
+        verification = verify_block(c, expect, 1)
+    all_verified = [verification["verified"]]
     exch = None
     if runner is not None:                                     # per-rank exchange figures over warmup + timed steps (gkc_comm_get_stats)
         cs = runner.stats(); n_st = max(1, args.steps + args.warmup)
+        ps_, pr_, init_ms = runner.comm.peer_bytes(world)
         mine_x = {"rank": rank, "owned_partitions": len(runner.owned()), "exchanges_per_step": cs["n_exchanges"] / n_st,
-                  "ms_transfer_per_step": cs["ms_transfer"] / n_st, "ms_host_per_step": cs["ms_host"] / n_st,
-                  "bytes_sent_per_step": cs["bytes_sent"] / n_st, "bytes_received_per_step": cs["bytes_received"] / n_st}
+                  "ms_transfer_per_step": cs["ms_transfer"] / n_st, "ms_transfer_per_exchange": cs["ms_transfer"] / max(1, cs["n_exchanges"]),
+                  "ms_host_per_step": cs["ms_host"] / n_st,
+                  "bytes_sent_per_step": cs["bytes_sent"] / n_st, "bytes_received_per_step": cs["bytes_received"] / n_st,
+                  "nccl_comm_init_rank_ms": init_ms, "communicator_create_s": comm_create_s,
+                  "bytes_sent_to_peer": [int(x) for x in ps_], "bytes_received_from_peer": [int(x) for x in pr_],     # whole run incl. the self-test, grouped send / recv path
+                  "selftest": selftest}
+        sys.stderr.write("[bench rank %d] ncclCommInitRank %.0f ms; %d exchanges, %.2f ms of transfer each; sent per peer %s MB, received per peer %s MB\n" % (
+            rank, init_ms, cs["n_exchanges"], mine_x["ms_transfer_per_exchange"], [int(x) >> 20 for x in ps_], [int(x) >> 20 for x in pr_]))
         if world > 1:
             exch = [None] * world
             dist.all_gather_object(exch, mine_x)
@@ -403,10 +487,21 @@ def main():
                 traffic = kt["hbm_bytes_per_step"] / max(1, ktime[dom][1] // max(1, args.steps)) if "hbm_bytes_per_step" in kt else kt["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
+        pipeline = None
+        try:   # the whole step against the HBM roof: every byte the step's kernels moved at the memory (PMC, single-lane passes) over the timed step
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == workload:
+                tot_b = sum(v_["hbm_bytes_per_step"] for n_, v_ in pt["kernels"].items() if n_.startswith("k_") and not n_.startswith("k_synth"))
+                pipeline = {"counter_bytes_per_step": tot_b, "bytes_per_valid_kmer": tot_b / max(1, valid), "achieved": tot_b / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
+                            "frac": tot_b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "source": "profiles/pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of one step (separate single-lane PMC passes) / this run's ms_per_step"}
+        except Exception:
+            pipeline = None
         out = {
             "metric": "distinct k-mers/s at k=%d" % k, "value": value, "unit": "distinct k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if k <= 31 else "u128",
+            "verified": verification["verified"], "verification": verification,
             "data": "synthetic (device generator, seeded; 150 bp reads, 30x, 1% substitutions)",
             "config": {"workload": workload,
                        "reads_per_gpu": n_reads, "partitions": parts, "valid_kmers": valid, "distinct_kmers": distinct,
@@ -414,13 +509,16 @@ def main():
                        "mean_kmers_per_superkmer": nbar, "distinct_ratio": d,
                        "model_bytes_per_kmer": algorithmic_bytes_per_kmer(k, L, nbar, d),
                        "model_GBps": valid / world * algorithmic_bytes_per_kmer(k, L, nbar, d) / (dt / args.steps) / 1e9,
+                       "model_note": "SURVEY 8(d)'s FIXED accounting (an 8-pass LSD radix sort: 128 of its 160 bytes per k-mer): this build sorts with one MSD scatter and a "
+                                     "register network, so model_GBps over-charges the bytes about 3.5x and can exceed the HBM peak; it is not a bandwidth. The measured "
+                                     "whole-pipeline figure is roofline.pipeline (PMC bytes per step / step time)",
                        "kernel_ms_per_step": {n_: round(ktime[n_][0] / args.steps, 3) for n_ in names}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate single-lane passes; bytes per step / launches per step)" if traffic else None,
                          "launches_per_step": int(launches_per_step), "launch_ms": dom_ms / launches_per_step,
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
-                         "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))},
+                         "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2")), "pipeline": pipeline},
         }
         # Stage B merges identical super-k-mer records before the expansion: every k-mer is still counted (the algorithmic bytes above are per k-mer of the
         # input), but the kernels after it move fewer keys. Both figures are reported: `frac` on the algorithmic bytes, `frac_on_moved_bytes` on what
@@ -467,9 +565,17 @@ def main():
         if exch is not None:
             out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push, "per_rank": exch}
         if world == 1 and not args.no_host_landed:
-            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=args.steps)
+            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=args.steps, expect=expect, parts=parts)
             if "abundance_min_2" in out["host_landed"]:
                 out["host_landed"]["abundance_min_2"]["vs_value"] = out["host_landed"]["abundance_min_2"]["value"] / value
+            if "abundance_min_1" in out["host_landed"]:
+                # SURVEY 8(d)'s wall for configs 2-4 ends with the last partition's Count[] in HOST memory at abundance-min 1: that figure, beside `value` (results in HBM)
+                out["value_host_landed"] = out["host_landed"]["abundance_min_1"]["value"]
+                out["value_host_landed_note"] = ("SURVEY 8(d) wall: first push -> every distinct k-mer's Count record in page-locked host memory, abundance-min 1 (%.1f ms per step, PCIe-bound: "
+                                                 "%.2f of the link); `value` ends with the records in HBM" % (out["host_landed"]["abundance_min_1"]["ms_per_step"], out["host_landed"]["abundance_min_1"]["frac_of_pcie"]))
+            for a_ in ("abundance_min_1", "abundance_min_2"):
+                if a_ in out["host_landed"] and "verified" in out["host_landed"][a_]:
+                    all_verified.append(out["host_landed"][a_]["verified"])
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
         if world == 1 and k == 31 and not args.no_bloom_mphf:
@@ -482,6 +588,7 @@ def main():
             ns = c.stats()["kmers_nb_solid"]
             blk = {"workload": "k=31, abundance-min 2, %d reads: count -> Bloom (11 bits / solid k-mer, 7 hashes) -> MPHF + abundance map" % n_reads,
                    "solid_kmers": ns, "count_ms": dt_cnt * 1e3}
+            vb = verify_block(c, expect, 2)
             for kind in ("neighbor", "cache", "basic"):
                 for rep_ in range(2):                             # the second build: scratch buffers come from the context's allocator, not from hipMalloc
                     bl = gkc.Bloom(c, kind, int(ns * 11.0), 7, k)
@@ -504,6 +611,11 @@ def main():
             amap, above = mp_.abundance_map(); t2 = time.perf_counter()
             blk.update({"mphf_build_ms": (t1 - t0) * 1e3, "mphf_keys_per_s": mp_.size / (t1 - t0), "mphf_bits_per_key": mp_.L.gkc_mphf_save_size(mp_.h) * 8 / max(1, mp_.size),
                         "abundance_map_ms_incl_d2h": (t2 - t1) * 1e3})
+            # ... and the structures built on the count: no false negative among the solid k-mers (asserted above), the MPHF is a bijection onto [0, n) — every cell of
+            # the abundance map was written exactly once (an abundance index of a solid k-mer is >= 2 > 0), and no abundance lies beyond the table
+            vb["bloom_mphf"] = "contains(every solid k-mer) == true: %s; abundance map: %d cells, all written: %s" % (npos1 == nq1 == ns, len(amap), bool((amap != 0).all()))
+            vb["verified"] = bool(vb["verified"] and npos1 == nq1 == ns and len(amap) == ns and bool((amap != 0).all()))
+            blk["verified"] = vb["verified"]; blk["verification"] = vb; all_verified.append(vb["verified"])
             blk["bloom_and_mphf_ready_ms"] = blk["count_ms"] + blk["bloom_neighbor_ms"] + blk["mphf_build_ms"]
             blk["distinct_kmers_per_s_to_bloom_and_mphf"] = c.stats()["kmers_nb_distinct"] / (blk["bloom_and_mphf_ready_ms"] * 1e-3)
             mp_.close(); del amap
@@ -532,10 +644,12 @@ def main():
             torch.cuda.synchronize()
             dt63 = (time.perf_counter() - t0) / 2
             s63 = c63.stats()
+            v63 = verify_block(c63, input_checksum(c63, [(b63, o63, n_reads, n_bases)]), 1); all_verified.append(v63["verified"])
             kt63 = {nme: ((c63.timing(nme)[0] - b63t[nme][0]), (c63.timing(nme)[1] - b63t[nme][1])) for nme in names}
             alg63, dom63, dom63_ms, ach63, ln63 = kernel_roofline(kt63, 2, n_bases, s63, 63, s63["kmers_nb_valid"], s63["kmers_nb_distinct"])
             out["config"]["k63"] = {"workload": "k=63, %d synthetic 150 bp reads, single-pass count, m=%d, %d partitions (BASELINE configs[3])" % (n_reads, m, p63),
                                     "steps": 2, "warmup": 1, "ms_per_step": dt63 * 1e3, "value": s63["kmers_nb_distinct"] / dt63, "unit": "distinct k-mers/s", "dtype": "u128",
+                                    "verified": v63["verified"], "verification": v63,
                                     "valid_kmers": s63["kmers_nb_valid"], "distinct_kmers": s63["kmers_nb_distinct"], "valid_kmers_per_s": s63["kmers_nb_valid"] / dt63,
                                     "kernel_ms_per_step": {n_: round(kt63[n_][0] / 2, 3) for n_ in names},
                                     "roofline": {"bound": "hbm", "kernel": dom63, "achieved": ach63, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach63 / HBM_PEAK_GBS,
@@ -578,7 +692,9 @@ def main():
             torch.cuda.synchronize()
             dt8 = (time.perf_counter() - t0) / 3
             s8 = c8.stats(); cs8 = r8.stats()
+            v8 = verify_block(c8, input_checksum(c8, ch8), 1); all_verified.append(v8["verified"])       # 32768 partitions, 4 pushes, two-level Stage A, the exchange's narrowing / import path
             out["config"]["share_of_8"] = {
+                "verified": v8["verified"], "verification": v8,
                 "workload": "BASELINE configs[2] per-GPU share on one GPU: k=31, %d of 10^9 reads, %d partitions (two-level Stage A), %d pushes + gkc_exchange (one-rank RCCL communicator)" % (SHARE_OF_8, p8, len(ch8)),
                 "steps": 3, "warmup": 1, "ms_per_step": dt8 * 1e3, "value": s8["kmers_nb_distinct"] / dt8, "unit": "distinct k-mers/s (this GPU's share)",
                 "x8_if_the_exchange_were_free": 8 * s8["kmers_nb_distinct"] / dt8,
@@ -604,12 +720,23 @@ def main():
                 out["cpu_baseline"] = port_b
         elif world == 1:
             out["cpu_baseline"] = None
+        out["all_blocks_verified"] = bool(all(all_verified))
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if not all(all_verified):
+            sys.stderr.write("bench.py: a timed block left results that are NOT the count of its input (see the `verified` fields)\n")
+            bad_rc = 3
+        else:
+            bad_rc = 0
+    else:
+        bad_rc = 0
     if c is not None:
         for b_, o_, _, _ in chunks:
             c.device_free(b_); c.device_free(o_)
     if use_dist:
+        t_rc = torch.tensor([bad_rc], device="cuda"); dist.all_reduce(t_rc, op=dist.ReduceOp.MAX); bad_rc = int(t_rc.item())      # a red `verified` fails every rank
         dist.barrier(); dist.destroy_process_group()
+    if bad_rc:
+        sys.exit(bad_rc)
 
 
 if __name__ == "__main__":

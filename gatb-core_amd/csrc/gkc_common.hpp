@@ -178,6 +178,7 @@ struct gkc_ctx {
     // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted
     void* sink = nullptr; uint64_t sink_cap = 0, sink_used = 0; bool sink_overflow = false;
     hipStream_t copy_stream = nullptr;
+    hipStream_t fetch_stream = nullptr;    // gkc_partition_counts: D2H of finished datasets, beside (not inside) the Stage-B lanes
     std::vector<hipEvent_t> landed_events;
     std::condition_variable cv_done;       // a dataset finished / the pass ended (gkc_wait_partition)
     std::thread stage_b_thread; bool stage_b_running = false; int stage_b_rc = GKC_OK;

@@ -19,6 +19,10 @@
 #include <string>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <dirent.h>
+#include <map>
+#include <mutex>
+#include <random>
 
 namespace {
 constexpr uint64_t MSG_CHUNK = 1ull << 28;     // 256 MiB per message: through torch's all_to_all_single a 1 GiB transfer is intact, a 1.9 GiB one comes back corrupt from
@@ -34,6 +38,8 @@ struct gkc_comm {
     std::vector<uint32_t> first;               // owner ranges [world+1]; empty until known
     bool owners_pinned = false; uint32_t owners_pass = ~0u; uint32_t owners_P = 0;
     gkc_comm_stats stats{};
+    std::vector<uint64_t> peer_sent, peer_recv;   // [world] bytes of grouped send / recv messages per peer (gkc_comm_peer_bytes)
+    double init_ms = 0;                        // wall of ncclCommInitRank (RCCL) / of the session handshake (file mailbox)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;      // transfer intervals not yet added to stats.ms_transfer
     DevBuf ag_send, ag_recv;                   // staging of the host all-gather (RCCL)
 };
@@ -121,6 +127,9 @@ int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std
             for (uint64_t o = 0; o < x.n_bytes; o += MSG_CHUNK) out.push_back(gkc_xfer{ x.peer, 0, (uint8_t*)x.d_ptr + o, std::min<uint64_t>(MSG_CHUNK, x.n_bytes - o) });
     };
     split(sends, s2); split(recvs, r2);
+    if (m->peer_sent.size() != (size_t)m->world) { m->peer_sent.assign(m->world, 0); m->peer_recv.assign(m->world, 0); }
+    for (const gkc_xfer& x : s2) if (x.peer >= 0 && x.peer < m->world) m->peer_sent[x.peer] += x.n_bytes;
+    for (const gkc_xfer& x : r2) if (x.peer >= 0 && x.peer < m->world) m->peer_recv[x.peer] += x.n_bytes;
     if (m->rccl) {
         NCCL_TRY(m, g_rccl.GroupStart());
         for (const gkc_xfer& x : s2) NCCL_TRY(m, g_rccl.Send(x.d_ptr, (size_t)x.n_bytes, ncclUint8, x.peer, m->nccl, st));
@@ -213,19 +222,53 @@ void gkc_comm_settle_timers(gkc_comm* m)
 
 // ------------------------------------------------------------------------------------------------ file-mailbox transport (gkc_comm_create_files)
 // Collective calls happen in the same order on every rank, so a per-communicator sequence number names the files of one call. A file becomes visible
-// atomically (written under a temporary name, then renamed); a reader polls for it. all-gather: rank r writes ag.<seq>.<r>, reads the others', and removes
+// atomically (written under a temporary name, then renamed); a reader polls for it. all-gather: rank r writes <tag>.ag.<seq>.<r>, reads the others', and removes
 // its own file of call seq-1 when it enters call seq+1 (every rank has read call seq-1 before it wrote its file of call seq). send/recv: one file per
 // message, named by (seq, source, destination, index of the message between the two in this call), removed by the receiver.
+// <tag> = <generation>.<nonce>: every communicator has its own file names, so what a crashed run left in the directory (ag.* / p2p.* with a header of the
+// expected size) is never read by a later run. generation = how many file communicators this process has made for the directory before (the ranks
+// create their communicators in the same order); the nonce is drawn by rank 0 and published in session.<generation>, the others answer with join.<tag>.<rank>
+// and wait for go.<tag>, which rank 0 writes once everybody has joined — a rank that picked up a stale session file waits for a go that never comes and
+// fails loudly instead of exchanging with nobody. Rank 0 of generation 0 removes the handshake files earlier runs left.
 namespace {
 struct FileBox {
-    std::string dir; int world, rank; uint64_t seq_ag = 0, seq_p2p = 0;
+    std::string dir, tag; int world, rank; uint64_t seq_ag = 0, seq_p2p = 0;
     std::vector<uint8_t> stage;
     static bool write_file(const std::string& path, const void* data, size_t n) {
         const std::string tmp = path + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb"); if (!f) return false;
         const bool ok = n == 0 || fwrite(data, 1, n, f) == n;
-        if (fclose(f) != 0 || !ok) return false;
-        return rename(tmp.c_str(), path.c_str()) == 0;
+        if (fclose(f) != 0 || !ok) { (void)unlink(tmp.c_str()); return false; }
+        if (rename(tmp.c_str(), path.c_str()) != 0) { (void)unlink(tmp.c_str()); return false; }
+        return true;
+    }
+    static void remove_matching(const std::string& dir, const std::vector<std::string>& prefixes) {
+        DIR* d = opendir(dir.c_str()); if (!d) return;
+        std::vector<std::string> gone;
+        while (struct dirent* e = readdir(d)) { const std::string n = e->d_name; for (const std::string& p : prefixes) if (n.compare(0, p.size(), p) == 0) { gone.push_back(n); break; } }
+        closedir(d);
+        for (const std::string& n : gone) (void)unlink((dir + "/" + n).c_str());
+    }
+    // the handshake described above; false: the others did not show up (or a stale session file was picked up) within the time limit
+    bool open_session(double timeout_s) {
+        static std::mutex mu; static std::map<std::string, uint64_t> generations;
+        uint64_t gen; { std::lock_guard<std::mutex> lk(mu); gen = generations[dir]++; }
+        const std::string session = dir + "/session." + std::to_string(gen);
+        uint64_t nonce = 0;
+        if (rank == 0) {
+            if (gen == 0) remove_matching(dir, { "session.", "join.", "go." });
+            std::random_device rd; nonce = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)getpid() << 20) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+            if (!write_file(session, &nonce, 8)) return false;
+        } else if (!read_file(session, &nonce, 8, timeout_s)) return false;
+        char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)nonce);
+        tag = std::to_string(gen) + "." + hex;
+        uint8_t one = 1;
+        if (rank == 0) {
+            for (int r = 1; r < world; r++) { if (!read_file(dir + "/join." + tag + "." + std::to_string(r), &one, 1, timeout_s)) return false; (void)unlink((dir + "/join." + tag + "." + std::to_string(r)).c_str()); }
+            return write_file(dir + "/go." + tag, &one, 1);
+        }
+        if (!write_file(dir + "/join." + tag + "." + std::to_string(rank), &one, 1)) return false;
+        return read_file(dir + "/go." + tag, &one, 1, timeout_s);
     }
     static bool read_file(const std::string& path, void* data, size_t n, double timeout_s) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -239,7 +282,7 @@ struct FileBox {
             usleep(200);
         }
     }
-    std::string ag_name(uint64_t seq, int r) const { return dir + "/ag." + std::to_string(seq) + "." + std::to_string(r); }
+    std::string ag_name(uint64_t seq, int r) const { return dir + "/" + tag + ".ag." + std::to_string(seq) + "." + std::to_string(r); }
     static int allgather(void* user, const void* mine, uint64_t n, void* all) {
         FileBox* b = (FileBox*)user;
         const uint64_t seq = b->seq_ag++;
@@ -259,14 +302,14 @@ struct FileBox {
             const gkc_xfer& x = sends[i];
             b->stage.resize((size_t)x.n_bytes);
             if (x.n_bytes && hipMemcpy(b->stage.data(), x.d_ptr, (size_t)x.n_bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-            const std::string name = b->dir + "/p2p." + std::to_string(seq) + "." + std::to_string(b->rank) + "." + std::to_string(x.peer) + "." + std::to_string(idx[x.peer]++);
+            const std::string name = b->dir + "/" + b->tag + ".p2p." + std::to_string(seq) + "." + std::to_string(b->rank) + "." + std::to_string(x.peer) + "." + std::to_string(idx[x.peer]++);
             if (!write_file(name, b->stage.data(), (size_t)x.n_bytes)) return 1;
         }
         std::fill(idx.begin(), idx.end(), 0u);
         for (uint32_t i = 0; i < n_recvs; i++) {
             const gkc_xfer& x = recvs[i];
             b->stage.resize((size_t)x.n_bytes);
-            const std::string name = b->dir + "/p2p." + std::to_string(seq) + "." + std::to_string(x.peer) + "." + std::to_string(b->rank) + "." + std::to_string(idx[x.peer]++);
+            const std::string name = b->dir + "/" + b->tag + ".p2p." + std::to_string(seq) + "." + std::to_string(x.peer) + "." + std::to_string(b->rank) + "." + std::to_string(idx[x.peer]++);
             if (!read_file(name, b->stage.data(), (size_t)x.n_bytes, 600.0)) return 1;
             (void)unlink(name.c_str());
             if (x.n_bytes && hipMemcpy(x.d_ptr, b->stage.data(), (size_t)x.n_bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
@@ -276,6 +319,7 @@ struct FileBox {
     static void destroy(void* user) {
         FileBox* b = (FileBox*)user;
         for (uint64_t s = b->seq_ag >= 2 ? b->seq_ag - 2 : 0; s < b->seq_ag; s++) (void)unlink(b->ag_name(s, b->rank).c_str());
+        if (b->rank == 0 && !b->tag.empty()) { (void)unlink((b->dir + "/go." + b->tag).c_str()); (void)unlink((b->dir + "/session." + b->tag.substr(0, b->tag.find('.'))).c_str()); }
         delete b;
     }
 };
@@ -360,7 +404,9 @@ int gkc_comm_create_rccl(gkc_ctx* c, const uint8_t id[GKC_COMM_ID_BYTES], int wo
     gkc_comm* m = *out;
     ncclUniqueId u; memcpy(&u, id, sizeof(u));
     if (!g_rccl.load()) { c->set_error(GKC_ERR_HIP, "RCCL is not available on this host (%s): a communicator over several GPUs needs librccl", g_rccl.why.c_str()); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
+    const auto t_init = std::chrono::steady_clock::now();
     const ncclResult_t r = g_rccl.CommInitRank(&m->nccl, world, u, rank);
+    m->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count();
     if (r != ncclSuccess) { c->set_error(GKC_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
     m->rccl = true;
     return GKC_OK;
@@ -378,6 +424,10 @@ int gkc_comm_create_files(gkc_ctx* c, const char* directory, int world, int rank
     GKC_TRY(comm_new(c, world, rank, out));
     FileBox* b = new FileBox();
     b->dir = directory; b->world = world; b->rank = rank;
+    if (!b->open_session(getenv("GKC_FILEBOX_TIMEOUT") ? atof(getenv("GKC_FILEBOX_TIMEOUT")) : 600.0)) {
+        delete b; gkc_comm_destroy(*out); *out = nullptr;
+        GKC_FAIL(c, GKC_ERR_ARG, "gkc_comm_create_files: rank %d of %d found no session with the other ranks in %s (stale files of an earlier run, or a rank that never started)", rank, world, directory);
+    }
     gkc_comm* m = *out;
     m->t.user = b; m->t.allgather_host = &FileBox::allgather; m->t.sendrecv_device = &FileBox::sendrecv;
     m->owned_user = b; m->owned_free = &FileBox::destroy;
@@ -572,6 +622,61 @@ int gkc_comm_loopback(gkc_ctx* c, gkc_comm* m, uint64_t n_bytes, uint64_t* misma
     src.release(); dst.release(); bad.release();
     *mismatches = h;
     return rc;
+}
+// Start-up self-test over REAL peers (gkc_comm_loopback reaches only the rank itself): one grouped exchange in which every rank sends n_bytes of a pattern keyed by
+// (source, destination) to every other rank and checks what arrives from each — the grouped ncclSend / ncclRecv path of gkc_exchange with its 256 MiB chunking between
+// every pair of GPUs, before any real record travels. Collective. mismatches: 8-byte words that differ, summed over the peers; ms: wall time of the exchange.
+int gkc_comm_selftest(gkc_ctx* c, gkc_comm* m, uint64_t n_bytes, uint64_t* mismatches, double* ms)
+{
+    if (!c || !m || m->ctx != c || !mismatches) return GKC_ERR_ARG;
+    GKC_HIP(c, hipSetDevice(c->device));
+    const int W = m->world, me = m->rank;
+    *mismatches = 0; if (ms) *ms = 0;
+    if (W == 1) return gkc_comm_loopback(c, m, n_bytes, mismatches, ms);
+    const uint64_t n = (n_bytes + 7) / 8;
+    DevBuf src, dst, bad;
+    int rc = c->ensure(src, (size_t)n * 8 * (W - 1));
+    if (rc == GKC_OK) rc = c->ensure(dst, (size_t)n * 8 * (W - 1));
+    if (rc == GKC_OK) rc = c->ensure(bad, 8);
+    GKC_TRY(gkc_comm_agree(m, rc, "gkc_comm_selftest"));
+    (void)hipMemsetAsync(bad.p, 0, 8, m->xstream); (void)hipMemsetAsync(dst.p, 0, (size_t)n * 8 * (W - 1), m->xstream);
+    std::vector<gkc_xfer> sends, recvs;
+    int slot = 0;
+    for (int r = 0; r < W; r++) {
+        if (r == me) continue;
+        uint64_t* sp = (uint64_t*)src.p + (size_t)slot * n; uint64_t* dp = (uint64_t*)dst.p + (size_t)slot * n;
+        hipLaunchKernelGGL(k_loop_fill, dim3(1024), dim3(256), 0, m->xstream, sp, n, (uint64_t)(1000003ull * (uint64_t)me + (uint64_t)r));
+        sends.push_back(gkc_xfer{ r, 0, sp, n * 8 }); recvs.push_back(gkc_xfer{ r, 0, dp, n * 8 });
+        slot++;
+    }
+    (void)hipStreamSynchronize(m->xstream);
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = gkc_comm_sendrecv(m, sends, recvs, m->xstream);
+    (void)hipStreamSynchronize(m->xstream);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    unsigned long long h = 0;
+    if (rc == GKC_OK) {
+        slot = 0;
+        for (int r = 0; r < W; r++) {
+            if (r == me) continue;
+            hipLaunchKernelGGL(k_loop_check, dim3(1024), dim3(256), 0, m->xstream, (const uint64_t*)dst.p + (size_t)slot * n, n, (uint64_t)(1000003ull * (uint64_t)r + (uint64_t)me), (unsigned long long*)bad.p);
+            slot++;
+        }
+        if (hipMemcpyAsync(&h, bad.p, 8, hipMemcpyDeviceToHost, m->xstream) != hipSuccess || hipStreamSynchronize(m->xstream) != hipSuccess) { c->set_error(GKC_ERR_HIP, "self-test check failed"); rc = GKC_ERR_HIP; }
+    }
+    src.release(); dst.release(); bad.release();
+    *mismatches = h;
+    return gkc_comm_agree(m, rc != GKC_OK ? rc : (h ? GKC_ERR_HIP : GKC_OK), "gkc_comm_selftest");      // one rank seeing garbage fails every rank
+}
+int gkc_comm_peer_bytes(gkc_comm* m, uint64_t* sent, uint64_t* received, double* init_ms)
+{
+    if (!m) return GKC_ERR_ARG;
+    for (int r = 0; r < m->world; r++) {
+        if (sent) sent[r] = (size_t)r < m->peer_sent.size() ? m->peer_sent[r] : 0;
+        if (received) received[r] = (size_t)r < m->peer_recv.size() ? m->peer_recv[r] : 0;
+    }
+    if (init_ms) *init_ms = m->init_ms;
+    return GKC_OK;
 }
 int gkc_gather_results(gkc_ctx* c, gkc_comm* m, int root)
 {

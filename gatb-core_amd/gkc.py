@@ -25,7 +25,7 @@ SYMBOLS = [
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
-    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_gather_results", "gkc_comm_loopback", "gkc_comm_destroy", "gkc_comm_set_owners",
+    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_gather_results", "gkc_comm_loopback", "gkc_comm_selftest", "gkc_comm_peer_bytes", "gkc_comm_destroy", "gkc_comm_set_owners",
     "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
     "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
     "gkc_sample_exact", "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
@@ -142,6 +142,8 @@ def lib():
         "gkc_comm_create_files": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, P(vp)]),
         "gkc_gather_results": (C.c_int, [vp, vp, C.c_int]),
         "gkc_comm_loopback": (C.c_int, [vp, vp, u64, P(u64), P(C.c_double)]),
+        "gkc_comm_selftest": (C.c_int, [vp, vp, u64, P(u64), P(C.c_double)]),
+        "gkc_comm_peer_bytes": (C.c_int, [vp, vp, vp, P(C.c_double)]),
         "gkc_comm_destroy": (None, [vp]),
         "gkc_comm_set_owners": (C.c_int, [vp, vp]),
         "gkc_comm_get_owners": (C.c_int, [vp, vp]),
@@ -556,6 +558,19 @@ class Comm:
         bad = C.c_uint64(0); ms = C.c_double(0)
         self.c._chk(self.L.gkc_comm_loopback(self.c.h, self.h, int(n_bytes), C.byref(bad), C.byref(ms)))
         return bad.value, ms.value
+
+    def selftest(self, n_bytes):
+        """collective: every rank sends n_bytes of a keyed pattern to every other rank in one grouped exchange and checks what arrives (gkc_comm_selftest);
+        raises on every rank when one of them saw garbage -> (mismatching words on this rank, ms)"""
+        bad = C.c_uint64(0); ms = C.c_double(0)
+        self.c._chk(self.L.gkc_comm_selftest(self.c.h, self.h, int(n_bytes), C.byref(bad), C.byref(ms)))
+        return bad.value, ms.value
+
+    def peer_bytes(self, world):
+        """-> (bytes sent to every peer, bytes received from every peer, ms ncclCommInitRank took)"""
+        a = np.zeros(world, np.uint64); b = np.zeros(world, np.uint64); ms = C.c_double(0)
+        self.c._chk(self.L.gkc_comm_peer_bytes(self.h, _p(a), _p(b), C.byref(ms)))
+        return a, b, ms.value
 
     def gather_results(self, root=0):
         """collective after finish_pass: every partition's Count[], the histogram and the statistics on `root` (gkc_gather_results)"""

@@ -242,6 +242,14 @@ int  gkc_gather_results(gkc_ctx* ctx, gkc_comm* comm, int root);
  * 256 MiB chunks as the messages of gkc_exchange) and compares what arrived. With one rank this is the only way to run ncclSend / ncclRecv and the chunking on
  * hardware. mismatches: 8-byte words that differ; ms: wall time of the transfer. */
 int  gkc_comm_loopback(gkc_ctx* ctx, gkc_comm* comm, uint64_t n_bytes, uint64_t* mismatches, double* ms);
+/* Start-up self-test over the real peers, collective: in ONE grouped exchange every rank sends n_bytes of a pattern keyed by (source, destination) to every other
+ * rank and checks what arrives from each — the send / receive path of gkc_exchange (RCCL: grouped ncclSend / ncclRecv over xGMI, cut into the same 256 MiB chunks)
+ * between every pair of GPUs before any record travels. A rank that receives anything but the pattern makes the call fail on EVERY rank (gkc_comm_agree).
+ * mismatches: 8-byte words that differ on this rank; ms: wall time of the exchange on this rank. One rank: the loopback above. */
+int  gkc_comm_selftest(gkc_ctx* ctx, gkc_comm* comm, uint64_t n_bytes, uint64_t* mismatches, double* ms);
+/* What went where: bytes this rank has sent to / received from every peer through the communicator's grouped send / receive path since it was created ([world] each,
+ * either may be NULL), and the wall time ncclCommInitRank took when the communicator was made (0 for the other transports). */
+int  gkc_comm_peer_bytes(gkc_comm* comm, uint64_t* sent /* [world] */, uint64_t* received /* [world] */, double* init_ms);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Bloom filter of solid k-mers — replaces BloomBuilder::build / IBloom::insert (kmer/impl/BloomBuilder.hpp:102-128,

@@ -3,9 +3,9 @@
 #   integration/check_integration.sh [scratch dir] [--link [gatb build dir with lib/Release/libgatbcore.a]]
 # 1. runs the reference's cmake CONFIGURE step in the scratch dir (generates gatb/system/api/config.hpp and the HDF5 configuration headers;
 #    nothing is built, the reference tree is not written);
-# 2. applies the patch to scratch copies of the five files it touches (integration/make_patched_sources.py);
-# 3. g++ -fsyntax-only of the reference's own template instantiation units that hold them — template/TemplateSpecialization2.cpp.in
-#    (SortingCountAlgorithm + PartitionsCommand), 3 (BloomAlgorithm, DebloomAlgorithm, DebloomMinimizerAlgorithm), 4 (MPHFAlgorithm) — for spans 32
+# 2. applies the patch to scratch copies of the six files it touches (integration/make_patched_sources.py);
+# 3. g++ -fsyntax-only of the reference's own template instantiation units that hold them — template/TemplateSpecialization1.cpp.in (ConfigurationAlgorithm),
+#    2 (SortingCountAlgorithm + PartitionsCommand), 3 (BloomAlgorithm, DebloomAlgorithm, DebloomMinimizerAlgorithm), 4 (MPHFAlgorithm) — for spans 32
 #    and 64 with -DGATB_WITH_DEVICE_COUNTING, plus explicit instantiations of PartitionsByDeviceCommand and of BloomDevice<LargeInt<1>>, <LargeInt<2>>;
 # 4. --link: compiles those units for the four spans and links a patched dbgh5 (and integration/unitigs_check.cpp) against them + libgatbcore.a,
 #    libhdf5.a and libgkc_hip.so (link only: running it needs a GPU) -> integration/_build/{dbgh5_device,unitigs_check}. The objects of the patched
@@ -33,9 +33,10 @@ FLAGS="-msse2 -msse4.2 -mpopcnt -std=c++11 -DNDEBUG -DINT128_FOUND -Wno-invalid-
 for K in 32 64 96 128; do
   { sed "s/\${KSIZE}/$K/g" "$REF/src/gatb/template/TemplateSpecialization2.cpp.in"
     echo "namespace gatb { namespace core { namespace kmer { namespace impl { template class PartitionsByDeviceCommand<$K>; } } } }"; } > "$SCRATCH/obj/ts2_$K.cpp.new"
+  sed "s/\${KSIZE}/$K/g" "$REF/src/gatb/template/TemplateSpecialization1.cpp.in" > "$SCRATCH/obj/ts1_$K.cpp.new"
   sed "s/\${KSIZE}/$K/g" "$REF/src/gatb/template/TemplateSpecialization3.cpp.in" > "$SCRATCH/obj/ts3_$K.cpp.new"
   sed "s/\${KSIZE}/$K/g" "$REF/src/gatb/template/TemplateSpecialization4.cpp.in" > "$SCRATCH/obj/ts4_$K.cpp.new"
-  for U in ts2 ts3 ts4; do cmp -s "$SCRATCH/obj/${U}_$K.cpp.new" "$SCRATCH/obj/${U}_$K.cpp" && rm "$SCRATCH/obj/${U}_$K.cpp.new" || mv "$SCRATCH/obj/${U}_$K.cpp.new" "$SCRATCH/obj/${U}_$K.cpp"; done
+  for U in ts1 ts2 ts3 ts4; do cmp -s "$SCRATCH/obj/${U}_$K.cpp.new" "$SCRATCH/obj/${U}_$K.cpp" && rm "$SCRATCH/obj/${U}_$K.cpp.new" || mv "$SCRATCH/obj/${U}_$K.cpp.new" "$SCRATCH/obj/${U}_$K.cpp"; done
 done
 cat > "$SCRATCH/obj/bloom_device.cpp" <<EOT
 #include <gatb/tools/collections/impl/Bloom.hpp>   /* the patched header: brings BloomDevice.hpp in */
@@ -47,7 +48,7 @@ template class BloomDevice<gatb::core::tools::math::LargeInt<2> >;
 EOT
 echo "[check_integration] syntax: SortingCountAlgorithm + PartitionsByDeviceCommand, Bloom / Debloom, MPHF units (spans 32, 64), BloomDevice"
 pids=""
-SYN="ts2_32 ts2_64 ts3_32 ts3_64 ts4_32 ts4_64 bloom_device"
+SYN="ts1_32 ts1_64 ts2_32 ts2_64 ts3_32 ts3_64 ts4_32 ts4_64 bloom_device"
 for f in $SYN; do g++ $FLAGS $INC -fsyntax-only "$SCRATCH/obj/$f.cpp" > "$SCRATCH/obj/$f.log" 2>&1 & pids="$pids $!"; done
 rc=0; for p in $pids; do wait $p || rc=1; done
 for f in $SYN; do grep -E "error" "$SCRATCH/obj/$f.log" | head -20 || true; done
@@ -57,11 +58,11 @@ if [ $LINK -eq 1 ]; then
   # no built reference yet: integration/build_reference.sh builds it with the reference's own cmake (~10 minutes), so the chain is reproducible from this repository
   test -f "$LIBDIR/lib/Release/libgatbcore.a" || bash "$HERE/build_reference.sh" "$LIBDIR" || { echo "no libgatbcore.a under $LIBDIR and the reference build failed"; exit 5; }
   test -f "$REPO/gatb-core_amd/csrc/libgkc_hip.so" || { echo "libgkc_hip.so missing"; exit 6; }
-  echo "[check_integration] compiling the patched instantiation units (3 units x 4 spans) and dbgh5"
+  echo "[check_integration] compiling the patched instantiation units (4 units x 4 spans) and dbgh5"
   # an object is rebuilt when its unit, a patched source, a binding header or gkc.h is newer (the units take minutes each at -O2)
   newest=$(ls -t "$SCRATCH"/inc/gatb/kmer/impl/*.cpp "$SCRATCH"/inc/gatb/tools/collections/impl/*.hpp "$HERE"/gatb_device/*.hpp "$REPO/include/gkc.h" | head -1)
   OBJS=""; jobs_running=0; rc=0; pids=""
-  for U in ts2 ts3 ts4; do for K in 32 64 96 128; do
+  for U in ts1 ts2 ts3 ts4; do for K in 32 64 96 128; do
     o="$SCRATCH/obj/${U}_$K.o"; OBJS="$OBJS $o"
     if [ ! -f "$o" ] || [ "$SCRATCH/obj/${U}_$K.cpp" -nt "$o" ] || [ "$newest" -nt "$o" ]; then
       g++ $FLAGS -O2 $INC -c "$SCRATCH/obj/${U}_$K.cpp" -o "$o" > "$SCRATCH/obj/${U}_$K.clog" 2>&1 & pids="$pids $!"

@@ -7,6 +7,7 @@ would apply (integration/gatb-core.device.patch).
 Six files are touched (file:line cited per hunk below); every edit is anchored on text of the reference file that must be found exactly once, and everything
 new is guarded by GATB_WITH_DEVICE_COUNTING, so the patched files still build the CPU path without the macro:
   kmer/impl/SortingCountAlgorithm.cpp       fillPartitions -> Stage A on the device, the partition command, the join, device time keys in getInfo()
+  kmer/impl/ConfigurationAlgorithm.cpp      partitions / passes sized from the HBM of the device instead of host RAM and disk
   tools/collections/impl/Bloom.hpp          BloomFactory::createBloom returns BloomDevice<T> for the item types / kinds the device knows
   kmer/impl/BloomAlgorithm.cpp              execute(): the solid k-mers are inserted where the counting step left them in HBM
   kmer/impl/MPHFAlgorithm.cpp               execute(): BooPHF built on the device, stored, loaded by the reference's own MapMPHF::load; populate() on the device
@@ -122,9 +123,20 @@ def insert_before(text, anchor, new):
     return text[:i] + new + text[i:]
 
 
+# fillPartitions (SortingCountAlgorithm.cpp:1244): the partition files of the disk shuffle. The device path writes none of them: ONE (empty) file keeps every
+# later call on _superKstorage valid (flushFiles, closeFiles, getFilesStats, the commands' constructor argument) without nb_partitions open files
+SUPERK = "\t\t\t_superKstorage = new SuperKmerBinFiles(_tmpStorageName_superK,\"superKparts\", _config._nb_partitions) ;\n"
+SUPERK_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+\t\t\t_superKstorage = new SuperKmerBinFiles(_tmpStorageName_superK,"superKparts", 1) ;      /* the super-k-mers stay in HBM: no partition file is written */
+#else
+"""
+
+
 def patch(src):
     """kmer/impl/SortingCountAlgorithm.cpp"""
     out = insert_after_line(src, SCA_INCLUDE_ANCHOR, SCA_INCLUDE)
+    a = once(out, SUPERK)
+    out = out[:a] + SUPERK_DEVICE + SUPERK + "#endif\n" + out[a + len(SUPERK):]
     a = once(out, FILL_BEGIN); b = out.index(FILL_END, a) + len(FILL_END)
     out = out[:a] + FILL_DEVICE + out[a:b] + "#endif\n" + out[b:]
     a = once(out, CMD_BEGIN) + len(CMD_BEGIN); b = once(out, CMD_END)
@@ -249,42 +261,61 @@ def patch_mphf_algo(src):
 DEBLOOM_ALGO = "src/gatb/kmer/impl/DebloomMinimizerAlgorithm.cpp"
 DB_MEMBER_ANCHOR = "    Model&        model;\n    IBloom<Type>* bloom;\n"
 DB_MEMBER = """#ifdef GATB_WITH_DEVICE_COUNTING
-    const u_int8_t* deviceMasks = 0;      /**< contains8 of every solid k-mer of the partition, in the order of the (sorted) solids vector: ONE batched device query */
+    /** the same for the i-th solid k-mer of the partition when its 8 neighbour tests came out of ONE batched device query (masks[i], in the order of `solids`) */
+    struct ByIndex
+    {
+        const FunctorKmersExtensionMinimizer& outer;  const std::vector<Type>& solids;  const u_int8_t* masks;
+        FunctorNeighbors neighbors;       /* own copy per thread (Dispatcher::iterate copies the functor): it caches the thread's index */
+        ByIndex (const FunctorKmersExtensionMinimizer& o, const std::vector<Type>& s, const u_int8_t* m) : outer(o), solids(s), masks(m), neighbors(o.functorNeighbors) {}
+        void operator() (const u_int64_t& i)  { outer.model.iterateNeighbors (solids[i], neighbors, bitset<8> (masks[i])); }
+    };
 #endif
-"""
-DB_CALL = "        bitset<8> mask =  bloom->contains8 (kmer.value);\n"
-DB_CALL_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
-        bitset<8> mask = deviceMasks != 0
-            ? bitset<8> (deviceMasks [std::lower_bound (functorNeighbors._solids.begin(), functorNeighbors._solids.end(), kmer.value) - functorNeighbors._solids.begin()])
-            : bloom->contains8 (kmer.value);
-#else
 """
 DB_LOOP_ANCHOR = "            /** We iterate the solid kmers. */\n            this->getDispatcher()->iterate (itKmers, functorKmers);\n"
 DB_LOOP_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
-            /* the filter is a BloomDevice: the 8 neighbour tests of every solid k-mer of the partition in one device query (gkc_bloom_contains8) */
-            std::vector<u_int8_t> deviceMasks;
-            if (BloomDevice<Type>* onDevice = dynamic_cast<BloomDevice<Type>*> (bloom))
+            /* the filter is a BloomDevice: the 8 neighbour tests of every solid k-mer of the partition in one device query (gkc_bloom_contains8), then the
+             * neighbours are iterated by index over the (sorted) solids vector — same neighbours, same insertions as one contains8 call per k-mer */
+            BloomDevice<Type>* onDevice = dynamic_cast<BloomDevice<Type>*> (bloom);
+            if (onDevice != 0  &&  !solids.empty()  &&  getenv ("GATB_DEVICE_NO_BATCHED_QUERIES") == 0)
             {
-                if (!solids.empty()  &&  getenv ("GATB_DEVICE_NO_BATCHED_QUERIES") == 0)
-                {
-                    deviceMasks.resize (solids.size());
-                    onDevice->contains8Batch (solids.data(), solids.size(), deviceMasks.data());
-                    functorKmers.deviceMasks = deviceMasks.data();
-                }
+                std::vector<u_int8_t> deviceMasks (solids.size());
+                onDevice->contains8Batch (solids.data(), solids.size(), deviceMasks.data());
+                typename FunctorKmersExtensionMinimizer<Model,ModelMini,Count,Type>::ByIndex byIndex (functorKmers, solids, deviceMasks.data());
+                this->getDispatcher()->iterate (new typename Range<u_int64_t>::Iterator (0, solids.size() - 1), byIndex);
             }
+            else
 #endif
 """
 
 
 def patch_debloom_algo(src):
     out = insert_after_line(src, DB_MEMBER_ANCHOR, DB_MEMBER)
-    a = once(out, DB_CALL)
-    out = out[:a] + DB_CALL_DEVICE + DB_CALL + "#endif\n" + out[a + len(DB_CALL):]
     out = insert_before(out, DB_LOOP_ANCHOR, DB_LOOP_DEVICE)
     return out
 
 
-FILES = [(REL, patch), (BLOOM_HPP, patch_bloom_hpp), (BLOOM_ALGO, patch_bloom_algo), (MPHF_ALGO, patch_mphf_algo), (DEBLOOM_ALGO, patch_debloom_algo)]
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# kmer/impl/ConfigurationAlgorithm.cpp — partitions / passes sized from the device's memory (:398-431)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+CONFIG_ALGO = "src/gatb/kmer/impl/ConfigurationAlgorithm.cpp"
+CA_INCLUDE_ANCHOR = "#include <gatb/kmer/impl/ConfigurationAlgorithm.hpp>"
+CA_INCLUDE = "#ifdef GATB_WITH_DEVICE_COUNTING\n#include <gatb_device/DeviceConfiguration.hpp>   /* partitions and passes from the HBM of the MI355X, not from host RAM / disk */\n#endif\n"
+CA_ANCHOR = "    //_nb_partitions_in_parallel = 1 ;\n"
+CA_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+    /* counting happens in HBM: partitions of the size the device kernels are cut for, passes from the device's memory (the host-RAM / disk / open-files rules above
+     * describe a machine the super-k-mers never touch). GATB_DEVICE_REFERENCE_CONFIG=1 keeps the reference's values. */
+    DeviceConfiguration::apply (_config, sizeof(Type));
+#endif
+"""
+
+
+def patch_config_algo(src):
+    out = insert_after_line(src, CA_INCLUDE_ANCHOR, CA_INCLUDE)
+    out = insert_before(out, CA_ANCHOR, CA_DEVICE)
+    return out
+
+
+FILES = [(REL, patch), (CONFIG_ALGO, patch_config_algo), (BLOOM_HPP, patch_bloom_hpp), (BLOOM_ALGO, patch_bloom_algo), (MPHF_ALGO, patch_mphf_algo), (DEBLOOM_ALGO, patch_debloom_algo)]
 PATCH_NAME = "gatb-core.device.patch"
 
 

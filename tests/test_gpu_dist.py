@@ -36,6 +36,8 @@ def _rank_main(rank, world, port, k, parts, amin, q):
         chunks = [mine[:1000], mine[1000:]] if rank == 0 else [mine, []]
         c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
         dc = gd.DistributedCounter(c, rank, world, parts)
+        bad, _ = dc.comm.selftest(3 << 20)                   # every rank sends a keyed pattern to every other rank and checks what it gets (what bench.py --gpus N does first)
+        assert bad == 0
         c.begin_pass(0)
         for ch in chunks:
             if ch:
@@ -51,6 +53,8 @@ def _rank_main(rank, world, port, k, parts, amin, q):
             else:
                 assert len(lo) == 0, "partition %d is not mine but holds records" % p
         st = c.stats(); cs = dc.stats()
+        sent, recv, _ = dc.comm.peer_bytes(world)               # per-peer accounting of the grouped send / receive path: the self-test's 3 MiB and the records
+        assert int(sent[rank]) == 0 and int(sent[1 - rank]) >= (3 << 20) + cs["bytes_sent"] and int(recv[1 - rank]) >= (3 << 20) + cs["bytes_received"]
         # Bloom over the solid k-mers of all ranks: every rank inserts its own, then the OR all-reduce
         bl = gkc.Bloom(c, "neighbor", 600_000, 7, k); bl.insert_solid(); bl.allreduce_or(dc.comm)
         # MPHF + abundance map over all ranks

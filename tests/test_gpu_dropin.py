@@ -91,7 +91,11 @@ def run_dbgh5(tag, outdir, env_extra=None, out_name=None, fastq=False, pipeline=
     out = os.path.join(outdir, out_name or (tag + "_dev"))
     cmd = [EXE, "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", outdir, "-nb-cores", cores,
            "-max-memory", mem, "-verbose", "0"] + ([] if pipeline else COUNT_ONLY) + extra
-    env = dict(os.environ); env.update(env_extra or {})
+    # GATB_DEVICE_REFERENCE_CONFIG: partitions and passes as the reference derives them from -max-memory / -nb-cores (the fixtures' layout); without it the patched
+    # ConfigurationAlgorithm sizes them from the HBM of the device (test_configuration_sized_from_the_device below)
+    env = dict(os.environ); env["GATB_DEVICE_REFERENCE_CONFIG"] = "1"; env.update(env_extra or {})
+    if env.get("GATB_DEVICE_REFERENCE_CONFIG") == "0":
+        del env["GATB_DEVICE_REFERENCE_CONFIG"]
     return subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), out + ".h5"
 
 
@@ -180,7 +184,7 @@ def test_a_bank_of_two_files_goes_to_the_device_as_text(tmp_path):
     out = str(tmp_path / "two_files")
     cmd = [EXE, "-in", a + "," + b, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", str(tmp_path), "-nb-cores", cores,
            "-max-memory", mem, "-verbose", "0", "-bloom", "none", "-debloom", "none", "-branching-nodes", "none", "-no-mphf"] + extra
-    r = subprocess.run(cmd, env=dict(os.environ, GATB_DEVICE_VERBOSE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, env=dict(os.environ, GATB_DEVICE_VERBOSE="1", GATB_DEVICE_REFERENCE_CONFIG="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     check_h5(out + ".h5", tag)
 
@@ -287,3 +291,22 @@ def test_device_time_keys_in_getinfo(tmp_path):
     info = subprocess.run([DBGINFO, "-in", h5], capture_output=True, text=True).stdout
     for key in ("fillsolid_time", "device_stage_a", "device_stage_b", "device_wait", "device_hand_over"):
         assert key in info, (key, info[-2500:])
+
+
+@needs_artefacts
+@pytest.mark.parametrize("tag", ["k21_default_parts", "k31_2parts_mphf", "k63_neighbor_mphf"])
+def test_configuration_sized_from_the_device(tmp_path, tag):
+    """SURVEY 8(f)4 / VERDICT r3 Missing #2: in the patched dbgh5 ConfigurationAlgorithm sizes partitions and passes from the HBM of the device
+    (integration/gatb_device/DeviceConfiguration.hpp) instead of host RAM and disk: whatever -max-memory says, these small inputs become ONE partition in one pass
+    (the fixtures' reference runs cut them into 4 / 2 / 1) — and the solid k-mers with their counts are the same set."""
+    z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    p, h5 = run_dbgh5(tag, str(tmp_path), {"GATB_DEVICE_REFERENCE_CONFIG": "0", "GATB_DEVICE_VERBOSE": "1"})
+    log = p.communicate(timeout=600)[0]
+    assert p.returncode == 0, log[-2000:]
+    assert "[device configuration]" in log and "1 pass(es), 1 partitions" in log, log[-2000:]
+    assert h5_attr(h5, "/dsk/solid/nb_partitions") == "1"
+    rec = 12 if k <= 31 else 20
+    raw = dump_dataset(h5, "/dsk/solid/0", "FILE")
+    n = len(raw) // rec; raw = raw[:n * rec].reshape(n, rec)
+    got = list(zip([int.from_bytes(bytes(r), "little") for r in raw[:, :rec - 4]], raw[:, rec - 4:].copy().view("<u4")[:, 0].tolist()))
+    assert got == sorted(x for part in parts for x in part)                     # ascending in the one dataset, same k-mers, same counts
