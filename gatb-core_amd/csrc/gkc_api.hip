@@ -144,7 +144,9 @@ static void ctx_destroy_now(gkc_ctx* c)
     if (c->stage_b_thread.joinable()) c->stage_b_thread.join();
     (void)hipStreamSynchronize(c->stream);
     c->drain_pending();
-    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    gkc_sink_shutdown(c);                                                // the unpack threads and their page-locked staging buffer
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->fetch_stream) { (void)hipStreamSynchronize(c->fetch_stream); (void)hipStreamDestroy(c->fetch_stream); }
     for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; i++) { c->h2d_bases[i].release(); c->h2d_offs[i].release(); if (c->h2d_copied[i]) (void)hipEventDestroy(c->h2d_copied[i]); if (c->h2d_scanned[i]) (void)hipEventDestroy(c->h2d_scanned[i]); }
@@ -268,8 +270,9 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
     free_pass_outputs(c, pass);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+    gkc_sink_reset(c);
     c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;        // the host sink holds ONE pass: the previous pass's records are overwritten from here on
-    for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; }
+    for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; D.sink_batch = nullptr; }
     for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
     c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
     if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, (size_t)c->nb_passes * ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
@@ -408,7 +411,8 @@ static int finish_pass_body(gkc_ctx* c)
     {   ScopedTimer tm(c, "total_stage_b");
         rc = gkc_count_pass(c);
     }
-    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // streamed results have landed
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // streamed results have landed ...
+    gkc_sink_drain(c);                                                   // ... and the packed batches have been expanded into the sink
     if (rc == GKC_OK && c->sink_overflow) { c->set_error(GKC_ERR_CAPACITY, "the host sink (%llu bytes) is too small for the pass; the records that did not fit stay on the device (gkc_partition_counts)", (unsigned long long)c->sink_cap); }
     return rc;
 }
@@ -454,8 +458,9 @@ int gkc_set_host_sink(gkc_ctx* c, void* pinned, uint64_t cap_bytes)
     GKC_HIP(c, hipSetDevice(c->device));
     if (pinned && !c->copy_stream) GKC_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    gkc_sink_reset(c);
     c->sink = pinned; c->sink_cap = pinned ? cap_bytes : 0; c->sink_used = 0; c->sink_overflow = false;
-    return GKC_OK;
+    return gkc_sink_prepare(c);                                          // 8-byte keys: the page-locked staging buffer of the packed transfer (7/16 of the sink)
 }
 int gkc_wait_partition(gkc_ctx* c, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid)
 {
@@ -469,6 +474,7 @@ int gkc_wait_partition(gkc_ctx* c, uint32_t pass, uint32_t part, const void** ho
         ev = D->landed;
     }
     if (ev) GKC_HIP(c, hipEventSynchronize(ev));
+    if (D->sink_batch) gkc_sink_wait_batch(c, D->sink_batch);           // packed on the wire: in the sink once the host threads have expanded the batch
     if (host_records) *host_records = D->h_counts;
     if (n_solid) *n_solid = D->n_solid;
     return GKC_OK;

@@ -132,10 +132,12 @@ struct Dataset {                          // result of (pass, part)
     bool done = false;
     const void* h_counts = nullptr;       // the same records in the host sink (gkc_set_host_sink), valid once `landed` has completed
     hipEvent_t landed = nullptr;          // D2H copy of the Stage-B batch this dataset belongs to (owned by the context's landed_events list)
+    const void* sink_batch = nullptr;     // ... or the packed batch it travelled in (gkc_sink.hip): in the sink once the host threads have expanded it
 };
 
 struct Timing { double ms = 0; uint64_t launches = 0; };
 
+struct gkc_unpacker;                      // gkc_sink.hip: staging buffer + host threads that expand packed result batches into the sink
 struct gkc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -178,6 +180,7 @@ struct gkc_ctx {
     // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted
     void* sink = nullptr; uint64_t sink_cap = 0, sink_used = 0; bool sink_overflow = false;
     hipStream_t copy_stream = nullptr;
+    gkc_unpacker* unpacker = nullptr;
     hipStream_t fetch_stream = nullptr;    // gkc_partition_counts: D2H of finished datasets, beside (not inside) the Stage-B lanes
     std::vector<hipEvent_t> landed_events;
     std::condition_variable cv_done;       // a dataset finished / the pass ended (gkc_wait_partition)
@@ -245,6 +248,14 @@ int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint
 int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap, uint64_t* nb, uint64_t* nsk, uint64_t* nk);
 
 int gkc_require_resident(gkc_ctx* c, const char* who);
+// packed result batches (gkc_sink.hip)
+bool  gkc_sink_packed(gkc_ctx* c);
+int   gkc_sink_prepare(gkc_ctx* c);
+void  gkc_sink_reset(gkc_ctx* c);
+void  gkc_sink_drain(gkc_ctx* c);
+void  gkc_sink_shutdown(gkc_ctx* c);
+void  gkc_sink_wait_batch(gkc_ctx* c, const void* batch);
+void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot, const std::vector<uint64_t>& solid_prefix, uint8_t* h_dest);
 struct gkc_comm;                              // gkc_dist.hip
 int gkc_comm_world(gkc_comm* m);
 int gkc_comm_rank(gkc_comm* m);

@@ -2108,15 +2108,26 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             }
             CB_HIP(hipGetLastError());
         }
-        CB_HIP(hipStreamSynchronize(cur_stream(c)));
-        // streamed results: the batch's records go to the host sink on the copy stream while the lanes count the next batches
-        const uint8_t* h_base = nullptr; hipEvent_t landed = nullptr;
+        // streamed results: the batch's records go to the host sink on the copy stream while the lanes count the next batches — packed (7 bytes per record
+        // instead of 16, expanded in place by host threads: gkc_sink.hip) when the keys are 8 bytes
+        const uint8_t* h_base = nullptr; hipEvent_t landed = nullptr; const void* sink_batch = nullptr;
+        bool room = false;
         if (c->sink && total_solid) {
             const uint64_t bytes = total_solid * OW * 8;
             std::lock_guard<std::mutex> lk(c->mu);
             if (c->sink_used + bytes > c->sink_cap) c->sink_overflow = true;          // the records stay on the device (gkc_partition_counts still serves them)
-            else {
-                h_base = (const uint8_t*)c->sink + c->sink_used; c->sink_used += bytes;
+            else { h_base = (const uint8_t*)c->sink + c->sink_used; c->sink_used += bytes; room = true; }
+        }
+        if (room && gkc_sink_packed(c)) {
+            std::vector<uint64_t> solid_prefix(nb + 1);
+            for (uint32_t i = 0; i <= nb; i++) solid_prefix[i] = ptot[2 * i + 1];
+            sink_batch = gkc_sink_send_packed(c, out, (const uint64_t*)B.ptot.p, solid_prefix, (uint8_t*)h_base);      // (synchronizes the lane's stream)
+        }
+        CB_HIP(hipStreamSynchronize(cur_stream(c)));
+        if (room && !sink_batch) {
+            const uint64_t bytes = total_solid * OW * 8;
+            std::lock_guard<std::mutex> lk(c->mu);
+            {
                 if (hipEventCreateWithFlags(&landed, hipEventDisableTiming) == hipSuccess &&
                     hipMemcpyAsync((void*)h_base, out, bytes, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess &&
                     hipEventRecord(landed, c->copy_stream) == hipSuccess) c->landed_events.push_back(landed);
@@ -2128,7 +2139,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
                 Dataset& D = c->datasets[(size_t)c->pass * c->nb_partitions + batch_parts[i]];
                 const uint64_t s0 = ptot[2 * i + 1], s1 = ptot[2 * (i + 1) + 1];
                 D.d_counts = (const uint8_t*)out + s0 * OW * 8;
-                D.h_counts = h_base ? h_base + s0 * OW * 8 : nullptr; D.landed = landed;
+                D.h_counts = h_base ? h_base + s0 * OW * 8 : nullptr; D.landed = landed; D.sink_batch = sink_batch;
                 D.n_solid = s1 - s0; D.n_distinct = ptot[2 * (i + 1)] - ptot[2 * i]; D.n_kmers = part_keys[batch_parts[i]]; D.done = true;
                 c->stats_now().kmers_nb_distinct += D.n_distinct; c->stats_now().kmers_nb_solid += D.n_solid;
             }
@@ -2155,6 +2166,7 @@ int gkc_count_pass(gkc_ctx* c)
         // ... and the host sink starts over as well: the failed attempt's copies are drained, its records are overwritten
         if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+        gkc_sink_reset(c);
         c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;
         GKC_HIP(c, hipMemsetAsync(c->histo_of(c->pass), 0, ((size_t)c->histo_max + 1) * 8, c->stream));
     }

@@ -1,0 +1,289 @@
+// gkc_sink.hip — streamed results, PACKED on the wire (gkc_set_host_sink, k <= 31): SURVEY §8(d) ends the clock when the last partition's Count[] is in host
+// memory, and at abundance-min 1 that is 16 bytes per distinct k-mer over PCIe — 58 GB per 10^8 reads, 1.1 s at the 52 GB/s the link gives, five times the
+// counting itself. The records of a partition are ascending keys with small abundances, so what crosses the link is
+//     per block of PK_BLOCK records: the first key (8 bytes), then per record 6 bytes of key DELTA + 1 byte of abundance            = 7 bytes instead of 16
+// and library threads on the host expand it into the exact in-memory layout of Kmer<span>::Count ({u64 value; i32 abundance; pad}, Abundance.hpp:68-129) at its
+// place in the caller's sink: what gkc_wait_partition hands out is byte for byte what the unpacked copy would have been (tests: the sink against
+// gkc_partition_counts). Rare values leave through an exception list (record index, value): a delta of 2^48-1 or more (the delta field then holds the escape
+// 0xFFFFFFFFFFFF), an abundance of 255 or more (escape 255). The reference's sink this stands in for is CountProcessorDump -> BagCache -> CollectionHDF5Patch
+// (CountProcessorDump.hpp:148-152): the consumer of whole Count[] blocks.
+//   device   k_pack_counts: one workgroup per block (blocks never straddle partitions, each has its own 16-byte-aligned 57344-byte slot), records -> 7-byte
+//            entries staged through LDS and written as 16-byte words; reads the batch's Count[] once, writes 0.44x of it
+//   link     ONE copy per Stage-B batch on the copy stream: [block bases | payload] then the exception entries, into a page-locked staging buffer of the library
+//   host     a pool of unpack threads: the first to reach a batch waits for its copy (HIP event) and sorts the exceptions, then all of them take blocks off an
+//            atomic counter (a block is independent of every other: base key + running sum of its deltas) and write the records with non-temporal 16-byte stores;
+//            the last one marks the batch landed (gkc_wait_partition / gkc_finish_pass wait for that)
+#include "gkc_common.hpp"
+#include "gkc_device.hpp"
+#include <algorithm>
+#include <atomic>
+#include <deque>
+#include <immintrin.h>
+
+namespace {
+constexpr uint32_t PK_BLOCK = 8192, PK_THREADS = 256;
+constexpr uint64_t PK_SLOT = (uint64_t)PK_BLOCK * 7;                 // 57344 bytes: a multiple of 16
+constexpr uint64_t PK_ESC = 0xFFFFFFFFFFFFull;
+constexpr uint64_t PK_KEY_EXC = 1ull << 63;
+}
+
+struct PackPlan { const uint32_t* blk_first; /* [nb + 1] first block slot of every partition of the batch */ const uint64_t* ptot; /* [2 (nb + 1)] (distinct, solid) prefixes */ uint32_t nb; };
+
+__global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint8_t* __restrict__ payload,
+                                                            uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 7 + 16];
+    __shared__ uint32_t s_p;
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {                                               // partition of block slot g: the largest p with blk_first[p] <= g
+        uint32_t lo = 0, hi = P.nb;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.blk_first[mid] <= g) lo = mid; else hi = mid; }
+        s_p = lo;
+    }
+    __syncthreads();
+    const uint32_t p = s_p, j = g - P.blk_first[p];
+    const uint64_t s1 = P.ptot[2 * (p + 1) + 1], r0 = P.ptot[2 * p + 1] + (uint64_t)j * PK_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)PK_BLOCK, s1 - r0);
+    if (t == 0) bases[g] = recs[2 * r0];
+    uint8_t* dstp = payload + (uint64_t)g * PK_SLOT;
+    for (uint32_t i0 = 0; i0 < n; i0 += PK_THREADS) {
+        const uint32_t i = i0 + t;
+        uint64_t d = 0; uint32_t ab8 = 0;
+        if (i < n) {
+            const ulonglong2 me = *reinterpret_cast<const ulonglong2*>(recs + 2 * (r0 + i));
+            const uint64_t prev = i ? recs[2 * (r0 + i - 1)] : me.x;
+            d = me.x - prev;
+            if (d >= PK_ESC) {
+                const unsigned long long e = atomicAdd(n_exc, 1ull);
+                if (e < exc_cap) { exc[2 * e] = PK_KEY_EXC | (r0 + i); exc[2 * e + 1] = me.x; }
+                d = PK_ESC;
+            }
+            const uint32_t ab = (uint32_t)me.y;
+            ab8 = ab;
+            if (ab >= 255u) {
+                const unsigned long long e = atomicAdd(n_exc, 1ull);
+                if (e < exc_cap) { exc[2 * e] = r0 + i; exc[2 * e + 1] = ab; }
+                ab8 = 255u;
+            }
+        }
+        uint8_t* o = s_out + 7 * t;
+        o[0] = (uint8_t)d; o[1] = (uint8_t)(d >> 8); o[2] = (uint8_t)(d >> 16); o[3] = (uint8_t)(d >> 24); o[4] = (uint8_t)(d >> 32); o[5] = (uint8_t)(d >> 40); o[6] = (uint8_t)ab8;
+        __syncthreads();
+        if (t < PK_THREADS * 7 / 16) reinterpret_cast<uint4*>(dstp + (uint64_t)i0 * 7)[t] = reinterpret_cast<const uint4*>(s_out)[t];      // 1792 bytes = 112 x 16
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct SinkBatch {
+    hipEvent_t copied = nullptr;                 // the batch's packed bytes are in the staging buffer
+    const uint8_t* stage = nullptr;              // [bases: 8 x nblk, padded to 64][payload: nblk x PK_SLOT][exceptions: 16 x n_exc]
+    uint64_t nblk = 0, n_exc = 0, pay_off = 0, exc_off = 0;
+    std::vector<uint64_t> blk_rec0; std::vector<uint32_t> blk_n;       // per block: first record (index in the batch), records
+    uint8_t* dest = nullptr;                     // the batch's records in the caller's sink
+    void* d_packed = nullptr;                    // device buffer, given back once copied
+    std::vector<std::pair<uint64_t, uint64_t>> exc;                    // sorted by (kind | record index)
+    bool ready = false, syncing = false;         // copy completed + exceptions sorted (under the pool's lock)
+    std::atomic<uint64_t> next{0}, finished{0};
+    std::atomic<bool> done{false};
+};
+
+struct gkc_unpacker {
+    gkc_ctx* c = nullptr;
+    std::vector<std::thread> threads;
+    std::mutex mu; std::condition_variable cv, cv_done;
+    std::deque<SinkBatch*> queue;                // batches whose blocks are not all taken yet, oldest first
+    std::vector<SinkBatch*> all;                 // every batch of the pass (owned)
+    bool stop = false;
+    uint8_t* staging = nullptr; uint64_t staging_cap = 0, staging_used = 0;
+
+    static uint64_t lookup(const std::vector<std::pair<uint64_t, uint64_t>>& exc, uint64_t tag)
+    {
+        auto it = std::lower_bound(exc.begin(), exc.end(), std::make_pair(tag, (uint64_t)0));
+        return it != exc.end() && it->first == tag ? it->second : 0;
+    }
+    static void unpack_block(const SinkBatch& B, uint64_t g)
+    {
+        const uint8_t* pay = B.stage + B.pay_off + g * PK_SLOT;
+        const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
+        uint64_t key = reinterpret_cast<const uint64_t*>(B.stage)[g];
+        __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 16);
+        for (uint32_t i = 0; i < n; i++) {
+            uint64_t w; memcpy(&w, pay + 7 * (size_t)i, 8);      // (one byte beyond the entry: the staging buffer is padded)
+            const uint64_t d = w & PK_ESC; uint32_t ab = (uint32_t)(w >> 48) & 255u;
+            if (i) key = d == PK_ESC ? lookup(B.exc, PK_KEY_EXC | (r0 + i)) : key + d;
+            if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
+            _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));      // {u64 value; i32 abundance; 4 bytes of padding = 0}
+        }
+    }
+    void worker()
+    {
+        (void)hipSetDevice(c->device);
+        for (;;) {
+            SinkBatch* B = nullptr;
+            {   std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    if (stop) return;
+                    if (!queue.empty()) {
+                        B = queue.front();
+                        if (B->ready) break;
+                        if (!B->syncing) { B->syncing = true; break; }       // this thread waits for the copy
+                    }
+                    cv.wait(lk);
+                }
+            }
+            if (!B->ready) {
+                (void)hipEventSynchronize(B->copied);
+                if (B->n_exc) {
+                    const uint64_t* e = reinterpret_cast<const uint64_t*>(B->stage + B->exc_off);
+                    B->exc.resize(B->n_exc);
+                    for (uint64_t i = 0; i < B->n_exc; i++) B->exc[i] = { e[2 * i], e[2 * i + 1] };
+                    std::sort(B->exc.begin(), B->exc.end());
+                }
+                if (B->d_packed) { c->dfree(B->d_packed); B->d_packed = nullptr; }
+                { std::lock_guard<std::mutex> lk(mu); B->ready = true; }
+                cv.notify_all();
+            }
+            for (;;) {
+                const uint64_t g = B->next.fetch_add(1);
+                if (g >= B->nblk) break;
+                unpack_block(*B, g);
+                if (B->finished.fetch_add(1) + 1 == B->nblk) {
+                    _mm_sfence();
+                    { std::lock_guard<std::mutex> lk(mu); B->done.store(true); }
+                    cv_done.notify_all(); c->cv_done.notify_all();
+                }
+            }
+            {   std::lock_guard<std::mutex> lk(mu);                              // every block of B has been taken: the next batch becomes the front
+                if (!queue.empty() && queue.front() == B && B->next.load() >= B->nblk) queue.pop_front();
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+static gkc_unpacker* unpacker_of(gkc_ctx* c)
+{
+    if (c->unpacker) return c->unpacker;
+    gkc_unpacker* U = new gkc_unpacker(); U->c = c;
+    int n = getenv("GKC_UNPACK_THREADS") ? atoi(getenv("GKC_UNPACK_THREADS")) : (int)std::min<unsigned>(64u, std::max(4u, std::thread::hardware_concurrency() / 4));
+    if (n < 1) n = 1;
+    for (int i = 0; i < n; i++) U->threads.emplace_back([U] { U->worker(); });
+    c->unpacker = U;
+    return U;
+}
+
+// whether the sink of this context takes packed batches (8-byte keys; GKC_SINK_PACKED=0 keeps the plain copies)
+bool gkc_sink_packed(gkc_ctx* c)
+{
+    static const bool off = getenv("GKC_SINK_PACKED") && atoi(getenv("GKC_SINK_PACKED")) == 0;
+    return c->sink && c->key_words == 1 && !off && ((uintptr_t)c->sink & 15) == 0;
+}
+
+// the staging buffer holds the packed stream of ONE pass (like the sink holds one pass of records): 7/16 of the sink + the block slack of every partition
+int gkc_sink_prepare(gkc_ctx* c)
+{
+    if (!gkc_sink_packed(c)) return GKC_OK;
+    gkc_unpacker* U = unpacker_of(c);
+    const uint64_t want = c->sink_cap / 16 * 7 + (uint64_t)c->nb_partitions * (PK_SLOT + 8) + ((uint64_t)64 << 20);
+    if (U->staging_cap < want) {
+        if (U->staging) (void)hipHostFree(U->staging);
+        U->staging = nullptr; U->staging_cap = 0;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return GKC_OK; }      // no staging buffer: the batches travel unpacked
+        U->staging = (uint8_t*)p; U->staging_cap = want;
+    }
+    return GKC_OK;
+}
+
+// start of a pass / a pass counted again: nothing of the previous one is in flight any more
+void gkc_sink_reset(gkc_ctx* c)
+{
+    gkc_unpacker* U = c->unpacker;
+    if (!U) return;
+    {   std::unique_lock<std::mutex> lk(U->mu);
+        U->cv_done.wait(lk, [&] { for (SinkBatch* B : U->all) if (!B->done.load()) return false; return true; });
+        U->queue.clear();
+    }
+    for (SinkBatch* B : U->all) { if (B->copied) (void)hipEventDestroy(B->copied); if (B->d_packed) c->dfree(B->d_packed); delete B; }
+    U->all.clear(); U->staging_used = 0;
+}
+void gkc_sink_drain(gkc_ctx* c)
+{
+    gkc_unpacker* U = c->unpacker;
+    if (!U) return;
+    std::unique_lock<std::mutex> lk(U->mu);
+    U->cv_done.wait(lk, [&] { for (SinkBatch* B : U->all) if (!B->done.load()) return false; return true; });
+}
+void gkc_sink_shutdown(gkc_ctx* c)
+{
+    gkc_unpacker* U = c->unpacker;
+    if (!U) return;
+    gkc_sink_reset(c);
+    { std::lock_guard<std::mutex> lk(U->mu); U->stop = true; }
+    U->cv.notify_all();
+    for (std::thread& t : U->threads) t.join();
+    if (U->staging) (void)hipHostFree(U->staging);
+    delete U; c->unpacker = nullptr;
+}
+void gkc_sink_wait_batch(gkc_ctx* c, const void* batch)
+{
+    gkc_unpacker* U = c->unpacker;
+    if (!U || !batch) return;
+    const SinkBatch* B = static_cast<const SinkBatch*>(batch);
+    std::unique_lock<std::mutex> lk(U->mu);
+    U->cv_done.wait(lk, [&] { return B->done.load(); });
+}
+
+// One Stage-B batch: d_out = its Count[] (total records, partition i = [solid_prefix[i], solid_prefix[i+1])), d_ptot = the (distinct, solid) prefixes on the device,
+// h_dest = where the records belong in the sink. Runs on the calling lane's stream up to the point where the copy can be queued; returns the batch handle
+// (nullptr: not packed — no staging room, too many exceptions — the caller sends the plain records).
+void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot, const std::vector<uint64_t>& solid_prefix, uint8_t* h_dest)
+{
+    gkc_unpacker* U = c->unpacker;
+    if (!U || !U->staging) return nullptr;
+    const uint32_t nb = (uint32_t)solid_prefix.size() - 1;
+    std::vector<uint32_t> blk_first(nb + 1);
+    uint64_t nblk = 0;
+    for (uint32_t i = 0; i < nb; i++) { blk_first[i] = (uint32_t)nblk; nblk += (solid_prefix[i + 1] - solid_prefix[i] + PK_BLOCK - 1) / PK_BLOCK; }
+    blk_first[nb] = (uint32_t)nblk;
+    if (nblk == 0 || nblk >= (1ull << 31)) return nullptr;
+    const uint64_t bases_bytes = (nblk * 8 + 63) / 64 * 64, pay_bytes = nblk * PK_SLOT;
+    const uint32_t exc_cap = 1u << 20;
+    DevBuf d_first; if (c->ensure(d_first, (size_t)(nb + 1) * 4) != GKC_OK) return nullptr;
+    uint8_t* d_packed = (uint8_t*)c->dalloc((size_t)(bases_bytes + pay_bytes + (uint64_t)exc_cap * 16 + 64));
+    if (!d_packed) { d_first.release(); return nullptr; }
+    hipStream_t st = cur_stream(c);
+    unsigned long long* d_nexc = reinterpret_cast<unsigned long long*>(d_packed + bases_bytes + pay_bytes + (uint64_t)exc_cap * 16);
+    unsigned long long h_nexc = 0;
+    bool ok = hipMemcpyAsync(d_first.p, blk_first.data(), (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess
+           && hipMemsetAsync(d_nexc, 0, 8, st) == hipSuccess;
+    if (ok) {
+        PackPlan P{ (const uint32_t*)d_first.p, d_ptot, nb };
+        hipLaunchKernelGGL(k_pack_counts, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_packed + bases_bytes,
+                           (uint64_t*)(d_packed + bases_bytes + pay_bytes), d_nexc, exc_cap);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h_nexc, d_nexc, 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    }
+    d_first.release();
+    if (!ok || h_nexc > exc_cap) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
+    SinkBatch* B = new SinkBatch();
+    const uint64_t need = bases_bytes + pay_bytes + h_nexc * 16 + 64;
+    {   std::lock_guard<std::mutex> lk(c->mu);
+        if (U->staging_used + need > U->staging_cap) { delete B; c->dfree(d_packed); return nullptr; }
+        B->stage = U->staging + U->staging_used; U->staging_used += (need + 63) / 64 * 64;
+    }
+    B->nblk = nblk; B->n_exc = h_nexc; B->pay_off = bases_bytes; B->exc_off = bases_bytes + pay_bytes; B->dest = h_dest; B->d_packed = d_packed;
+    B->blk_rec0.resize(nblk); B->blk_n.resize(nblk);
+    for (uint32_t i = 0; i < nb; i++) {
+        const uint64_t s0 = solid_prefix[i], s1 = solid_prefix[i + 1];
+        for (uint64_t r = s0, g = blk_first[i]; r < s1; r += PK_BLOCK, g++) { B->blk_rec0[g] = r; B->blk_n[g] = (uint32_t)std::min<uint64_t>(PK_BLOCK, s1 - r); }
+    }
+    bool queued = hipEventCreateWithFlags(&B->copied, hipEventDisableTiming) == hipSuccess
+               && hipMemcpyAsync((void*)B->stage, d_packed, (size_t)(bases_bytes + pay_bytes), hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess
+               && (h_nexc == 0 || hipMemcpyAsync((void*)(B->stage + B->exc_off), d_packed + B->exc_off, (size_t)h_nexc * 16, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
+               && hipEventRecord(B->copied, c->copy_stream) == hipSuccess;
+    if (!queued) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); if (B->copied) (void)hipEventDestroy(B->copied); delete B; c->dfree(d_packed); return nullptr; }
+    { std::lock_guard<std::mutex> lk(U->mu); U->all.push_back(B); U->queue.push_back(B); }
+    U->cv.notify_all();
+    return B;
+}

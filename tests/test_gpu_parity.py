@@ -375,6 +375,47 @@ def test_size_independent_properties(gkc, k, n, parts):
     c.device_free(db); c.device_free(do)
 
 
+def test_share_of_8_path_at_full_size(gkc):
+    """BASELINE configs[2]'s per-GPU share exactly as bench.py's `share_of_8` block runs it (that path had no correctness check anywhere): k=31,
+    1.25e8 reads in FOUR pushes, 32768 partitions (two-level Stage A: 4096 groups of 8), every push followed by gkc_exchange through a one-rank RCCL communicator
+    (planning, narrowing of the own segments, import path). Size-independent properties: the multiset checksum of the records == the independent kernel's over the
+    four chunks, sum of abundances == valid k-mers, sampled partitions strictly ascending and holding only k-mers whose minimizer maps to them."""
+    from gatb_core_amd import dist as gd
+    k, m, L, n, parts, pushes = 31, 10, 150, 125_000_000, 32768, 4
+    c = gkc.Counter(0)
+    rep = simple_repart(m, parts)
+    c.configure(k, m, parts, rep)
+    per = n // pushes
+    chunks = []
+    cs, nv = 0, 0
+    for i in range(pushes):
+        db, do = c.synth_reads_device(2, per, L, n * L // 30, 10000, first_read=i * per)
+        s_, n_ = c.kmer_checksum_device(db, do, per, per * L)
+        cs = (cs + int(s_)) & ((1 << 64) - 1); nv += int(n_)
+        chunks.append((db, do))
+    dc = gd.DistributedCounter(c, 0, 1, parts)
+    c.begin_pass(0)
+    for db, do in chunks:
+        c.push_reads_device(db, do, per, per * L); dc.exchange()
+    c.finish_pass()
+    got = c.result_checksum()
+    assert (int(got[0]), int(got[1])) == (cs, nv)
+    st = c.stats()
+    assert st["kmers_nb_valid"] == nv == n * (L - k + 1)
+    for p in range(0, parts, parts // 16 + 1):
+        lo, hi, ab = c.partition(0, p)
+        assert (lo[1:] > lo[:-1]).all() and (ab >= 1).all()
+        for a in lo[::max(1, len(lo) // 8)].tolist():
+            s = "".join("ACTG"[(a >> (2 * (k - 1 - i))) & 3] for i in range(k))
+            mins, _ = gko.minimizers(s, k, m)
+            assert rep[mins[0]] == p
+    h = c.histogram()
+    assert int(h.sum()) == st["kmers_nb_distinct"] and int((h * np.arange(len(h), dtype=np.uint64)).sum()) == nv
+    dc.comm.close()
+    for db, do in chunks:
+        c.device_free(db); c.device_free(do)
+
+
 def test_multi_pass_with_two_lanes_and_solidity(gkc):
     """three passes over 6e6 reads (2.4e8 keys per pass: the two-lane Stage B with its probe batch, results of earlier passes
     resident), abundance window [2, 50]: the records of all passes together == the multiset of valid k-mers with that abundance
@@ -609,6 +650,45 @@ def test_streamed_results_land_in_the_host_sink(gkc):
     c.set_host_sink(tiny)
     c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
     assert b"sink" in (c.L.gkc_last_error(c.h) or b"")
+    for p in range(parts):
+        assert np.array_equal(c.partition_records(0, p), ref.part_records(p))
+    c.set_host_sink(None)
+
+
+@pytest.mark.parametrize("k,amin", [(31, 1), (21, 2), (15, 1)])
+def test_packed_sink_escapes_and_block_boundaries(gkc, k, amin):
+    """The batches of an 8-byte-key count cross PCIe PACKED (csrc/gkc_sink.hip: per block of 8192 records a base key, then 6-byte key deltas + 1-byte abundances) and
+    host threads expand them in the sink: what gkc_wait_partition hands out must be byte for byte gkc_partition_counts. Input chosen so that every special case
+    occurs: one read copied 700 times (abundances >= 255: the 1-byte field escapes to the exception list), few k-mers per partition (gaps >= 2^48 between
+    consecutive keys at k=31: the delta field escapes), partitions of more than one block (k=15: many records in few partitions) and empty partitions."""
+    rng = np.random.default_rng(5)
+    reads = synth_reads(20000 if k == 15 else 3000, 400000 if k == 15 else 20000, 150, seed=62, n_rate=0.001)
+    reads += [reads[0]] * 700 + [b"A" * 150] * 300 + [b"ACGT" * 40] * 260
+    bases, offs = gko.pack_reads(reads)
+    m, parts = min(k - 1, 8), (3 if k == 15 else 40)
+    rep = simple_repart(m, parts)
+    if k == 21:
+        rep[rep == 5] = 6                                    # an empty partition
+    c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
+    sink = gkc.HostBuffer(256 << 20)
+    c.set_host_sink(sink)
+    for rnd in range(2):                                     # the second pass reuses the staging buffer and the unpack threads
+        c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
+        big_ab = big_gap = multi_block = 0
+        for p in range(parts):
+            view, n = c.wait_partition(0, p)
+            dev = c.partition_records(0, p)
+            assert n * 16 == len(dev)
+            if n:
+                assert view is not None and np.array_equal(view, dev), (k, p, n)
+                r = dev.view(np.uint64).reshape(-1, 2)
+                big_ab += int((r[:, 1] >= 255).sum()); big_gap += int((np.diff(r[:, 0]) >= np.uint64((1 << 48) - 1)).sum()); multi_block += int(n > 8192)
+        assert big_ab > 0
+        if k == 31:
+            assert big_gap > 0
+        if k == 15:
+            assert multi_block > 0
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, abundance_min=amin)
     for p in range(parts):
         assert np.array_equal(c.partition_records(0, p), ref.part_records(p))
     c.set_host_sink(None)

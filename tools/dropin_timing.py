@@ -67,7 +67,7 @@ def main():
             cmd = [exe, "-in", fa, "-kmer-size", "31", "-abundance-min", amin, "-nb-cores", str(cores), "-max-memory", maxmem, "-out", out, "-verbose", "0"] + flags
             t0 = time.time(); r = subprocess.run(cmd, cwd=work, env=e, capture_output=True, text=True); wall = time.time() - t0
             if os.environ.get("GATB_DEVICE_VERBOSE"):
-                print("#   " + "\n#   ".join(l for l in (r.stdout + r.stderr).splitlines() if l.startswith("[device") or "[gkc]" in l)[:4000])
+                print("#   " + "\n#   ".join(l for l in (r.stdout + r.stderr).splitlines() if l.startswith("[device") or "[gkc" in l)[:4000])
             if r.returncode != 0:
                 print("# %s FAILED rc %d: %s" % (name, r.returncode, (r.stdout + r.stderr)[-400:])); return None
             v = info(out + ".h5"); v["_wall"] = "%.2f" % wall
