@@ -19,20 +19,29 @@
 #include <atomic>
 #include <deque>
 #include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace {
 constexpr uint32_t PK_BLOCK = 8192, PK_THREADS = 256;
-constexpr uint64_t PK_SLOT = (uint64_t)PK_BLOCK * 7;                 // 57344 bytes: a multiple of 16
-constexpr uint64_t PK_ESC = 0xFFFFFFFFFFFFull;
+// entry = [key delta : W - 1 bytes][abundance : 1 byte], W = 7 where the partitions are dense (10^8 reads at abundance-min 1: 8.9e5 records per partition, 0.03 % of the
+// deltas do not fit 48 bits), W = 8 where they are sparse (abundance-min 2: 1.4e5 per partition, 1 % would escape — and every escape is a sorted-list lookup on the host)
+constexpr uint64_t pk_slot(int W) { return (uint64_t)PK_BLOCK * (uint64_t)W; }      // 57344 / 65536 bytes: multiples of 16
+constexpr uint64_t pk_esc(int W) { return (1ull << (8 * (W - 1))) - 1ull; }
 constexpr uint64_t PK_KEY_EXC = 1ull << 63;
+constexpr uint64_t PK_DENSE = 300000;                                   // records per partition from which 6-byte deltas are used
 }
 
 struct PackPlan { const uint32_t* blk_first; /* [nb + 1] first block slot of every partition of the batch */ const uint64_t* ptot; /* [2 (nb + 1)] (distinct, solid) prefixes */ uint32_t nb; };
 
+template <int W>
 __global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint8_t* __restrict__ payload,
                                                             uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 7 + 16];
+    constexpr uint64_t PK_ESC = pk_esc(W), PK_SLOT = pk_slot(W);
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * W + 16];
     __shared__ uint32_t s_p;
     const uint32_t g = blockIdx.x, t = threadIdx.x;
     if (t == 0) {                                               // partition of block slot g: the largest p with blk_first[p] <= g
@@ -66,10 +75,12 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __re
                 ab8 = 255u;
             }
         }
-        uint8_t* o = s_out + 7 * t;
-        o[0] = (uint8_t)d; o[1] = (uint8_t)(d >> 8); o[2] = (uint8_t)(d >> 16); o[3] = (uint8_t)(d >> 24); o[4] = (uint8_t)(d >> 32); o[5] = (uint8_t)(d >> 40); o[6] = (uint8_t)ab8;
+        uint8_t* o = s_out + W * t;
+#pragma unroll
+        for (int b = 0; b < W - 1; b++) o[b] = (uint8_t)(d >> (8 * b));
+        o[W - 1] = (uint8_t)ab8;
         __syncthreads();
-        if (t < PK_THREADS * 7 / 16) reinterpret_cast<uint4*>(dstp + (uint64_t)i0 * 7)[t] = reinterpret_cast<const uint4*>(s_out)[t];      // 1792 bytes = 112 x 16
+        if (t < PK_THREADS * W / 16) reinterpret_cast<uint4*>(dstp + (uint64_t)i0 * W)[t] = reinterpret_cast<const uint4*>(s_out)[t];      // 1792 / 2048 bytes = 112 / 128 x 16
         __syncthreads();
     }
 }
@@ -77,8 +88,9 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __re
 // ------------------------------------------------------------------------------------------------ host side
 struct SinkBatch {
     hipEvent_t copied = nullptr;                 // the batch's packed bytes are in the staging buffer
+    hipEvent_t copy_start = nullptr;             // GKC_SINK_DEBUG: when the copy stream got to it
     const uint8_t* stage = nullptr;              // [bases: 8 x nblk, padded to 64][payload: nblk x PK_SLOT][exceptions: 16 x n_exc]
-    uint64_t nblk = 0, n_exc = 0, pay_off = 0, exc_off = 0;
+    uint64_t nblk = 0, n_exc = 0, pay_off = 0, exc_off = 0; int width = 7;
     std::vector<uint64_t> blk_rec0; std::vector<uint32_t> blk_n;       // per block: first record (index in the batch), records
     uint8_t* dest = nullptr;                     // the batch's records in the caller's sink
     void* d_packed = nullptr;                    // device buffer, given back once copied
@@ -86,7 +98,10 @@ struct SinkBatch {
     bool ready = false, syncing = false;         // copy completed + exceptions sorted (under the pool's lock)
     std::atomic<uint64_t> next{0}, finished{0};
     std::atomic<bool> done{false};
+    std::chrono::steady_clock::time_point t_queued, t_ready;           // GKC_SINK_DEBUG
+    double pack_ms = 0;
 };
+static const bool g_sink_debug = getenv("GKC_SINK_DEBUG") != nullptr;
 
 struct gkc_unpacker {
     gkc_ctx* c = nullptr;
@@ -102,20 +117,22 @@ struct gkc_unpacker {
         auto it = std::lower_bound(exc.begin(), exc.end(), std::make_pair(tag, (uint64_t)0));
         return it != exc.end() && it->first == tag ? it->second : 0;
     }
-    static void unpack_block(const SinkBatch& B, uint64_t g)
+    template <int W> static void unpack_block_w(const SinkBatch& B, uint64_t g)
     {
-        const uint8_t* pay = B.stage + B.pay_off + g * PK_SLOT;
+        constexpr uint64_t PK_ESC = pk_esc(W);
+        const uint8_t* pay = B.stage + B.pay_off + g * pk_slot(W);
         const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
         uint64_t key = reinterpret_cast<const uint64_t*>(B.stage)[g];
         __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 16);
         for (uint32_t i = 0; i < n; i++) {
-            uint64_t w; memcpy(&w, pay + 7 * (size_t)i, 8);      // (one byte beyond the entry: the staging buffer is padded)
-            const uint64_t d = w & PK_ESC; uint32_t ab = (uint32_t)(w >> 48) & 255u;
+            uint64_t w; memcpy(&w, pay + W * (size_t)i, 8);      // (W = 7: one byte beyond the entry; the staging buffer is padded)
+            const uint64_t d = w & PK_ESC; uint32_t ab = (uint32_t)(w >> (8 * (W - 1))) & 255u;
             if (i) key = d == PK_ESC ? lookup(B.exc, PK_KEY_EXC | (r0 + i)) : key + d;
             if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
             _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));      // {u64 value; i32 abundance; 4 bytes of padding = 0}
         }
     }
+    static void unpack_block(const SinkBatch& B, uint64_t g) { if (B.width == 7) unpack_block_w<7>(B, g); else unpack_block_w<8>(B, g); }
     void worker()
     {
         (void)hipSetDevice(c->device);
@@ -141,6 +158,7 @@ struct gkc_unpacker {
                     std::sort(B->exc.begin(), B->exc.end());
                 }
                 if (B->d_packed) { c->dfree(B->d_packed); B->d_packed = nullptr; }
+                B->t_ready = std::chrono::steady_clock::now();
                 { std::lock_guard<std::mutex> lk(mu); B->ready = true; }
                 cv.notify_all();
             }
@@ -150,6 +168,13 @@ struct gkc_unpacker {
                 unpack_block(*B, g);
                 if (B->finished.fetch_add(1) + 1 == B->nblk) {
                     _mm_sfence();
+                    if (g_sink_debug) {
+                        const auto now = std::chrono::steady_clock::now();
+                        float copy_ms = -1; if (B->copy_start) (void)hipEventElapsedTime(&copy_ms, B->copy_start, B->copied);
+                        fprintf(stderr, "[gkc sink] batch of %llu blocks (%.2f GB packed, %llu exceptions): pack %.1f ms, queued -> copied %.1f ms (the copy itself %.1f ms), unpack %.1f ms\n", (unsigned long long)B->nblk,
+                                (double)(B->nblk * pk_slot(B->width)) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
+                                std::chrono::duration<double, std::milli>(now - B->t_ready).count());
+                    }
                     { std::lock_guard<std::mutex> lk(mu); B->done.store(true); }
                     cv_done.notify_all(); c->cv_done.notify_all();
                 }
@@ -162,11 +187,39 @@ struct gkc_unpacker {
     }
 };
 
+// The unpack threads run on the cores of the NUMA node that holds the buffers they stream through (the page-locked staging buffer and the caller's sink are allocated
+// by the thread that set the sink up, on its node): measured on the 2-socket host of the MI355X box, the same 16-24 threads expand a batch in 20 ms or in 50-80 ms
+// depending on where the scheduler happened to put them. get_mempolicy(MPOL_F_NODE | MPOL_F_ADDR) names the node of a page; /sys lists its cores.
+static int numa_node_of(const void* p)
+{
+    int node = -1;
+    if (syscall(SYS_get_mempolicy, &node, nullptr, 0ul, const_cast<void*>(p), 3ul /* MPOL_F_NODE | MPOL_F_ADDR */) != 0) return -1;
+    return node;
+}
+static bool cpus_of_node(int node, cpu_set_t* set)
+{
+    char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r"); if (!f) return false;
+    char buf[4096]; const bool got = fgets(buf, sizeof buf, f) != nullptr; fclose(f);
+    if (!got) return false;
+    CPU_ZERO(set); int n = 0;
+    for (char* q = buf; *q; ) {
+        char* e; const long a = strtol(q, &e, 10); if (e == q) break;
+        long b = a; if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+        for (long i = a; i <= b && i < CPU_SETSIZE; i++) { CPU_SET((int)i, set); n++; }
+        q = *e == ',' ? e + 1 : e; if (*e != ',') break;
+    }
+    return n > 0;
+}
+static void pin_unpackers(gkc_unpacker* U);
+
 static gkc_unpacker* unpacker_of(gkc_ctx* c)
 {
     if (c->unpacker) return c->unpacker;
     gkc_unpacker* U = new gkc_unpacker(); U->c = c;
-    int n = getenv("GKC_UNPACK_THREADS") ? atoi(getenv("GKC_UNPACK_THREADS")) : (int)std::min<unsigned>(64u, std::max(4u, std::thread::hardware_concurrency() / 4));
+    // measured on the 2 x 64-core host of the MI355X box (tools/hostmem_probe/unpack_probe): 16 threads expand 14e9 records/s (100 GB/s read + 230 GB/s of non-temporal
+    // writes) with or without a device -> host copy running beside them; 64 threads fall to 6e9/s beside the copy stream, 128 to 4e9/s even alone
+    int n = getenv("GKC_UNPACK_THREADS") ? atoi(getenv("GKC_UNPACK_THREADS")) : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
     if (n < 1) n = 1;
     for (int i = 0; i < n; i++) U->threads.emplace_back([U] { U->worker(); });
     c->unpacker = U;
@@ -185,7 +238,7 @@ int gkc_sink_prepare(gkc_ctx* c)
 {
     if (!gkc_sink_packed(c)) return GKC_OK;
     gkc_unpacker* U = unpacker_of(c);
-    const uint64_t want = c->sink_cap / 16 * 7 + (uint64_t)c->nb_partitions * (PK_SLOT + 8) + ((uint64_t)64 << 20);
+    const uint64_t want = c->sink_cap / 16 * 8 + (uint64_t)c->nb_partitions * (pk_slot(8) + 8) + ((uint64_t)64 << 20);
     if (U->staging_cap < want) {
         if (U->staging) (void)hipHostFree(U->staging);
         U->staging = nullptr; U->staging_cap = 0;
@@ -193,7 +246,18 @@ int gkc_sink_prepare(gkc_ctx* c)
         if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return GKC_OK; }      // no staging buffer: the batches travel unpacked
         U->staging = (uint8_t*)p; U->staging_cap = want;
     }
+    pin_unpackers(U);
     return GKC_OK;
+}
+
+static void pin_unpackers(gkc_unpacker* U)
+{
+    if (getenv("GKC_UNPACK_NO_PIN") || !U->staging) return;
+    const int node = numa_node_of(U->c->sink ? U->c->sink : (const void*)U->staging);
+    cpu_set_t set;
+    if (node < 0 || !cpus_of_node(node, &set)) return;
+    for (std::thread& t : U->threads) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
+    if (g_sink_debug) fprintf(stderr, "[gkc sink] %zu unpack threads on the cores of NUMA node %d (where the sink lives)\n", U->threads.size(), node);
 }
 
 // start of a pass / a pass counted again: nothing of the previous one is in flight any more
@@ -205,7 +269,7 @@ void gkc_sink_reset(gkc_ctx* c)
         U->cv_done.wait(lk, [&] { for (SinkBatch* B : U->all) if (!B->done.load()) return false; return true; });
         U->queue.clear();
     }
-    for (SinkBatch* B : U->all) { if (B->copied) (void)hipEventDestroy(B->copied); if (B->d_packed) c->dfree(B->d_packed); delete B; }
+    for (SinkBatch* B : U->all) { if (B->copied) (void)hipEventDestroy(B->copied); if (B->copy_start) (void)hipEventDestroy(B->copy_start); if (B->d_packed) c->dfree(B->d_packed); delete B; }
     U->all.clear(); U->staging_used = 0;
 }
 void gkc_sink_drain(gkc_ctx* c)
@@ -248,20 +312,24 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     for (uint32_t i = 0; i < nb; i++) { blk_first[i] = (uint32_t)nblk; nblk += (solid_prefix[i + 1] - solid_prefix[i] + PK_BLOCK - 1) / PK_BLOCK; }
     blk_first[nb] = (uint32_t)nblk;
     if (nblk == 0 || nblk >= (1ull << 31)) return nullptr;
-    const uint64_t bases_bytes = (nblk * 8 + 63) / 64 * 64, pay_bytes = nblk * PK_SLOT;
+    const int width = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= PK_DENSE ? 7 : 8;
+    const uint64_t bases_bytes = (nblk * 8 + 63) / 64 * 64, pay_bytes = nblk * pk_slot(width);
     const uint32_t exc_cap = 1u << 20;
     DevBuf d_first; if (c->ensure(d_first, (size_t)(nb + 1) * 4) != GKC_OK) return nullptr;
     uint8_t* d_packed = (uint8_t*)c->dalloc((size_t)(bases_bytes + pay_bytes + (uint64_t)exc_cap * 16 + 64));
     if (!d_packed) { d_first.release(); return nullptr; }
     hipStream_t st = cur_stream(c);
+    const auto t_pack0 = std::chrono::steady_clock::now();
     unsigned long long* d_nexc = reinterpret_cast<unsigned long long*>(d_packed + bases_bytes + pay_bytes + (uint64_t)exc_cap * 16);
     unsigned long long h_nexc = 0;
     bool ok = hipMemcpyAsync(d_first.p, blk_first.data(), (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess
            && hipMemsetAsync(d_nexc, 0, 8, st) == hipSuccess;
     if (ok) {
         PackPlan P{ (const uint32_t*)d_first.p, d_ptot, nb };
-        hipLaunchKernelGGL(k_pack_counts, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_packed + bases_bytes,
-                           (uint64_t*)(d_packed + bases_bytes + pay_bytes), d_nexc, exc_cap);
+        if (width == 7) hipLaunchKernelGGL((k_pack_counts<7>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_packed + bases_bytes,
+                                           (uint64_t*)(d_packed + bases_bytes + pay_bytes), d_nexc, exc_cap);
+        else hipLaunchKernelGGL((k_pack_counts<8>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_packed + bases_bytes,
+                                (uint64_t*)(d_packed + bases_bytes + pay_bytes), d_nexc, exc_cap);
         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h_nexc, d_nexc, 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     }
     d_first.release();
@@ -272,17 +340,19 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
         if (U->staging_used + need > U->staging_cap) { delete B; c->dfree(d_packed); return nullptr; }
         B->stage = U->staging + U->staging_used; U->staging_used += (need + 63) / 64 * 64;
     }
-    B->nblk = nblk; B->n_exc = h_nexc; B->pay_off = bases_bytes; B->exc_off = bases_bytes + pay_bytes; B->dest = h_dest; B->d_packed = d_packed;
+    B->nblk = nblk; B->n_exc = h_nexc; B->width = width; B->pay_off = bases_bytes; B->exc_off = bases_bytes + pay_bytes; B->dest = h_dest; B->d_packed = d_packed;
     B->blk_rec0.resize(nblk); B->blk_n.resize(nblk);
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t s0 = solid_prefix[i], s1 = solid_prefix[i + 1];
         for (uint64_t r = s0, g = blk_first[i]; r < s1; r += PK_BLOCK, g++) { B->blk_rec0[g] = r; B->blk_n[g] = (uint32_t)std::min<uint64_t>(PK_BLOCK, s1 - r); }
     }
-    bool queued = hipEventCreateWithFlags(&B->copied, hipEventDisableTiming) == hipSuccess
+    if (g_sink_debug && hipEventCreate(&B->copy_start) == hipSuccess) (void)hipEventRecord(B->copy_start, c->copy_stream);
+    bool queued = hipEventCreateWithFlags(&B->copied, g_sink_debug ? hipEventDefault : hipEventDisableTiming) == hipSuccess
                && hipMemcpyAsync((void*)B->stage, d_packed, (size_t)(bases_bytes + pay_bytes), hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess
                && (h_nexc == 0 || hipMemcpyAsync((void*)(B->stage + B->exc_off), d_packed + B->exc_off, (size_t)h_nexc * 16, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
                && hipEventRecord(B->copied, c->copy_stream) == hipSuccess;
     if (!queued) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); if (B->copied) (void)hipEventDestroy(B->copied); delete B; c->dfree(d_packed); return nullptr; }
+    B->t_queued = std::chrono::steady_clock::now(); B->pack_ms = std::chrono::duration<double, std::milli>(B->t_queued - t_pack0).count();
     { std::lock_guard<std::mutex> lk(U->mu); U->all.push_back(B); U->queue.push_back(B); }
     U->cv.notify_all();
     return B;

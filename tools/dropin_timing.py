@@ -67,7 +67,7 @@ def main():
             cmd = [exe, "-in", fa, "-kmer-size", "31", "-abundance-min", amin, "-nb-cores", str(cores), "-max-memory", maxmem, "-out", out, "-verbose", "0"] + flags
             t0 = time.time(); r = subprocess.run(cmd, cwd=work, env=e, capture_output=True, text=True); wall = time.time() - t0
             if os.environ.get("GATB_DEVICE_VERBOSE"):
-                print("#   " + "\n#   ".join(l for l in (r.stdout + r.stderr).splitlines() if l.startswith("[device") or "[gkc" in l)[:4000])
+                print("#   " + "\n#   ".join(l for l in (r.stdout + r.stderr).splitlines() if l.startswith("[device") or "[gkc" in l)[:int(os.environ.get("DROPIN_LOG_CHARS", "4000"))])
             if r.returncode != 0:
                 print("# %s FAILED rc %d: %s" % (name, r.returncode, (r.stdout + r.stderr)[-400:])); return None
             v = info(out + ".h5"); v["_wall"] = "%.2f" % wall
@@ -85,6 +85,8 @@ def main():
                      ("patched, the REFERENCE's Configuration, -max-memory 200000 (few huge partitions)", DEV, {"GATB_DEVICE_REFERENCE_CONFIG": "1"}, "200000"),
                      ("patched (default), bank iterated by the reference's reader (GATB_DEVICE_NO_TEXT=1)", DEV, {"GATB_DEVICE_NO_TEXT": "1"}, "5000")]
             for name, exe, env, maxmem in runs:
+                if os.environ.get("DROPIN_ONLY") and os.environ["DROPIN_ONLY"] not in name:
+                    continue
                 v = run(name, exe, env, count_only, maxmem)
                 if v is None:
                     continue
