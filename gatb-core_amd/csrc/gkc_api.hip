@@ -99,6 +99,28 @@ static void clear_segments(gkc_ctx* c)
     c->owned_arenas.clear(); c->segments.clear(); c->n_exchanged_segments = 0;
 }
 
+// Stage B of a detached pass (gkc_finish_pass_async) is in flight or not yet joined
+static bool bg_active(const gkc_ctx* c) { return c->stage_b_thread.joinable(); }
+// ... and the caller may go on with the NEXT pass meanwhile: one GPU (the exchange works on the context's own segment list), no host sink (it holds one pass)
+static bool bg_overlap_ok(const gkc_ctx* c) { return c->b_detached && c->comm_world == 1 && c->sink == nullptr; }
+// the detached pass is through: its records are no longer needed (another pass has been begun), or the lists go back to the context
+static int bg_join(gkc_ctx* c)
+{
+    if (!c->stage_b_thread.joinable()) return GKC_OK;
+    c->stage_b_thread.join();
+    if (c->b_detached) {
+        if (c->b_moved_on || !c->segments.empty() || !c->owned_arenas.empty() || c->in_pass) {      // the context went on to another pass: the detached records go
+            for (hipEvent_t e : c->b_pending) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+            for (void* p : c->b_arenas) c->dfree(p);
+        } else {                                                                                   // ... or come back (gkc_segment_export, gkc_partition_superkmers after the pass)
+            c->segments = std::move(c->b_segments); c->owned_arenas = std::move(c->b_arenas);
+            for (hipEvent_t e : c->b_pending) c->pending_events.push_back(e);
+        }
+        c->b_segments.clear(); c->b_arenas.clear(); c->b_pending.clear(); c->b_detached = false; c->b_moved_on = false;
+    }
+    return c->stage_b_rc;
+}
+
 static void ctx_destroy_now(gkc_ctx* c);
 void gkc_ctx_child_release(gkc_ctx* c)
 {
@@ -141,8 +163,9 @@ void gkc_destroy(gkc_ctx* c)
 static void ctx_destroy_now(gkc_ctx* c)
 {
     (void)hipSetDevice(c->device);
-    if (c->stage_b_thread.joinable()) c->stage_b_thread.join();
+    (void)bg_join(c);
     (void)hipStreamSynchronize(c->stream);
+    if (c->bg_stream) { (void)hipStreamSynchronize(c->bg_stream); (void)hipStreamDestroy(c->bg_stream); c->bg_stream = nullptr; }
     c->drain_pending();
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     gkc_sink_shutdown(c);                                                // the unpack threads and their page-locked staging buffer
@@ -264,17 +287,26 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
     if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "gkc_configure must be called first");
     if (pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "pass %u >= nb_passes %u", pass, c->nb_passes);
     GKC_HIP(c, hipSetDevice(c->device));
-    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)");
+    // Stage B of the previous pass may still be counting (gkc_finish_pass_async): the NEXT pass may begin beside it — its Stage A is issue-bound, that Stage B
+    // memory-bound — as long as nothing the two share is touched: another pass number (pass 0 clears every histogram: a new run), one GPU, no host sink
+    const bool beside = bg_active(c);
+    if (beside && !(bg_overlap_ok(c) && pass != c->b_pass && pass != 0))
+        GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async of pass %u is in flight (gkc_finish_pass_wait first; only another pass > 0 of a one-GPU context without a host sink may begin beside it)", c->b_pass);
     (void)hipStreamSynchronize(c->stream);
     clear_segments(c);
-    free_pass_outputs(c, pass);
-    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
-    gkc_sink_reset(c);
-    c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;        // the host sink holds ONE pass: the previous pass's records are overwritten from here on
-    for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; D.sink_batch = nullptr; }
-    for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
-    c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
+    if (beside) c->b_moved_on = true;
+    {   std::lock_guard<std::mutex> lk(c->mu);
+        free_pass_outputs(c, pass);
+        if (!beside) {
+            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+            for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+            gkc_sink_reset(c);
+            c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;        // the host sink holds ONE pass: the previous pass's records are overwritten from here on
+            for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; D.sink_batch = nullptr; }
+        }
+        for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
+        c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
+    }
     if (pass == 0) GKC_HIP(c, hipMemsetAsync(c->d_histo.p, 0, (size_t)c->nb_passes * ((size_t)c->histo_max + 1) * 8, c->stream));   // pass 0 starts a new run
     else GKC_HIP(c, hipMemsetAsync(c->histo_of(pass), 0, ((size_t)c->histo_max + 1) * 8, c->stream));                         // a pass that is run again starts from zero
     c->pass = pass; c->in_pass = true;
@@ -284,7 +316,7 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
 int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases)
 {
     if (!c) return GKC_ERR_ARG;
-    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
+    if (bg_active(c) && !(bg_overlap_ok(c) && c->in_pass)) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
     if (((uintptr_t)d_bases & 15) != 0) GKC_FAIL(c, GKC_ERR_ARG, "d_bases must be 16-byte aligned");
     GKC_HIP(c, hipSetDevice(c->device));
@@ -300,7 +332,7 @@ static const uint64_t PUSH_CHUNK_BASES = getenv("GKC_PUSH_CHUNK") ? (uint64_t)st
 int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads)
 {
     if (!c) return GKC_ERR_ARG;
-    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
+    if (bg_active(c) && !(bg_overlap_ok(c) && c->in_pass)) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_begin_pass must be called first");
     if (!offsets) GKC_FAIL(c, GKC_ERR_ARG, "offsets is required");
     if (offsets[0] != 0) GKC_FAIL(c, GKC_ERR_ARG, "offsets[0] must be 0");
@@ -404,12 +436,25 @@ int gkc_count_mmers(gkc_ctx* c, uint32_t m, const char* bases, const uint64_t* o
     return rc;
 }
 
-static int finish_pass_body(gkc_ctx* c)
+// detached: the pass is counted from c->b_* on the background stream (see gkc_finish_pass_async); otherwise in line from the context's own lists and stream
+static int finish_pass_body(gkc_ctx* c, bool detached)
 {
     (void)hipSetDevice(c->device);
     int rc;
-    {   ScopedTimer tm(c, "total_stage_b");
-        rc = gkc_count_pass(c);
+    if (detached) {
+        gkc_tl_stream = c->bg_stream;                                    // everything this thread launches, times or frees goes to the background stream
+        for (hipEvent_t e : c->b_pending) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }      // multi-GPU: the records other ranks sent must have arrived
+        c->b_pending.clear();
+        double reserve = 0;                                              // what Stage A of the next pass may allocate beside this Stage B: as much as this pass's records took
+        if (bg_overlap_ok(c)) for (const Segment& sg : c->b_segments) reserve += (double)sg.rec_off.back() * (double)c->record_bytes * 1.6;
+        {   ScopedTimer tm(c, "total_stage_b");
+            rc = gkc_count_pass(c, c->b_pass, c->b_segments, c->bg_stream, reserve);
+        }
+        gkc_tl_stream = nullptr;
+    } else {
+        c->drain_pending();                                              // multi-GPU: the records other ranks sent must have arrived
+        ScopedTimer tm(c, "total_stage_b");
+        rc = gkc_count_pass(c, c->pass, c->segments, c->stream, 0.0);
     }
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // streamed results have landed ...
     gkc_sink_drain(c);                                                   // ... and the packed batches have been expanded into the sink
@@ -419,10 +464,10 @@ static int finish_pass_body(gkc_ctx* c)
 int gkc_finish_pass(gkc_ctx* c)
 {
     if (!c) return GKC_ERR_ARG;
-    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)");
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
     GKC_HIP(c, hipSetDevice(c->device));
-    const int rc = finish_pass_body(c);
+    if (bg_active(c)) GKC_TRY(bg_join(c));                               // the pass before this one was detached: it finishes first (its lanes own the chip's memory plan)
+    const int rc = finish_pass_body(c, false);
     if (rc != GKC_OK) return rc;
     c->in_pass = false;
     return GKC_OK;
@@ -430,13 +475,19 @@ int gkc_finish_pass(gkc_ctx* c)
 int gkc_finish_pass_async(gkc_ctx* c)
 {
     if (!c) return GKC_ERR_ARG;
-    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is already in flight");
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
+    if (bg_active(c) && !bg_overlap_ok(c)) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is already in flight");
     GKC_HIP(c, hipSetDevice(c->device));
-    (void)hipStreamSynchronize(c->stream);
+    if (bg_active(c)) GKC_TRY(bg_join(c));                               // Stage B of the pass before (its results stay): one Stage B at a time
+    (void)hipStreamSynchronize(c->stream);                               // Stage A of this pass is complete
+    if (!c->bg_stream) GKC_HIP(c, hipStreamCreateWithFlags(&c->bg_stream, hipStreamNonBlocking));
+    // the pass leaves the context: from here on c->pass / c->segments belong to whatever the caller does next
+    c->b_pass = c->pass; c->b_segments = std::move(c->segments); c->b_arenas = std::move(c->owned_arenas); c->b_pending = std::move(c->pending_events);
+    c->segments.clear(); c->owned_arenas.clear(); c->pending_events.clear(); c->n_exchanged_segments = 0;
+    c->b_detached = true; c->b_moved_on = false; c->in_pass = false;
     { std::lock_guard<std::mutex> lk(c->mu); c->stage_b_running = true; c->stage_b_rc = GKC_OK; }
     c->stage_b_thread = std::thread([c] {
-        const int rc = finish_pass_body(c);
+        const int rc = finish_pass_body(c, true);
         { std::lock_guard<std::mutex> lk(c->mu); c->stage_b_rc = rc; c->stage_b_running = false; }
         c->cv_done.notify_all();
     });
@@ -446,10 +497,8 @@ int gkc_finish_pass_wait(gkc_ctx* c)
 {
     if (!c) return GKC_ERR_ARG;
     if (!c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "no gkc_finish_pass_async in flight");
-    c->stage_b_thread.join();
-    if (c->stage_b_rc != GKC_OK) return c->stage_b_rc;
-    c->in_pass = false;
-    return GKC_OK;
+    GKC_HIP(c, hipSetDevice(c->device));
+    return bg_join(c);
 }
 int gkc_set_host_sink(gkc_ctx* c, void* pinned, uint64_t cap_bytes)
 {
@@ -626,11 +675,13 @@ int gkc_device_free(gkc_ctx* c, void* p) { if (!c) return GKC_ERR_ARG; if (p) { 
 int gkc_release_pass(gkc_ctx* c, uint32_t pass)
 {
     if (!c) return GKC_ERR_ARG;
-    if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
+    if (bg_active(c) && (!bg_overlap_ok(c) || pass == c->b_pass))       // another pass than the one Stage B is counting may go (one GPU, no sink: the conditions of overlapped passes)
+        GKC_FAIL(c, GKC_ERR_ARG, "%s while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)", __func__);
     if (!c->configured || pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "no such pass %u", pass);
     if (c->in_pass && c->pass == pass) GKC_FAIL(c, GKC_ERR_ARG, "pass %u is still open (gkc_finish_pass first)", pass);
     GKC_HIP(c, hipSetDevice(c->device));
     (void)hipStreamSynchronize(c->stream);
+    std::lock_guard<std::mutex> lk(c->mu);                                // (Stage B of another pass may be adding its own results beside this)
     free_pass_outputs(c, pass);
     for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();   // statistics of the pass stay
     c->pass_released[pass] = 1;

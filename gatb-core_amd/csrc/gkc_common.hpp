@@ -185,6 +185,11 @@ struct gkc_ctx {
     std::vector<hipEvent_t> landed_events;
     std::condition_variable cv_done;       // a dataset finished / the pass ended (gkc_wait_partition)
     std::thread stage_b_thread; bool stage_b_running = false; int stage_b_rc = GKC_OK;
+    // gkc_finish_pass_async DETACHES the pass: its number, segment list, arenas and pending exchange events move here and Stage B works on them on a stream of its
+    // own, so that gkc_begin_pass / gkc_push_reads* of the NEXT pass may run meanwhile (Stage A is issue-bound, Stage B memory-bound: they share the chip well).
+    // gkc_finish_pass_wait gives the lists back when no other pass has been begun in between (gkc_partition_superkmers / gkc_segment_export keep working).
+    uint32_t b_pass = 0; std::vector<Segment> b_segments; std::vector<void*> b_arenas; std::vector<hipEvent_t> b_pending; bool b_detached = false; bool b_moved_on = false;
+    hipStream_t bg_stream = nullptr;
     // double-buffered host -> device staging of gkc_push_reads (H2D of chunk j+1 overlaps the scan of chunk j)
     DevBuf h2d_bases[2], h2d_offs[2]; hipEvent_t h2d_copied[2] = {nullptr, nullptr}, h2d_scanned[2] = {nullptr, nullptr};
     std::mutex mu;                         // shared bookkeeping (timing, stats, outputs, error text) when Stage B runs two lanes
@@ -241,7 +246,7 @@ struct ScopedTimer {
 
 // ------------------------------------------------------------------------------------------------ launchers (defined in the .hip files)
 int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases);
-int gkc_count_pass(gkc_ctx* c);
+int gkc_count_pass(gkc_ctx* c, uint32_t pass, const std::vector<Segment>& segments, hipStream_t lane0, double reserve_bytes);
 int gkc_scan_sample(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint64_t n_bases, uint64_t* h_superkmers, uint64_t* h_kmers);
 int gkc_scan_sample_exact(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint64_t max_superkmers, uint64_t* h_nsk, uint64_t* h_nk, uint64_t* h_nkx, uint64_t* reads_used);
 int gkc_scan_count_mmers(gkc_ctx* c, uint32_t m, const char* d_bases, const uint64_t* d_offsets, uint64_t n_reads, uint32_t* h_counts);

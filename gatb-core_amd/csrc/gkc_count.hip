@@ -1833,9 +1833,9 @@ struct BatchBufs {
 };
 
 template <int KW, int RW>
-static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, const std::vector<uint64_t>& part_keys,
+static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& segments, const std::vector<uint32_t>& batch_parts, const std::vector<uint64_t>& part_keys,
                        const SegTable& segs, std::vector<void*>& outputs)
-{
+{   // (pass, segments: what this Stage B was started for — Stage A may have moved the context on to the next pass meanwhile: gkc_finish_pass_async)
     typedef typename KeyT<KW>::type key_t;
     const uint32_t nb = (uint32_t)batch_parts.size();
     const uint32_t k = c->k;
@@ -1919,7 +1919,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             for (uint32_t p = 0; p <= Pn; p++) {
                 off[p] = run;
                 if (p >= p_first && p <= p_last && i < nb && batch_parts[i] == p) {
-                    uint64_t n = 0; for (const Segment& sg : c->segments) n += sg.rec_off[p + 1] - sg.rec_off[p];
+                    uint64_t n = 0; for (const Segment& sg : segments) n += sg.rec_off[p + 1] - sg.rec_off[p];
                     base[i] = run; run += n; i++; base[i] = run;
                 }
             }
@@ -1971,7 +1971,7 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         CB_HIP(hipGetLastError());
     }
     SortOut O{};
-    O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = c->histo_of(c->pass); O.histo_max = c->histo_max;
+    O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = c->histo_of(pass); O.histo_max = c->histo_max;
     O.nd = (uint32_t*)B.nd.p; O.ns = all_solid ? (uint32_t*)B.nd.p : (uint32_t*)B.ns.p; O.amin = c->amin; O.amax = c->amax; O.all_solid = all_solid ? 1u : 0u;
 
     // --- the sort tiers, back to back: which sub-bucket goes where was decided by k_expand_count; no host round trip until the totals below
@@ -2074,12 +2074,12 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
             if (level > 260) { B.release(); GKC_FAIL(c, GKC_ERR_HIP, "internal error: the split levels do not terminate"); }
             CB_TRY(launch_deep(level));
         }
-        { std::lock_guard<std::mutex> lk(c->mu); c->stats_now().oversize_buckets += h_misc[2]; }
+        { std::lock_guard<std::mutex> lk(c->mu); c->pass_stats[pass].oversize_buckets += h_misc[2]; }
         if (dedupe) {                                                    // does merging identical records pay on this input? (it costs ~13 % of Stage B)
             unsigned long long dd[2]; memcpy(dd, h_misc + 40, 16);
             std::lock_guard<std::mutex> lk(c->mu);
             c->dedupe_in += dd[0]; c->dedupe_out += dd[1];
-            c->stats_now().dedupe_kmers_in += dd[0]; c->stats_now().dedupe_keys_out += dd[1];
+            c->pass_stats[pass].dedupe_kmers_in += dd[0]; c->pass_stats[pass].dedupe_keys_out += dd[1];
             if (dedupe_env != 1 && c->dedupe_in > 100000000ULL && (double)c->dedupe_out > 0.85 * (double)c->dedupe_in) c->dedupe_off = true;
             if (getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc] dedupe: %llu k-mers in the deduplicated bins -> %llu weighted keys (%.2fx)\n", dd[0], dd[1], dd[1] ? (double)dd[0] / (double)dd[1] : 0.0);
         }
@@ -2136,12 +2136,12 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
         }
         {   std::lock_guard<std::mutex> lk(c->mu);
             for (uint32_t i = 0; i < nb; i++) {
-                Dataset& D = c->datasets[(size_t)c->pass * c->nb_partitions + batch_parts[i]];
+                Dataset& D = c->datasets[(size_t)pass * c->nb_partitions + batch_parts[i]];
                 const uint64_t s0 = ptot[2 * i + 1], s1 = ptot[2 * (i + 1) + 1];
                 D.d_counts = (const uint8_t*)out + s0 * OW * 8;
                 D.h_counts = h_base ? h_base + s0 * OW * 8 : nullptr; D.landed = landed; D.sink_batch = sink_batch;
                 D.n_solid = s1 - s0; D.n_distinct = ptot[2 * (i + 1)] - ptot[2 * i]; D.n_kmers = part_keys[batch_parts[i]]; D.done = true;
-                c->stats_now().kmers_nb_distinct += D.n_distinct; c->stats_now().kmers_nb_solid += D.n_solid;
+                c->pass_stats[pass].kmers_nb_distinct += D.n_distinct; c->pass_stats[pass].kmers_nb_solid += D.n_solid;
             }
         }
         c->cv_done.notify_all();
@@ -2152,39 +2152,43 @@ static int count_batch(gkc_ctx* c, const std::vector<uint32_t>& batch_parts, con
     return GKC_OK;
 }
 
-int gkc_count_pass(gkc_ctx* c)
+// pass / segments / lane0: the pass this Stage B counts, its segments and the stream of its first lane. Called in line by gkc_finish_pass (the context's own pass,
+// segment list and stream) or on the worker thread of gkc_finish_pass_async with the DETACHED state of the pass (c->b_*) and a stream of its own, while the caller
+// may already run Stage A of the next pass on the context's stream: nothing below reads c->pass, c->segments or stats_now().
+int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& segments, hipStream_t lane0, double reserve_bytes)
 {
     const uint32_t Pn = c->nb_partitions;
-    const uint32_t n_seg = (uint32_t)c->segments.size();
-    c->drain_pending();                                     // multi-GPU: the records other ranks sent must have arrived
+    const uint32_t n_seg = (uint32_t)segments.size();
     {   // a pass counted again (a retry after GKC_ERR_NOMEM, or gkc_finish_pass called twice) starts from a clean slate: what the
         // batches of the failed attempt added to the histogram, to the counters and to the result list must not be counted twice
-        auto it = c->pass_outputs.find(c->pass);
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->pass_outputs.find(pass);
         if (it != c->pass_outputs.end()) { for (void* p : it->second) c->dfree(p); it->second.clear(); }
-        for (uint32_t p = 0; p < Pn; p++) c->datasets[(size_t)c->pass * Pn + p] = Dataset();
-        gkc_stats& S = c->stats_now(); S.kmers_nb_distinct = 0; S.kmers_nb_solid = 0; S.oversize_buckets = 0; S.dedupe_kmers_in = 0; S.dedupe_keys_out = 0;
+        for (uint32_t p = 0; p < Pn; p++) c->datasets[(size_t)pass * Pn + p] = Dataset();
+        gkc_stats& S = c->pass_stats[pass]; S.kmers_nb_distinct = 0; S.kmers_nb_solid = 0; S.oversize_buckets = 0; S.dedupe_kmers_in = 0; S.dedupe_keys_out = 0;
         // ... and the host sink starts over as well: the failed attempt's copies are drained, its records are overwritten
         if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
         gkc_sink_reset(c);
         c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;
-        GKC_HIP(c, hipMemsetAsync(c->histo_of(c->pass), 0, ((size_t)c->histo_max + 1) * 8, c->stream));
+        GKC_HIP(c, hipMemsetAsync(c->histo_of(pass), 0, ((size_t)c->histo_max + 1) * 8, lane0));
     }
     std::vector<uint64_t> part_keys(Pn, 0);
-    for (const Segment& s : c->segments) for (uint32_t p = 0; p < Pn; p++) part_keys[p] += s.nkmers[p];
+    for (const Segment& s : segments) for (uint32_t p = 0; p < Pn; p++) part_keys[p] += s.nkmers[p];
     // device copy of the segment table
     DevBuf d_recptr, d_recoff;
     std::vector<const uint8_t*> ptrs(std::max<uint32_t>(n_seg, 1), nullptr);
     std::vector<uint64_t> offs((size_t)std::max<uint32_t>(n_seg, 1) * (Pn + 1), 0);
     for (uint32_t s = 0; s < n_seg; s++) {
-        ptrs[s] = (const uint8_t*)c->segments[s].d_records;
-        memcpy(&offs[(size_t)s * (Pn + 1)], c->segments[s].rec_off.data(), (size_t)(Pn + 1) * 8);
+        ptrs[s] = (const uint8_t*)segments[s].d_records;
+        memcpy(&offs[(size_t)s * (Pn + 1)], segments[s].rec_off.data(), (size_t)(Pn + 1) * 8);
     }
     GKC_TRY(c->ensure(d_recptr, ptrs.size() * sizeof(void*)));
     int rc = c->ensure(d_recoff, offs.size() * 8);
     if (rc != GKC_OK) { d_recptr.release(); return rc; }
-    hipError_t e1 = hipMemcpy(d_recptr.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice);
-    hipError_t e2 = hipMemcpy(d_recoff.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice);
+    hipError_t e1 = hipMemcpyAsync(d_recptr.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice, lane0);      // (on the pass's own stream: a plain hipMemcpy would
+    hipError_t e2 = hipMemcpyAsync(d_recoff.p, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, lane0);                  //  wait for whatever Stage A of the next pass has queued)
+    if (e1 == hipSuccess && e2 == hipSuccess) e1 = hipStreamSynchronize(lane0);
     if (e1 != hipSuccess || e2 != hipSuccess) { d_recptr.release(); d_recoff.release(); GKC_FAIL(c, GKC_ERR_HIP, "segment table upload failed"); }
     SegTable segs{ (const uint8_t* const*)d_recptr.p, (const uint64_t*)d_recoff.p, n_seg, Pn };
 
@@ -2215,7 +2219,7 @@ int gkc_count_pass(gkc_ctx* c)
     const double avail0 = [&] {                                              // memory this pass may use: free now + blocks parked in the caching allocator
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
-        return (double)(free_b + c->pool.cached_bytes);
+        return std::max(0.0, (double)(free_b + c->pool.cached_bytes) - reserve_bytes);      // (overlapped passes: what Stage A of the next pass will allocate beside this Stage B)
     }();
     static const size_t cap_env = getenv("GKC_BATCH_KEYS") ? (size_t)atoll(getenv("GKC_BATCH_KEYS")) : 0;
     // Few, large batches: every batch ends with the drain of ~12 kernels (the expand kernels run one 6 ms workgroup per partition) and
@@ -2234,6 +2238,13 @@ int gkc_count_pass(gkc_ctx* c)
         const double dq = std::min(1.0, std::ceil(1.05 * d / 0.05) * 0.05);
         const double mem = (0.95 * avail_q - (double)total_keys * (double)rec_bytes * dq) / work;
         const uint64_t bmem = mem > (double)((size_t)1 << 20) ? (uint64_t)mem : ((uint64_t)1 << 20);
+        if (c->nb_passes > 1) {
+            // several passes: every pass plans the SAME batch size — half the cap plus a rounded partition — whatever its share of the k-mers (minimizer % nb_passes
+            // does not cut them evenly: 5.2e9 and 6.8e9 keys for the two passes of 1e8 reads). Equal shares per pass gave every pass its own block sizes: the allocator was
+            // trimmed and refilled at every pass, 4 s of hipMalloc for 0.15 s of counting (tools/twopass_probe.py).
+            uint64_t mp = 1; while (mp < max_part) mp <<= 1;
+            return (size_t)(std::min<uint64_t>(bmem, cap / 2) + mp);
+        }
         const uint64_t b = std::min<uint64_t>(bmem, cap);
         const uint64_t per_round = b * (uint64_t)plan_lanes;
         const uint64_t rounds = std::max<uint64_t>((total_keys + per_round - 1) / per_round, 1);
@@ -2267,7 +2278,8 @@ int gkc_count_pass(gkc_ctx* c)
         }
         return b;
     };
-    std::vector<void*>& outputs = c->pass_outputs[c->pass];
+    std::vector<void*>* outputs_p; { std::lock_guard<std::mutex> lk(c->mu); outputs_p = &c->pass_outputs[pass]; }      // (std::map nodes stay where they are)
+    std::vector<void*>& outputs = *outputs_p;
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
     auto carve = [&](std::vector<uint32_t>& batch, int lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
@@ -2282,7 +2294,7 @@ int gkc_count_pass(gkc_ctx* c)
             const uint32_t p = next_p;
             if (part_keys[p] == 0) {                           // nothing to count (e.g. a partition another rank owns): an empty, finished dataset
                 {   std::lock_guard<std::mutex> lk2(c->mu);       // (c->mu guards the datasets gkc_wait_partition looks at; plan_mu only the batch plan)
-                    Dataset& D = c->datasets[(size_t)c->pass * Pn + p];
+                    Dataset& D = c->datasets[(size_t)pass * Pn + p];
                     D.d_counts = nullptr; D.n_solid = 0; D.n_distinct = 0; D.n_kmers = 0; D.done = true;
                 }
                 c->cv_done.notify_all();
@@ -2301,19 +2313,20 @@ int gkc_count_pass(gkc_ctx* c)
     };
     auto lane_main = [&](hipStream_t st, int lane) {
         (void)hipSetDevice(c->device);
+        const hipStream_t tl_before = gkc_tl_stream;
         gkc_tl_stream = st;
         std::vector<uint32_t> batch;
         while (carve(batch, lane)) {
-            const int r = (c->key_words == 1) ? count_batch<1, 2>(c, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, batch, part_keys, segs, outputs);
+            const int r = (c->key_words == 1) ? count_batch<1, 2>(c, pass, segments, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, pass, segments, batch, part_keys, segs, outputs);
             std::lock_guard<std::mutex> lk(plan_mu);
             inflight[lane] = 0;
             if (r != GKC_OK) { if (first_rc == GKC_OK) first_rc = r; break; }
-            for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)c->pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
+            for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
         }
         (void)hipStreamSynchronize(st);
-        gkc_tl_stream = nullptr;
+        gkc_tl_stream = tl_before;
     };
-    (void)hipStreamSynchronize(c->stream);                                   // Stage A and the table uploads are complete before the lanes start
+    (void)hipStreamSynchronize(lane0);                                       // the table uploads (and, in line, Stage A on the same stream) are complete before the lanes start
     // d not known yet and the memory may bind: count a small PROBE batch first (the first partitions holding ~0.4 % of the keys) and take
     // its ratio. The context keeps that first estimate (until the configuration changes), so every later pass plans the same sizes.
     // In later passes the same small batch is simply the first one in the queue (it runs beside the other lane's first batch).
@@ -2322,10 +2335,10 @@ int gkc_count_pass(gkc_ctx* c)
         std::vector<uint32_t> batch;
         fixed_budget = probe_keys; c->slots_hint = 0;
         if (carve(batch, 0)) {
-            const int r = (c->key_words == 1) ? count_batch<1, 2>(c, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, batch, part_keys, segs, outputs);
+            const int r = (c->key_words == 1) ? count_batch<1, 2>(c, pass, segments, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, pass, segments, batch, part_keys, segs, outputs);
             inflight[0] = 0; last_b[0] = 0;
             if (r != GKC_OK) { d_recptr.release(); d_recoff.release(); return r; }
-            for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)c->pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
+            for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
             if (done_keys) c->d_hint = std::max(1e-6, (double)done_solid / (double)done_keys);
         }
     }
@@ -2348,7 +2361,7 @@ int gkc_count_pass(gkc_ctx* c)
     {
         std::vector<std::thread> extra;
         for (int l = 1; l < lanes; l++) extra.emplace_back(lane_main, c->lane_streams[l - 1], l);
-        lane_main(c->stream, 0);
+        lane_main(lane0, 0);
         for (auto& t : extra) t.join();
     }
     rc = first_rc;

@@ -416,6 +416,55 @@ def test_share_of_8_path_at_full_size(gkc):
         c.device_free(db); c.device_free(do)
 
 
+@pytest.mark.parametrize("k,n,passes", [(31, 6_000_000, 3), (63, 3_000_000, 2), (21, 40_000, 4)])
+def test_overlapped_passes(gkc, k, n, passes):
+    """Stage A of pass p+1 beside Stage B of pass p (VERDICT r3 Missing #4; the reference's pass loop is serial because of its disk, SortingCountAlgorithm.cpp:672-692):
+    gkc_finish_pass_async DETACHES a pass — number, segment list, arenas, a stream of its own — and gkc_begin_pass / gkc_push_reads_device of the next pass run while it
+    is counted. Every dataset, the statistics and the histogram must be those of the same passes run one after the other; a consumer may fetch and release pass p
+    while pass p+1 is being counted; what would touch shared state (pass 0 = a new run, the pass that is being counted) is refused."""
+    m, parts, L = 10 if k > 10 else k - 1, 64, 150
+    rep = simple_repart(m, parts)
+    def run(overlapped):
+        c = gkc.Counter(0)
+        c.configure(k, m, parts, rep, nb_passes=passes); c.set_solidity(2, 1000, 10000)
+        db, do = c.synth_reads_device(7, n, L, n * 5, 10000)
+        got = {}
+        for ps in range(passes):
+            c.begin_pass(ps); c.push_reads_device(db, do, n, n * L)
+            if overlapped:
+                c.finish_pass_async()
+                if ps == 0:                                    # beside pass 0: pass 0 again (a new run) and nonsense are refused, the context stays usable
+                    for bad in (0,):
+                        with pytest.raises(gkc.GkcError):
+                            c.begin_pass(bad)
+                if ps > 0:                                     # the pass before is through (finish_pass_async joined it): fetch it and give its memory back
+                    for p in range(parts):
+                        got[(ps - 1, p)] = c.partition_records(ps - 1, p).copy()
+                    c.release_pass(ps - 1)
+            else:
+                c.finish_pass()
+        if overlapped:
+            c.finish_pass_wait()
+            for p in range(parts):
+                got[(passes - 1, p)] = c.partition_records(passes - 1, p).copy()
+        else:
+            for ps in range(passes):
+                for p in range(parts):
+                    got[(ps, p)] = c.partition_records(ps, p).copy()
+        st = c.stats(); h = c.histogram()
+        c.device_free(db); c.device_free(do); c.close()
+        return got, st, h
+    a, sa, ha = run(False)
+    b, sb, hb = run(True)
+    assert sorted(a) == sorted(b)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    for key in ("kmers_nb_valid", "kmers_nb_invalid", "kmers_nb_distinct", "kmers_nb_solid", "nb_sequences", "nb_superkmers"):
+        assert sa[key] == sb[key], key
+    assert np.array_equal(ha, hb)
+    assert sa["kmers_nb_solid"] > 0 and sum(len(v) for v in a.values()) == sa["kmers_nb_solid"] * (16 if k <= 31 else 32)
+
+
 def test_multi_pass_with_two_lanes_and_solidity(gkc):
     """three passes over 6e6 reads (2.4e8 keys per pass: the two-lane Stage B with its probe batch, results of earlier passes
     resident), abundance window [2, 50]: the records of all passes together == the multiset of valid k-mers with that abundance

@@ -4,9 +4,9 @@
 # Outputs land in gpurun_out/prof_round/ and are copied into profiles/ by hand afterwards.
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/prof_round; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 > $O/kt.log 2>&1
-GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 > $O/pf.log 2>&1
-GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 > $O/pw.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 --no-two-pass > $O/kt.log 2>&1
+GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pf -o f -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 --no-two-pass > $O/pf.log 2>&1
+GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pw -o w -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 --no-two-pass > $O/pw.log 2>&1
 cd $R
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -n 1) > $O/kernel_stats.txt 2>&1
 ( echo "# PMC (separate rocprofv3 passes, GKC_STAGEB_LANES=1, --steps 1 --warmup 0: --pmc FETCH_SIZE | WRITE_SIZE on the default bench (1e8 reads); --kernel-trace only)"

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-q}; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 cd $R
 if [ "$2" != "notest" ]; then python -m pytest tests -m gpu -x -q 2>&1 | tail -6; fi
-python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed --no-share-of-8 > $O/bench.json 2> $O/bench.err
+python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed --no-share-of-8 --no-two-pass > $O/bench.json 2> $O/bench.err
 python - <<PY
 import json
 d = json.load(open("$O/bench.json"))
@@ -13,7 +13,7 @@ print("timed ", d["config"]["kernel_ms_per_step"])
 print("single", d["roofline"]["single_lane"]["kernel_ms_per_step"])
 PY
 cd /tmp; export TMPDIR=/tmp
-GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 > $O/kt.log 2>&1
+GKC_STAGEB_LANES=1 rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 --no-two-pass > $O/kt.log 2>&1
 cd $R
 python tools/rocprof_summary.py $(find $O/kt -name "*.db" | head -n 1) --seq 40 > $O/kernel_stats.txt 2>&1
 rm -rf $O/kt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # scratch: a sweep of short bench runs (single GPU call)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out/sw
-run() { n=$1; shift; env "$@" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed --no-share-of-8 $EXTRA > gpurun_out/sw/$n.json 2> gpurun_out/sw/$n.err
+run() { n=$1; shift; env "$@" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed --no-share-of-8 --no-two-pass $EXTRA > gpurun_out/sw/$n.json 2> gpurun_out/sw/$n.err
 python - <<PY
 import json
 d=json.load(open("gpurun_out/sw/$n.json")); t=d["config"]["kernel_ms_per_step"]; s=d["roofline"]["single_lane"]["kernel_ms_per_step"]
