@@ -2242,8 +2242,10 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
             // several passes: every pass plans the SAME batch size — half the cap plus a rounded partition — whatever its share of the k-mers (minimizer % nb_passes
             // does not cut them evenly: 5.2e9 and 6.8e9 keys for the two passes of 1e8 reads). Equal shares per pass gave every pass its own block sizes: the allocator was
             // trimmed and refilled at every pass, 4 s of hipMalloc for 0.15 s of counting (tools/twopass_probe.py).
+            // (a small pass — the tests' — is one batch of its own size, rounded up to a power of two so that passes of similar size still plan alike)
             uint64_t mp = 1; while (mp < max_part) mp <<= 1;
-            return (size_t)(std::min<uint64_t>(bmem, cap / 2) + mp);
+            uint64_t tk = 1; while (tk < total_keys) tk <<= 1;
+            return (size_t)(std::min<uint64_t>(std::min<uint64_t>(bmem, cap / 2), tk) + mp);
         }
         const uint64_t b = std::min<uint64_t>(bmem, cap);
         const uint64_t per_round = b * (uint64_t)plan_lanes;
