@@ -492,7 +492,7 @@ def main():
         try:   # the whole step against the HBM roof: every byte the step's kernels moved at the memory (PMC, single-lane passes) over the timed step
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload:
-                tot_b = sum(v_["hbm_bytes_per_step"] for n_, v_ in pt["kernels"].items() if n_.startswith("k_") and not n_.startswith("k_synth"))
+                tot_b = sum(v_["hbm_bytes_per_step"] for n_, v_ in pt["kernels"].items() if n_.startswith("k_") and not n_.startswith("k_synth") and "checksum" not in n_)      # (the step's kernels: not the input generator, not the verification)
                 pipeline = {"counter_bytes_per_step": tot_b, "bytes_per_valid_kmer": tot_b / max(1, valid), "achieved": tot_b / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
                             "frac": tot_b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "source": "profiles/pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of one step (separate single-lane PMC passes) / this run's ms_per_step"}
@@ -563,6 +563,11 @@ def main():
                                               "launch_ms": iso[dom][0] / il, "achieved": alg[dom] / (iso[dom][0] * 1e-3) / 1e9,
                                               "frac": alg[dom] / (iso[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                               "kernel_ms_per_step": {n_: round(iso[n_][0], 3) for n_ in names}}
+            if traffic:                                        # the PMC passes are single-lane passes too: THIS pair is a bandwidth
+                sl = out["roofline"]["single_lane"]
+                sl["traffic_per_launch"] = traffic
+                sl["hbm_GBps_from_counters"] = traffic / (sl["launch_ms"] * 1e-3) / 1e9
+                sl["frac_from_counters"] = sl["hbm_GBps_from_counters"] / HBM_PEAK_GBS
         if exch is not None:
             out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push, "per_rank": exch}
         if world == 1 and not args.no_host_landed:

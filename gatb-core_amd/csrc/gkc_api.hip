@@ -321,7 +321,41 @@ int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_off
     if (((uintptr_t)d_bases & 15) != 0) GKC_FAIL(c, GKC_ERR_ARG, "d_bases must be 16-byte aligned");
     GKC_HIP(c, hipSetDevice(c->device));
     ScopedTimer tm(c, "total_stage_a");
-    return gkc_scan_push(c, d_bases, d_offsets, n_reads, n_bases);
+    // A push is one segment with its own per-push buffers (0.8 bytes of descriptors per base, the record arena, above 4096 partitions its refined copy): those of ONE
+    // push of 2e8 reads (3e10 bases) are 23 + 20 + 20 GB of fresh hipMallocs beside 100+ GB of parked blocks of other sizes — 2.6 s per step (DESIGN r3 §14). A push beyond
+    // PUSH_SPLIT_BASES is therefore scanned in slices of about that many bases, cut at a read whose first base is 16-byte aligned (the scan loads 16 bytes at a time): every
+    // slice is a segment of its own, and the slices ask the allocator for the same blocks one after the other. Same records, same counts (a read is never cut).
+    static const uint64_t PUSH_SPLIT_BASES = getenv("GKC_PUSH_SPLIT") ? (uint64_t)std::max<long long>(1024, atoll(getenv("GKC_PUSH_SPLIT"))) : 16000000000ull;
+    if (n_bases <= PUSH_SPLIT_BASES + PUSH_SPLIT_BASES / 4 || n_reads < 2) return gkc_scan_push(c, d_bases, d_offsets, n_reads, n_bases);
+    auto off_at = [&](uint64_t r, uint64_t* v) -> int { GKC_HIP(c, hipMemcpy(v, d_offsets + r, 8, hipMemcpyDeviceToHost)); return GKC_OK; };
+    DevBuf d_off;
+    uint64_t r0 = 0, base0 = 0;
+    const uint64_t n_slices = (n_bases + PUSH_SPLIT_BASES - 1) / PUSH_SPLIT_BASES;
+    int rc = GKC_OK;
+    for (uint64_t j = 1; j <= n_slices && rc == GKC_OK && r0 < n_reads; j++) {
+        uint64_t r1 = n_reads, base1 = n_bases;
+        if (j < n_slices) {
+            const uint64_t target = n_bases / n_slices * j;
+            uint64_t lo = r0 + 1, hi = n_reads;                               // first read at or behind the target (binary search in the device table: 8-byte fetches)
+            while (lo < hi && rc == GKC_OK) { const uint64_t mid = (lo + hi) / 2; uint64_t v = 0; rc = off_at(mid, &v); if (v < target) lo = mid + 1; else hi = mid; }
+            if (rc != GKC_OK) break;
+            std::vector<uint64_t> win((size_t)std::min<uint64_t>(4096, n_reads - lo + 1));        // ... and from there the first one that starts on a multiple of 16
+            GKC_HIP(c, hipMemcpy(win.data(), d_offsets + lo, win.size() * 8, hipMemcpyDeviceToHost));
+            size_t w = 0; while (w < win.size() && ((win[w] & 15) != 0 || lo + w >= n_reads)) w++;
+            if (w == win.size()) continue;                                    // none in reach: this slice grows into the next one
+            r1 = lo + w; base1 = win[w];
+        }
+        const uint64_t nr = r1 - r0;
+        rc = c->ensure(d_off, (size_t)(nr + 1) * 8);
+        if (rc != GKC_OK) break;
+        GKC_HIP(c, hipMemcpyAsync(d_off.p, d_offsets + r0, (size_t)(nr + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (base0) hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)((nr + 1 + 255) / 256)), dim3(256), 0, c->stream, (uint64_t*)d_off.p, nr + 1, base0);
+        rc = gkc_scan_push(c, d_bases + base0, (const uint64_t*)d_off.p, nr, base1 - base0);
+        r0 = r1; base0 = base1;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    d_off.release();
+    return rc;
 }
 
 // Host buffers: the reads go to the device in chunks of about PUSH_CHUNK_BASES through two staging buffers — the H2D copy of chunk j+1

@@ -2379,11 +2379,23 @@ int gkc_result_checksum_impl(gkc_ctx* c, uint64_t* checksum, uint64_t* sum_abund
 {
     DevBuf d; GKC_TRY(c->ensure(d, 16));
     GKC_HIP(c, hipMemsetAsync(d.p, 0, 16, cur_stream(c)));
+    // datasets of one Stage-B batch lie one behind the other: one launch per contiguous run (a handful per pass), not one per dataset
+    const size_t rb = c->key_words == 1 ? 16 : 32;
+    const uint8_t* run = nullptr; uint64_t run_n = 0;
+    auto flush = [&]() {
+        if (!run_n) return;
+        const unsigned grid = (unsigned)std::min<uint64_t>((run_n + 255) / 256, 8192);
+        if (c->key_words == 1) hipLaunchKernelGGL((k_result_checksum<1>), dim3(grid), dim3(256), 0, cur_stream(c), (const uint64_t*)run, run_n, (unsigned long long*)d.p);
+        else                   hipLaunchKernelGGL((k_result_checksum<2>), dim3(grid), dim3(256), 0, cur_stream(c), (const uint64_t*)run, run_n, (unsigned long long*)d.p);
+        run_n = 0;
+    };
     for (const Dataset& D : c->datasets) {
         if (!D.done || !D.n_solid) continue;
-        if (c->key_words == 1) hipLaunchKernelGGL((k_result_checksum<1>), dim3(1024), dim3(256), 0, cur_stream(c), (const uint64_t*)D.d_counts, D.n_solid, (unsigned long long*)d.p);
-        else                   hipLaunchKernelGGL((k_result_checksum<2>), dim3(1024), dim3(256), 0, cur_stream(c), (const uint64_t*)D.d_counts, D.n_solid, (unsigned long long*)d.p);
+        if (run_n && (const uint8_t*)D.d_counts == run + run_n * rb) { run_n += D.n_solid; continue; }
+        flush();
+        run = (const uint8_t*)D.d_counts; run_n = D.n_solid;
     }
+    flush();
     uint64_t h[2];
     hipError_t e = hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, cur_stream(c));
     if (e == hipSuccess) e = hipStreamSynchronize(cur_stream(c));
