@@ -135,7 +135,7 @@ public:
     int       ranks () const { return _ranks; }
     int       rank  () const { return _rank;  }
 
-    void beginPass (size_t pass)  { check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0;  _progressReported = 0; }
+    void beginPass (size_t pass)  { check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0;  _progressReported = 0; }      /* (a debt of a refused text pass stays) */
 
     /** one block of reads to Stage A (the caller holds the packers' lock: one thread drives the context at a time); multi-rank: the exchanges that are due */
     void push (const char* bases, const uint64_t* offsets, uint64_t nbReads)
@@ -289,7 +289,9 @@ public:
             if (!ok)
             {
                 if (_ranks > 1)  { throw system::Exception ("device counting: %s is not FASTA / FASTQ text the device parser takes; with several ranks set GATB_DEVICE_NO_TEXT=1", files[fi].c_str()); }
-                if (progress != 0  &&  _progressReported > 0)  { progress->inc ((u_int64_t)0 - _progressReported);  _progressReported = 0; }      /* the pass starts again, iterated: what was reported is taken back */
+                /* the pass starts again, iterated: what has been reported already is owed — the iterating functors report that much less (reportable()); a progress
+                 * listener cannot be wound back (Progress::inc loops over the steps it is given, Progress.cpp:119-129) */
+                {  std::lock_guard<std::mutex> guard (_timesLock);  _progressDebt += _progressReported;  _progressReported = 0;  }
                 return false;
             }
         }
@@ -347,6 +349,14 @@ public:
         for (int i = 0; i < 4; i++)  { clock.now = 0;  mine.start (names[i]);  clock.now = (u_int32_t) (ms[i] + 0.5);  mine.stop (names[i]); }
         into += mine;
     }
+    /** how much of n sequences an iterating functor may report to the progress listener: what the refused text path had reported for this pass comes off first */
+    u_int64_t reportable (u_int64_t n)
+    {
+        std::lock_guard<std::mutex> guard (_timesLock);
+        const u_int64_t owed = std::min (n, _progressDebt);
+        _progressDebt -= owed;
+        return n - owed;
+    }
     /** called by every partition command: seconds it waited for Stage B / spent handing its records over */
     void addCommandTimes (double waitS, double handOverS)  { std::lock_guard<std::mutex> guard (_timesLock);  _waitS += waitS;  _handOverS += handOverS; }
 
@@ -372,7 +382,7 @@ private:
     size_t    _nbPartitions;
     size_t    _kmerSize = 0;
     double    _finishWall = 0;
-    u_int64_t _progressReported = 0;
+    u_int64_t _progressReported = 0, _progressDebt = 0;
     std::mutex _timesLock;
     double    _waitS = 0, _handOverS = 0;
 };
@@ -409,7 +419,7 @@ public:
         _bases.insert (_bases.end(), sequence.getDataBuffer(), sequence.getDataBuffer() + len);
         _offsets.push_back (_bases.size());
         if (_bases.size() >= (size_t)BLOCK_BYTES)  { flush(); }
-        if (_nbWritten++ > 500000)  { _progress->inc (_nbWritten);  _nbWritten = 0; }
+        if (_nbWritten++ > 500000)  { const u_int64_t n = DeviceSession::singleton().reportable (_nbWritten);  if (n > 0) { _progress->inc (n); }  _nbWritten = 0; }
     }
 
 private:

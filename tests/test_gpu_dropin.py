@@ -310,3 +310,37 @@ def test_configuration_sized_from_the_device(tmp_path, tag):
     n = len(raw) // rec; raw = raw[:n * rec].reshape(n, rec)
     got = list(zip([int.from_bytes(bytes(r), "little") for r in raw[:, :rec - 4]], raw[:, rec - 4:].copy().view("<u4")[:, 0].tolist()))
     assert got == sorted(x for part in parts for x in part)                     # ascending in the one dataset, same k-mers, same counts
+
+
+@needs_artefacts
+def test_text_the_device_parser_refuses_goes_through_the_iterated_bank(tmp_path):
+    """A multi-line FASTQ (sequence and quality wrapped over two lines each) is what the reference's reader takes (BankFasta.cpp:488-571) and the device parser refuses
+    (GKC_ERR_FORMAT: not expressible line by line): DeviceSession::pushTextFiles gives up, the pass starts again with the bank iterated, the datasets are the fixture's.
+    Run with -verbose 1: the progress the text path had reported is owed to the listener, never wound back (a negative increment would spin in Progress::inc)."""
+    tag = "k21_default_parts"
+    z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    recs, name, seq = [], None, []
+    def flush():
+        if name is not None:
+            sq = b"".join(seq); h = len(sq) // 2
+            recs.append(b"@" + name + b"\n" + sq[:h] + b"\n" + sq[h:] + b"\n+\n" + b"I" * h + b"\n" + b"I" * (len(sq) - h) + b"\n")
+    for line in bytes(z["fasta"]).split(b"\n"):
+        if line.startswith(b">"):
+            flush(); name = line[1:]; seq = []
+        elif line:
+            seq.append(line.strip())
+    flush()
+    fq = str(tmp_path / "wrapped.fq"); open(fq, "wb").write(b"".join(recs))
+    extra, mem, cores = CASES[tag]
+    out = str(tmp_path / "wrapped")
+    cmd = [EXE, "-in", fq, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", str(tmp_path), "-nb-cores", "4", "-max-memory", mem, "-verbose", "1"] + COUNT_ONLY + extra
+    r = subprocess.run(cmd, env=dict(os.environ, GATB_DEVICE_VERBOSE="1", GATB_DEVICE_REFERENCE_CONFIG="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "device counting" in r.stderr
+    z2 = np.load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    rec = 12
+    got = []
+    for p_ in range(int(h5_attr(out + ".h5", "/dsk/solid/nb_partitions"))):
+        raw = dump_dataset(out + ".h5", "/dsk/solid/%d" % p_, "FILE"); n = len(raw) // rec; raw = raw[:n * rec].reshape(n, rec)
+        got += list(zip([int.from_bytes(bytes(x), "little") for x in raw[:, :8]], raw[:, 8:].copy().view("<u4")[:, 0].tolist()))
+    assert sorted(got) == sorted(x for part in parts for x in part)            # (-nb-cores 4: the reference's Configuration may cut other partitions; the k-mers and counts are the fixture's)
