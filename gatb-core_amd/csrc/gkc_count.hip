@@ -185,9 +185,18 @@ template <int KW> __device__ __forceinline__ uint32_t sub_index(typename KeyT<KW
 }
 
 constexpr int EXPAND_THREADS = 512;
-// A key on its way through the sort is the canonical k-mer shifted left by WEIGHT_BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
-// of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. 2k + WEIGHT_BITS <= 64 / 128 for k <= 31 / 63.
-constexpr int WEIGHT_BITS = 2;
+// A key on its way through the sort is the canonical k-mer shifted left by wb WEIGHT BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
+// of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. wb is chosen per batch (weight_bits_of): 2 .. 4 — the
+// records have 4 spare bits below their nucleotides — as many as the sort can carry: 8-byte keys sort with the f64-tagged network while what is left of a key below
+// its sub-bucket index fits a double's mantissa (2k + wb - sub_bits <= 52: k = 31 -> 3, k <= 30 -> 4). A key of 2k + wb bits may be WEIGHT_DROP_MAX = 1 bit
+// longer than the 64 / 128 it is stored in (k = 31, k = 63 with wb = 3): the TOP bit falls off in the shift, and nothing is lost — every key of a level-1 sub-bucket
+// shares it (it is the top bit of the sub-bucket's index), k_expand_count notes it beside the sub-bucket (b_consumed, bit 4) and the two kernels that write the
+// Count records (k_gather_counts, k_root_write) put it back. The order inside a sub-bucket does not depend on a bit all its keys share. One bit and not two: the
+// stored key must never be all ones (the scatter's EMPTY, the sort's padding). With one bit dropped that would take a k-mer [C|G] G..G — neither is canonical
+// (their reverse complements C..C[C|G] are smaller); with two, A G..G is canonical and would be all ones at weight 16.
+// Measured (1e8 reads, k = 30, no bit dropped: profiles/r04_weight_bits_experiment.txt): weights up to 4 / 8 / 16 merge 1.65x / 1.85x / 1.98x, step 230 / 215 / 211 ms.
+constexpr int WEIGHT_BITS_MIN = 2, WEIGHT_BITS_MAX = 4, WEIGHT_DROP_MAX = 1;
+constexpr uint32_t CONS_BITS_MASK = 0x0Fu, CONS_GIANT = 0x80u; constexpr int CONS_DROP_SHIFT = 4;      // b_consumed: sub-bucket bits | dropped top bits << 4 | giant flag
 
 
 // ------------------------------------------------------------------------------------------------ B1 expand_count
@@ -228,7 +237,8 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
                                                                   uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
                                                                   TierLists T,
                                                                   const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
-                                                                  uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */)
+                                                                  uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */,
+                                                                  uint32_t drop /* top bits of a k-mer that do not fit the stored key (<= sub_bits of every partition) */)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
@@ -275,13 +285,14 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
         const uint32_t j = b + i, n = s_hist[j];
         const uint32_t g = (uint32_t)(pd.sub_base + j);
-        b_start[g] = pd.key_base + run; b_n[g] = n; b_consumed[g] = (uint8_t)pd.sub_bits;
+        const uint32_t cons = pd.sub_bits | ((drop ? j >> (pd.sub_bits - drop) : 0u) << CONS_DROP_SHIFT);      // the sub-bucket's keys all start with these `drop` bits
+        b_start[g] = pd.key_base + run; b_n[g] = n; b_consumed[g] = (uint8_t)cons;
         if (n > T.cap1) {
             if (n <= T.cap2) wglist_push(&s_big, g, T.big_count, T.big_list);
             else if (n <= T.cap3) wglist_push(&s_wg, g, T.wg_count, T.wg_list);
             else {
                 wglist_push(&s_split, g, T.split_count, T.split_list);
-                if (n > GIANT_MIN) { const uint32_t y = atomicAdd(T.giant_count, 1u); if (y < GIANT_MAX) { T.giant_list[y] = g; b_consumed[g] = (uint8_t)(pd.sub_bits | 0x80u); } }
+                if (n > GIANT_MIN) { const uint32_t y = atomicAdd(T.giant_count, 1u); if (y < GIANT_MAX) { T.giant_list[y] = g; b_consumed[g] = (uint8_t)(cons | CONS_GIANT); } }
             }
         }
         run += (n + 3u) & ~3u;
@@ -309,7 +320,7 @@ constexpr int PAIR_THREADS = 1024;
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
                                                                        const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
-                                                                       uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */)
+                                                                       uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */, uint32_t wb /* weight bits */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub] parked key or EMPTY
     __shared__ uint32_t s_item;
@@ -334,10 +345,10 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         for (; r < r1; r += PAIR_THREADS) {
             const uint64_t R[2] = {nx.x, nx.y};
             if (r + PAIR_THREADS < r1) nx = recs[r + PAIR_THREADS];                  // next record in flight while this one is expanded
-            const unsigned long long wq = R[1] & 3ull;                              // the record's weight - 1 (WEIGHT_BITS below the nucleotides; 0 unless the records were deduplicated)
+            const unsigned long long wq = R[1] & ((1ull << wb) - 1ull);                              // the record's weight - 1 (below the nucleotides; 0 unless the records were deduplicated)
             for_each_kmer16(R, k, [&](uint64_t c) {
                 const uint32_t q = (uint32_t)(c >> pd.shift);
-                unsigned long long h = (c << WEIGHT_BITS) | wq;                      // never all ones: the all-G k-mer is not canonical
+                unsigned long long h = (c << wb) | wq;                               // (a 65th bit falls off: see above) never all ones: neither G..G nor CG..G is canonical
                 for (;;) {
                     const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
                     if (y != EMPTY) {
@@ -377,7 +388,7 @@ __device__ __forceinline__ void lds_xchg128(unsigned long long* slot, uint64_t i
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                         const uint64_t* __restrict__ b_start, u128* __restrict__ keys,
                                                                         const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
-                                                                        uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */)
+                                                                        uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */, uint32_t wb /* weight bits */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub][2] parked key (low word, high word) or EMPTY
   for (;;) {
@@ -404,10 +415,10 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
         for (; r < r1; r += PAIR_THREADS) {
             const uint64_t R[4] = {nx0.x, nx0.y, nx1.x, nx1.y};
             if (r + PAIR_THREADS < r1) { nx0 = recs[2 * (r + PAIR_THREADS)]; nx1 = recs[2 * (r + PAIR_THREADS) + 1]; }   // next record in flight
-            const uint64_t wq = R[3] & 3ull;                                          // the record's weight - 1
+            const uint64_t wq = R[3] & ((1ull << wb) - 1ull);                                                   // the record's weight - 1
             for_each_kmer32(R, k, [&](u128 c) {
                 const uint32_t q = sub_index<2>(c, pd.shift);
-                const u128 st = (c << WEIGHT_BITS) | (u128)wq;                           // never all ones: the all-G k-mer is not canonical
+                const u128 st = (c << wb) | (u128)wq;                                    // (a 129th bit falls off) never all ones: neither G..G nor CG..G is canonical
                 uint64_t h_lo = (uint64_t)st, h_hi = (uint64_t)(st >> 64);
                 for (;;) {
                     uint64_t y_lo, y_hi;
@@ -447,6 +458,7 @@ struct SortOut {
     uint32_t* nd;             // [n_sub] distinct k-mers of the level-1 sub-bucket (they sit at the head of its slot range; a split sub-bucket: anywhere in it)
     uint32_t* ns;             // [n_sub] of those, the ones inside the solidity window (== nd, the same array, when the window is open)
     int32_t amin, amax; uint32_t all_solid;
+    uint32_t wb;              // weight bits below the k-mer in every key of the batch
 };
 
 __device__ __forceinline__ void put_count(const SortOut& O, uint64_t slot, uint32_t c)
@@ -631,12 +643,12 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
 #ifndef GKC_EXP_NOSORT
     bitonic_wave<KW, KPL, F>(v, lane);
 #endif
-    // run-length count (B3), weighted: e = lane*KPL + r is the sorted rank; a key is the k-mer above WEIGHT_BITS bits of (multiplicity - 1): equal k-mers are
+    // run-length count (B3), weighted: e = lane*KPL + r is the sorted rank; a key is the k-mer above O.wb bits of (multiplicity - 1): equal k-mers are
     // adjacent whatever their weights, the abundance of a run is the sum of its weights
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
     const key_t next_first = Shfl<KW>::down(v[0]);
-    constexpr uint32_t WMASK = (1u << WEIGHT_BITS) - 1u;
-    auto differs = [](key_t a, key_t b) -> uint32_t { return ((a ^ b) > (key_t)WMASK) ? 1u : 0u; };
+    const uint32_t WB = O.wb, WMASK = (1u << WB) - 1u;
+    auto differs = [WMASK](key_t a, key_t b) -> uint32_t { return ((a ^ b) > (key_t)WMASK) ? 1u : 0u; };
     // whole-lane bit masks (bit r = rank lane*KPL + r): one compare per key, the tail logic on the masks
     uint32_t neq = lane == 0 ? 1u : differs(v[0], prev_last);                      // k-mer differs from the one before it (rank 0: always)
 #pragma unroll
@@ -677,7 +689,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
             const uint32_t c = run - prevw;                                       // the run that ends here: every weight since the previous run end
             prevw = run;
 #ifndef GKC_EXP_NORLESTORE
-            if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WEIGHT_BITS; else outk[start + idx] = v[r] >> WEIGHT_BITS;
+            if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
             put_count(O, start + idx, c);
 #else
             if (c == 0x7fffffffu) outk[start + idx] = v[r];
@@ -845,8 +857,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
         if (lane == 0 && w > 0) prev_last = s_last[w - 1];
         if (lane == 63 && w < NW - 1) next_first = s_first[w + 1];
         const uint32_t E0 = w * CAPW + lane * KPL;
-        constexpr uint32_t WMASK = (1u << WEIGHT_BITS) - 1u;
-        auto differs = [](key_t a, key_t b) -> bool { return (a ^ b) > (key_t)WMASK; };     // the k-mers above the weight bits differ
+        const uint32_t WB = O.wb, WMASK = (1u << WB) - 1u;
+        auto differs = [WMASK](key_t a, key_t b) -> bool { return (a ^ b) > (key_t)WMASK; };     // the k-mers above the weight bits differ
         uint32_t tailm = 0, inm = 0;
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
             if ((tailm >> r) & 1) {
                 const uint32_t c = run - prevw;
                 prevw = run;
-                if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WEIGHT_BITS; else outk[start + idx] = v[r] >> WEIGHT_BITS;
+                if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
                 put_count(O, start + idx, c); idx++;
                 nsol += ((int32_t)c >= O.amin && (int32_t)c <= O.amax) ? 1u : 0u;
                 const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
@@ -921,16 +933,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
 // at once (round 2 fetched the lists to the host between the levels: ~1 ms of latency per level and batch for 1.3 % of the keys). Results land in the
 // primary key buffer at the piece's own slots; the root's nd / ns counters collect them.
 struct SplitPlan { uint32_t left, bits, shift; };
-__device__ __forceinline__ SplitPlan split_plan(unsigned long long or_lo, unsigned long long or_hi, uint32_t consumed, uint32_t key_bits /* 2k + WEIGHT_BITS */, uint32_t max_bits)
+__device__ __forceinline__ SplitPlan split_plan(unsigned long long or_lo, unsigned long long or_hi, uint32_t consumed, uint32_t key_bits /* 2k + weight bits */, uint32_t max_bits, uint32_t wb)
 {
     const uint32_t diff_bits = or_hi ? 128 - __clzll((long long)or_hi) : (or_lo ? 64 - __clzll((long long)or_lo) : 0);   // number of low bits that may differ between keys
     const uint32_t have = key_bits - consumed;
-    const uint32_t span = diff_bits < have ? diff_bits : have;              // low bits still unused and not shared by all keys; the lowest WEIGHT_BITS are not k-mer bits
-    SplitPlan p; p.left = span > (uint32_t)WEIGHT_BITS ? span - WEIGHT_BITS : 0u; p.bits = 0; p.shift = 0;   // informative k-mer bits (0: all keys are one k-mer)
+    const uint32_t span = diff_bits < have ? diff_bits : have;              // low bits still unused and not shared by all keys; the lowest wb are not k-mer bits
+    SplitPlan p; p.left = span > wb ? span - wb : 0u; p.bits = 0; p.shift = 0;   // informative k-mer bits (0: all keys are one k-mer)
     if (p.left == 0) return p;
     // always as many bits as the tables hold: the pieces that come out small are listed in runs (see k_deep_split), and a cluster under a longer shared prefix spreads
     p.bits = min(max_bits, p.left);
-    p.shift = span - p.bits;                                                // >= WEIGHT_BITS: equal k-mers stay together whatever their weights
+    p.shift = span - p.bits;                                                // >= wb: equal k-mers stay together whatever their weights
     return p;
 }
 struct DeepItem { uint64_t start; uint32_t n; uint32_t root; uint32_t consumed; uint32_t buf; };      // buf: 0 = keys are in the primary buffer, 1 = in the ping-pong buffer
@@ -970,8 +982,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
         DeepItem d;
         if (root_list) {
             const uint32_t g = root_list[it]; const uint32_t cb = b_cons[g];
-            if (cb & 0x80u) continue;                         // a giant: split by many workgroups (k_giant_*)
-            d.start = b_start[g]; d.n = b_n[g]; d.root = g; d.consumed = cb; d.buf = 0;
+            if (cb & CONS_GIANT) continue;                    // a giant: split by many workgroups (k_giant_*)
+            d.start = b_start[g]; d.n = b_n[g]; d.root = g; d.consumed = cb & CONS_BITS_MASK; d.buf = 0;
         } else d = q_in[it];
         if (d.n <= n_lo || d.n > n_hi) continue;              // the other launch's item
         const key_t* src = (d.buf ? keysB : keysA) + d.start;
@@ -993,20 +1005,20 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
 #pragma unroll
                 for (int u = 0; u < DEEP_MLP; u++) v[u] = src[i + u * DEEP_THREADS];
 #pragma unroll
-                for (int u = 0; u < DEEP_MLP; u++) { acc |= v[u] ^ k0; wsum += ((uint32_t)v[u] & ((1u << WEIGHT_BITS) - 1u)) + 1u; }
+                for (int u = 0; u < DEEP_MLP; u++) { acc |= v[u] ^ k0; wsum += ((uint32_t)v[u] & ((1u << O.wb) - 1u)) + 1u; }
             }
-            for (; i < d.n; i += DEEP_THREADS) { const key_t v1 = src[i]; acc |= v1 ^ k0; wsum += ((uint32_t)v1 & ((1u << WEIGHT_BITS) - 1u)) + 1u; }
+            for (; i < d.n; i += DEEP_THREADS) { const key_t v1 = src[i]; acc |= v1 ^ k0; wsum += ((uint32_t)v1 & ((1u << O.wb) - 1u)) + 1u; }
             unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)((u128)acc >> 64);
 #pragma unroll
             for (int dd = 32; dd >= 1; dd >>= 1) { lo |= __shfl_down(lo, dd, 64); hi |= __shfl_down(hi, dd, 64); wsum += __shfl_down(wsum, dd, 64); }
             if (lane == 0) { if (lo) atomicOr(&s_or[0], lo); if (KW == 2 && hi) atomicOr(&s_or[1], hi); atomicAdd(&s_or[2], wsum); }
         }
         __syncthreads();
-        const SplitPlan P = split_plan(s_or[0], s_or[1], d.consumed, two_k, max_bits);
+        const SplitPlan P = split_plan(s_or[0], s_or[1], d.consumed, two_k, max_bits, O.wb);
         const uint32_t left = P.left;
         if (left == 0) {                                       // one k-mer, abundance n (CountNumber is int32)
             if (t == 0) {
-                keysA[d.start] = src[0] >> WEIGHT_BITS;
+                keysA[d.start] = src[0] >> O.wb;
                 const uint32_t c = s_or[2] > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)s_or[2];
                 put_count(O, d.start, c);
                 atomicAdd(&O.histo[c >= O.histo_max ? O.histo_max : c], 1ULL);
@@ -1106,7 +1118,7 @@ constexpr int GIANT_THREADS = 1024, GIANT_MLP = GIANT_CHUNK / GIANT_THREADS;
 struct GiantTables { unsigned long long* gor; uint32_t* ghist; uint32_t* gcur; const uint32_t* list; const uint32_t* count; };   // [MAX][4] (OR low, OR high, total weight), [MAX][MAX_SUB], [MAX][MAX_SUB]
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
-                                                             uint8_t* __restrict__ cnt8)
+                                                             uint8_t* __restrict__ cnt8, uint32_t wb)
 {
     typedef typename KeyT<KW>::type key_t;
     const uint32_t y = blockIdx.y;
@@ -1122,7 +1134,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<
 #pragma unroll
         for (int u = 0; u < GIANT_MLP; u++) { const uint32_t i = c0 + u * GIANT_THREADS + threadIdx.x; v[u] = i < n ? src[i] : k0; }
 #pragma unroll
-        for (int u = 0; u < GIANT_MLP; u++) { acc |= v[u] ^ k0; if (c0 + u * GIANT_THREADS + threadIdx.x < n) wsum += ((uint32_t)v[u] & ((1u << WEIGHT_BITS) - 1u)) + 1u; }
+        for (int u = 0; u < GIANT_MLP; u++) { acc |= v[u] ^ k0; if (c0 + u * GIANT_THREADS + threadIdx.x < n) wsum += ((uint32_t)v[u] & ((1u << wb) - 1u)) + 1u; }
         // the root's abundance plane is read slot by slot by the gather: clear it (start is a multiple of 4)
         for (uint32_t i = threadIdx.x; i < GIANT_CHUNK / 4; i += GIANT_THREADS) if (c0 + 4 * i < n) {
             if (c0 + 4 * i + 4 <= n) reinterpret_cast<uint32_t*>(cnt8 + start + c0)[i] = 0u;
@@ -1136,7 +1148,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_or(const typename KeyT<
 }
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename KeyT<KW>::type* __restrict__ keysA, GiantTables G, const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n,
-                                                               const uint8_t* __restrict__ b_cons, uint32_t two_k, uint32_t max_bits)
+                                                               const uint8_t* __restrict__ b_cons, uint32_t two_k, uint32_t max_bits, uint32_t wb)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_cnt[MAX_SUB];
@@ -1145,7 +1157,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename Key
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     if ((uint64_t)blockIdx.x * GIANT_CHUNK >= n) return;
-    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
+    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & CONS_BITS_MASK, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS), wb);
     if (P.left == 0) return;
     const uint32_t nsub = 1u << P.bits, mask = nsub - 1u;
     for (uint32_t i = threadIdx.x; i < nsub; i += GIANT_THREADS) s_cnt[i] = 0;
@@ -1175,12 +1187,12 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(typename KeyT<KW>:
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
+    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & CONS_BITS_MASK, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS), O.wb);
     if (P.left == 0) {                                         // one k-mer, abundance = the total weight (CountNumber is int32)
         if (t == 0) {
             const unsigned long long wsum = G.gor[4 * y + 2];
             const uint32_t c = wsum > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)wsum;
-            keysA[start] = keysA[start] >> WEIGHT_BITS;         // the k-mer without its weight bits, where the gather expects it
+            keysA[start] = keysA[start] >> O.wb;                // the k-mer without its weight bits, where the gather expects it
             put_count(O, start, c);
             atomicAdd(&O.histo[c >= O.histo_max ? O.histo_max : c], 1ULL);
             atomicAdd(&O.nd[g], 1u);
@@ -1243,7 +1255,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_plan(typename KeyT<KW>:
 template <int KW>
 __global__ __launch_bounds__(GIANT_THREADS) void k_giant_scatter(const typename KeyT<KW>::type* __restrict__ keysA, typename KeyT<KW>::type* __restrict__ keysB, GiantTables G,
                                                                   const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint8_t* __restrict__ b_cons,
-                                                                  uint32_t two_k, uint32_t max_bits)
+                                                                  uint32_t two_k, uint32_t max_bits, uint32_t wb)
 {
     typedef typename KeyT<KW>::type key_t;
     const uint32_t y = blockIdx.y;
@@ -1251,7 +1263,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_scatter(const typename 
     const uint32_t g = G.list[y];
     const uint64_t start = b_start[g]; const uint32_t n = b_n[g];
     if ((uint64_t)blockIdx.x * GIANT_CHUNK >= n) return;
-    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & 0x7Fu, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS));
+    const SplitPlan P = split_plan(G.gor[4 * y], G.gor[4 * y + 1], b_cons[g] & CONS_BITS_MASK, two_k, min(max_bits, (uint32_t)MAX_SUB_BITS), wb);
     if (P.left == 0) return;
     const uint32_t mask = (1u << P.bits) - 1u;
     const key_t* src = keysA + start; key_t* dst = keysB + start;
@@ -1351,9 +1363,12 @@ template <int KW>
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename KeyT<KW>::type* __restrict__ keys, const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ cnt32,
                                                                    const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint32_t* __restrict__ nd,
                                                                    const uint64_t* __restrict__ off_s, uint32_t n_buckets, uint32_t split_min /* sub-buckets beyond were split */,
-                                                                   int32_t amin, int32_t amax, uint32_t all_solid, uint64_t* __restrict__ out)
+                                                                   int32_t amin, int32_t amax, uint32_t all_solid, uint64_t* __restrict__ out,
+                                                                   const uint8_t* __restrict__ b_cons, uint32_t top_shift /* where a sub-bucket's dropped top bit goes back: 2k - 1 */)
 {
     constexpr int OW = (KW == 1) ? 2 : 4;
+    typedef typename KeyT<KW>::type key_t;
+    constexpr uint64_t START_MASK = (1ULL << 62) - 1ULL;          // (slot numbers are far below 2^62: the dropped bit rides on top of the sub-bucket's first slot in LDS)
     __shared__ uint32_t s_pre[GATHER_THREADS / 64][64], s_skip[GATHER_THREADS / 64][64];
     __shared__ uint64_t s_start[GATHER_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1375,21 +1390,22 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
         if (total == 0) continue;
         pre[lane] = x - span;
         skp[lane] = z - rs;
-        sta[lane] = in ? b_start[g] : 0ull;
+        sta[lane] = in ? (b_start[g] | ((uint64_t)((b_cons[g] >> CONS_DROP_SHIFT) & 3u) << 62)) : 0ull;
         uint64_t o = off_s[g0];                                 // first output record of the group
         // (the wave's own LDS writes are visible to its later reads: same wave, in order)
         for (uint32_t s0 = 0; s0 < total; s0 += 64 * GATHER_UNROLL) {
-            uint64_t slot[GATHER_UNROLL]; uint32_t b8[GATHER_UNROLL], sk[GATHER_UNROLL];
+            uint64_t slot[GATHER_UNROLL]; uint32_t b8[GATHER_UNROLL], sk[GATHER_UNROLL], tp[GATHER_UNROLL];
             typename KeyT<KW>::type kk[GATHER_UNROLL];                                  // the keys are fetched with the abundance bytes, not behind them: all loads of a step in flight at once
 #pragma unroll
             for (int u = 0; u < GATHER_UNROLL; u++) {
                 const uint32_t s = s0 + u * 64 + lane;
-                b8[u] = 0; slot[u] = 0; sk[u] = 0; kk[u] = 0;
+                b8[u] = 0; slot[u] = 0; sk[u] = 0; kk[u] = 0; tp[u] = 0;
                 if (s < total) {
                     uint32_t lo = 0;
 #pragma unroll
                     for (int st = 32; st >= 1; st >>= 1) if (pre[lo + st] <= s) lo += st;     // largest b with pre[b] <= s (lo + st <= 63)
-                    slot[u] = sta[lo] + (s - pre[lo]);
+                    const uint64_t st0 = sta[lo];
+                    slot[u] = (st0 & START_MASK) + (s - pre[lo]); tp[u] = (uint32_t)(st0 >> 62);
                     sk[u] = skp[lo];
                     b8[u] = cnt8[slot[u]];
                     kk[u] = keys[slot[u]];
@@ -1403,7 +1419,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
                 const bool ok = c != 0 && (all_solid || ((int32_t)c >= amin && (int32_t)c <= amax));      // CountRange::includes (closed interval)
                 const unsigned long long bal = __ballot(ok);
                 if (ok) {
-                    const typename KeyT<KW>::type key = kk[u];
+                    const key_t key = kk[u] | ((key_t)tp[u] << top_shift);
                     uint64_t* dst = out + (o + sk[u] + __popcll(bal & lt_mask)) * OW;
                     if (KW == 1) store16(dst, (uint64_t)key, (uint64_t)c);
                     else {
@@ -1495,15 +1511,18 @@ __global__ __launch_bounds__(ROOT_THREADS) void k_root_scan(RootTables R)
 template <int KW>
 __global__ __launch_bounds__(256) void k_root_write(const typename KeyT<KW>::type* __restrict__ keys, const uint8_t* __restrict__ cnt8, const uint32_t* __restrict__ cnt32,
                                                     const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint32_t* __restrict__ root_list, RootTables R,
-                                                    const uint64_t* __restrict__ off_s, int32_t amin, int32_t amax, uint32_t all_solid, uint64_t* __restrict__ out)
+                                                    const uint64_t* __restrict__ off_s, int32_t amin, int32_t amax, uint32_t all_solid, uint64_t* __restrict__ out,
+                                                    const uint8_t* __restrict__ b_cons, uint32_t top_shift /* as in k_gather_counts */)
 {
     constexpr int OW = (KW == 1) ? 2 : 4;
+    typedef typename KeyT<KW>::type key_t;
     const int lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ULL << lane) - 1ULL;
     const uint32_t wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
     const uint32_t n_chunks = *R.n_chunks;
     for (uint32_t c = wave; c < n_chunks; c += n_waves) {
         const uint32_t i = R.root_of[c], g = root_list[i];
+        const key_t top = (key_t)((b_cons[g] >> CONS_DROP_SHIFT) & 3u) << top_shift;
         const uint64_t start = b_start[g]; const uint32_t n = b_n[g], s0 = (c - R.base[i]) * ROOT_CHUNK;
         uint64_t o = off_s[g] + (R.cnt[c] - R.cnt[R.base[i]]);
         for (uint32_t j0 = s0; j0 < s0 + ROOT_CHUNK && j0 < n; j0 += 64) {       // (uniform trip count: the ballots see all lanes)
@@ -1513,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_root_write(const typename KeyT<KW>::typ
             const bool ok = cc != 0 && (all_solid || ((int32_t)cc >= amin && (int32_t)cc <= amax));
             const unsigned long long bal = __ballot(ok);
             if (ok) {
-                const typename KeyT<KW>::type key = keys[start + j];
+                const key_t key = keys[start + j] | top;
                 uint64_t* dst = out + (o + __popcll(bal & lt_mask)) * OW;
                 if (KW == 1) store16(dst, (uint64_t)key, (uint64_t)cc);
                 else {
@@ -1559,7 +1578,7 @@ __global__ void k_result_checksum(const uint64_t* __restrict__ recs, uint64_t n,
 //                  reverse complement: the same canonical k-mers either way) is dropped into one of <= 4096 bins of the partition by a hash of its content
 //                  (LDS histogram -> scan -> LDS cursors), in a scratch arena laid out like the partition's records;
 //   k_dedupe_sort  one wave per bin (~64 records): 128-bit register sort, run lengths, and the bin is rewritten in place as one record per run and per
-//                  2^WEIGHT_BITS copies — (copies - 1) in the record's WEIGHT_BITS spare bits below its nucleotides — followed by empty records (nbK = 0: the
+//                  2^wb copies (wb: the batch's weight bits) — (copies - 1) in the record's spare bits below its nucleotides — followed by empty records (nbK = 0: the
 //                  expansion kernels skip them). A bin beyond the wave's registers is left as it is (weights 1).
 // bins of 100..200 records (measured, 1e8 reads, one lane, k_dedupe_bin + k_dedupe_sort per step: mean <= 24: 46.6 ms, 48: 45.8, 96: 45.1, 160: 41.1, 200: 40.3; with 512-record
 // bins and a double-size network, mean <= 320: 44.4, 440: 41.9): fewer bins are fewer open 32-byte sectors per workgroup in the binning scatter — 1024 instead of 4096,
@@ -1689,7 +1708,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
 template <int RW, int KPL>
 __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::KPL_MAX] /* record r * 64 + lane of the bin */, const uint32_t n, const int lane,
                                                 uint64_t* __restrict__ s_win /* [SLOTS][RW] of this wave */,
-                                                DRec<RW> (&rec)[DDCap<RW>::KPL_MAX], uint32_t (&cnt)[DDCap<RW>::KPL_MAX], unsigned long long& in_keys)
+                                                DRec<RW> (&rec)[DDCap<RW>::KPL_MAX], uint32_t (&cnt)[DDCap<RW>::KPL_MAX], unsigned long long& in_keys, const uint32_t WCAP /* copies one record stands for at most */)
 {
     constexpr int KM = DDCap<RW>::KPL_MAX, SB = DDCap<RW>::SLOT_BITS;
     uint64_t key[KPL];
@@ -1722,7 +1741,6 @@ __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(lt, d, 64); if (lane >= d) lt = y > lt ? y : lt; }
     int prev = __shfl_up(lt, 1, 64); if (lane == 0) prev = -1;
-    constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
     uint32_t nout = 0;
 #pragma unroll
     for (int r = 0; r < KPL; r++) if ((tailm >> r) & 1) {
@@ -1737,9 +1755,10 @@ __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::
 template <int RW>
 __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
                                                              uint64_t* __restrict__ rec_end /* [P] */, uint32_t nb, uint32_t* __restrict__ ticket,
-                                                             unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */)
+                                                             unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */, uint32_t wb /* weight bits of the batch */)
 {
     constexpr int KM = DDCap<RW>::KPL_MAX, SLOTS = DDCap<RW>::SLOTS, DDS_WAVES = DDCap<RW>::WAVES;
+    const uint32_t WCAP = 1u << wb;
     __shared__ __attribute__((aligned(16))) uint64_t s_win[DDS_WAVES][SLOTS * RW];      // 64 KB
     __shared__ volatile uint32_t s_next, s_pos;             // bin whose output may be placed now; where
     __shared__ uint32_t s_item;
@@ -1777,10 +1796,10 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
 #pragma unroll
             for (int r = 0; r < KM; r++) cnt[r] = 0;
             uint32_t nout = 0; int kpl = 0;                                   // kpl 0: the bin is moved as it is
-            if (n >= 2 && n <= 64) { nout = dd_sort_bin<RW, 1>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 1; }
-            else if (n > 64 && n <= 128) { nout = dd_sort_bin<RW, 2>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 2; }
-            else if (KM >= 4 && n > 128 && n <= 256) { nout = dd_sort_bin<RW, (KM >= 4 ? 4 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 4; }
-            else if (KM >= 8 && n > 256 && n <= 512) { nout = dd_sort_bin<RW, (KM >= 8 ? 8 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik); kpl = 8; }
+            if (n >= 2 && n <= 64) { nout = dd_sort_bin<RW, 1>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 1; }
+            else if (n > 64 && n <= 128) { nout = dd_sort_bin<RW, 2>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 2; }
+            else if (KM >= 4 && n > 128 && n <= 256) { nout = dd_sort_bin<RW, (KM >= 4 ? 4 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 4; }
+            else if (KM >= 8 && n > 256 && n <= 512) { nout = dd_sort_bin<RW, (KM >= 8 ? 8 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 8; }
             uint32_t x = nout;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
@@ -1800,7 +1819,6 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
             __threadfence_block();
             if (lane == 0) { s_pos = pos0 + total; __threadfence_block(); s_next = bin + 1; }
             if (kpl) {
-                constexpr uint32_t WCAP = 1u << WEIGHT_BITS;
                 uint32_t pos = pos0 + x - nout;
 #pragma unroll
                 for (int r = 0; r < KM; r++) if (cnt[r]) {
@@ -1824,6 +1842,18 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
 
 // ------------------------------------------------------------------------------------------------ host orchestration
 constexpr uint32_t PART_ALIGN = 256;            // a partition's slot range starts on a multiple of this many slots
+// weight bits of a batch whose partitions all have at least min_bits sub-bucket bits (see the note at the top of the file). GKC_WEIGHT_BITS (tests, experiments)
+// asks for a number; it is honoured as far as the keys stay valid.
+template <int KW> static uint32_t weight_bits_of(uint32_t k, uint32_t min_bits)
+{
+    static const int env = getenv("GKC_WEIGHT_BITS") ? atoi(getenv("GKC_WEIGHT_BITS")) : 0;
+    const int stored = 64 * KW, drop_ok = (int)std::min<uint32_t>(min_bits, (uint32_t)WEIGHT_DROP_MAX);
+    const int valid = std::min<int>(WEIGHT_BITS_MAX, stored + drop_ok - 2 * (int)k);               // >= WEIGHT_BITS_MIN for every k the key width is used for
+    int wb = valid;
+    if (KW == 1) wb = std::min<int>(wb, std::max<int>(WEIGHT_BITS_MIN, 52 + (int)min_bits - 2 * (int)k));   // the f64-tagged network is worth more than a weight bit
+    if (env) wb = std::min(env, valid);
+    return (uint32_t)std::max<int>(WEIGHT_BITS_MIN, wb);
+}
 constexpr int DEEP_FIXED = 4;                   // split levels launched unconditionally (a level with an empty queue returns at once); more only if the last one left work
 constexpr int DEEP_COUNTERS = 8;                // per-level counter triples (next level's queue length, sort list length, item ticket), used cyclically
 struct BatchBufs {
@@ -1845,6 +1875,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     uint64_t n_slots = 0, n_sub = 0;
     const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;       // mean keys of a level-1 bucket
     const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
+    const uint32_t wb_goal = weight_bits_of<KW>(k, max_bits1);
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t np = part_keys[batch_parts[i]];
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
@@ -1852,7 +1883,10 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         while (bits < max_bits1 && bits < 2 * k && (np >> bits) > target) bits++;
         // 8-byte keys: a small partition still gets enough sub-buckets for what is left of a key below the sub-bucket index (k-mer + weight bits) to fit a double's
         // mantissa, so that the whole batch sorts with the f64-tagged network (one partition with fewer would switch the batch to the integer network: +30 %)
-        if (KW == 1 && getenv("GKC_MAX_SUB_BITS") == nullptr) while (bits < max_bits1 && 2 * k + WEIGHT_BITS - bits > 52) bits++;
+        // — with the weight bits the batch could have if every partition had all its sub-bucket bits (k = 31: 13 bits for 3 weight bits)
+        if (KW == 1 && getenv("GKC_MAX_SUB_BITS") == nullptr) while (bits < max_bits1 && 2 * k + wb_goal - bits > 52) bits++;
+        // (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can push the key's top bit out)
+        if (KW == 2 && getenv("GKC_MAX_SUB_BITS") == nullptr) while (bits < max_bits1 && bits < 2 * k && 2 * k + wb_goal - bits > 128) bits++;
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pidx[i] = n_sub;
@@ -1861,6 +1895,9 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     }
     pidx[nb] = n_sub;
     if (n_sub >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "too many sub-buckets in one batch");
+    uint32_t min_bits1 = 64; for (uint32_t i = 0; i < nb; i++) min_bits1 = std::min(min_bits1, pd[i].sub_bits);
+    const uint32_t wb = weight_bits_of<KW>(k, nb ? min_bits1 : 0u);
+    const uint32_t drop = 2 * k + wb > 64u * KW ? 2 * k + wb - 64u * KW : 0u;      // top bits of a key that fall off the stored word (<= WEIGHT_DROP_MAX <= min_bits1)
     constexpr uint32_t CAP1 = WaveCapT1<KW>::CAP, CAP2 = WaveCapHuge<KW>::CAP;
     constexpr int K1 = WaveCapHuge<KW>::KPL / 2;
     constexpr uint32_t C1 = 4 * 64 * K1;                                    // workgroup tier: 4 waves x 64 x K1 keys (4096 / 2048)
@@ -1941,7 +1978,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             CB_TRY(c->ensure(B.dd_end, (size_t)Pn * 8));
             ScopedTimer tm(c, "dedupe_sort");
             hipLaunchKernelGGL((k_dedupe_sort<RW>), dim3(std::min(nb, 512u)), dim3(DDCap<RW>::WAVES * 64), 0, cur_stream(c), (uint64_t*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
-                               (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals);
+                               (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals, wb);
             CB_HIP(hipGetLastError());
             segs_b.rec = (const uint8_t* const*)B.dd_ptr.p; segs_b.rec_off = (const uint64_t*)B.dd_off.p; segs_b.n_seg = 1; segs_b.rec_end = (const uint64_t*)B.dd_end.p;
         }
@@ -1949,7 +1986,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     {   ScopedTimer tm(c, "expand_count");
         static const uint32_t cwgs_env = getenv("GKC_COUNT_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_COUNT_WGS"))) : 0u;
         hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nb, cwgs_env) : nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
-                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nb, misc + 7);
+                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nb, misc + 7, drop);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
@@ -1961,12 +1998,12 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             const size_t lds = (size_t)MAX_SUB * 12;
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
-                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6);
+                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6, wb);
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
-                               (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6);
+                               (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6, wb);
         }
         CB_HIP(hipGetLastError());
     }
@@ -1974,10 +2011,10 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     O.cnt8 = (uint8_t*)B.cnt8.p; O.cnt32 = (uint32_t*)B.cnt.p; O.histo = c->histo_of(pass); O.histo_max = c->histo_max;
     O.nd = (uint32_t*)B.nd.p; O.ns = all_solid ? (uint32_t*)B.nd.p : (uint32_t*)B.ns.p; O.amin = c->amin; O.amax = c->amax; O.all_solid = all_solid ? 1u : 0u;
 
+    O.wb = wb;
     // --- the sort tiers, back to back: which sub-bucket goes where was decided by k_expand_count; no host round trip until the totals below
-    uint32_t min_bits1 = 64; for (uint32_t i = 0; i < nb; i++) min_bits1 = std::min(min_bits1, pd[i].sub_bits);
     // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
-    const bool tag = KW == 1 && 2 * k + WEIGHT_BITS - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
+    const bool tag = KW == 1 && 2 * k + wb - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
     constexpr bool FT = KW == 1;
     key_t* const keysA = (key_t*)B.keysA.p; key_t* const keysB = (key_t*)B.keysB.p;
     const uint64_t* const bs = (const uint64_t*)B.b_start.p; const uint32_t* const bn = (const uint32_t*)B.b_n.p; const uint8_t* const bc = (const uint8_t*)B.b_cons.p;
@@ -2022,9 +2059,9 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         const uint32_t bits_small = std::min<uint32_t>(deep_bits, DEEP_SMALL_BITS), bits_large = std::min<uint32_t>(deep_bits, (uint32_t)MAX_SUB_BITS);
         static std::once_flag once_deep; std::call_once(once_deep, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_deep_split<KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)8 << MAX_SUB_BITS)); });
         hipLaunchKernelGGL((k_deep_split<KW>), dim3(deep_grid), dim3(DEEP_THREADS), (size_t)8 << bits_small, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 2, q_out, cn + 0,
-                           (SortItem*)B.sitems.p, cn + 1, 2 * k + WEIGHT_BITS, bits_small, 0u, DEEP_SMALL_N, CAP1, O);
+                           (SortItem*)B.sitems.p, cn + 1, 2 * k + wb, bits_small, 0u, DEEP_SMALL_N, CAP1, O);
         hipLaunchKernelGGL((k_deep_split<KW>), dim3(std::min(deep_grid, 512u)), dim3(DEEP_THREADS), (size_t)8 << bits_large, cur_stream(c), keysA, keysB, roots, bs, bn, bc, q_in, n_in, cn + 3, q_out, cn + 0,
-                           (SortItem*)B.sitems.p, cn + 1, 2 * k + WEIGHT_BITS, bits_large, DEEP_SMALL_N, 0xFFFFFFFFu, CAP1, O);
+                           (SortItem*)B.sitems.p, cn + 1, 2 * k + wb, bits_large, DEEP_SMALL_N, 0xFFFFFFFFu, CAP1, O);
         const unsigned sgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((sort_cap + 3) / 4, 256 * 8));
         if (tag) hipLaunchKernelGGL((k_sort_items<KW, FT>), dim3(sgrid), dim3(SORT_THREADS), 0, cur_stream(c), keysA, (const key_t*)keysB, (const SortItem*)B.sitems.p, (const uint32_t*)(cn + 1), 0u, O);
         else hipLaunchKernelGGL((k_sort_items<KW, false>), dim3(sgrid), dim3(SORT_THREADS), 0, cur_stream(c), keysA, (const key_t*)keysB, (const SortItem*)B.sitems.p, (const uint32_t*)(cn + 1), 0u, O);
@@ -2039,11 +2076,11 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             GiantTables G{ (unsigned long long*)B.giant.p, (uint32_t*)((uint8_t*)B.giant.p + gor_bytes), (uint32_t*)((uint8_t*)B.giant.p + gor_bytes + tab_bytes),
                            (const uint32_t*)T.giant_list, (const uint32_t*)T.giant_count };
             uint32_t* cn = counters_of(1);
-            hipLaunchKernelGGL((k_giant_or<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, (uint8_t*)B.cnt8.p);
-            hipLaunchKernelGGL((k_giant_hist<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, 2 * k + WEIGHT_BITS, deep_bits);
+            hipLaunchKernelGGL((k_giant_or<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, (uint8_t*)B.cnt8.p, wb);
+            hipLaunchKernelGGL((k_giant_hist<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, G, bs, bn, bc, 2 * k + wb, deep_bits, wb);
             hipLaunchKernelGGL((k_giant_plan<KW>), dim3(GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), keysA, G, bs, bn, bc, (DeepItem*)B.q[1].p, cn + 0,
-                               (SortItem*)B.sitems.p, cn + 1, 2 * k + WEIGHT_BITS, deep_bits, CAP1, O);
-            hipLaunchKernelGGL((k_giant_scatter<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysB, G, bs, bn, bc, 2 * k + WEIGHT_BITS, deep_bits);
+                               (SortItem*)B.sitems.p, cn + 1, 2 * k + wb, deep_bits, CAP1, O);
+            hipLaunchKernelGGL((k_giant_scatter<KW>), dim3(GIANT_WGS, GIANT_MAX), dim3(GIANT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysB, G, bs, bn, bc, 2 * k + wb, deep_bits, wb);
             CB_HIP(hipGetLastError());
         }
         for (int level = 1; level <= DEEP_FIXED; level++) CB_TRY(launch_deep(level));
@@ -2093,7 +2130,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         if (n_sub) {
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_sub + 255) / 256, 256 * 16));
             hipLaunchKernelGGL((k_gather_counts<KW>), dim3(grid), dim3(GATHER_THREADS), 0, cur_stream(c), (const key_t*)keysA, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p,
-                               bs, bn, (const uint32_t*)O.nd, (const uint64_t*)B.off_s.p, (uint32_t)n_sub, cap3, c->amin, c->amax, O.all_solid, (uint64_t*)out);
+                               bs, bn, (const uint32_t*)O.nd, (const uint64_t*)B.off_s.p, (uint32_t)n_sub, cap3, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - 1);
             if (h_misc[2]) {                                                       // the split sub-buckets: records at their pieces' heads
                 const uint32_t n_roots = h_misc[2];
                 const uint64_t chunks_cap = n_slots / ROOT_CHUNK + n_roots + 1;
@@ -2104,7 +2141,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
                 hipLaunchKernelGGL(k_root_count, dim3(rgrid), dim3(256), 0, cur_stream(c), (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, bs, bn, (const uint32_t*)T.split_list, R, c->amin, c->amax, O.all_solid);
                 hipLaunchKernelGGL(k_root_scan, dim3(1), dim3(ROOT_THREADS), 0, cur_stream(c), R);
                 hipLaunchKernelGGL((k_root_write<KW>), dim3(rgrid), dim3(256), 0, cur_stream(c), (const key_t*)keysA, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, bs, bn, (const uint32_t*)T.split_list, R,
-                                   (const uint64_t*)B.off_s.p, c->amin, c->amax, O.all_solid, (uint64_t*)out);
+                                   (const uint64_t*)B.off_s.p, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - 1);
             }
             CB_HIP(hipGetLastError());
         }

@@ -848,14 +848,17 @@ def test_exact_repartitor_sample(gkc, k, m, freq):
         assert used == eused and np.array_equal(a, ea) and np.array_equal(b, eb) and np.array_equal(d, ed), (thr, used, eused)
 
 
-@pytest.mark.parametrize("switch", ["GKC_NO_F64", "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0", "GKC_DEEP_BITS=2", "GKC_WG_MAX=1024", "GKC_DEDUPE=0", "GKC_DEDUPE=1", "GKC_MAX_SUB_BITS=1", "GKC_MAX_SUB_BITS=6"])
+@pytest.mark.parametrize("switch", ["GKC_NO_F64", "GKC_SCAN_NO_DESC", "GKC_SCAN_GLOBAL_ATOMICS", "GKC_BATCH_LPT=0", "GKC_DEEP_BITS=2", "GKC_WG_MAX=1024", "GKC_DEDUPE=0", "GKC_DEDUPE=1", "GKC_MAX_SUB_BITS=1", "GKC_MAX_SUB_BITS=6",
+                                    "GKC_WEIGHT_BITS=2", "GKC_WEIGHT_BITS=4", "GKC_WEIGHT_BITS=4,GKC_MAX_SUB_BITS=0", "GKC_WEIGHT_BITS=3,GKC_NO_F64"])
 def test_alternative_kernel_paths_stay_bit_exact(gkc, switch):
     """A/B switches that select another HIP code path of the same library (integer instead of f64-tagged compare-exchange; the Stage A fallbacks: emit pass
     that recomputes instead of reading descriptors, global-atomic cursors instead of LDS ones; partitions in batch order; split levels of 2 bits each, which
     forces more of them than the fixed launches; no workgroup tier; 2 / 64 sub-buckets per partition, which makes every sub-bucket a root of the split levels —
-    with 2 they are "giants" split by many workgroups together): each must give the oracle's records on an input with N's, ragged reads,
-    low-complexity reads (oversize buckets) and enough k-mers per partition for every tier to run — k = 31, k = 41 and k = 63 (the longest records the
-    256-bit canonical form of the deduplication sees).
+    with 2 they are "giants" split by many workgroups together; 2 / 3 / 4 weight bits under the k-mer of a sort key — by default 3 at k = 31 and k = 63, where the
+    key's top bit then lives in the sub-bucket's index and not in the stored word, 4 at k <= 30; a request the partitions' sub-bucket bits cannot carry is cut
+    down): each must give the oracle's records on an input with N's, ragged reads, low-complexity reads (oversize buckets), reads copied 16 .. 50 times (merged
+    records at every weight up to the cap and beyond it), G-rich reads (the stored keys closest to the all-ones padding / EMPTY word) and enough k-mers per
+    partition for every tier to run — k = 30, k = 31, k = 41 and k = 63 (the longest records the 256-bit canonical form of the deduplication sees).
     (The measured-slower round-2 kernels left the product: branch experiments-r02, logs in profiles/r02_*_experiment.txt.)"""
     import json, os, subprocess, sys
     code = r'''
@@ -867,9 +870,11 @@ from tests.util import simple_repart, synth_reads
 gkc = ge.load().gkc
 reads = synth_reads(30000, 60000, 150, seed=97, n_rate=0.001, ragged=True)
 reads += [b"A" * 150] * 300 + [b"ACACACACAC" * 15] * 300 + [(b"ACGTTGCA" * 19)[:150]] * 200
+reads += [b"G" * 150] * 40 + [b"A" + b"G" * 149] * 40 + [b"C" + b"G" * 149] * 20 + [b"T" + b"G" * 100 + b"A" + b"G" * 48] * 17
+reads += [reads[7]] * 50 + [reads[11]] * 16 + [reads[13]] * 17 + [reads[17]] * 33
 bases, offs = gko.pack_reads(reads)
 res = {}
-for k, m, parts in ((31, 8, 3), (41, 9, 2), (63, 10, 2)):
+for k, m, parts in ((30, 8, 3), (31, 8, 3), (41, 9, 2), (63, 10, 2)):
     rep = simple_repart(m, parts)
     c = gkc.Counter(0); c.configure(k, m, parts, rep); c.count(bases, offs)
     ref = gko.Dsk(bases, offs, k, m, parts, rep, threads=4)
@@ -881,7 +886,7 @@ print(json.dumps(res))
         name, _, val = kv.partition("="); env[name] = val or "1"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
-    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"31": True, "41": True, "63": True}
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == {"30": True, "31": True, "41": True, "63": True}
 
 
 def test_read_length_statistics(gkc):

@@ -6,9 +6,9 @@ set -e
 cd "$(dirname "$0")/../gatb-core_amd/csrc"
 name=$1; shift
 rm -rf variants/$name; mkdir -p variants/$name
-for f in gkc_api gkc_scan gkc_count gkc_bloom gkc_fastx gkc_mphf gkc_dist; do
+for f in gkc_api gkc_scan gkc_count gkc_sink gkc_bloom gkc_fastx gkc_mphf gkc_dist; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c $f.hip -o variants/$name/$f.o &
 done
-wait; for f in gkc_api gkc_scan gkc_count gkc_bloom gkc_fastx gkc_mphf gkc_dist; do test -f variants/$name/$f.o || { echo "compile of $f failed"; exit 1; }; done
+wait; for f in gkc_api gkc_scan gkc_count gkc_sink gkc_bloom gkc_fastx gkc_mphf gkc_dist; do test -f variants/$name/$f.o || { echo "compile of $f failed"; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libgkc_hip_$name.so variants/$name/*.o -ldl
 echo built variants/libgkc_hip_$name.so
