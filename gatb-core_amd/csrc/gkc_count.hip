@@ -1067,8 +1067,8 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
             const uint32_t v = s_cnt[b + i];
             if (!v) continue;
             if (v > cap1) cls += 0x10000u;
-            else if (v > M || !merge) cls += 1u;
-            else { const uint32_t e = s_cur[b + i], w = e / M; atomicMin(&s_gs[w], e); atomicMax(&s_ge[w], e + v); }
+            else if (v > M) cls += 1u;
+            else if (merge) { const uint32_t e = s_cur[b + i], w = e / M; atomicMin(&s_gs[w], e); atomicMax(&s_ge[w], e + v); }
         }
         __syncthreads();
         if (merge) for (uint32_t w = t; w < nwin; w += DEEP_THREADS) if (s_ge[w]) cls += 1u;
@@ -1091,9 +1091,41 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
                 if (!v) continue;
                 const uint64_t st = d.start + s_cur[b + i];
                 if (v > cap1) { DeepItem c; c.start = st; c.n = v; c.root = d.root; c.consumed = cons_child; c.buf = d.buf ^ 1u; q_out[iq++] = c; }
-                else if (v > M || !merge) { SortItem si; si.start = st; si.n_buf = v | buf_bit; si.root = d.root; sort_list[is++] = si; }
+                else if (v > M) { SortItem si; si.start = st; si.n_buf = v | buf_bit; si.root = d.root; sort_list[is++] = si; }
             }
             if (merge) for (uint32_t w = t; w < nwin; w += DEEP_THREADS) if (s_ge[w]) {
+                SortItem si; si.start = d.start + s_gs[w]; si.n_buf = (s_ge[w] - s_gs[w]) | buf_bit; si.root = d.root; sort_list[is++] = si;
+            }
+        }
+        // an item of more windows than the tables hold (beyond DEEP_WINDOWS * M keys: a root the giant path did not take, or a huge piece of one): the same
+        // runs, DEEP_WINDOWS windows at a time, each round with its own reservation — every item lists <= 2 n / M + 1 entries whatever its size (the list's
+        // capacity is sized for that: sort_cap in count_batch)
+        if (!merge) for (uint32_t w0 = 0; w0 < nwin; w0 += DEEP_WINDOWS) {
+            const uint32_t nw = min((uint32_t)DEEP_WINDOWS, nwin - w0);
+            __syncthreads();
+            for (uint32_t i = t; i < nw; i += DEEP_THREADS) { s_gs[i] = 0xFFFFFFFFu; s_ge[i] = 0u; }
+            __syncthreads();
+            for (uint32_t i = 0; i < per; i++) if (b + i < nsub) {
+                const uint32_t v = s_cnt[b + i];
+                if (!v || v > M) continue;
+                const uint32_t e = s_cur[b + i], w = e / M;
+                if (w >= w0 && w - w0 < nw) { atomicMin(&s_gs[w - w0], e); atomicMax(&s_ge[w - w0], e + v); }
+            }
+            __syncthreads();
+            uint32_t c2 = 0;
+            for (uint32_t w = t; w < nw; w += DEEP_THREADS) if (s_ge[w]) c2++;
+            uint32_t y2 = c2;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t yy = __shfl_up(y2, dd, 64); if (lane >= dd) y2 += yy; }
+            if (lane == 63) s_wsum[wave] = y2;
+            __syncthreads();
+            uint32_t pre2 = y2 - c2, tot2 = 0;
+            for (int w = 0; w < DEEP_THREADS / 64; w++) { if (w < wave) pre2 += s_wsum[w]; tot2 += s_wsum[w]; }
+            if (t == 0) s_base_sort = tot2 ? atomicAdd(n_sort_p, tot2) : 0u;
+            __syncthreads();
+            uint32_t is = s_base_sort + pre2;
+            const uint32_t buf_bit = (d.buf ^ 1u) << 31;
+            for (uint32_t w = t; w < nw; w += DEEP_THREADS) if (s_ge[w]) {
                 SortItem si; si.start = d.start + s_gs[w]; si.n_buf = (s_ge[w] - s_gs[w]) | buf_bit; si.root = d.root; sort_list[is++] = si;
             }
         }
@@ -1844,9 +1876,10 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
 constexpr uint32_t PART_ALIGN = 256;            // a partition's slot range starts on a multiple of this many slots
 // weight bits of a batch whose partitions all have at least min_bits sub-bucket bits (see the note at the top of the file). GKC_WEIGHT_BITS (tests, experiments)
 // asks for a number; it is honoured as far as the keys stay valid.
+static int weight_bits_env() { static const int env = getenv("GKC_WEIGHT_BITS") ? atoi(getenv("GKC_WEIGHT_BITS")) : 0; return env; }
 template <int KW> static uint32_t weight_bits_of(uint32_t k, uint32_t min_bits)
 {
-    static const int env = getenv("GKC_WEIGHT_BITS") ? atoi(getenv("GKC_WEIGHT_BITS")) : 0;
+    const int env = weight_bits_env();
     const int stored = 64 * KW, drop_ok = (int)std::min<uint32_t>(min_bits, (uint32_t)WEIGHT_DROP_MAX);
     const int valid = std::min<int>(WEIGHT_BITS_MAX, stored + drop_ok - 2 * (int)k);               // >= WEIGHT_BITS_MIN for every k the key width is used for
     int wb = valid;
@@ -1876,17 +1909,28 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;       // mean keys of a level-1 bucket
     const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
     const uint32_t wb_goal = weight_bits_of<KW>(k, max_bits1);
+    const int stored_or_mantissa = KW == 1 ? 52 : 128;
+    const uint32_t need_goal = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + (int)wb_goal - stored_or_mantissa));
+    const uint32_t need_min = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + WEIGHT_BITS_MIN - stored_or_mantissa));
+    bool goal_ok = weight_bits_env() != 0;              // (weight bits asked for: the sub-bucket bits they need, whatever the sizes)
+    {   uint64_t tot = 0; for (uint32_t i = 0; i < nb; i++) tot += part_keys[batch_parts[i]];
+        const uint64_t mean = nb ? tot / nb : 0;
+        uint32_t bm = 0; while (bm < max_bits1 && (mean >> bm) > target) bm++;
+        goal_ok = goal_ok || bm + 1 >= need_goal;
+    }
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t np = part_keys[batch_parts[i]];
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
         uint32_t bits = 0;
         while (bits < max_bits1 && bits < 2 * k && (np >> bits) > target) bits++;
         // 8-byte keys: a small partition still gets enough sub-buckets for what is left of a key below the sub-bucket index (k-mer + weight bits) to fit a double's
-        // mantissa, so that the whole batch sorts with the f64-tagged network (one partition with fewer would switch the batch to the integer network: +30 %)
-        // — with the weight bits the batch could have if every partition had all its sub-bucket bits (k = 31: 13 bits for 3 weight bits)
-        if (KW == 1 && getenv("GKC_MAX_SUB_BITS") == nullptr) while (bits < max_bits1 && 2 * k + wb_goal - bits > 52) bits++;
-        // (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can push the key's top bit out)
-        if (KW == 2 && getenv("GKC_MAX_SUB_BITS") == nullptr) while (bits < max_bits1 && bits < 2 * k && 2 * k + wb_goal - bits > 128) bits++;
+        // mantissa, so that the whole batch sorts with the f64-tagged network (one partition with fewer would switch the batch to the integer network: +30 %).
+        // With which weight bits? Those the batch could have at best (wb_goal; k = 31: 3, which takes all 13 sub-bucket bits) if its MEAN partition is within one
+        // bit of what they need — the few small partitions of such a batch then get the bits too; a batch of small partitions (32768 partitions of 4.5e5 k-mers:
+        // 10 bits) only gets what the smallest weights need — twice the sub-buckets for a few dozen keys each cost more than the third weight bit saves (the
+        // 8-GPU share: 325 -> 369 ms) — and runs with fewer weight bits. (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can
+        // push the key's top bit out.)
+        if (getenv("GKC_MAX_SUB_BITS") == nullptr) bits = std::min<uint32_t>(std::max(bits, goal_ok ? need_goal : need_min), 2 * k);
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pidx[i] = n_sub;

@@ -889,6 +889,40 @@ print(json.dumps(res))
     assert json.loads(out.stdout.strip().splitlines()[-1]) == {"30": True, "31": True, "41": True, "63": True}
 
 
+def test_split_items_beyond_the_window_tables():
+    """A split item of more keys than DEEP_WINDOWS windows of cap1 / 2 slots cover (5.2e5 keys with 8-byte keys) that the giant path did not take — the 65th ..
+    80th root beyond GIANT_MIN keys of a batch — lists its small pieces as runs too, DEEP_WINDOWS windows at a time (it used to list every small piece on its own:
+    up to 8192 entries against a list sized for 4 n / cap1 + 1). GKC_MAX_SUB_BITS=0 makes every partition one sub-bucket, i.e. one root: 80 partitions of > 5.3e5
+    k-mers each are 64 giants and 16 such items. Records and histogram against the oracle; the independent checksum kernel agrees as well."""
+    import json, os, subprocess, sys
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+from oracle import gko
+from tests.util import simple_repart
+gkc = ge.load().gkc
+k, m, parts, n, L = 31, 8, 80, 600000, 150
+rep = simple_repart(m, parts)
+c = gkc.Counter(0); c.configure(k, m, parts, rep)
+db, do = c.synth_reads_device(11, n, L, 2000000, 10000)
+bases = c.device_to_host(db, n * L); offs = np.arange(n + 1, dtype=np.uint64) * L
+cs, nv = c.kmer_checksum_device(db, do, n, n * L)
+c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+ref = gko.Dsk(bases, offs, k, m, parts, rep, threads=8)
+big = sum(1 for p in range(parts) if int(ref.part_records(p).view(np.uint64).reshape(-1, 2)[:, 1].sum()) > 530000)      # k-mers of the partition = the sum of its abundances
+ok = all(np.array_equal(c.partition_records(0, p), ref.part_records(p)) for p in range(parts)) and np.array_equal(c.histogram(), ref.histogram())
+got = c.result_checksum()
+print(json.dumps({"ok": bool(ok), "checksum": (int(got[0]), int(got[1])) == (int(cs), int(nv)), "roots": int(c.stats()["oversize_buckets"]), "big": int(big)}))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["GKC_MAX_SUB_BITS"] = "0"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] and res["checksum"], res
+    assert res["roots"] == 80 and res["big"] >= 68, res                     # every partition went to the split levels, (nearly) all beyond the window tables
+
+
 def test_read_length_statistics(gkc):
     """gkc_stats.seq_len_min / max / sq_sum: BankStats::update (BankKmers.hpp:176-186) over every pushed read, several pushes"""
     reads = synth_reads(3000, 9000, 150, seed=5, n_rate=0.001, ragged=True) + [b"ACGT" * 3, b"A" * 700]
