@@ -256,9 +256,10 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
         dt = (time.perf_counter() - t0) / ns_
         st = c.stats()
         landed = st["kmers_nb_solid"] * 16
-        # what crosses the link: the batches travel packed (csrc/gkc_sink.hip) unless GKC_SINK_PACKED=0 — 7 bytes per record where the partitions are dense, 8 where sparse
-        packed = os.environ.get("GKC_SINK_PACKED", "1") != "0"
-        wire = st["kmers_nb_solid"] * ((7 if st["kmers_nb_solid"] / max(1, parts) >= 300000 else 8) if packed else 16)
+        # what crosses the link: the batches travel packed (csrc/gkc_sink.hip) unless GKC_SINK_PACKED=0 — 6.3 bytes per record where the partitions are dense and most
+        # abundances are 1, 7 where dense, 8 where sparse; the library counts the bytes it queued (gkc_stats.reserved[1])
+        packed = st.get("sink_wire_bytes", 0) > 0
+        wire = st["sink_wire_bytes"] if packed else st["kmers_nb_solid"] * 16
         err = (c.L.gkc_last_error(c.h) or b"").decode()
         out["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s with every solid Count[] in page-locked host memory",
                                           "ms_per_step": dt * 1e3, "steps": ns_, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,

@@ -634,6 +634,7 @@ int gkc_get_stats(gkc_ctx* c, gkc_stats* out)
         t.superkmer_bytes += S.superkmer_bytes; t.oversize_buckets += S.oversize_buckets; t.dedupe_kmers_in += S.dedupe_kmers_in; t.dedupe_keys_out += S.dedupe_keys_out;
     }
     if (c->pass < c->pass_stats.size()) t.reserved[0] = c->pass_stats[c->pass].nb_sequences;      // pass_nb_sequences: reads pushed in the CURRENT pass (nb_sequences is pass 0's)
+    t.reserved[1] = c->sink_wire_bytes;                                                            // bytes the packed result batches of the last counted pass took on the link
     *out = t;
     return GKC_OK;
 }

@@ -2,6 +2,8 @@
 // memory, and at abundance-min 1 that is 16 bytes per distinct k-mer over PCIe — 58 GB per 10^8 reads, 1.1 s at the 52 GB/s the link gives, five times the
 // counting itself. The records of a partition are ascending keys with small abundances, so what crosses the link is
 //     per block of PK_BLOCK records: the first key (8 bytes), then per record 6 bytes of key DELTA + 1 byte of abundance            = 7 bytes instead of 16
+//     — and at abundance-min 1, where most records are the singletons of sequencing errors (84 % of the 30x input), the abundance byte travels only for the
+//     records whose abundance is NOT 1: 6 bytes of delta + 1 bit in the block's bitmap + a byte in the batch's abundance stream for those = 6.3 bytes (PK6)
 // and library threads on the host expand it into the exact in-memory layout of Kmer<span>::Count ({u64 value; i32 abundance; pad}, Abundance.hpp:68-129) at its
 // place in the caller's sink: what gkc_wait_partition hands out is byte for byte what the unpacked copy would have been (tests: the sink against
 // gkc_partition_counts). Rare values leave through an exception list (record index, value): a delta of 2^48-1 or more (the delta field then holds the escape
@@ -32,6 +34,11 @@ constexpr uint64_t pk_slot(int W) { return (uint64_t)PK_BLOCK * (uint64_t)W; }  
 constexpr uint64_t pk_esc(int W) { return (1ull << (8 * (W - 1))) - 1ull; }
 constexpr uint64_t PK_KEY_EXC = 1ull << 63;
 constexpr uint64_t PK_DENSE = 300000;                                   // records per partition from which 6-byte deltas are used
+// PK6 (width 6): a block slot = PK_BLOCK 6-byte deltas (escape 2^48 - 1 as in width 7) + a bitmap of PK_BLOCK bits (abundance != 1); the abundance bytes of the
+// flagged records, in record order, sit in the batch's abundance stream from the block's offset on (u32 per block in the header, written by the block's workgroup
+// after ONE reservation on the stream's cursor: the order of the blocks in the stream is whatever it came out as)
+constexpr uint64_t PK6_ENTRIES = (uint64_t)PK_BLOCK * 6, PK6_SLOT = PK6_ENTRIES + PK_BLOCK / 8;                 // 49152 + 1024 bytes: a multiple of 16
+constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PK6_SLOT : pk_slot(width); }
 }
 
 struct PackPlan { const uint32_t* blk_first; /* [nb + 1] first block slot of every partition of the batch */ const uint64_t* ptot; /* [2 (nb + 1)] (distinct, solid) prefixes */ uint32_t nb; };
@@ -85,12 +92,79 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __re
     }
 }
 
+__global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint32_t* __restrict__ cb_off,
+                                                             uint8_t* __restrict__ payload, uint8_t* __restrict__ cb_stream, unsigned long long* __restrict__ cb_cursor,
+                                                             uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
+{
+    constexpr uint64_t PK_ESC = pk_esc(7);
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 6];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bits[PK_BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cb[PK_BLOCK];
+    __shared__ uint32_t s_p, s_wcnt[PK_THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) {                                               // partition of block slot g: the largest p with blk_first[p] <= g
+        uint32_t lo = 0, hi = P.nb;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.blk_first[mid] <= g) lo = mid; else hi = mid; }
+        s_p = lo;
+    }
+    for (uint32_t i = t; i < PK_BLOCK / 64; i += PK_THREADS) s_bits[i] = 0ull;
+    __syncthreads();
+    const uint32_t p = s_p, j = g - P.blk_first[p];
+    const uint64_t s1 = P.ptot[2 * (p + 1) + 1], r0 = P.ptot[2 * p + 1] + (uint64_t)j * PK_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)PK_BLOCK, s1 - r0);
+    if (t == 0) bases[g] = recs[2 * r0];
+    uint8_t* dstp = payload + (uint64_t)g * PK6_SLOT;
+    uint32_t run = 0;                                           // flagged records of the chunks before this one (the same in every thread)
+    for (uint32_t i0 = 0; i0 < n; i0 += PK_THREADS) {
+        const uint32_t i = i0 + t;
+        uint64_t d = 0; uint32_t ab8 = 1;
+        if (i < n) {
+            const ulonglong2 me = *reinterpret_cast<const ulonglong2*>(recs + 2 * (r0 + i));
+            const uint64_t prev = i ? recs[2 * (r0 + i - 1)] : me.x;
+            d = me.x - prev;
+            if (d >= PK_ESC) {
+                const unsigned long long e = atomicAdd(n_exc, 1ull);
+                if (e < exc_cap) { exc[2 * e] = PK_KEY_EXC | (r0 + i); exc[2 * e + 1] = me.x; }
+                d = PK_ESC;
+            }
+            const uint32_t ab = (uint32_t)me.y;
+            ab8 = ab;
+            if (ab >= 255u) {
+                const unsigned long long e = atomicAdd(n_exc, 1ull);
+                if (e < exc_cap) { exc[2 * e] = r0 + i; exc[2 * e + 1] = ab; }
+                ab8 = 255u;
+            }
+        }
+        const bool flag = ab8 != 1u;
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) { s_bits[(i0 >> 6) + wave] = bal; s_wcnt[wave] = (uint32_t)__popcll(bal); }
+        uint8_t* o = s_out + 6 * t;
+#pragma unroll
+        for (int b = 0; b < 6; b++) o[b] = (uint8_t)(d >> (8 * b));
+        __syncthreads();
+        uint32_t before = run, total = 0;
+#pragma unroll
+        for (int w = 0; w < PK_THREADS / 64; w++) { if (w < (int)wave) before += s_wcnt[w]; total += s_wcnt[w]; }
+        if (flag) s_cb[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)ab8;
+        run += total;
+        if (t < PK_THREADS * 6 / 16) reinterpret_cast<uint4*>(dstp + (uint64_t)i0 * 6)[t] = reinterpret_cast<const uint4*>(s_out)[t];      // 1536 bytes = 96 x 16
+        __syncthreads();
+    }
+    if (t < PK_BLOCK / 8 / 16) reinterpret_cast<uint4*>(dstp + PK6_ENTRIES)[t] = reinterpret_cast<const uint4*>(s_bits)[t];               // the bitmap: 1024 bytes = 64 x 16
+    if (t == 0) { s_base = run ? atomicAdd(cb_cursor, (unsigned long long)run) : 0ull; cb_off[g] = (uint32_t)s_base; }                   // (the stream is shorter than 2^32 bytes: one byte per record at most)
+    __syncthreads();
+    uint8_t* cb = cb_stream + s_base;
+    for (uint32_t i = t; i < run; i += PK_THREADS) cb[i] = s_cb[i];
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct SinkBatch {
     hipEvent_t copied = nullptr;                 // the batch's packed bytes are in the staging buffer
     hipEvent_t copy_start = nullptr;             // GKC_SINK_DEBUG: when the copy stream got to it
     const uint8_t* stage = nullptr;              // [bases: 8 x nblk, padded to 64][payload: nblk x PK_SLOT][exceptions: 16 x n_exc]
     uint64_t nblk = 0, n_exc = 0, pay_off = 0, exc_off = 0; int width = 7;
+    uint64_t cboff_off = 0, cb_off = 0, n_cb = 0;        // width 6: the blocks' offsets into the abundance stream (u32 each), the stream, its length
     std::vector<uint64_t> blk_rec0; std::vector<uint32_t> blk_n;       // per block: first record (index in the batch), records
     uint8_t* dest = nullptr;                     // the batch's records in the caller's sink
     void* d_packed = nullptr;                    // device buffer, given back once copied
@@ -132,7 +206,30 @@ struct gkc_unpacker {
             _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));      // {u64 value; i32 abundance; 4 bytes of padding = 0}
         }
     }
-    static void unpack_block(const SinkBatch& B, uint64_t g) { if (B.width == 7) unpack_block_w<7>(B, g); else unpack_block_w<8>(B, g); }
+    static void unpack_block_6(const SinkBatch& B, uint64_t g)
+    {
+        constexpr uint64_t PK_ESC = pk_esc(7);
+        const uint8_t* pay = B.stage + B.pay_off + g * PK6_SLOT;
+        const uint64_t* bits = reinterpret_cast<const uint64_t*>(pay + PK6_ENTRIES);
+        const uint8_t* cb = B.stage + B.cb_off + reinterpret_cast<const uint32_t*>(B.stage + B.cboff_off)[g];
+        const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
+        uint64_t key = reinterpret_cast<const uint64_t*>(B.stage)[g];
+        __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 16);
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            uint64_t m = bits[i0 >> 6];
+            const uint32_t e = std::min<uint32_t>(n, i0 + 64);
+            for (uint32_t i = i0; i < e; i++, m >>= 1) {
+                uint64_t w; memcpy(&w, pay + 6 * (size_t)i, 8);      // (two bytes beyond the entry: the next entry or the bitmap)
+                const uint64_t d = w & PK_ESC;
+                if (i) key = d == PK_ESC ? lookup(B.exc, PK_KEY_EXC | (r0 + i)) : key + d;
+                const uint32_t f = (uint32_t)(m & 1ull);                 // 16 % of the records, at random: no branch on it (the byte under the cursor is read either way;
+                uint32_t ab = 1u + f * ((uint32_t)*cb - 1u); cb += f;    // the stream is followed by padding)
+                if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
+                _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));
+            }
+        }
+    }
+    static void unpack_block(const SinkBatch& B, uint64_t g) { if (B.width == 6) unpack_block_6(B, g); else if (B.width == 7) unpack_block_w<7>(B, g); else unpack_block_w<8>(B, g); }
     void worker()
     {
         (void)hipSetDevice(c->device);
@@ -172,7 +269,7 @@ struct gkc_unpacker {
                         const auto now = std::chrono::steady_clock::now();
                         float copy_ms = -1; if (B->copy_start) (void)hipEventElapsedTime(&copy_ms, B->copy_start, B->copied);
                         fprintf(stderr, "[gkc sink] batch of %llu blocks (%.2f GB packed, %llu exceptions): pack %.1f ms, queued -> copied %.1f ms (the copy itself %.1f ms), unpack %.1f ms\n", (unsigned long long)B->nblk,
-                                (double)(B->nblk * pk_slot(B->width)) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
+                                (double)(B->nblk * pk_slot_of(B->width) + B->n_cb) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
                                 std::chrono::duration<double, std::milli>(now - B->t_ready).count());
                     }
                     { std::lock_guard<std::mutex> lk(mu); B->done.store(true); }
@@ -270,7 +367,7 @@ void gkc_sink_reset(gkc_ctx* c)
         U->queue.clear();
     }
     for (SinkBatch* B : U->all) { if (B->copied) (void)hipEventDestroy(B->copied); if (B->copy_start) (void)hipEventDestroy(B->copy_start); if (B->d_packed) c->dfree(B->d_packed); delete B; }
-    U->all.clear(); U->staging_used = 0;
+    U->all.clear(); U->staging_used = 0; c->sink_wire_bytes = 0;
 }
 void gkc_sink_drain(gkc_ctx* c)
 {
@@ -312,35 +409,50 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     for (uint32_t i = 0; i < nb; i++) { blk_first[i] = (uint32_t)nblk; nblk += (solid_prefix[i + 1] - solid_prefix[i] + PK_BLOCK - 1) / PK_BLOCK; }
     blk_first[nb] = (uint32_t)nblk;
     if (nblk == 0 || nblk >= (1ull << 31)) return nullptr;
-    const int width = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= PK_DENSE ? 7 : 8;
-    const uint64_t bases_bytes = (nblk * 8 + 63) / 64 * 64, pay_bytes = nblk * pk_slot(width);
+    // width of an entry: 8 where the partitions are sparse, 7 where dense, 6 (+ bitmap + abundance stream) where dense and most abundances are 1 — expected at
+    // abundance-min 1 (sequencing errors) and checked batch by batch: a batch whose stream came out longer than 0.85 bytes per record switches the context back to 7
+    static const bool no6 = getenv("GKC_SINK_WIDTH6") && atoi(getenv("GKC_SINK_WIDTH6")) == 0;
+    static const uint64_t dense_min = getenv("GKC_SINK_DENSE") ? (uint64_t)atoll(getenv("GKC_SINK_DENSE")) : PK_DENSE;      // (tests: 1 = every batch is "dense")
+    const bool dense = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= dense_min;
+    const int width = !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;
+    const uint64_t n_rec = solid_prefix[nb];
+    const uint64_t bases_bytes = (nblk * 8 + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0, hdr_bytes = bases_bytes + cboff_bytes;
+    const uint64_t pay_bytes = nblk * pk_slot_of(width), cb_cap = width == 6 ? (n_rec + 63) / 64 * 64 : 0;
     const uint32_t exc_cap = 1u << 20;
     DevBuf d_first; if (c->ensure(d_first, (size_t)(nb + 1) * 4) != GKC_OK) return nullptr;
-    uint8_t* d_packed = (uint8_t*)c->dalloc((size_t)(bases_bytes + pay_bytes + (uint64_t)exc_cap * 16 + 64));
+    uint8_t* d_packed = (uint8_t*)c->dalloc((size_t)(hdr_bytes + pay_bytes + cb_cap + (uint64_t)exc_cap * 16 + 64));
     if (!d_packed) { d_first.release(); return nullptr; }
     hipStream_t st = cur_stream(c);
     const auto t_pack0 = std::chrono::steady_clock::now();
-    unsigned long long* d_nexc = reinterpret_cast<unsigned long long*>(d_packed + bases_bytes + pay_bytes + (uint64_t)exc_cap * 16);
-    unsigned long long h_nexc = 0;
+    uint8_t* const d_pay = d_packed + hdr_bytes; uint8_t* const d_cb = d_pay + pay_bytes; uint8_t* const d_exc = d_cb + cb_cap;
+    unsigned long long* d_nexc = reinterpret_cast<unsigned long long*>(d_exc + (uint64_t)exc_cap * 16);        // [0] exceptions [1] bytes of the abundance stream
+    unsigned long long h_cnt[2] = {0, 0};
     bool ok = hipMemcpyAsync(d_first.p, blk_first.data(), (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess
-           && hipMemsetAsync(d_nexc, 0, 8, st) == hipSuccess;
+           && hipMemsetAsync(d_nexc, 0, 16, st) == hipSuccess;
     if (ok) {
         PackPlan P{ (const uint32_t*)d_first.p, d_ptot, nb };
-        if (width == 7) hipLaunchKernelGGL((k_pack_counts<7>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_packed + bases_bytes,
-                                           (uint64_t*)(d_packed + bases_bytes + pay_bytes), d_nexc, exc_cap);
-        else hipLaunchKernelGGL((k_pack_counts<8>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_packed + bases_bytes,
-                                (uint64_t*)(d_packed + bases_bytes + pay_bytes), d_nexc, exc_cap);
-        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(&h_nexc, d_nexc, 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        if (width == 6) hipLaunchKernelGGL(k_pack_counts6, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, (uint32_t*)(d_packed + bases_bytes),
+                                           d_pay, d_cb, d_nexc + 1, (uint64_t*)d_exc, d_nexc, exc_cap);
+        else if (width == 7) hipLaunchKernelGGL((k_pack_counts<7>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
+                                                (uint64_t*)d_exc, d_nexc, exc_cap);
+        else hipLaunchKernelGGL((k_pack_counts<8>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
+                                (uint64_t*)d_exc, d_nexc, exc_cap);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h_cnt, d_nexc, 16, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     }
     d_first.release();
-    if (!ok || h_nexc > exc_cap) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
+    const unsigned long long h_nexc = h_cnt[0], h_ncb = h_cnt[1];
+    if (!ok || h_nexc > exc_cap || h_ncb > cb_cap) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
+    if (width == 6 && (double)h_ncb > 0.85 * (double)n_rec) c->sink_no6 = true;      // (this batch still travels as it was packed: 7.1 bytes per record at worst)
     SinkBatch* B = new SinkBatch();
-    const uint64_t need = bases_bytes + pay_bytes + h_nexc * 16 + 64;
+    const uint64_t cb_stage = (h_ncb + 63) / 64 * 64;
+    const uint64_t need = hdr_bytes + pay_bytes + cb_stage + h_nexc * 16 + 64;
     {   std::lock_guard<std::mutex> lk(c->mu);
         if (U->staging_used + need > U->staging_cap) { delete B; c->dfree(d_packed); return nullptr; }
         B->stage = U->staging + U->staging_used; U->staging_used += (need + 63) / 64 * 64;
+        c->sink_wire_bytes += hdr_bytes + pay_bytes + h_ncb + h_nexc * 16;
     }
-    B->nblk = nblk; B->n_exc = h_nexc; B->width = width; B->pay_off = bases_bytes; B->exc_off = bases_bytes + pay_bytes; B->dest = h_dest; B->d_packed = d_packed;
+    B->nblk = nblk; B->n_exc = h_nexc; B->width = width; B->pay_off = hdr_bytes; B->cboff_off = bases_bytes; B->cb_off = hdr_bytes + pay_bytes; B->n_cb = h_ncb;
+    B->exc_off = hdr_bytes + pay_bytes + cb_stage; B->dest = h_dest; B->d_packed = d_packed;
     B->blk_rec0.resize(nblk); B->blk_n.resize(nblk);
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t s0 = solid_prefix[i], s1 = solid_prefix[i + 1];
@@ -348,8 +460,9 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     }
     if (g_sink_debug && hipEventCreate(&B->copy_start) == hipSuccess) (void)hipEventRecord(B->copy_start, c->copy_stream);
     bool queued = hipEventCreateWithFlags(&B->copied, g_sink_debug ? hipEventDefault : hipEventDisableTiming) == hipSuccess
-               && hipMemcpyAsync((void*)B->stage, d_packed, (size_t)(bases_bytes + pay_bytes), hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess
-               && (h_nexc == 0 || hipMemcpyAsync((void*)(B->stage + B->exc_off), d_packed + B->exc_off, (size_t)h_nexc * 16, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
+               && hipMemcpyAsync((void*)B->stage, d_packed, (size_t)(hdr_bytes + pay_bytes), hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess
+               && (h_ncb == 0 || hipMemcpyAsync((void*)(B->stage + B->cb_off), d_cb, (size_t)h_ncb, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
+               && (h_nexc == 0 || hipMemcpyAsync((void*)(B->stage + B->exc_off), d_exc, (size_t)h_nexc * 16, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
                && hipEventRecord(B->copied, c->copy_stream) == hipSuccess;
     if (!queued) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); if (B->copied) (void)hipEventDestroy(B->copied); delete B; c->dfree(d_packed); return nullptr; }
     B->t_queued = std::chrono::steady_clock::now(); B->pack_ms = std::chrono::duration<double, std::milli>(B->t_queued - t_pack0).count();

@@ -372,7 +372,9 @@ class Counter:
 
     def stats(self):
         s = Stats(); self._chk(self.L.gkc_get_stats(self.h, C.byref(s)))
-        return {n: getattr(s, n) for n, _ in Stats._fields_ if n != "reserved"}
+        d = {n: getattr(s, n) for n, _ in Stats._fields_ if n != "reserved"}
+        d["pass_nb_sequences"] = int(s.reserved[0]); d["sink_wire_bytes"] = int(s.reserved[1])
+        return d
 
     def timing(self, name):
         ms = C.c_double(); n = C.c_uint64()

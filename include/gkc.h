@@ -146,7 +146,8 @@ typedef struct gkc_stats {
     uint64_t seq_len_min;         /* pass 0 only: shortest / longest read and the sum of the squared read lengths — what BankStats::update keeps   */
     uint64_t seq_len_max;         /* (BankKmers.hpp:164-200: seq_size_min / max / deviation of getInfo(), SortingCountAlgorithm.cpp:735-739);       */
     uint64_t seq_len_sq_sum;      /* seq_len_min is 0 when no read was pushed                                                                       */
-    uint64_t reserved[2];
+    uint64_t reserved[2];         /* [0] reads pushed in the CURRENT pass (nb_sequences is pass 0's); [1] bytes the packed result batches of the last counted pass took on
+                                     the link to the host sink (gkc_set_host_sink; 0: nothing travelled packed)                                                       */
 } gkc_stats;
 int gkc_get_stats(gkc_ctx* ctx, gkc_stats* out);
 

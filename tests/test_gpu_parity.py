@@ -743,6 +743,60 @@ def test_packed_sink_escapes_and_block_boundaries(gkc, k, amin):
     c.set_host_sink(None)
 
 
+@pytest.mark.parametrize("switch", ["GKC_SINK_DENSE=1", "GKC_SINK_DENSE=1,GKC_SINK_WIDTH6=0", "GKC_SINK_DENSE=1,GKC_UNPACK_THREADS=1"])
+def test_packed_sink_entry_widths(switch):
+    """The three entry widths of the packed transfer on the same inputs (GKC_SINK_DENSE=1 declares every batch dense): 6-byte deltas + abundance bitmap + abundance
+    stream (abundance-min 1, the default there), 7-byte entries (GKC_SINK_WIDTH6=0, and abundance-min 2), with delta escapes (k=31: few records per partition, gaps
+    beyond 2^48), abundance escapes (a read copied 700 times), partitions of several blocks (k=15) and an empty one; an error-free input (nearly every abundance
+    > 1) makes the first batch switch the context from 6 to 7 for the following ones. What lands in the sink == gkc_partition_counts == the oracle; the bytes
+    the library says it queued (gkc_stats.reserved[1]) are what the widths promise where the partitions fill their blocks."""
+    import json, os, subprocess, sys
+    code = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+from oracle import gko
+from tests.util import simple_repart, synth_reads
+gkc = ge.load().gkc
+res = {}
+for name, k, amin, sub in (("k15", 15, 1, 0.01), ("k31", 31, 1, 0.01), ("k21_amin2", 21, 2, 0.01), ("k15_clean", 15, 1, 0.0)):
+    reads = synth_reads(20000 if k == 15 else 3000, 400000 if k == 15 else 20000, 150, seed=62, n_rate=0.001, sub_rate=sub)
+    reads += [reads[0]] * 700 + [b"A" * 150] * 300 + [b"ACGT" * 40] * 260
+    bases, offs = gko.pack_reads(reads)
+    m, parts = min(k - 1, 8), (3 if k == 15 else 40)
+    rep = simple_repart(m, parts)
+    if k == 21: rep[rep == 5] = 6
+    c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
+    sink = gkc.HostBuffer(256 << 20); c.set_host_sink(sink)
+    ok = True; wire = []
+    for rnd in range(2):
+        c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
+        nrec = 0
+        for p in range(parts):
+            view, n = c.wait_partition(0, p)
+            dev = c.partition_records(0, p)
+            ok = ok and n * 16 == len(dev) and (n == 0 or (view is not None and np.array_equal(view, dev)))
+            nrec += n
+        wire.append(c.stats()["sink_wire_bytes"] / max(1, nrec))
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, abundance_min=amin)
+    ok = ok and all(np.array_equal(c.partition_records(0, p), ref.part_records(p)) for p in range(parts))
+    c.set_host_sink(None)
+    res[name] = {"ok": bool(ok), "bytes_per_record": wire}
+print(json.dumps(res))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for kv in switch.split(","):
+        name, _, val = kv.partition("="); env[name] = val or "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert all(v["ok"] for v in res.values()), res
+    assert all(0 < b < 9 for n_, v in res.items() if n_.startswith("k15") for b in v["bytes_per_record"]), res      # (partitions of a few records still travel as whole block slots)
+    if "WIDTH6=0" not in switch:
+        assert res["k15"]["bytes_per_record"][0] < 7.0, res                                 # 6-byte entries where most abundances are 1 ...
+        assert res["k15_clean"]["bytes_per_record"][1] < res["k15_clean"]["bytes_per_record"][0], res      # ... and back to 7-byte entries where they are not
+
+
 def test_push_reads_in_overlapped_chunks(gkc):
     """gkc_push_reads sends host reads in chunks through two staging buffers (H2D of chunk j+1 under the scan of chunk j): forced to many
     small chunks (GKC_PUSH_CHUNK) the counts must not change, whatever the read boundaries"""
