@@ -2364,6 +2364,8 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     std::vector<void*>* outputs_p; { std::lock_guard<std::mutex> lk(c->mu); outputs_p = &c->pass_outputs[pass]; }      // (std::map nodes stay where they are)
     std::vector<void*>& outputs = *outputs_p;
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
+    bool first_done[4] = { false, false, false, false };
+    static const size_t sink_first_div = getenv("GKC_SINK_FIRST_DIV") ? (size_t)std::max(1, atoi(getenv("GKC_SINK_FIRST_DIV"))) : 4;
     auto carve = [&](std::vector<uint32_t>& batch, int lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
         batch.clear();
@@ -2372,6 +2374,10 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         size_t budget = budget_now(lane);
         if (tight && lane != 0) return false;
         if (probe_pending) { probe_pending = false; budget = probe_keys; }      // the pass's first batch is the small probe batch, every pass (same batches, same blocks)
+        // streamed results: the link idles until the first batch has been counted and packed — the first batch of every lane is a quarter of the others (same
+        // working buffers: they are sized for the budget), the copies start ~25 ms sooner
+        else if (c->sink && !first_done[lane] && sink_first_div > 1) budget = std::max<size_t>(budget / sink_first_div, (size_t)1 << 20);
+        first_done[lane] = true;
         uint64_t acc = 0;
         while (next_p < Pn) {
             const uint32_t p = next_p;

@@ -268,7 +268,9 @@ struct gkc_unpacker {
                     if (g_sink_debug) {
                         const auto now = std::chrono::steady_clock::now();
                         float copy_ms = -1; if (B->copy_start) (void)hipEventElapsedTime(&copy_ms, B->copy_start, B->copied);
-                        fprintf(stderr, "[gkc sink] batch of %llu blocks (%.2f GB packed, %llu exceptions): pack %.1f ms, queued -> copied %.1f ms (the copy itself %.1f ms), unpack %.1f ms\n", (unsigned long long)B->nblk,
+                        const auto t00 = all.empty() ? B->t_queued : all.front()->t_queued;
+                        fprintf(stderr, "[gkc sink] +%.1f ms: batch of %llu blocks (%.2f GB packed, %llu exceptions): pack %.1f ms, queued -> copied %.1f ms (the copy itself %.1f ms), unpack %.1f ms\n",
+                                std::chrono::duration<double, std::milli>(B->t_queued - t00).count(), (unsigned long long)B->nblk,
                                 (double)(B->nblk * pk_slot_of(B->width) + B->n_cb) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
                                 std::chrono::duration<double, std::milli>(now - B->t_ready).count());
                     }

@@ -22,10 +22,11 @@ t0 = time.perf_counter(); c.set_host_sink(sink); print("set_host_sink: %.2f s" %
 for amin in [int(x) for x in os.environ.get('PROBE_AMIN', '1,2').split(',')]:
     c.set_solidity(amin, 2147483647, 10000)
     step()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); per = []
     for _ in range(steps):
-        step()
+        t1 = time.perf_counter(); step(); per.append("%.0f" % ((time.perf_counter() - t1) * 1e3))
     dt = (time.perf_counter() - t0) / steps
+    print("   per step (ms):", " ".join(per), "| median %s" % sorted(per, key=float)[len(per) // 2], flush=True)
     st = c.stats()
     print("abundance-min %d: %.1f ms per step, %d solid records (%.1f GB of Count[]), %.2e distinct k-mers/s" % (amin, dt * 1e3, st["kmers_nb_solid"], st["kmers_nb_solid"] * 16 / 1e9, st["kmers_nb_distinct"] / dt), flush=True)
     for nme in ("total_stage_a", "total_stage_b", "compact"):
