@@ -2364,7 +2364,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     std::vector<void*>* outputs_p; { std::lock_guard<std::mutex> lk(c->mu); outputs_p = &c->pass_outputs[pass]; }      // (std::map nodes stay where they are)
     std::vector<void*>& outputs = *outputs_p;
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
-    bool first_done[4] = { false, false, false, false };
+    bool first_done[4] = { false, false, false, false }; uint64_t keys_left = total_keys;
     static const size_t sink_first_div = getenv("GKC_SINK_FIRST_DIV") ? (size_t)std::max(1, atoi(getenv("GKC_SINK_FIRST_DIV"))) : 4;
     auto carve = [&](std::vector<uint32_t>& batch, int lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
@@ -2376,7 +2376,13 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         if (probe_pending) { probe_pending = false; budget = probe_keys; }      // the pass's first batch is the small probe batch, every pass (same batches, same blocks)
         // streamed results: the link idles until the first batch has been counted and packed — the first batch of every lane is a quarter of the others (same
         // working buffers: they are sized for the budget), the copies start ~25 ms sooner
-        else if (c->sink && !first_done[lane] && sink_first_div > 1) budget = std::max<size_t>(budget / sink_first_div, (size_t)1 << 20);
+        // — and the last one as well: what is left when the last copy has landed is the expansion of the last batch on the host
+        else if (c->sink && sink_first_div > 1 && !c->key_budget) {
+            const size_t small = std::max<size_t>(budget / sink_first_div, (size_t)1 << 20), tail = small * (size_t)lanes;      // keys kept back for the small last batches
+            if (!first_done[lane]) budget = small;
+            else if (keys_left <= tail + small / 2) budget = small;
+            else if (keys_left < budget + tail) budget = std::max<size_t>(small, (size_t)(keys_left - tail));
+        }
         first_done[lane] = true;
         uint64_t acc = 0;
         while (next_p < Pn) {
@@ -2398,6 +2404,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         if (align && next_p < Pn && batch.size() > align)
             for (const size_t keep = batch.size() / align * align; batch.size() > keep; batch.pop_back()) { next_p = batch.back(); acc -= part_keys[batch.back()]; }
         inflight[lane] = (double)acc * per_key_now();
+        keys_left -= std::min<uint64_t>(keys_left, acc);
         return !batch.empty();
     };
     auto lane_main = [&](hipStream_t st, int lane) {
