@@ -188,7 +188,7 @@ constexpr int EXPAND_THREADS = 512;
 // A key on its way through the sort is the canonical k-mer shifted left by wb WEIGHT BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
 // of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. wb is chosen per batch (weight_bits_of): 2 .. 4 — the
 // records have 4 spare bits below their nucleotides — as many as the sort can carry: 8-byte keys sort with the f64-tagged network while what is left of a key below
-// its sub-bucket index fits a double's mantissa (2k + wb - sub_bits <= 52: k = 31 -> 3, k <= 30 -> 4). A key of 2k + wb bits may be WEIGHT_DROP_MAX = 1 bit
+// its sub-bucket index fits the 61 bits that network orders (KTAG64: 2k + wb - sub_bits <= 61). A key of 2k + wb bits may be WEIGHT_DROP_MAX = 1 bit
 // longer than the 64 / 128 it is stored in (k = 31, k = 63 with wb = 3): the TOP bit falls off in the shift, and nothing is lost — every key of a level-1 sub-bucket
 // shares it (it is the top bit of the sub-bucket's index), k_expand_count notes it beside the sub-bucket (b_consumed, bit 4) and the two kernels that write the
 // Count records (k_gather_counts, k_root_write) put it back. The order inside a sub-bucket does not depend on a bit all its keys share. One bit and not two: the
@@ -516,10 +516,16 @@ template <> struct Shfl<2> {
 #ifndef GKC_CROSS_MINMAX
 #define GKC_CROSS_MINMAX 1     // cross-lane steps of tagged keys as exec-masked v_min_f64 / v_max_f64 blocks (0: 64-bit compare + selects)
 #endif
-// In-lane compare-exchange. F (8-byte keys only): the keys of the bucket carry the exponent tag of a double in their 12 top bits (see
-// TAG64 below), so they are positive normal doubles whose order is the integer order, and the exchange is the two native 64-bit
-// instructions v_min_f64 / v_max_f64 instead of a 64-bit compare and four selects. Cross-lane steps compare the same bit patterns as integers.
+// In-lane compare-exchange. F (8-byte keys only): the keys of the bucket carry a tag in their top bits that makes them positive normal doubles, whose order is the
+// order of their bit patterns, and the exchange is the two native 64-bit instructions v_min_f64 / v_max_f64 (they return one of their operands, bit for bit)
+// instead of a 64-bit compare and four selects. Cross-lane steps compare the same bit patterns as integers.
+//   TAG64 / TAG64_MANT (the record deduplication's hash words): exponent 0x433 above 52 bits.
+//   KTAG64 / KTAG64_MANT (the key sorts): only the top THREE bits are the tag — sign 0, exponent bits 10 and 9 = 1, 0 — and the 9 exponent bits below them belong
+//   to the key with the 52 mantissa bits: exponents 0x400 .. 0x5FF, never 0 (denormal), never 0x7FF (infinity / NaN), so 61 key bits sort this way. (Rounds 2-3
+//   kept the whole exponent fixed: 52 bits, which made every partition take 12-13 sub-bucket bits whatever its size.) The three bits the tag replaces are bits all
+//   keys of a bucket share: 2k + weight bits - sub-bucket bits <= 61, checked per launch, integer path otherwise.
 constexpr uint64_t TAG64 = 0x4330000000000000ULL, TAG64_MANT = 0x000FFFFFFFFFFFFFULL;
+constexpr uint64_t KTAG64 = 0x4000000000000000ULL, KTAG64_MANT = 0x1FFFFFFFFFFFFFFFULL; constexpr int KTAG64_BITS = 61;
 template <int KW, bool F> __device__ __forceinline__ void ce_inlane(typename KeyT<KW>::type& a, typename KeyT<KW>::type& b)
 {
     if constexpr (F && KW == 1) {
@@ -632,13 +638,13 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
 {
     typedef typename KeyT<KW>::type key_t;
     key_t v[KPL];
-    key_t top = 0;                                               // F: the 12 top bits every key of the bucket shares (replaced by the tag while sorting)
+    key_t top = 0;                                               // F: the 3 top bits every key of the bucket shares (replaced by the tag while sorting)
 #pragma unroll
     for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[i] : KeyT<KW>::max(); }
     if constexpr (F && KW == 1) {
-        top = src[0] & ~TAG64_MANT;
+        top = src[0] & ~KTAG64_MANT;
 #pragma unroll
-        for (int r = 0; r < KPL; r++) v[r] = (v[r] & TAG64_MANT) | TAG64;          // padding (all ones) becomes TAG64_PAD: above every key
+        for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTAG64_MANT) | KTAG64;        // padding (all ones) becomes the largest tagged value: not below any key
     }
 #ifndef GKC_EXP_NOSORT
     bitonic_wave<KW, KPL, F>(v, lane);
@@ -689,7 +695,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
             const uint32_t c = run - prevw;                                       // the run that ends here: every weight since the previous run end
             prevw = run;
 #ifndef GKC_EXP_NORLESTORE
-            if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
+            if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & KTAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
             put_count(O, start + idx, c);
 #else
             if (c == 0x7fffffffu) outk[start + idx] = v[r];
@@ -818,9 +824,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
         for (int r = 0; r < KPL; r++) { const uint32_t i = w * CAPW + r * 64 + lane; v[r] = i < n ? src[start + i] : KeyT<KW>::max(); }
         key_t top = 0;
         if constexpr (F && KW == 1) {
-            top = src[start] & ~TAG64_MANT;
+            top = src[start] & ~KTAG64_MANT;
 #pragma unroll
-            for (int r = 0; r < KPL; r++) v[r] = (v[r] & TAG64_MANT) | TAG64;
+            for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTAG64_MANT) | KTAG64;
         }
         bitonic_wave<KW, KPL, F>(v, lane);
         key_t* mine = s_x + (size_t)w * CAPW;
@@ -900,7 +906,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
             if ((tailm >> r) & 1) {
                 const uint32_t c = run - prevw;
                 prevw = run;
-                if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & TAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
+                if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & KTAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
                 put_count(O, start + idx, c); idx++;
                 nsol += ((int32_t)c >= O.amin && (int32_t)c <= O.amax) ? 1u : 0u;
                 const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
@@ -1883,7 +1889,7 @@ template <int KW> static uint32_t weight_bits_of(uint32_t k, uint32_t min_bits)
     const int stored = 64 * KW, drop_ok = (int)std::min<uint32_t>(min_bits, (uint32_t)WEIGHT_DROP_MAX);
     const int valid = std::min<int>(WEIGHT_BITS_MAX, stored + drop_ok - 2 * (int)k);               // >= WEIGHT_BITS_MIN for every k the key width is used for
     int wb = valid;
-    if (KW == 1) wb = std::min<int>(wb, std::max<int>(WEIGHT_BITS_MIN, 52 + (int)min_bits - 2 * (int)k));   // the f64-tagged network is worth more than a weight bit
+    if (KW == 1) wb = std::min<int>(wb, std::max<int>(WEIGHT_BITS_MIN, KTAG64_BITS + (int)min_bits - 2 * (int)k));   // the f64-tagged network is worth more than a weight bit
     if (env) wb = std::min(env, valid);
     return (uint32_t)std::max<int>(WEIGHT_BITS_MIN, wb);
 }
@@ -1906,10 +1912,16 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     std::vector<PartDesc> pd(nb);
     std::vector<uint64_t> pidx(nb + 1);
     uint64_t n_slots = 0, n_sub = 0;
-    const uint32_t target = (KW == 1) ? SUB_TARGET : SUB_TARGET / 2;       // mean keys of a level-1 bucket
+    static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
+    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
+    // mean keys of a level-1 bucket, counted in k-mers BEFORE identical records are merged: with the merge on (8-byte keys: ~1.8x fewer keys on 30x reads) twice as
+    // many — 12 sub-bucket bits instead of 13 for the partitions of the 1e8-read bench: first sort tier 46.8 -> 38.3 ms, the larger tiers +8, scatter -4: 220 -> 214 ms
+    // (possible since the tagged sort carries 61 key bits: profiles/r04_weight_bits_experiment.txt)
+    static const uint32_t target_env = getenv("GKC_SUB_TARGET") ? (uint32_t)std::max(1, atoi(getenv("GKC_SUB_TARGET"))) : 0u;
+    const uint32_t target = target_env ? target_env : (KW == 1) ? (dedupe ? 2 * SUB_TARGET : SUB_TARGET) : SUB_TARGET / 2;
     const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
     const uint32_t wb_goal = weight_bits_of<KW>(k, max_bits1);
-    const int stored_or_mantissa = KW == 1 ? 52 : 128;
+    const int stored_or_mantissa = KW == 1 ? KTAG64_BITS : 128;
     const uint32_t need_goal = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + (int)wb_goal - stored_or_mantissa));
     const uint32_t need_min = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + WEIGHT_BITS_MIN - stored_or_mantissa));
     bool goal_ok = weight_bits_env() != 0;              // (weight bits asked for: the sub-bucket bits they need, whatever the sizes)
@@ -1923,13 +1935,11 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         if (np >= (1ULL << 32)) GKC_FAIL(c, GKC_ERR_ARG, "partition %u holds %llu k-mers (>= 2^32): use more partitions", batch_parts[i], (unsigned long long)np);
         uint32_t bits = 0;
         while (bits < max_bits1 && bits < 2 * k && (np >> bits) > target) bits++;
-        // 8-byte keys: a small partition still gets enough sub-buckets for what is left of a key below the sub-bucket index (k-mer + weight bits) to fit a double's
-        // mantissa, so that the whole batch sorts with the f64-tagged network (one partition with fewer would switch the batch to the integer network: +30 %).
-        // With which weight bits? Those the batch could have at best (wb_goal; k = 31: 3, which takes all 13 sub-bucket bits) if its MEAN partition is within one
-        // bit of what they need — the few small partitions of such a batch then get the bits too; a batch of small partitions (32768 partitions of 4.5e5 k-mers:
-        // 10 bits) only gets what the smallest weights need — twice the sub-buckets for a few dozen keys each cost more than the third weight bit saves (the
-        // 8-GPU share: 325 -> 369 ms) — and runs with fewer weight bits. (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can
-        // push the key's top bit out.)
+        // 8-byte keys: a small partition still gets enough sub-buckets for what is left of a key below the sub-bucket index (k-mer + weight bits) to fit the 61 bits the
+        // f64-tagged network orders, so that the whole batch sorts with it (one partition with fewer would switch the batch to the integer network: +30 %) — with the
+        // weight bits the batch could have at best (wb_goal) if its MEAN partition is within one bit of what they need, else with the smallest weights. At k = 31
+        // that is 4 / 3 bits (rounds 2-3, 52-bit tag: 13 / 12 bits whatever the partition's size — the 8-GPU share on one GPU, 32768 partitions of 4.5e5 k-mers,
+        // 325 -> 278 ms when the tag was widened). (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can push the key's top bit out.)
         if (getenv("GKC_MAX_SUB_BITS") == nullptr) bits = std::min<uint32_t>(std::max(bits, goal_ok ? need_goal : need_min), 2 * k);
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
@@ -1939,7 +1949,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     }
     pidx[nb] = n_sub;
     if (n_sub >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "too many sub-buckets in one batch");
-    uint32_t min_bits1 = 64; for (uint32_t i = 0; i < nb; i++) min_bits1 = std::min(min_bits1, pd[i].sub_bits);
+    uint32_t min_bits1 = 64, max_bits_b = 0; for (uint32_t i = 0; i < nb; i++) { min_bits1 = std::min(min_bits1, pd[i].sub_bits); max_bits_b = std::max(max_bits_b, pd[i].sub_bits); }
     const uint32_t wb = weight_bits_of<KW>(k, nb ? min_bits1 : 0u);
     const uint32_t drop = 2 * k + wb > 64u * KW ? 2 * k + wb - 64u * KW : 0u;      // top bits of a key that fall off the stored word (<= WEIGHT_DROP_MAX <= min_bits1)
     constexpr uint32_t CAP1 = WaveCapT1<KW>::CAP, CAP2 = WaveCapHuge<KW>::CAP;
@@ -1990,8 +2000,6 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // Identical super-k-mer records of a partition are merged first (8-byte keys; see k_dedupe_*): the expansion then reads the batch's own deduplicated copy
     SegTable segs_b = segs;
     std::vector<uint64_t> dd_base_h, dd_off_h; const void* dd_arena_h = nullptr;      // sources of asynchronous copies: alive until the batch is through
-    static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
-    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
     if (dedupe) {
         unsigned long long* const dd_totals = reinterpret_cast<unsigned long long*>(misc + 40);     // k-mers into / out of the deduplication of this batch
         const uint32_t Pn = segs.P, p_first = batch_parts.front(), p_last = batch_parts.back();
@@ -2039,8 +2047,8 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         // Measured, two lanes, 1e8 reads: one workgroup per partition 266-273 ms per step, 160-192 workgroups 249-251, 128: 252, 96: 256.
         static const uint32_t scatter_wgs = getenv("GKC_SCATTER_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCATTER_WGS"))) : 176u;
         if constexpr (KW == 1) {
-            const size_t lds = (size_t)MAX_SUB * 12;
-            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+            const size_t lds_max = (size_t)MAX_SUB * 12, lds = ((size_t)12 << max_bits_b);          // parking slots + cursors of the batch's largest sub-bucket count
+            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
             hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
                                (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6, wb);
         } else {
@@ -2058,7 +2066,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     O.wb = wb;
     // --- the sort tiers, back to back: which sub-bucket goes where was decided by k_expand_count; no host round trip until the totals below
     // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
-    const bool tag = KW == 1 && 2 * k + wb - min_bits1 <= 52 && getenv("GKC_NO_F64") == nullptr;
+    const bool tag = KW == 1 && 2 * k + wb - min_bits1 <= (uint32_t)KTAG64_BITS && getenv("GKC_NO_F64") == nullptr;
     constexpr bool FT = KW == 1;
     key_t* const keysA = (key_t*)B.keysA.p; key_t* const keysB = (key_t*)B.keysB.p;
     const uint64_t* const bs = (const uint64_t*)B.b_start.p; const uint32_t* const bn = (const uint32_t*)B.b_n.p; const uint8_t* const bc = (const uint8_t*)B.b_cons.p;
