@@ -188,14 +188,15 @@ constexpr int EXPAND_THREADS = 512;
 // A key on its way through the sort is the canonical k-mer shifted left by wb WEIGHT BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
 // of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. wb is chosen per batch (weight_bits_of): 2 .. 4 — the
 // records have 4 spare bits below their nucleotides — as many as the sort can carry: 8-byte keys sort with the f64-tagged network while what is left of a key below
-// its sub-bucket index fits the 61 bits that network orders (KTAG64: 2k + wb - sub_bits <= 61). A key of 2k + wb bits may be WEIGHT_DROP_MAX = 1 bit
-// longer than the 64 / 128 it is stored in (k = 31, k = 63 with wb = 3): the TOP bit falls off in the shift, and nothing is lost — every key of a level-1 sub-bucket
-// shares it (it is the top bit of the sub-bucket's index), k_expand_count notes it beside the sub-bucket (b_consumed, bit 4) and the two kernels that write the
-// Count records (k_gather_counts, k_root_write) put it back. The order inside a sub-bucket does not depend on a bit all its keys share. One bit and not two: the
-// stored key must never be all ones (the scatter's EMPTY, the sort's padding). With one bit dropped that would take a k-mer [C|G] G..G — neither is canonical
-// (their reverse complements C..C[C|G] are smaller); with two, A G..G is canonical and would be all ones at weight 16.
+// its sub-bucket index fits the 61 bits that network orders (KTAG64: 2k + wb - sub_bits <= 61). A key of 2k + wb bits may be up to WEIGHT_DROP_MAX = 2
+// bits longer than the 64 / 128 it is stored in (k = 31, k = 63 with wb = 3, 4): the TOP bits fall off in the shift, and nothing is lost — every key of a level-1
+// sub-bucket shares them (they are the top bits of the sub-bucket's index), k_expand_count notes them beside the sub-bucket (b_consumed, bits 4-5) and the two kernels
+// that write the Count records (k_gather_counts, k_root_write) put them back. The order inside a sub-bucket does not depend on bits all its keys share. The stored
+// key must never be all ones (the scatter's EMPTY, the sort's padding). With one bit dropped that would take a k-mer [C|G] G..G — neither is canonical (their reverse
+// complements C..C[C|G] are smaller); with two, A G..G is canonical and would be all ones at the largest weight — so with two bits dropped a record stands for at
+// most 2^wb - 1 copies (weight_cap_of): the weight field is never all ones, whatever the k-mer.
 // Measured (1e8 reads, k = 30, no bit dropped: profiles/r04_weight_bits_experiment.txt): weights up to 4 / 8 / 16 merge 1.65x / 1.85x / 1.98x, step 230 / 215 / 211 ms.
-constexpr int WEIGHT_BITS_MIN = 2, WEIGHT_BITS_MAX = 4, WEIGHT_DROP_MAX = 1;
+constexpr int WEIGHT_BITS_MIN = 2, WEIGHT_BITS_MAX = 4, WEIGHT_DROP_MAX = 2;
 constexpr uint32_t CONS_BITS_MASK = 0x0Fu, CONS_GIANT = 0x80u; constexpr int CONS_DROP_SHIFT = 4;      // b_consumed: sub-bucket bits | dropped top bits << 4 | giant flag
 
 
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
             const unsigned long long wq = R[1] & ((1ull << wb) - 1ull);                              // the record's weight - 1 (below the nucleotides; 0 unless the records were deduplicated)
             for_each_kmer16(R, k, [&](uint64_t c) {
                 const uint32_t q = (uint32_t)(c >> pd.shift);
-                unsigned long long h = (c << wb) | wq;                               // (a 65th bit falls off: see above) never all ones: neither G..G nor CG..G is canonical
+                unsigned long long h = (c << wb) | wq;                               // (bits beyond the 64th fall off: see above) never all ones
                 for (;;) {
                     const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
                     if (y != EMPTY) {
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
             const uint64_t wq = R[3] & ((1ull << wb) - 1ull);                                                   // the record's weight - 1
             for_each_kmer32(R, k, [&](u128 c) {
                 const uint32_t q = sub_index<2>(c, pd.shift);
-                const u128 st = (c << wb) | (u128)wq;                                    // (a 129th bit falls off) never all ones: neither G..G nor CG..G is canonical
+                const u128 st = (c << wb) | (u128)wq;                                    // (bits beyond the 128th fall off) never all ones
                 uint64_t h_lo = (uint64_t)st, h_hi = (uint64_t)(st >> 64);
                 for (;;) {
                     uint64_t y_lo, y_hi;
@@ -1402,7 +1403,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_counts(const typename
                                                                    const uint64_t* __restrict__ b_start, const uint32_t* __restrict__ b_n, const uint32_t* __restrict__ nd,
                                                                    const uint64_t* __restrict__ off_s, uint32_t n_buckets, uint32_t split_min /* sub-buckets beyond were split */,
                                                                    int32_t amin, int32_t amax, uint32_t all_solid, uint64_t* __restrict__ out,
-                                                                   const uint8_t* __restrict__ b_cons, uint32_t top_shift /* where a sub-bucket's dropped top bit goes back: 2k - 1 */)
+                                                                   const uint8_t* __restrict__ b_cons, uint32_t top_shift /* where a sub-bucket's dropped top bits go back: 2k - their number */)
 {
     constexpr int OW = (KW == 1) ? 2 : 4;
     typedef typename KeyT<KW>::type key_t;
@@ -1793,10 +1794,9 @@ __device__ __forceinline__ uint32_t dd_sort_bin(const DRec<RW> (&in)[DDCap<RW>::
 template <int RW>
 __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t* __restrict__ arena, const uint64_t* __restrict__ rec_base, DedupeTables D, const PartDesc* __restrict__ parts,
                                                              uint64_t* __restrict__ rec_end /* [P] */, uint32_t nb, uint32_t* __restrict__ ticket,
-                                                             unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */, uint32_t wb /* weight bits of the batch */)
+                                                             unsigned long long* __restrict__ totals /* [0] k-mers in [1] k-mers out */, uint32_t WCAP /* copies one record may stand for */)
 {
     constexpr int KM = DDCap<RW>::KPL_MAX, SLOTS = DDCap<RW>::SLOTS, DDS_WAVES = DDCap<RW>::WAVES;
-    const uint32_t WCAP = 1u << wb;
     __shared__ __attribute__((aligned(16))) uint64_t s_win[DDS_WAVES][SLOTS * RW];      // 64 KB
     __shared__ volatile uint32_t s_next, s_pos;             // bin whose output may be placed now; where
     __shared__ uint32_t s_item;
@@ -1952,6 +1952,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     uint32_t min_bits1 = 64, max_bits_b = 0; for (uint32_t i = 0; i < nb; i++) { min_bits1 = std::min(min_bits1, pd[i].sub_bits); max_bits_b = std::max(max_bits_b, pd[i].sub_bits); }
     const uint32_t wb = weight_bits_of<KW>(k, nb ? min_bits1 : 0u);
     const uint32_t drop = 2 * k + wb > 64u * KW ? 2 * k + wb - 64u * KW : 0u;      // top bits of a key that fall off the stored word (<= WEIGHT_DROP_MAX <= min_bits1)
+    const uint32_t wcap = drop >= 2 ? (1u << wb) - 1u : (1u << wb);                // copies one merged record may stand for (see the note at the top of the file)
     constexpr uint32_t CAP1 = WaveCapT1<KW>::CAP, CAP2 = WaveCapHuge<KW>::CAP;
     constexpr int K1 = WaveCapHuge<KW>::KPL / 2;
     constexpr uint32_t C1 = 4 * 64 * K1;                                    // workgroup tier: 4 waves x 64 x K1 keys (4096 / 2048)
@@ -2030,7 +2031,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             CB_TRY(c->ensure(B.dd_end, (size_t)Pn * 8));
             ScopedTimer tm(c, "dedupe_sort");
             hipLaunchKernelGGL((k_dedupe_sort<RW>), dim3(std::min(nb, 512u)), dim3(DDCap<RW>::WAVES * 64), 0, cur_stream(c), (uint64_t*)B.dd_arena.p, (const uint64_t*)B.dd_base.p, DT, (const PartDesc*)B.pd.p,
-                               (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals, wb);
+                               (uint64_t*)B.dd_end.p, nb, misc + 44, dd_totals, wcap);
             CB_HIP(hipGetLastError());
             segs_b.rec = (const uint8_t* const*)B.dd_ptr.p; segs_b.rec_off = (const uint64_t*)B.dd_off.p; segs_b.n_seg = 1; segs_b.rec_end = (const uint64_t*)B.dd_end.p;
         }
@@ -2182,7 +2183,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         if (n_sub) {
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_sub + 255) / 256, 256 * 16));
             hipLaunchKernelGGL((k_gather_counts<KW>), dim3(grid), dim3(GATHER_THREADS), 0, cur_stream(c), (const key_t*)keysA, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p,
-                               bs, bn, (const uint32_t*)O.nd, (const uint64_t*)B.off_s.p, (uint32_t)n_sub, cap3, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - 1);
+                               bs, bn, (const uint32_t*)O.nd, (const uint64_t*)B.off_s.p, (uint32_t)n_sub, cap3, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - drop);
             if (h_misc[2]) {                                                       // the split sub-buckets: records at their pieces' heads
                 const uint32_t n_roots = h_misc[2];
                 const uint64_t chunks_cap = n_slots / ROOT_CHUNK + n_roots + 1;
@@ -2193,7 +2194,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
                 hipLaunchKernelGGL(k_root_count, dim3(rgrid), dim3(256), 0, cur_stream(c), (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, bs, bn, (const uint32_t*)T.split_list, R, c->amin, c->amax, O.all_solid);
                 hipLaunchKernelGGL(k_root_scan, dim3(1), dim3(ROOT_THREADS), 0, cur_stream(c), R);
                 hipLaunchKernelGGL((k_root_write<KW>), dim3(rgrid), dim3(256), 0, cur_stream(c), (const key_t*)keysA, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p, bs, bn, (const uint32_t*)T.split_list, R,
-                                   (const uint64_t*)B.off_s.p, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - 1);
+                                   (const uint64_t*)B.off_s.p, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - drop);
             }
             CB_HIP(hipGetLastError());
         }
