@@ -338,8 +338,16 @@ def main():
     use_dist = world > 1 or os.environ.get("GKC_FORCE_DIST") == "1"       # GKC_FORCE_DIST=1: exercise the exchange path with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # GKC_BENCH_BACKEND=gloo: the dry run of this file's several-rank path on a box with fewer GPUs than ranks (the ranks share the devices, the exchange goes
+        # through the host-staged transport of gatb_core_amd.dist; RCCL refuses two ranks on one device). Never what the driver runs; the line says which one it was.
+        backend = os.environ.get("GKC_BENCH_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
+    red_dev = "cuda" if (not use_dist or dist.get_backend() == "nccl") else "cpu"      # where the few scalars of the line are all-reduced
     gkc = ge.load().gkc
     if not os.path.exists(gkc.SO):
         raise SystemExit("libgkc_hip.so missing: run __graft_entry__.build()")
@@ -417,11 +425,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        t = torch.tensor([dt], device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     st = c.stats()
     distinct = st["kmers_nb_distinct"]; valid = st["kmers_nb_valid"]
     if world > 1:
-        t = torch.tensor([distinct, valid], device="cuda", dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
+        t = torch.tensor([distinct, valid], device=red_dev, dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
     ktime = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
     # OUTSIDE the clock: the records the last timed step left on the device are the count of the reads it was given (every rank: its reads in, the partitions it
     # owns out; over all ranks the two sides must meet)
@@ -574,7 +582,9 @@ def main():
                 sl["hbm_GBps_from_counters"] = traffic / (sl["launch_ms"] * 1e-3) / 1e9
                 sl["frac_from_counters"] = sl["hbm_GBps_from_counters"] / HBM_PEAK_GBS
         if exch is not None:
-            out["exchange"] = {"transport": "RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push, "per_rank": exch}
+            out["exchange"] = {"transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if red_dev == "cuda" else
+                               ("DRY RUN (GKC_BENCH_BACKEND=%s): host-staged transport, the ranks share %d device(s); %d pushes per pass" % (dist.get_backend(), torch.cuda.device_count(), n_push)),
+                               "per_rank": exch}
         if world == 1 and not args.no_host_landed:
             out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=args.steps, expect=expect, parts=parts)
             if "abundance_min_2" in out["host_landed"]:
@@ -779,7 +789,7 @@ def main():
         for b_, o_, _, _ in chunks:
             c.device_free(b_); c.device_free(o_)
     if use_dist:
-        t_rc = torch.tensor([bad_rc], device="cuda"); dist.all_reduce(t_rc, op=dist.ReduceOp.MAX); bad_rc = int(t_rc.item())      # a red `verified` fails every rank
+        t_rc = torch.tensor([bad_rc], device=red_dev); dist.all_reduce(t_rc, op=dist.ReduceOp.MAX); bad_rc = int(t_rc.item())      # a red `verified` fails every rank
         dist.barrier(); dist.destroy_process_group()
     if bad_rc:
         sys.exit(bad_rc)
