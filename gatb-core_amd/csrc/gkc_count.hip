@@ -527,6 +527,27 @@ template <> struct Shfl<2> {
 //   keys of a bucket share: 2k + weight bits - sub-bucket bits <= 61, checked per launch, integer path otherwise.
 constexpr uint64_t TAG64 = 0x4330000000000000ULL, TAG64_MANT = 0x000FFFFFFFFFFFFFULL;
 constexpr uint64_t KTAG64 = 0x4000000000000000ULL, KTAG64_MANT = 0x1FFFFFFFFFFFFFFFULL; constexpr int KTAG64_BITS = 61;
+constexpr int KTAG128_BITS = 125;            // 16-byte keys: the same tag on the TOP word (three shared top bits), all 64 bits of the low word are key bits
+template <int KW> struct KTagBits { static constexpr int value = KW == 1 ? KTAG64_BITS : KTAG128_BITS; };
+// 16-byte keys (round 4): the order of two keys written out on their 64-bit halves. The compiler's own `y < x` on unsigned __int128 costs ~23 VALU instructions
+// per compare-exchange on gfx950 (the i1 results are materialised through v_cndmask / v_and, 5 s_nop per exchange); spelled out it is 3 compares + 2 SALU ops,
+// and the exchange 8 selects (11 VALU) — or, with the TOP word tagged like an 8-byte key (KTag<2>: its three top bits, which all keys of a bucket share, replaced
+// by the double tag), v_min_f64 / v_max_f64 on the top words and 4 selects on the low ones (9 VALU).
+template <int KW> __device__ __forceinline__ bool key_lt(typename KeyT<KW>::type a, typename KeyT<KW>::type b)
+{
+    if constexpr (KW == 1) return a < b;
+    else { const uint64_t ah = (uint64_t)(a >> 64), al = (uint64_t)a, bh = (uint64_t)(b >> 64), bl = (uint64_t)b; return (ah < bh) | ((ah == bh) & (al < bl)); }
+}
+// the k-mers of two keys differ (the low WMASK bits are the weight)
+template <int KW> __device__ __forceinline__ bool key_differs(typename KeyT<KW>::type a, typename KeyT<KW>::type b, uint32_t WMASK)
+{
+    if constexpr (KW == 1) return (a ^ b) > (uint64_t)WMASK;
+    else return (((uint64_t)(a >> 64) ^ (uint64_t)(b >> 64)) | (((uint64_t)a ^ (uint64_t)b) & ~(uint64_t)WMASK)) != 0;
+}
+// tag of the f64-ordered form of a key: the whole 8-byte key, or the top word of a 16-byte one
+template <int KW> struct KTag;
+template <> struct KTag<1> { static __device__ __forceinline__ uint64_t mant() { return KTAG64_MANT; }  static __device__ __forceinline__ uint64_t tag() { return KTAG64; } };
+template <> struct KTag<2> { static __device__ __forceinline__ u128 mant() { return ((u128)KTAG64_MANT << 64) | (u128)~0ULL; }  static __device__ __forceinline__ u128 tag() { return (u128)KTAG64 << 64; } };
 template <int KW, bool F> __device__ __forceinline__ void ce_inlane(typename KeyT<KW>::type& a, typename KeyT<KW>::type& b)
 {
     if constexpr (F && KW == 1) {
@@ -535,7 +556,16 @@ template <int KW, bool F> __device__ __forceinline__ void ce_inlane(typename Key
         asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
         asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
         a = (uint64_t)__double_as_longlong(lo); b = (uint64_t)__double_as_longlong(hi);
-    } else { const typename KeyT<KW>::type x = a, y = b; const bool sw = y < x; a = sw ? y : x; b = sw ? x : y; }
+    } else if constexpr (F && KW == 2) {
+        const uint64_t ah = (uint64_t)(a >> 64), al = (uint64_t)a, bh = (uint64_t)(b >> 64), bl = (uint64_t)b;
+        const bool sw = (bh < ah) | ((bh == ah) & (bl < al));
+        const double x = __longlong_as_double((long long)ah), y = __longlong_as_double((long long)bh);
+        double mn, mx;
+        asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(x), "v"(y));
+        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(x), "v"(y));
+        const uint64_t l0 = sw ? bl : al, l1 = sw ? al : bl;
+        a = ((u128)(uint64_t)__double_as_longlong(mn) << 64) | l0; b = ((u128)(uint64_t)__double_as_longlong(mx) << 64) | l1;
+    } else { const typename KeyT<KW>::type x = a, y = b; const bool sw = key_lt<KW>(y, x); a = sw ? y : x; b = sw ? x : y; }
 }
 
 // bitonic network over N = 64*KPL keys (blocked index e = lane*KPL + r), all comparators ascending, as compile-time recursion so
@@ -569,7 +599,7 @@ template <int KW, int KPL, int S, bool F = false> struct HalfClean {            
                     }
                 } else {
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LS>(v[r]); const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
+                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LS>(v[r]); const bool ylt = key_lt<KW>(y, v[r]); v[r] = (ylt == low) ? y : v[r]; }
                 }
             }
             HalfClean<KW, KPL, S / 2, F>::run(v, lane);
@@ -616,7 +646,7 @@ template <int KW, int KPL, int SIZE, bool F = false> struct BitonicMerge {      
                 } else {
                 key_t w[KPL];
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LMASK>(v[KPL - 1 - r]); const bool ylt = y < v[r]; w[r] = (ylt == low) ? y : v[r]; }
+                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LMASK>(v[KPL - 1 - r]); const bool ylt = key_lt<KW>(y, v[r]); w[r] = (ylt == low) ? y : v[r]; }
 #pragma unroll
                 for (int r = 0; r < KPL; r++) v[r] = w[r];
                 }
@@ -642,10 +672,10 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     key_t top = 0;                                               // F: the 3 top bits every key of the bucket shares (replaced by the tag while sorting)
 #pragma unroll
     for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[i] : KeyT<KW>::max(); }
-    if constexpr (F && KW == 1) {
-        top = src[0] & ~KTAG64_MANT;
+    if constexpr (F) {
+        top = src[0] & ~KTag<KW>::mant();
 #pragma unroll
-        for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTAG64_MANT) | KTAG64;        // padding (all ones) becomes the largest tagged value: not below any key
+        for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTag<KW>::mant()) | KTag<KW>::tag();        // padding (all ones) becomes the largest tagged value: not below any key
     }
 #ifndef GKC_EXP_NOSORT
     bitonic_wave<KW, KPL, F>(v, lane);
@@ -655,7 +685,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
     const key_t next_first = Shfl<KW>::down(v[0]);
     const uint32_t WB = O.wb, WMASK = (1u << WB) - 1u;
-    auto differs = [WMASK](key_t a, key_t b) -> uint32_t { return ((a ^ b) > (key_t)WMASK) ? 1u : 0u; };
+    auto differs = [WMASK](key_t a, key_t b) -> uint32_t { return key_differs<KW>(a, b, WMASK) ? 1u : 0u; };
     // whole-lane bit masks (bit r = rank lane*KPL + r): one compare per key, the tail logic on the masks
     uint32_t neq = lane == 0 ? 1u : differs(v[0], prev_last);                      // k-mer differs from the one before it (rank 0: always)
 #pragma unroll
@@ -696,7 +726,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
             const uint32_t c = run - prevw;                                       // the run that ends here: every weight since the previous run end
             prevw = run;
 #ifndef GKC_EXP_NORLESTORE
-            if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & KTAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
+            if constexpr (F) outk[start + idx] = ((v[r] & KTag<KW>::mant()) | top) >> WB; else outk[start + idx] = v[r] >> WB;
             put_count(O, start + idx, c);
 #else
             if (c == 0x7fffffffu) outk[start + idx] = v[r];
@@ -824,10 +854,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
 #pragma unroll
         for (int r = 0; r < KPL; r++) { const uint32_t i = w * CAPW + r * 64 + lane; v[r] = i < n ? src[start + i] : KeyT<KW>::max(); }
         key_t top = 0;
-        if constexpr (F && KW == 1) {
-            top = src[start] & ~KTAG64_MANT;
+        if constexpr (F) {
+            top = src[start] & ~KTag<KW>::mant();
 #pragma unroll
-            for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTAG64_MANT) | KTAG64;
+            for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTag<KW>::mant()) | KTag<KW>::tag();
         }
         bitonic_wave<KW, KPL, F>(v, lane);
         key_t* mine = s_x + (size_t)w * CAPW;
@@ -841,7 +871,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
                 const key_t* other = s_x + (size_t)(w ^ (SZ - 1)) * CAPW;
                 const bool low = (w & (SZ >> 1)) == 0;
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const key_t y = other[(KPL - 1 - r) * 64 + (63 - lane)]; const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
+                for (int r = 0; r < KPL; r++) { const key_t y = other[(KPL - 1 - r) * 64 + (63 - lane)]; const bool ylt = key_lt<KW>(y, v[r]); v[r] = (ylt == low) ? y : v[r]; }
             }
 #pragma unroll
             for (int S = SZ >> 2; S >= 1; S >>= 1) {              // half-cleaners whose partner is another wave: w ^ S, same register and lane
@@ -852,7 +882,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
                 const key_t* other = s_x + (size_t)(w ^ S) * CAPW;
                 const bool low = (w & S) == 0;
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const key_t y = other[r * 64 + lane]; const bool ylt = y < v[r]; v[r] = (ylt == low) ? y : v[r]; }
+                for (int r = 0; r < KPL; r++) { const key_t y = other[r * 64 + lane]; const bool ylt = key_lt<KW>(y, v[r]); v[r] = (ylt == low) ? y : v[r]; }
             }
             HalfClean<KW, KPL, CAPW / 2, F>::run(v, lane);        // the rest of the merge stays inside the wave
         }
@@ -865,7 +895,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
         if (lane == 63 && w < NW - 1) next_first = s_first[w + 1];
         const uint32_t E0 = w * CAPW + lane * KPL;
         const uint32_t WB = O.wb, WMASK = (1u << WB) - 1u;
-        auto differs = [WMASK](key_t a, key_t b) -> bool { return (a ^ b) > (key_t)WMASK; };     // the k-mers above the weight bits differ
+        auto differs = [WMASK](key_t a, key_t b) -> bool { return key_differs<KW>(a, b, WMASK); };     // the k-mers above the weight bits differ
         uint32_t tailm = 0, inm = 0;
 #pragma unroll
         for (int r = 0; r < KPL; r++) {
@@ -907,7 +937,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_wg_sort(const typename KeyT<KW>:
             if ((tailm >> r) & 1) {
                 const uint32_t c = run - prevw;
                 prevw = run;
-                if constexpr (F && KW == 1) outk[start + idx] = ((v[r] & KTAG64_MANT) | top) >> WB; else outk[start + idx] = v[r] >> WB;
+                if constexpr (F) outk[start + idx] = ((v[r] & KTag<KW>::mant()) | top) >> WB; else outk[start + idx] = v[r] >> WB;
                 put_count(O, start + idx, c); idx++;
                 nsol += ((int32_t)c >= O.amin && (int32_t)c <= O.amax) ? 1u : 0u;
                 const uint32_t hb = c >= O.histo_max ? O.histo_max : c;
@@ -1889,7 +1919,7 @@ template <int KW> static uint32_t weight_bits_of(uint32_t k, uint32_t min_bits)
     const int stored = 64 * KW, drop_ok = (int)std::min<uint32_t>(min_bits, (uint32_t)WEIGHT_DROP_MAX);
     const int valid = std::min<int>(WEIGHT_BITS_MAX, stored + drop_ok - 2 * (int)k);               // >= WEIGHT_BITS_MIN for every k the key width is used for
     int wb = valid;
-    if (KW == 1) wb = std::min<int>(wb, std::max<int>(WEIGHT_BITS_MIN, KTAG64_BITS + (int)min_bits - 2 * (int)k));   // the f64-tagged network is worth more than a weight bit
+    wb = std::min<int>(wb, std::max<int>(WEIGHT_BITS_MIN, KTagBits<KW>::value + (int)min_bits - 2 * (int)k));   // the f64-tagged network is worth more than a weight bit
     if (env) wb = std::min(env, valid);
     return (uint32_t)std::max<int>(WEIGHT_BITS_MIN, wb);
 }
@@ -1921,7 +1951,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     const uint32_t target = target_env ? target_env : (KW == 1) ? (dedupe ? 2 * SUB_TARGET : SUB_TARGET) : SUB_TARGET / 2;
     const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
     const uint32_t wb_goal = weight_bits_of<KW>(k, max_bits1);
-    const int stored_or_mantissa = KW == 1 ? KTAG64_BITS : 128;
+    const int stored_or_mantissa = KTagBits<KW>::value;      // (16-byte keys: 125, which covers the 128 - 2k - wb >= -2 the dropped top bits need)
     const uint32_t need_goal = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + (int)wb_goal - stored_or_mantissa));
     const uint32_t need_min = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + WEIGHT_BITS_MIN - stored_or_mantissa));
     bool goal_ok = weight_bits_env() != 0;              // (weight bits asked for: the sub-bucket bits they need, whatever the sizes)
@@ -2067,8 +2097,9 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     O.wb = wb;
     // --- the sort tiers, back to back: which sub-bucket goes where was decided by k_expand_count; no host round trip until the totals below
     // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
-    const bool tag = KW == 1 && 2 * k + wb - min_bits1 <= (uint32_t)KTAG64_BITS && getenv("GKC_NO_F64") == nullptr;
-    constexpr bool FT = KW == 1;
+    // (16-byte keys, round 4: the same tag on the key's top word — v_min/max_f64 there, selects on the low word: KTag<2>)
+    const bool tag = 2 * k + wb <= (uint32_t)KTagBits<KW>::value + min_bits1 && getenv("GKC_NO_F64") == nullptr;
+    constexpr bool FT = true;
     key_t* const keysA = (key_t*)B.keysA.p; key_t* const keysB = (key_t*)B.keysB.p;
     const uint64_t* const bs = (const uint64_t*)B.b_start.p; const uint32_t* const bn = (const uint32_t*)B.b_n.p; const uint8_t* const bc = (const uint8_t*)B.b_cons.p;
     {   ScopedTimer tm(c, "bucket_sort");
