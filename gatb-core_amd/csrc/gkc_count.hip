@@ -35,10 +35,28 @@ struct PartDesc {          // one per partition of the current Stage-B batch
     uint32_t part;         // partition id
     uint32_t sub_bits;     // log2(#sub-buckets)
     uint32_t shift;        // canonical >> shift = sub-bucket id  (2k - sub_bits)
-    uint32_t pad;
+    uint32_t pad;          // 0, or (entries of a sliced batch, see count_batch) log2(slices of the partition) << 16 | slice: the entry expands that share of the partition's records
     uint64_t key_base;     // first key of the partition in the batch key buffer
     uint64_t sub_base;     // first sub-bucket of the partition in the batch sub-bucket tables
+    uint64_t aux;          // entries of a sliced batch: first word of the entry's row in the per-(slice, sub-bucket) tables
 };
+// SEVERAL WORKGROUPS PER PARTITION (round 4). The expansion kernels run one workgroup per work-list ENTRY. Normally an entry is a partition. A batch with partitions far
+// beyond the size the batches are planned for (a caller that configures 256 partitions for 1e8 reads — the reference's own Configuration at -max-memory 200000 —
+// gets 5e7 k-mers per partition: 256 workgroups of very different sizes for 256 CUs, 2 waves per SIMD) is SLICED instead: a partition is 2^s entries, entry w
+// expanding the w-th share of its records (of every segment). The counting pass leaves every slice's per-sub-bucket counts c[w][b] in a table; the LAST slice of a
+// partition to finish adds them up, lays the partition's sub-buckets out as always and gives every slice its own place inside every sub-bucket:
+//     [slice 0's pairs][slice 1's pairs] ... [slice W-1's pairs][the odd keys of the slices, one each at most, in slice order]
+// — the pair scatter writes aligned 16-byte pairs and is left with at most one parked key per sub-bucket at the end: a slice's c & ~1 keys fill its pair range
+// (every range starts on an even slot: sub-buckets start on multiples of 4), its odd key goes to its slot in the tail. No hole, no global cursor, no extra
+// expansion work; the sort tiers see the same contiguous sub-buckets as ever.
+struct SliceTables { uint32_t* start; /* in: c[w][b]; out: first slot of the slice's pair range, relative to the partition's first key */ uint32_t* tail; /* slot of the slice's odd key */ uint32_t* done; /* [entries] slices of the partition that have counted (at the partition's first entry) */ };
+// records [lo, hi) of a segment's partition range [r0, r1) that slice w of 2^sl_bits takes
+__device__ __forceinline__ void slice_range(uint64_t r0, uint64_t r1, uint32_t pad, uint64_t& lo, uint64_t& hi)
+{
+    const uint32_t sl_bits = pad >> 16, w = pad & 0xFFFFu;
+    const uint64_t n = r1 - r0;
+    lo = r0 + ((n * w) >> sl_bits); hi = r0 + ((n * (w + 1)) >> sl_bits);
+}
 
 struct SegTable {          // device copy of the segment list
     const uint8_t* const* rec;      // [n_seg] arena pointers
@@ -239,10 +257,12 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
                                                                   TierLists T,
                                                                   const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
                                                                   uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */,
-                                                                  uint32_t drop /* top bits of a k-mer that do not fit the stored key (<= sub_bits of every partition) */)
+                                                                  uint32_t drop /* top bits of a k-mer that do not fit the stored key (<= sub_bits of every partition) */,
+                                                                  SliceTables ST /* sliced batch: the tables (start != nullptr) */)
 {
     typedef typename KeyT<KW>::type key_t;
     __shared__ uint32_t s_hist[MAX_SUB];
+    __shared__ uint32_t s_last;
     __shared__ uint32_t s_wsum[EXPAND_THREADS / 64];
     __shared__ WgList s_big, s_wg, s_split;
     __shared__ uint32_t s_item;
@@ -258,7 +278,8 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     if (threadIdx.x == 0) { s_big.n = 0; s_wg.n = 0; s_split.n = 0; }
     __syncthreads();
     for (uint32_t s = 0; s < segs.n_seg; s++) {
-        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const uint8_t* base = segs.rec[s];
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
@@ -269,6 +290,26 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         }
     }
     __syncthreads();
+    const uint32_t n_slices = 1u << (pd.pad >> 16), slice = pd.pad & 0xFFFFu;
+    const uint64_t row0 = pd.aux - (uint64_t)slice * nsub;                  // the partition's rows of the slice tables: one per slice, consecutive
+    if (ST.start) {
+        // sliced batch: the slice's counts go to its row; the last slice of the partition to get here lays the partition out
+        for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) ST.start[pd.aux + i] = s_hist[i];
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&ST.done[bi - slice], 1u) == n_slices - 1u ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) continue;
+        __threadfence();
+        if (n_slices > 1) {
+            for (uint32_t i = threadIdx.x; i < nsub; i += EXPAND_THREADS) {
+                uint32_t n = 0;
+                for (uint32_t w = 0; w < n_slices; w++) n += ST.start[row0 + (uint64_t)w * nsub + i];
+                s_hist[i] = n;
+            }
+            __syncthreads();
+        }
+    }
     // exclusive scan of the counters -> absolute key offsets of the sub-buckets; every sub-bucket starts on a multiple of 4 slots (pair scatter)
     const uint32_t per = (nsub + EXPAND_THREADS - 1) / EXPAND_THREADS;      // <= 16
     const uint32_t b = threadIdx.x * per;
@@ -288,6 +329,15 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         const uint32_t g = (uint32_t)(pd.sub_base + j);
         const uint32_t cons = pd.sub_bits | ((drop ? j >> (pd.sub_bits - drop) : 0u) << CONS_DROP_SHIFT);      // the sub-bucket's keys all start with these `drop` bits
         b_start[g] = pd.key_base + run; b_n[g] = n; b_consumed[g] = (uint8_t)cons;
+        if (ST.start) {                                                      // every slice's place inside the sub-bucket: pair ranges in slice order, then the odd keys
+            uint32_t pos = run, oddm = 0;
+            for (uint32_t w = 0; w < n_slices; w++) {
+                const uint64_t at = row0 + (uint64_t)w * nsub + j;
+                const uint32_t cw = ST.start[at];
+                ST.start[at] = pos; pos += cw & ~1u; oddm |= (cw & 1u) << w;
+            }
+            for (uint32_t w = 0; w < n_slices; w++) ST.tail[row0 + (uint64_t)w * nsub + j] = pos + __popc(oddm & ((1u << w) - 1u));      // (read only by a slice whose count is odd)
+        }
         if (n > T.cap1) {
             if (n <= T.cap2) wglist_push(&s_big, g, T.big_count, T.big_list);
             else if (n <= T.cap3) wglist_push(&s_wg, g, T.wg_count, T.wg_list);
@@ -321,7 +371,8 @@ constexpr int PAIR_THREADS = 1024;
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
                                                                        const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
-                                                                       uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */, uint32_t wb /* weight bits */)
+                                                                       uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */, uint32_t wb /* weight bits */,
+                                                                       SliceTables ST /* sliced batch (start != nullptr): the entry is a slice of a partition's records with its own place in every sub-bucket */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub] parked key or EMPTY
     __shared__ uint32_t s_item;
@@ -335,11 +386,12 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + nsub);                     // [nsub] next free slot of the sub-bucket
     constexpr unsigned long long EMPTY = ~0ULL;
-    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { s_pend[i] = EMPTY; s_cur[i] = (uint32_t)(b_start[pd.sub_base + i] - pd.key_base); }
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { s_pend[i] = EMPTY; s_cur[i] = ST.start ? ST.start[pd.aux + i] : (uint32_t)(b_start[pd.sub_base + i] - pd.key_base); }
     __syncthreads();
     uint64_t* out = keys + pd.key_base;
     for (uint32_t s = 0; s < segs.n_seg; s++) {
-        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
         uint64_t r = r0 + threadIdx.x;
         ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
@@ -368,7 +420,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[s_cur[i]] = v; }
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long v = s_pend[i]; if (v != EMPTY) out[ST.start ? ST.tail[pd.aux + i] : s_cur[i]] = v; }      // (a slice's odd key: its slot in the sub-bucket's tail)
   }
 }
 
@@ -389,7 +441,8 @@ __device__ __forceinline__ void lds_xchg128(unsigned long long* slot, uint64_t i
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                         const uint64_t* __restrict__ b_start, u128* __restrict__ keys,
                                                                         const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
-                                                                        uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */, uint32_t wb /* weight bits */)
+                                                                        uint32_t nb, uint32_t* __restrict__ ticket /* partitions are handed out to the workgroups of the launch */, uint32_t wb /* weight bits */,
+                                                                        SliceTables ST /* sliced batch: see k_expand_scatter_pair */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_pend[];       // [nsub][2] parked key (low word, high word) or EMPTY
   for (;;) {
@@ -404,11 +457,12 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
     const uint32_t nsub = 1u << pd.sub_bits;
     uint32_t* s_cur = reinterpret_cast<uint32_t*>(s_pend + 2 * (size_t)nsub);        // [nsub] next free slot of the sub-bucket
     constexpr unsigned long long EMPTY = ~0ULL;
-    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { s_pend[2 * i] = EMPTY; s_pend[2 * i + 1] = EMPTY; s_cur[i] = (uint32_t)(b_start[pd.sub_base + i] - pd.key_base); }
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { s_pend[2 * i] = EMPTY; s_pend[2 * i + 1] = EMPTY; s_cur[i] = ST.start ? ST.start[pd.aux + i] : (uint32_t)(b_start[pd.sub_base + i] - pd.key_base); }
     __syncthreads();
     ulonglong2* out = reinterpret_cast<ulonglong2*>(keys + pd.key_base);              // one 16-byte key per element (x = low word, y = high word)
     for (uint32_t s = 0; s < segs.n_seg; s++) {
-        const uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
+        if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);     // 32-byte records: two elements each
         uint64_t r = r0 + threadIdx.x;
         ulonglong2 nx0 = make_ulonglong2(0, 0), nx1 = nx0;
@@ -438,7 +492,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long lo = s_pend[2 * i], hi = s_pend[2 * i + 1]; if (hi != EMPTY || lo != EMPTY) out[s_cur[i]] = make_ulonglong2(lo, hi); }
+    for (uint32_t i = threadIdx.x; i < nsub; i += PAIR_THREADS) { const unsigned long long lo = s_pend[2 * i], hi = s_pend[2 * i + 1]; if (hi != EMPTY || lo != EMPTY) out[ST.start ? ST.tail[pd.aux + i] : s_cur[i]] = make_ulonglong2(lo, hi); }
   }
 }
 
@@ -1926,8 +1980,8 @@ template <int KW> static uint32_t weight_bits_of(uint32_t k, uint32_t min_bits)
 constexpr int DEEP_FIXED = 4;                   // split levels launched unconditionally (a level with an empty queue returns at once); more only if the last one left work
 constexpr int DEEP_COUNTERS = 8;                // per-level counter triples (next level's queue length, sort list length, item ticket), used cyclically
 struct BatchBufs {
-    DevBuf pd, keysA, keysB, cnt, cnt8, b_start, b_n, b_cons, l_big, l_wg, l_split, misc, nd, ns, off_d, off_s, chunk, q[2], sitems, giant, glist, rbase, rroot, rcnt, dd_arena, dd_base, dd_bins, dd_lg, dd_off, dd_ptr, dd_end, pidx, ptot, order;
-    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start, &b_n, &b_cons, &l_big, &l_wg, &l_split, &misc, &nd, &ns, &off_d, &off_s, &chunk, &q[0], &q[1], &sitems, &giant, &glist, &rbase, &rroot, &rcnt, &dd_arena, &dd_base, &dd_bins, &dd_lg, &dd_off, &dd_ptr, &dd_end, &pidx, &ptot, &order };
+    DevBuf pd, keysA, keysB, cnt, cnt8, b_start, b_n, b_cons, l_big, l_wg, l_split, misc, nd, ns, off_d, off_s, chunk, q[2], sitems, giant, glist, rbase, rroot, rcnt, dd_arena, dd_base, dd_bins, dd_lg, dd_off, dd_ptr, dd_end, pidx, ptot, order, vpd, vstart, vtail, vdone;
+    void release() { DevBuf* all[] = { &pd, &keysA, &keysB, &cnt, &cnt8, &b_start, &b_n, &b_cons, &l_big, &l_wg, &l_split, &misc, &nd, &ns, &off_d, &off_s, &chunk, &q[0], &q[1], &sitems, &giant, &glist, &rbase, &rroot, &rcnt, &dd_arena, &dd_base, &dd_bins, &dd_lg, &dd_off, &dd_ptr, &dd_end, &pidx, &ptot, &order, &vpd, &vstart, &vtail, &vdone };
                      for (DevBuf* d : all) d->release(); }
 };
 
@@ -1943,7 +1997,19 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     std::vector<uint64_t> pidx(nb + 1);
     uint64_t n_slots = 0, n_sub = 0;
     static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
-    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0;
+    // Sliced batch (see SliceTables): a partition beyond GKC_SLICE_MIN k-mers (default 8e6: twice and more what the batches and the drop-in's Configuration aim
+    // at, and where the bins of the record deduplication are full) is expanded by up to 16 workgroups, so that an entry is 2e6 .. 4e6 k-mers like a planned
+    // partition; GKC_SLICES=0 switches it off (tests lower the threshold). The record deduplication (one workgroup per partition, bins for <= 8e5 records: on such
+    // partitions it costs more than it saves — 242 ms for 256 partitions of 1e8 reads) is skipped for a sliced batch.
+    // Measured, 1e8 reads, k = 31, two lanes (profiles/r04_sliced_partitions.txt): 256 partitions 600 -> 375 ms per step (expand_count 109 -> 19 ms, expand_scatter
+    // 238 -> 90 ms single lane; what is left of the gap to the 4096-partition step, 203 ms, is the split levels: every 2^13-th of such a partition is 5700 keys,
+    // beyond the sort tiers), 64 partitions 387 ms, 1024 partitions 346 -> 323 ms.
+    const uint64_t slice_min = getenv("GKC_SLICE_MIN") ? (uint64_t)std::max(1, atoi(getenv("GKC_SLICE_MIN"))) : 8000000ull;
+    const uint64_t slice_keys = std::max<uint64_t>(1, slice_min / 4);
+    const bool slices_on = !(getenv("GKC_SLICES") && atoi(getenv("GKC_SLICES")) == 0);
+    bool sliced = false;
+    if (slices_on) for (uint32_t i = 0; i < nb; i++) sliced = sliced || part_keys[batch_parts[i]] > slice_min;
+    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0 && !sliced;
     // mean keys of a level-1 bucket, counted in k-mers BEFORE identical records are merged: with the merge on (8-byte keys: ~1.8x fewer keys on 30x reads) twice as
     // many — 12 sub-bucket bits instead of 13 for the partitions of the 1e8-read bench: first sort tier 46.8 -> 38.3 ms, the larger tiers +8, scatter -4: 220 -> 214 ms
     // (possible since the tagged sort carries 61 key bits: profiles/r04_weight_bits_experiment.txt)
@@ -1971,7 +2037,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         // that is 4 / 3 bits (rounds 2-3, 52-bit tag: 13 / 12 bits whatever the partition's size — the 8-GPU share on one GPU, 32768 partitions of 4.5e5 k-mers,
         // 325 -> 278 ms when the tag was widened). (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can push the key's top bit out.)
         if (getenv("GKC_MAX_SUB_BITS") == nullptr) bits = std::min<uint32_t>(std::max(bits, goal_ok ? need_goal : need_min), 2 * k);
-        pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0;
+        pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0; pd[i].aux = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pidx[i] = n_sub;
         n_slots += (np + (3ull << bits) + PART_ALIGN - 1) / PART_ALIGN * PART_ALIGN;       // sub-buckets start on multiples of 4 slots (pair scatter)
@@ -1980,6 +2046,17 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     pidx[nb] = n_sub;
     if (n_sub >= (1ULL << 31)) GKC_FAIL(c, GKC_ERR_ARG, "too many sub-buckets in one batch");
     uint32_t min_bits1 = 64, max_bits_b = 0; for (uint32_t i = 0; i < nb; i++) { min_bits1 = std::min(min_bits1, pd[i].sub_bits); max_bits_b = std::max(max_bits_b, pd[i].sub_bits); }
+    // the expansion's work list: one entry per partition, or (sliced batch) 2^s entries per partition, each a share of its records
+    std::vector<PartDesc> vpd; std::vector<uint32_t> v_parent; uint64_t slice_words = 0;
+    if (sliced) for (uint32_t i = 0; i < nb; i++) {
+        const uint64_t np = part_keys[batch_parts[i]];
+        uint32_t sb = 0; while (sb < 4 && np > slice_min && (np >> sb) > slice_keys) sb++;
+        for (uint32_t w = 0; w < (1u << sb); w++) {
+            PartDesc e = pd[i]; e.pad = (sb << 16) | w; e.aux = slice_words; slice_words += 1ull << e.sub_bits;
+            vpd.push_back(e); v_parent.push_back(i);
+        }
+    }
+    const uint32_t nv = sliced ? (uint32_t)vpd.size() : nb;
     const uint32_t wb = weight_bits_of<KW>(k, nb ? min_bits1 : 0u);
     const uint32_t drop = 2 * k + wb > 64u * KW ? 2 * k + wb - 64u * KW : 0u;      // top bits of a key that fall off the stored word (<= WEIGHT_DROP_MAX <= min_bits1)
     const uint32_t wcap = drop >= 2 ? (1u << wb) - 1u : (1u << wb);                // copies one merged record may stand for (see the note at the top of the file)
@@ -2010,13 +2087,22 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     CB_TRY(c->ensure(B.pidx, (size_t)(nb + 1) * 8)); CB_TRY(c->ensure(B.ptot, (size_t)(nb + 1) * 16));
     // the expansion kernels run one workgroup per partition: workgroup i takes the i-th LARGEST partition, so that the launch does not end on one long
     // workgroup (partition sizes spread 2-3x around their mean). Only the assignment changes: the layout of the batch stays in partition order.
-    std::vector<uint32_t> order(nb);
-    for (uint32_t i = 0; i < nb; i++) order[i] = i;
+    std::vector<uint32_t> order(nv);
+    for (uint32_t i = 0; i < nv; i++) order[i] = i;
     static const bool lpt = getenv("GKC_BATCH_LPT") ? atoi(getenv("GKC_BATCH_LPT")) != 0 : true;
-    if (lpt) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return part_keys[batch_parts[a]] > part_keys[batch_parts[b]]; });
-    CB_TRY(c->ensure(B.order, (size_t)nb * 4));
-    CB_HIP(hipMemcpyAsync(B.order.p, order.data(), (size_t)nb * 4, hipMemcpyHostToDevice, cur_stream(c)));
+    auto keys_of_entry = [&](uint32_t v) -> uint64_t { return sliced ? part_keys[batch_parts[v_parent[v]]] >> (vpd[v].pad >> 16) : part_keys[batch_parts[v]]; };
+    if (lpt) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys_of_entry(a) > keys_of_entry(b); });
+    CB_TRY(c->ensure(B.order, (size_t)nv * 4));
+    CB_HIP(hipMemcpyAsync(B.order.p, order.data(), (size_t)nv * 4, hipMemcpyHostToDevice, cur_stream(c)));
     CB_HIP(hipMemcpyAsync(B.pd.p, pd.data(), nb * sizeof(PartDesc), hipMemcpyHostToDevice, cur_stream(c)));
+    SliceTables ST{ nullptr, nullptr, nullptr };
+    if (sliced) {
+        CB_TRY(c->ensure(B.vpd, (size_t)nv * sizeof(PartDesc))); CB_TRY(c->ensure(B.vstart, (size_t)slice_words * 4)); CB_TRY(c->ensure(B.vtail, (size_t)slice_words * 4)); CB_TRY(c->ensure(B.vdone, (size_t)nv * 4));
+        CB_HIP(hipMemcpyAsync(B.vpd.p, vpd.data(), (size_t)nv * sizeof(PartDesc), hipMemcpyHostToDevice, cur_stream(c)));
+        CB_HIP(hipMemsetAsync(B.vdone.p, 0, (size_t)nv * 4, cur_stream(c)));
+        ST.start = (uint32_t*)B.vstart.p; ST.tail = (uint32_t*)B.vtail.p; ST.done = (uint32_t*)B.vdone.p;
+    }
+    const PartDesc* const d_entries = sliced ? (const PartDesc*)B.vpd.p : (const PartDesc*)B.pd.p;          // what the expansion kernels walk
     CB_HIP(hipMemcpyAsync(B.pidx.p, pidx.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, cur_stream(c)));
     CB_HIP(hipMemsetAsync(B.misc.p, 0, 64 * 4, cur_stream(c)));
     CB_HIP(hipMemsetAsync(B.nd.p, 0, (size_t)std::max<uint64_t>(n_sub, 1) * 4, cur_stream(c)));
@@ -2068,8 +2154,8 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     }
     {   ScopedTimer tm(c, "expand_count");
         static const uint32_t cwgs_env = getenv("GKC_COUNT_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_COUNT_WGS"))) : 0u;
-        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nb, cwgs_env) : nb), dim3(EXPAND_THREADS), 0, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
-                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nb, misc + 7, drop);
+        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nv, cwgs_env) : nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
+                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
@@ -2080,13 +2166,13 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         if constexpr (KW == 1) {
             const size_t lds_max = (size_t)MAX_SUB * 12, lds = ((size_t)12 << max_bits_b);          // parking slots + cursors of the batch's largest sub-bucket count
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
-            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
-                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6, wb);
+            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), d_entries, segs_b, k,
+                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(std::min(nb, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), (const PartDesc*)B.pd.p, segs_b, k,
-                               (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p, nb, misc + 6, wb);
+            hipLaunchKernelGGL(k_expand_scatter_pair2, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), d_entries, segs_b, k,
+                               (const uint64_t*)B.b_start.p, (u128*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
         }
         CB_HIP(hipGetLastError());
     }

@@ -203,6 +203,27 @@ def test_oversize_buckets_low_complexity(gkc):
     assert c.stats()["oversize_buckets"] > 0
 
 
+@pytest.mark.parametrize("k,m,parts,n_reads,skew,smin", [(31, 10, 1, 100_000, False, 1), (31, 9, 3, 160_000, False, 1_000_000), (63, 10, 2, 150_000, False, 1), (21, 8, 2, 120_000, False, 3_000_000),
+                                                         (31, 10, 5, 110_000, True, 2_000_000), (41, 10, 4, 130_000, True, 1), (63, 11, 3, 90_000, True, 1_500_000)])
+def test_sliced_partitions_few_huge(gkc, monkeypatch, k, m, parts, n_reads, skew, smin):
+    """Several workgroups per partition: a partition far beyond the planned size is expanded by up to 16 workgroups, each taking a share of its
+    records, with its own pair range + odd-key slot inside every sub-bucket (SliceTables in csrc/gkc_count.hip). GKC_SLICE_MIN makes partitions of 3e6 .. 1.2e7
+    k-mers take the path that partitions beyond 1.6e7 k-mers take by default (16 slices with 1; 2 .. 8 with the larger thresholds; `skew`: one huge partition
+    beside small unsliced ones in the same batch). Records, statistics and histogram against the oracle; N's, ragged reads, low-complexity reads (split roots,
+    giants) and copied reads included; then the same input with the slices switched off."""
+    monkeypatch.setenv("GKC_SLICE_MIN", str(smin))
+    reads = synth_reads(n_reads, n_reads * 5, 150, seed=3 * k + parts, n_rate=0.0005, ragged=True)
+    reads += [b"A" * 150] * 200 + [b"ACACACACAC" * 15] * 200 + [b"G" * 150] * 30 + [reads[5]] * 40
+    rep = simple_repart(m, parts)
+    if skew:
+        rep = (rep.astype(np.uint32) % (8 * (parts - 1))).astype(np.uint16)
+        rep = np.where(rep < parts - 1, rep + 1, 0).astype(np.uint16)             # partition 0 takes 7/8 of the minimizers
+    device_vs_oracle(gkc, reads, k, m, parts, rep=rep)
+    device_vs_oracle(gkc, reads, k, m, parts, rep=rep, batches=3, amin=2, amax=40)        # several segments (every slice takes its share of each), a solidity window
+    monkeypatch.setenv("GKC_SLICES", "0")
+    device_vs_oracle(gkc, reads[:20000], k, m, parts, rep=rep)
+
+
 def test_superkmer_buckets_match_partition_contract(gkc):
     """A5/A6: the device buckets, re-encoded in the reference wire format and decoded by the oracle (B1), hold exactly
     the k-mers the oracle's partitions hold (tile boundaries may split a super-k-mer; the k-mer multiset is the contract)"""
@@ -338,7 +359,8 @@ def test_synth_generator_and_checksum_property(gkc):
     c.device_free(db); c.device_free(do)
 
 
-@pytest.mark.parametrize("k,n,parts", [(31, 2_000_000, 512), (31, 100_000_000, 4096), (63, 50_000_000, 2048), (63, 100_000_000, 4096), (21, 100_000_000, 32768), (47, 30_000_000, 9000)])
+@pytest.mark.parametrize("k,n,parts", [(31, 2_000_000, 512), (31, 100_000_000, 4096), (63, 50_000_000, 2048), (63, 100_000_000, 4096), (21, 100_000_000, 32768), (47, 30_000_000, 9000),
+                                       (31, 100_000_000, 256), (31, 30_000_000, 16), (63, 40_000_000, 64)])      # few HUGE partitions: several workgroups per partition (slices)
 def test_size_independent_properties(gkc, k, n, parts):
     """2e6 reads, then BASELINE configs[1] (k=31, 1e8 reads) and configs[3] (k=63, 1e8 reads; also 5e7) at full size:
     size-independent properties — multiset checksum (independent one-thread-per-read kernel vs counted records), sum of
@@ -355,7 +377,7 @@ def test_size_independent_properties(gkc, k, n, parts):
     st = c.stats()
     assert st["kmers_nb_valid"] == nv == n * (L - k + 1)
     tot = 0
-    for p in range(0, parts, max(37, parts // 24)):
+    for p in range(0, parts, max(37, parts // 24) if parts > 256 else max(1, parts // 3)):
         lo, hi, ab = c.partition(0, p)
         if k <= 31:
             assert (lo[1:] > lo[:-1]).all()

@@ -1,12 +1,16 @@
-#!/bin/bash
-# scratch: a sweep of short bench runs (single GPU call)
-R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out/sw
-run() { n=$1; shift; env "$@" python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-k63 --no-bloom-mphf --no-host-landed --no-share-of-8 --no-two-pass $EXTRA > gpurun_out/sw/$n.json 2> gpurun_out/sw/$n.err
-python - <<PY
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "sliced or size_independent or alternative or fuzz or bit_exact or oversize" 2>&1 | tail -6
+run() { tag=$1; shift; env "$@" python bench.py --partitions ${P:-256} --steps 2 --warmup 1 --no-cpu-baseline --no-host-landed --no-k63 --no-bloom-mphf --no-share-of-8 --no-two-pass > gpurun_out/c_$tag.json 2> gpurun_out/c_$tag.err; python - <<PY
 import json
-d=json.load(open("gpurun_out/sw/$n.json")); t=d["config"]["kernel_ms_per_step"]; s=d["roofline"]["single_lane"]["kernel_ms_per_step"]
-print("$n: ms_per_step %.1f A %.1f B %.1f | single: %s" % (d["ms_per_step"], t["total_stage_a"], t["total_stage_b"], {k: round(v, 1) for k, v in s.items()}))
+try:
+    d=json.load(open("gpurun_out/c_$tag.json")); k=d["config"]["kernel_ms_per_step"]
+    print("$tag", round(d["ms_per_step"],1), d["verified"], {a:round(b) for a,b in k.items()})
+    print("   single", {a:round(b) for a,b in d["roofline"]["single_lane"]["kernel_ms_per_step"].items()})
+except Exception as e: print("$tag failed", e)
 PY
 }
-EXTRA="--partitions 256" run p256 A=1
-EXTRA="--partitions 1024" run p1024 A=1
+P=256 run p256 A=1
+P=256 run p256_off GKC_SLICES=0
+P=64 run p64 A=1
+P=1024 run p1024 A=1
+P=1024 run p1024_s GKC_SLICE_MIN=8000000
+P=4096 run p4096 A=1
