@@ -52,7 +52,10 @@ const char* gkc_version(void);
  * Model.hpp:1032-1064) and `Repartitor::operator()` (kmer/impl/PartiInfo.hpp:323).
  *   repart      u16[4^m]  minimizer value -> partition  (the table Repartitor::load reads, PartiInfo.cpp:223-262)
  *   freq_order  u32[4^m]  or NULL; required iff minimizer_type==GKC_MINIMIZER_FREQ (RepartitionAlgorithm.cpp:311-384)
- * k in [3,63] (k<=2 refused like SortingCountAlgorithm.cpp:662-666), m in [2,min(k-1,14)], nb_partitions in [1,65535]. */
+ * k in [3,63] (k<=2 refused like SortingCountAlgorithm.cpp:662-666), m in [2,min(k-1,14)], nb_partitions in [1,65535].
+ * Sizing: Stage B is planned for partitions of 2e6 .. 4e6 k-mers (what gkc_device_memory-driven callers and the drop-in's DeviceConfiguration choose: ~4000
+ * partitions for 1e8 reads of 150 bp). Any count is correct; partitions beyond 8e6 k-mers are expanded by several workgroups each but skip the record
+ * deduplication and send their sub-buckets through one split level (256 partitions for 1e8 reads: 375 ms per pass against 203 ms with 4096). */
 int gkc_configure(gkc_ctx* ctx, uint32_t k, uint32_t m, uint32_t nb_partitions, uint32_t nb_passes,
                   int minimizer_type, const uint16_t* repart, const uint32_t* freq_order);
 
