@@ -381,7 +381,9 @@ def main():
     if use_dist:
         from gatb_core_amd import dist as gdist          # noqa
         t_c0 = time.perf_counter()
-        runner = gdist.DistributedCounter(c, rank, world, parts)
+        runner = gdist.DistributedCounter(c, rank, world, parts, try_rccl=os.environ.get("GKC_BENCH_TRY_RCCL") == "1")      # (RCCL refused on any rank: host-staged fallback, reported in `exchange.transport`)
+        if rank == 0 or "fallback" in (gdist.LAST_COMM_KIND or ""):
+            sys.stderr.write("[bench rank %d] communicator: %s\n" % (rank, gdist.LAST_COMM_KIND))
         comm_create_s = time.perf_counter() - t_c0
         # Start-up self-test over the REAL peers, before anything is timed (default on with several ranks; GKC_COMM_SELFTEST=0 skips it): every pair of GPUs exchanges
         # 64 MiB and 300 MiB (two chunks of the 256 MiB chunking) of a keyed pattern through the communicator's grouped ncclSend / ncclRecv path — the first thing
@@ -582,8 +584,9 @@ def main():
                 sl["hbm_GBps_from_counters"] = traffic / (sl["launch_ms"] * 1e-3) / 1e9
                 sl["frac_from_counters"] = sl["hbm_GBps_from_counters"] / HBM_PEAK_GBS
         if exch is not None:
-            out["exchange"] = {"transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if red_dev == "cuda" else
-                               ("DRY RUN (GKC_BENCH_BACKEND=%s): host-staged transport, the ranks share %d device(s); %d pushes per pass" % (dist.get_backend(), torch.cuda.device_count(), n_push)),
+            kind = gdist.LAST_COMM_KIND or "rccl"
+            out["exchange"] = {"transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if kind == "rccl" and red_dev == "cuda" else
+                               ("%s%s; %d pushes per pass" % ("DRY RUN (GKC_BENCH_BACKEND=%s, the ranks share %d device(s)): " % (dist.get_backend(), torch.cuda.device_count()) if red_dev != "cuda" else "", kind, n_push)),
                                "per_rank": exch}
         if world == 1 and not args.no_host_landed:
             out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=args.steps, expect=expect, parts=parts)

@@ -61,15 +61,41 @@ class HostStagedTransport:
             self.c.host_to_device(ptr, t.numpy())
 
 
-def make_comm(counter, group=None):
-    """communicator of this rank for ``counter`` (see module docstring). Without an initialised process group: a one-rank RCCL communicator."""
+LAST_COMM_KIND = None       # "rccl" | "host-staged" | "host-staged (fallback: <why>)": what make_comm gave this process last (bench.py reports it)
+
+
+def make_comm(counter, group=None, try_rccl=None):
+    """communicator of this rank for ``counter`` (see module docstring). Without an initialised process group: a one-rank RCCL communicator.
+
+    Backend "nccl": every rank opens its RCCL communicator inside the library; the ranks then tell each other whether that worked, and if it failed on ANY of
+    them (RCCL inside libgkc_hip.so has never met real peers before the first multi-GPU run: a refusal there must not cost the run) ALL of them switch to
+    the host-staged transport over a gloo group created for the purpose — slower by the PCIe round trip, same results, and LAST_COMM_KIND says so.
+    ``try_rccl=True`` makes a gloo-backed group attempt RCCL first as well (the dry run of this very fallback: two ranks on one device are refused by RCCL)."""
+    global LAST_COMM_KIND
     if not dist.is_initialized():
+        LAST_COMM_KIND = "rccl"
         return gkc.Comm.rccl(counter, gkc.Comm.unique_id(), 1, 0)
     world = dist.get_world_size(group); rank = dist.get_rank(group)
-    if dist.get_backend(group) == "nccl":
+    is_nccl = dist.get_backend(group) == "nccl"
+    if is_nccl or try_rccl:
         box = [gkc.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        return gkc.Comm.rccl(counter, box[0], world, rank)
+        comm, why = None, None
+        try:
+            comm = gkc.Comm.rccl(counter, box[0], world, rank)
+        except Exception as e:      # noqa  (gkc.GkcError: the library's message names the RCCL call that failed)
+            why = "rank %d: %s" % (rank, str(e)[:300])
+        votes = [None] * world
+        dist.all_gather_object(votes, why, group=group)
+        bad = [v for v in votes if v]
+        if not bad:
+            LAST_COMM_KIND = "rccl"
+            return comm
+        # (a communicator that did open on this rank is left alone: destroying half of a broken clique may hang)
+        staged_group = dist.new_group(backend="gloo") if is_nccl else group
+        LAST_COMM_KIND = "host-staged (fallback: RCCL communicator refused on %d of %d ranks; %s)" % (len(bad), world, bad[0])
+        return gkc.Comm.transport(counter, HostStagedTransport(counter, staged_group), world, rank)
+    LAST_COMM_KIND = "host-staged"
     return gkc.Comm.transport(counter, HostStagedTransport(counter, group), world, rank)
 
 
@@ -78,9 +104,9 @@ class DistributedCounter:
     Per pass: counter.begin_pass(p); [counter.push_reads*(...); self.exchange()]*; counter.finish_pass(). The number of pushes may differ
     between ranks as long as every rank calls exchange() the same number of times (a call without new pushes sends nothing)."""
 
-    def __init__(self, counter, rank, world, nb_partitions, group=None, comm=None, owners=None):
+    def __init__(self, counter, rank, world, nb_partitions, group=None, comm=None, owners=None, try_rccl=None):
         self.c, self.rank, self.world, self.P, self.group = counter, rank, world, nb_partitions, group
-        self.comm = comm if comm is not None else make_comm(counter, group)
+        self.comm = comm if comm is not None else make_comm(counter, group, try_rccl=try_rccl)
         if owners is not None:
             self.comm.set_owners(owners)
 

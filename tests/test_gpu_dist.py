@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, k, parts, amin, q):
+def _rank_main(rank, world, port, k, parts, amin, q, try_rccl=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +35,10 @@ def _rank_main(rank, world, port, k, parts, amin, q):
         mine = reads[:1800] if rank == 0 else reads[1800:]
         chunks = [mine[:1000], mine[1000:]] if rank == 0 else [mine, []]
         c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
-        dc = gd.DistributedCounter(c, rank, world, parts)
+        dc = gd.DistributedCounter(c, rank, world, parts, try_rccl=try_rccl)
+        # try_rccl: both ranks first ask the library for an RCCL communicator (refused: two ranks on one device), agree on the refusal and fall back to the host-staged
+        # transport — the path a multi-GPU run takes if RCCL inside libgkc_hip.so does not come up between real peers (gatb-core_amd/dist.py:make_comm)
+        assert gd.LAST_COMM_KIND == "host-staged" if not try_rccl else gd.LAST_COMM_KIND.startswith("host-staged (fallback: RCCL communicator refused on 2 of 2 ranks"), gd.LAST_COMM_KIND
         bad, _ = dc.comm.selftest(3 << 20)                   # every rank sends a keyed pattern to every other rank and checks what it gets (what bench.py --gpus N does first)
         assert bad == 0
         c.begin_pass(0)
@@ -66,12 +69,12 @@ def _rank_main(rank, world, port, k, parts, amin, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,parts,amin", [(31, 12, 2), (41, 8, 1)])
-def test_two_ranks_one_gpu_end_to_end(k, parts, amin):
+@pytest.mark.parametrize("k,parts,amin,try_rccl", [(31, 12, 2, False), (41, 8, 1, False), (31, 12, 2, True)])
+def test_two_ranks_one_gpu_end_to_end(k, parts, amin, try_rccl):
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, k, parts, amin, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, k, parts, amin, q, try_rccl)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     [p.join(timeout=120) for p in procs]
