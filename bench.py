@@ -224,16 +224,19 @@ def fastq_parse_leg(c, n_reads=1_000_000, L=150):
             "text_GBps": t.numel() / best / 1e9, "gbases_per_s": n_reads * L / best / 1e9, "ms": best * 1e3}
 
 
-def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, expect=None, parts=0):
+def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, expect=None, parts=0, amins=(1, 2), host_to_host=True):
     """SURVEY §8(d) wall: from the first push to the last partition's Count[] in (page-locked) host memory. Every Stage-B batch is copied into
     the host sink on a copy stream while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns when everything has landed.
     Reported beside `value` (which stops with the results in HBM), at abundance-min 1 (every distinct k-mer travels: PCIe-bound) and 2."""
     import torch
     out = {}
+    RB = c.rec_bytes                                          # 16 (k <= 31) / 32 (k <= 63): Kmer<span>::Count in memory
+    t_alloc = time.perf_counter()
     try:
-        sink = gkc.HostBuffer(int(distinct * 16 * 1.01) + (64 << 20))
+        sink = gkc.HostBuffer(int(distinct * RB * 1.01) + (64 << 20))
     except Exception as e:      # noqa
-        return {"error": "page-locked sink of %.1f GB: %s" % (distinct * 16 / 1e9, e)}
+        return {"error": "page-locked sink of %.1f GB: %s" % (distinct * RB / 1e9, e)}
+    out["sink_GB"] = sink.nbytes / 1e9; out["sink_alloc_s"] = time.perf_counter() - t_alloc
     # what the box's PCIe link sustains device -> page-locked host (one 4 GB copy)
     probe = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
     n_probe = min(4 << 30, sink.nbytes) // (1 << 30)
@@ -245,7 +248,7 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
     del probe
     out["pcie_d2h_GBps"] = pcie
     c.set_host_sink(sink)
-    for amin in (1, 2):
+    for amin in amins:
         c.set_solidity(amin, 2147483647, 10000)
         step(); sync()                                        # the batch plan changes with the solidity window: one untimed step
         ns_ = n_steps_amin2 if amin == 2 else n_steps
@@ -255,11 +258,11 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
         sync()
         dt = (time.perf_counter() - t0) / ns_
         st = c.stats()
-        landed = st["kmers_nb_solid"] * 16
+        landed = st["kmers_nb_solid"] * RB
         # what crosses the link: the batches travel packed (csrc/gkc_sink.hip) unless GKC_SINK_PACKED=0 — 6.3 bytes per record where the partitions are dense and most
         # abundances are 1, 7 where dense, 8 where sparse; the library counts the bytes it queued (gkc_stats.reserved[1])
         packed = st.get("sink_wire_bytes", 0) > 0
-        wire = st["sink_wire_bytes"] if packed else st["kmers_nb_solid"] * 16
+        wire = st["sink_wire_bytes"] if packed else st["kmers_nb_solid"] * RB
         err = (c.L.gkc_last_error(c.h) or b"").decode()
         out["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s with every solid Count[] in page-locked host memory",
                                           "ms_per_step": dt * 1e3, "steps": ns_, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
@@ -282,6 +285,8 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
     # PCIe at BOTH ends (never `value`): bases in page-locked host memory in (gkc_push_reads: H2D of chunk j+1 under the scan of chunk j), every solid Count[]
     # into the page-locked sink out; 5e7 reads of the same generator (30x over their own genome)
     try:
+        if not host_to_host:
+            raise StopIteration
         n2, L = 50_000_000, 150
         db, do = c.synth_reads_device(2, n2, L, n2 * 5, 10000)
         pin = gkc.HostBuffer(n2 * L)
@@ -297,9 +302,11 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
             t0 = time.perf_counter(); step2(); step2(); sync(); dt = (time.perf_counter() - t0) / 2
             st = c.stats()
             h2h["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s, pinned host bases in -> solid Count[] in pinned host memory",
-                                              "ms_per_step": dt * 1e3, "steps": 2, "count_bytes_out_GB": st["kmers_nb_solid"] * 16 / 1e9}
+                                              "ms_per_step": dt * 1e3, "steps": 2, "count_bytes_out_GB": st["kmers_nb_solid"] * RB / 1e9}
         out["host_to_host"] = h2h
         del pin
+    except StopIteration:
+        pass
     except Exception as e:      # noqa
         out["host_to_host"] = {"error": repr(e)}
     c.set_host_sink(None)
@@ -714,6 +721,21 @@ def main():
                                     "roofline": {"bound": "hbm", "kernel": dom63, "achieved": ach63, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach63 / HBM_PEAK_GBS,
                                                  "traffic": None, "launches_per_step": int(ln63), "launch_ms": dom63_ms / ln63,
                                                  "algorithmic_bytes_per_launch": alg63[dom63] / ln63, "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))}}
+            if not args.no_host_landed:
+                # SURVEY 8(d)'s wall for configs[3]: every distinct 63-mer's 32-byte Count record in page-locked host memory (abundance-min 1): 147 GB of records, 16 bytes
+                # per record on the link (csrc/gkc_sink.hip, 16-byte keys); one untimed + one timed step, verified like the others
+                def sync63():
+                    torch.cuda.synchronize()
+                try:
+                    hl63 = host_landed_leg(c63, gkc, step63, sync63, s63["kmers_nb_distinct"], n_steps=1, expect=input_checksum(c63, [(b63, o63, n_reads, n_bases)]), parts=p63,
+                                           amins=(1,), host_to_host=False)
+                except Exception as e:      # noqa
+                    hl63 = {"error": repr(e)}
+                out["config"]["k63"]["host_landed"] = hl63
+                if "abundance_min_1" in hl63:
+                    out["config"]["k63"]["value_host_landed"] = hl63["abundance_min_1"]["value"]
+                    if "verified" in hl63["abundance_min_1"]:
+                        all_verified.append(hl63["abundance_min_1"]["verified"])
             c63.device_free(b63); c63.device_free(o63); c63.close()
         if world == 1 and k == 31 and not args.no_share_of_8:
             # BASELINE configs[2]'s per-GPU share on THIS GPU: 1.25e8 reads of the 10^9-read stream, the partition count the 8-GPU run uses (-> two-level Stage A),

@@ -263,6 +263,7 @@ void  gkc_sink_drain(gkc_ctx* c);
 void  gkc_sink_shutdown(gkc_ctx* c);
 void  gkc_sink_wait_batch(gkc_ctx* c, const void* batch);
 void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot, const std::vector<uint64_t>& solid_prefix, uint8_t* h_dest);
+const char* gkc_sink_last_refusal();                          // why this thread's last gkc_sink_send_packed returned nullptr
 struct gkc_comm;                              // gkc_dist.hip
 int gkc_comm_world(gkc_comm* m);
 int gkc_comm_rank(gkc_comm* m);

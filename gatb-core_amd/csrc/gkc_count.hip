@@ -2334,6 +2334,10 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         if (room && !sink_batch) {
             const uint64_t bytes = total_solid * OW * 8;
             std::lock_guard<std::mutex> lk(c->mu);
+            if (gkc_sink_packed(c)) {                                  // a packing context whose batch travels plain: its bytes belong to what the library queued on the link
+                c->sink_wire_bytes += bytes;
+                if (getenv("GKC_SINK_DEBUG") || getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc sink] a batch of %llu records travels unpacked: %s\n", (unsigned long long)total_solid, gkc_sink_last_refusal());
+            }
             {
                 if (hipEventCreateWithFlags(&landed, hipEventDisableTiming) == hipSuccess &&
                     hipMemcpyAsync((void*)h_base, out, bytes, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess &&

@@ -39,6 +39,13 @@ constexpr uint64_t PK_DENSE = 300000;                                   // recor
 // after ONE reservation on the stream's cursor: the order of the blocks in the stream is whatever it came out as)
 constexpr uint64_t PK6_ENTRIES = (uint64_t)PK_BLOCK * 6, PK6_SLOT = PK6_ENTRIES + PK_BLOCK / 8;                 // 49152 + 1024 bytes: a multiple of 16
 constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PK6_SLOT : pk_slot(width); }
+// 16-byte keys (k >= 32; round 4, second session): the same scheme on 32-byte Count records {u128 value; i32 abundance; 12 bytes of padding} (Abundance.hpp:68-129 with
+// LargeInt<2>): per block the first key (16 bytes), per record [key delta : 15 or 16 bytes][abundance : 1 byte] = widths 16 / 17 instead of 32. A partition of 5.6e5 records in a
+// 126-bit key space has deltas of ~2^107 — but canonical k-mers thin out towards the top of the key space (density 2 (1 - x)), and with 14-byte deltas 0.1-0.4 % of them escaped
+// (1e6 exception entries per batch of 2.6e8 records: measured, the batches fell back to plain copies): 15 bytes where the partitions are dense (a delta of 2^120 - 1 or more —
+// a few per batch — escapes through TWO exception entries, low and high word), the full 16 bytes where they are sparse (no key escape at all).
+constexpr uint64_t PK_KEY_EXC_HI = (1ull << 63) | (1ull << 62);
+constexpr uint64_t PK2_DENSE = 100000;                                 // records per partition from which 15-byte deltas are used
 }
 
 struct PackPlan { const uint32_t* blk_first; /* [nb + 1] first block slot of every partition of the batch */ const uint64_t* ptot; /* [2 (nb + 1)] (distinct, solid) prefixes */ uint32_t nb; };
@@ -158,6 +165,62 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
     for (uint32_t i = t; i < run; i += PK_THREADS) cb[i] = s_cb[i];
 }
 
+// 16-byte keys: recs = 4 words per record (value low, value high, abundance, 0); bases = 2 words per block; W = 16 (15-byte deltas) or 17 (16-byte deltas)
+template <int W>
+__global__ __launch_bounds__(PK_THREADS) void k_pack_counts2(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint8_t* __restrict__ payload,
+                                                             uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
+{
+    typedef unsigned __int128 u128;
+    constexpr uint64_t PK_SLOT = pk_slot(W);
+    constexpr int WORDS16 = PK_THREADS * W / 16;                // 256 / 272 16-byte words per chunk of PK_THREADS entries
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * W + 16];
+    __shared__ uint32_t s_p;
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        uint32_t lo = 0, hi = P.nb;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.blk_first[mid] <= g) lo = mid; else hi = mid; }
+        s_p = lo;
+    }
+    __syncthreads();
+    const uint32_t p = s_p, j = g - P.blk_first[p];
+    const uint64_t s1 = P.ptot[2 * (p + 1) + 1], r0 = P.ptot[2 * p + 1] + (uint64_t)j * PK_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)PK_BLOCK, s1 - r0);
+    if (t == 0) { bases[2 * (uint64_t)g] = recs[4 * r0]; bases[2 * (uint64_t)g + 1] = recs[4 * r0 + 1]; }
+    uint8_t* dstp = payload + (uint64_t)g * PK_SLOT;
+    for (uint32_t i0 = 0; i0 < n; i0 += PK_THREADS) {
+        const uint32_t i = i0 + t;
+        uint64_t d_lo = 0, d_hi = 0; uint32_t ab8 = 0;
+        if (i < n) {
+            const ulonglong2 me = *reinterpret_cast<const ulonglong2*>(recs + 4 * (r0 + i));
+            const uint32_t ab = (uint32_t)recs[4 * (r0 + i) + 2];
+            ulonglong2 pv = me;
+            if (i) pv = *reinterpret_cast<const ulonglong2*>(recs + 4 * (r0 + i - 1));
+            const u128 d = (((u128)me.y << 64) | me.x) - (((u128)pv.y << 64) | pv.x);
+            d_lo = (uint64_t)d; d_hi = (uint64_t)(d >> 64);
+            if (W == 16 && (d_hi >> 56) != 0) d_hi = ~0ull, d_lo = ~0ull;                        // does not fit 120 bits: escape below
+            if (W == 16 && d_lo == ~0ull && (d_hi & 0xFFFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFFFull) {  // the escape pattern (also a true delta of exactly 2^120 - 1)
+                const unsigned long long e = atomicAdd(n_exc, 2ull);
+                if (e + 1 < exc_cap) { exc[2 * e] = PK_KEY_EXC | (r0 + i); exc[2 * e + 1] = me.x; exc[2 * e + 2] = PK_KEY_EXC_HI | (r0 + i); exc[2 * e + 3] = me.y; }
+            }
+            ab8 = ab;
+            if (ab >= 255u) {
+                const unsigned long long e = atomicAdd(n_exc, 1ull);
+                if (e < exc_cap) { exc[2 * e] = r0 + i; exc[2 * e + 1] = ab; }
+                ab8 = 255u;
+            }
+        }
+        uint8_t* o = s_out + W * t;
+#pragma unroll
+        for (int b = 0; b < 8; b++) o[b] = (uint8_t)(d_lo >> (8 * b));
+#pragma unroll
+        for (int b = 0; b < W - 9; b++) o[8 + b] = (uint8_t)(d_hi >> (8 * b));
+        o[W - 1] = (uint8_t)ab8;
+        __syncthreads();
+        for (int w = t; w < WORDS16; w += PK_THREADS) reinterpret_cast<uint4*>(dstp + (uint64_t)i0 * W)[w] = reinterpret_cast<const uint4*>(s_out)[w];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct SinkBatch {
     hipEvent_t copied = nullptr;                 // the batch's packed bytes are in the staging buffer
@@ -229,7 +292,32 @@ struct gkc_unpacker {
             }
         }
     }
-    static void unpack_block(const SinkBatch& B, uint64_t g) { if (B.width == 6) unpack_block_6(B, g); else if (B.width == 7) unpack_block_w<7>(B, g); else unpack_block_w<8>(B, g); }
+    template <int W> static void unpack_block_2(const SinkBatch& B, uint64_t g)         // 16-byte keys: 32-byte records {value low, value high, abundance, 0}
+    {
+        typedef unsigned __int128 u128;
+        const uint8_t* pay = B.stage + B.pay_off + g * pk_slot(W);
+        const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
+        const uint64_t* b2 = reinterpret_cast<const uint64_t*>(B.stage) + 2 * g;
+        u128 key = ((u128)b2[1] << 64) | b2[0];
+        __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 32);
+        for (uint32_t i = 0; i < n; i++) {
+            uint64_t lo, hi; memcpy(&lo, pay + W * (size_t)i, 8); memcpy(&hi, pay + W * (size_t)i + 8, 8);      // (W = 16: the 8th byte of `hi` is the abundance)
+            uint32_t ab = pay[W * (size_t)i + W - 1];
+            if (W == 16) hi &= 0xFFFFFFFFFFFFFFull;
+            if (i) {
+                if (W == 16 && lo == ~0ull && hi == 0xFFFFFFFFFFFFFFull) key = ((u128)lookup(B.exc, PK_KEY_EXC_HI | (r0 + i)) << 64) | lookup(B.exc, PK_KEY_EXC | (r0 + i));
+                else key += ((u128)hi << 64) | lo;
+            }
+            if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
+            _mm_stream_si128(out + 2 * (size_t)i, _mm_set_epi64x((long long)(uint64_t)(key >> 64), (long long)(uint64_t)key));
+            _mm_stream_si128(out + 2 * (size_t)i + 1, _mm_set_epi64x(0ll, (long long)(uint64_t)ab));
+        }
+    }
+    static void unpack_block(const SinkBatch& B, uint64_t g)
+    {
+        if (B.width == 6) unpack_block_6(B, g); else if (B.width == 7) unpack_block_w<7>(B, g); else if (B.width == 8) unpack_block_w<8>(B, g);
+        else if (B.width == 16) unpack_block_2<16>(B, g); else unpack_block_2<17>(B, g);
+    }
     void worker()
     {
         (void)hipSetDevice(c->device);
@@ -329,7 +417,8 @@ static gkc_unpacker* unpacker_of(gkc_ctx* c)
 bool gkc_sink_packed(gkc_ctx* c)
 {
     static const bool off = getenv("GKC_SINK_PACKED") && atoi(getenv("GKC_SINK_PACKED")) == 0;
-    return c->sink && c->key_words == 1 && !off && ((uintptr_t)c->sink & 15) == 0;
+    static const bool off2 = getenv("GKC_SINK_PACKED2") && atoi(getenv("GKC_SINK_PACKED2")) == 0;       // (16-byte keys only)
+    return c->sink && (c->key_words == 1 || !off2) && !off && ((uintptr_t)c->sink & 15) == 0;
 }
 
 // the staging buffer holds the packed stream of ONE pass (like the sink holds one pass of records): 7/16 of the sink + the block slack of every partition
@@ -337,7 +426,8 @@ int gkc_sink_prepare(gkc_ctx* c)
 {
     if (!gkc_sink_packed(c)) return GKC_OK;
     gkc_unpacker* U = unpacker_of(c);
-    const uint64_t want = c->sink_cap / 16 * 8 + (uint64_t)c->nb_partitions * (pk_slot(8) + 8) + ((uint64_t)64 << 20);
+    const uint64_t want = c->key_words == 1 ? c->sink_cap / 16 * 8 + (uint64_t)c->nb_partitions * (pk_slot(8) + 8) + ((uint64_t)64 << 20)
+                                            : c->sink_cap / 32 * 17 + (uint64_t)c->nb_partitions * (pk_slot(17) + 16) + ((uint64_t)64 << 20);
     if (U->staging_cap < want) {
         if (U->staging) (void)hipHostFree(U->staging);
         U->staging = nullptr; U->staging_cap = 0;
@@ -401,26 +491,32 @@ void gkc_sink_wait_batch(gkc_ctx* c, const void* batch)
 // One Stage-B batch: d_out = its Count[] (total records, partition i = [solid_prefix[i], solid_prefix[i+1])), d_ptot = the (distinct, solid) prefixes on the device,
 // h_dest = where the records belong in the sink. Runs on the calling lane's stream up to the point where the copy can be queued; returns the batch handle
 // (nullptr: not packed — no staging room, too many exceptions — the caller sends the plain records).
+static thread_local const char* g_sink_why = "";                   // why the last gkc_sink_send_packed of this thread returned nullptr (GKC_SINK_DEBUG)
+const char* gkc_sink_last_refusal() { return g_sink_why; }
 void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot, const std::vector<uint64_t>& solid_prefix, uint8_t* h_dest)
 {
     gkc_unpacker* U = c->unpacker;
+    g_sink_why = "no staging buffer";
     if (!U || !U->staging) return nullptr;
     const uint32_t nb = (uint32_t)solid_prefix.size() - 1;
     std::vector<uint32_t> blk_first(nb + 1);
     uint64_t nblk = 0;
     for (uint32_t i = 0; i < nb; i++) { blk_first[i] = (uint32_t)nblk; nblk += (solid_prefix[i + 1] - solid_prefix[i] + PK_BLOCK - 1) / PK_BLOCK; }
     blk_first[nb] = (uint32_t)nblk;
+    g_sink_why = "no records / too many blocks";
     if (nblk == 0 || nblk >= (1ull << 31)) return nullptr;
     // width of an entry: 8 where the partitions are sparse, 7 where dense, 6 (+ bitmap + abundance stream) where dense and most abundances are 1 — expected at
     // abundance-min 1 (sequencing errors) and checked batch by batch: a batch whose stream came out longer than 0.85 bytes per record switches the context back to 7
     static const bool no6 = getenv("GKC_SINK_WIDTH6") && atoi(getenv("GKC_SINK_WIDTH6")) == 0;
     static const uint64_t dense_min = getenv("GKC_SINK_DENSE") ? (uint64_t)atoll(getenv("GKC_SINK_DENSE")) : PK_DENSE;      // (tests: 1 = every batch is "dense")
-    const bool dense = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= dense_min;
-    const int width = !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;
+    const bool wide = c->key_words == 2;
+    const bool dense = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= (wide ? std::min<uint64_t>(dense_min, PK2_DENSE) : dense_min);
+    const int width = wide ? (dense ? 16 : 17) : !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;
     const uint64_t n_rec = solid_prefix[nb];
-    const uint64_t bases_bytes = (nblk * 8 + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0, hdr_bytes = bases_bytes + cboff_bytes;
+    const uint64_t bases_bytes = (nblk * (wide ? 16 : 8) + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0, hdr_bytes = bases_bytes + cboff_bytes;
     const uint64_t pay_bytes = nblk * pk_slot_of(width), cb_cap = width == 6 ? (n_rec + 63) / 64 * 64 : 0;
     const uint32_t exc_cap = 1u << 20;
+    g_sink_why = "no device memory for the packed copy";
     DevBuf d_first; if (c->ensure(d_first, (size_t)(nb + 1) * 4) != GKC_OK) return nullptr;
     uint8_t* d_packed = (uint8_t*)c->dalloc((size_t)(hdr_bytes + pay_bytes + cb_cap + (uint64_t)exc_cap * 16 + 64));
     if (!d_packed) { d_first.release(); return nullptr; }
@@ -435,6 +531,10 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
         PackPlan P{ (const uint32_t*)d_first.p, d_ptot, nb };
         if (width == 6) hipLaunchKernelGGL(k_pack_counts6, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, (uint32_t*)(d_packed + bases_bytes),
                                            d_pay, d_cb, d_nexc + 1, (uint64_t*)d_exc, d_nexc, exc_cap);
+        else if (width == 16) hipLaunchKernelGGL((k_pack_counts2<16>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
+                                                 (uint64_t*)d_exc, d_nexc, exc_cap);
+        else if (width == 17) hipLaunchKernelGGL((k_pack_counts2<17>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
+                                                 (uint64_t*)d_exc, d_nexc, exc_cap);
         else if (width == 7) hipLaunchKernelGGL((k_pack_counts<7>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
                                                 (uint64_t*)d_exc, d_nexc, exc_cap);
         else hipLaunchKernelGGL((k_pack_counts<8>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
@@ -443,13 +543,14 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     }
     d_first.release();
     const unsigned long long h_nexc = h_cnt[0], h_ncb = h_cnt[1];
+    g_sink_why = !ok ? "pack launch failed" : "too many exceptions";
     if (!ok || h_nexc > exc_cap || h_ncb > cb_cap) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
     if (width == 6 && (double)h_ncb > 0.85 * (double)n_rec) c->sink_no6 = true;      // (this batch still travels as it was packed: 7.1 bytes per record at worst)
     SinkBatch* B = new SinkBatch();
     const uint64_t cb_stage = (h_ncb + 63) / 64 * 64;
     const uint64_t need = hdr_bytes + pay_bytes + cb_stage + h_nexc * 16 + 64;
     {   std::lock_guard<std::mutex> lk(c->mu);
-        if (U->staging_used + need > U->staging_cap) { delete B; c->dfree(d_packed); return nullptr; }
+        if (U->staging_used + need > U->staging_cap) { g_sink_why = "staging buffer full"; delete B; c->dfree(d_packed); return nullptr; }
         B->stage = U->staging + U->staging_used; U->staging_used += (need + 63) / 64 * 64;
         c->sink_wire_bytes += hdr_bytes + pay_bytes + h_ncb + h_nexc * 16;
     }
@@ -466,7 +567,7 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
                && (h_ncb == 0 || hipMemcpyAsync((void*)(B->stage + B->cb_off), d_cb, (size_t)h_ncb, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
                && (h_nexc == 0 || hipMemcpyAsync((void*)(B->stage + B->exc_off), d_exc, (size_t)h_nexc * 16, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
                && hipEventRecord(B->copied, c->copy_stream) == hipSuccess;
-    if (!queued) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); if (B->copied) (void)hipEventDestroy(B->copied); delete B; c->dfree(d_packed); return nullptr; }
+    if (!queued) { g_sink_why = "copy could not be queued"; (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); if (B->copied) (void)hipEventDestroy(B->copied); delete B; c->dfree(d_packed); return nullptr; }
     B->t_queued = std::chrono::steady_clock::now(); B->pack_ms = std::chrono::duration<double, std::milli>(B->t_queued - t_pack0).count();
     { std::lock_guard<std::mutex> lk(U->mu); U->all.push_back(B); U->queue.push_back(B); }
     U->cv.notify_all();

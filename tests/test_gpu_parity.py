@@ -765,6 +765,51 @@ def test_packed_sink_escapes_and_block_boundaries(gkc, k, amin):
     c.set_host_sink(None)
 
 
+@pytest.mark.parametrize("k,amin,dense", [(63, 1, 0), (63, 1, 1), (41, 2, 1), (33, 1, 1), (47, 1, 0)])
+def test_packed_sink_16_byte_keys(gkc, monkeypatch, k, amin, dense):
+    """k >= 32: the 32-byte Count records {u128 value; i32 abundance; padding} cross PCIe packed as well (csrc/gkc_sink.hip, k_pack_counts2: per block of 8192 records a
+    16-byte base key, then [15- or 16-byte key delta][1-byte abundance] = 16 / 17 bytes instead of 32) and are expanded in the sink by the library's threads: what
+    gkc_wait_partition hands out must be byte for byte gkc_partition_counts, and that the oracle's records. `dense` (GKC_SINK_DENSE=1) takes the 15-byte deltas on
+    partitions of few records — every gap beyond 2^120 escapes through the two-entry exception path; a read copied 700 times gives abundances >= 255 (escape of
+    the abundance byte); k=33 at 20000 reads in 2 partitions gives partitions of several blocks; an empty partition; two passes over the same staging buffer."""
+    if dense:
+        monkeypatch.setenv("GKC_SINK_DENSE", "1")
+    big = k == 33
+    reads = synth_reads(20000 if big else 3000, 400000 if big else 20000, 150, seed=62 + k, n_rate=0.001)
+    reads += [reads[0]] * 700 + [b"A" * 150] * 300 + [b"ACGT" * 40] * 260
+    bases, offs = gko.pack_reads(reads)
+    m, parts = 8, (2 if big else 3000 if (dense and k >= 60) else 24)         # (3000 partitions of ~60 records in a 126-bit key space: gaps beyond 2^120)
+    rep = simple_repart(m, parts)
+    if k == 41:
+        rep[rep == 5] = 6                                    # an empty partition
+    c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
+    sink = gkc.HostBuffer(512 << 20)
+    c.set_host_sink(sink)
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, abundance_min=amin)
+    for rnd in range(2):
+        c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
+        big_ab = big_gap = multi_block = nrec = 0
+        for p in range(parts):
+            view, n = c.wait_partition(0, p)
+            dev = c.partition_records(0, p)
+            assert n * 32 == len(dev)
+            nrec += n
+            if n:
+                assert view is not None and np.array_equal(view, dev), (k, p, n)
+                r = dev.view(np.uint64).reshape(-1, 4)
+                big_ab += int((r[:, 2] >= 255).sum()); multi_block += int(n > 8192)
+                hi = r[:, 1].astype(object); big_gap += int(sum(1 for a, b in zip(hi[:-1], hi[1:]) if (int(b) - int(a)) >> 56))
+            assert np.array_equal(dev, ref.part_records(p))
+        assert big_ab > 0
+        if dense and k >= 60:
+            assert big_gap > 0                               # deltas beyond 2^120 travelled as escapes
+        if big:
+            assert multi_block > 0
+        wire = c.stats()["sink_wire_bytes"]
+        assert 0 < wire < nrec * 32 or nrec < 8192 * parts   # (partitions of a few records still travel as whole block slots)
+    c.set_host_sink(None)
+
+
 @pytest.mark.parametrize("switch", ["GKC_SINK_DENSE=1", "GKC_SINK_DENSE=1,GKC_SINK_WIDTH6=0", "GKC_SINK_DENSE=1,GKC_UNPACK_THREADS=1"])
 def test_packed_sink_entry_widths(switch):
     """The three entry widths of the packed transfer on the same inputs (GKC_SINK_DENSE=1 declares every batch dense): 6-byte deltas + abundance bitmap + abundance
