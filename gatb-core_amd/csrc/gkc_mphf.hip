@@ -27,6 +27,7 @@ namespace {
 constexpr int MPHF_LEVELS = 25;                                   // BooPHF.h:1029
 constexpr uint64_t MPHF_SEED = 18006821046139946489ULL;           // std::mt19937_64 rng(37); rng()   (BooPHF.hpp:246-249)
 constexpr int MPHF_THREADS = 256;
+constexpr int GKC_MPHF_REBUILD_ORDERED = -1000;                    // internal: mphf_build_from_list -> mphf_build_arrays
 
 struct MphfLevels {                                               // by value into the kernels
     uint64_t domain[MPHF_LEVELS];                                 // bits of level i (multiple of 64)
@@ -120,6 +121,102 @@ __global__ void k_mphf_compact(const uint64_t* __restrict__ keys, uint64_t n, in
     if (i >= n) return;
     const uint64_t e = flag_excl[i], nx = (i + 1 < n) ? flag_excl[i + 1] : *flag_total;
     if (nx != e) { if (wide) { out[2 * e] = keys[2 * i]; out[2 * e + 1] = keys[2 * i + 1]; } else out[e] = keys[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------ region build of a level (round 4, second session)
+// k_mphf_insert / k_mphf_flag / the flag scan / k_mphf_compact cost two global atomics, one random 4-byte gather and ~50 bytes of flag traffic per alive key and level: at the
+// chip's global-atomic rate (~2e10 /s) level 0 of 5.8e8 keys alone is ~37 ms of atomics. The level's bit array depends on the keys' slots only, not on their order, so the
+// keys are first bucketed by REGION of their slot (2^19 bits = 64 KB of the level's array; LDS histogram / cursors per workgroup, static key -> workgroup assignment,
+// like the Bloom build), then one workgroup per region builds its piece in LDS — `seen` and `collided`, LDS atomics — writes both out with plain stores (regions are
+// disjoint word ranges) and appends the region's keys whose slot collided to the next level's list (one global atomic per wave and round). k_mphf_clear and the rank
+// scan then run as before. The next list comes out in region order instead of key order — nothing depends on it except the codes of keys that survive all 24
+// filtering levels, for which the caller rebuilds with the ordered path (probability ~1e-13 per key).
+constexpr uint32_t MR_BITS = 19, MR_WORDS = 1u << (MR_BITS - 5), MR_MAX_REGIONS = 8192, MR_WGS = 1024, MR_THREADS = 1024;
+template <bool SCATTER>
+__global__ __launch_bounds__(MR_THREADS) void k_mphf_regions(const uint64_t* __restrict__ keys, uint64_t n, int wide, int level, uint64_t domain, uint64_t chunk, uint32_t n_regions,
+                                                              uint32_t* __restrict__ wg_cnt, const uint64_t* __restrict__ region_off, uint64_t* __restrict__ items)
+{
+    extern __shared__ uint32_t s_r[];                              // [n_regions] count / cursor (absolute slot: fewer than 2^32 keys per level here)
+    for (uint32_t r = threadIdx.x; r < n_regions; r += MR_THREADS) s_r[r] = SCATTER ? (uint32_t)region_off[r] + wg_cnt[(uint64_t)blockIdx.x * n_regions + r] : 0u;
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+    for (uint64_t g = i0 + threadIdx.x; g < i1; g += MR_THREADS) {
+        const uint64_t lo = wide ? keys[2 * g] : keys[g], hi = wide ? keys[2 * g + 1] : 0;
+        const uint64_t pos = mphf_level_hash(lo, hi, wide, level) % domain;
+        const uint32_t r = (uint32_t)(pos >> MR_BITS);
+        const uint32_t slot = atomicAdd(&s_r[r], 1u);
+        if (SCATTER) {
+            const uint64_t at = slot;
+            if (wide) { items[2 * at] = lo; items[2 * at + 1] = hi; } else items[at] = lo;
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < n_regions; r += MR_THREADS) wg_cnt[(uint64_t)blockIdx.x * n_regions + r] = s_r[r];
+    }
+}
+__global__ void k_mr_wg_prefix(uint32_t* __restrict__ wg_cnt, uint32_t n_wgs, uint32_t n_regions, uint64_t* __restrict__ region_tot)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_regions) return;
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < n_wgs; w++) { const uint32_t t = wg_cnt[(uint64_t)w * n_regions + r]; wg_cnt[(uint64_t)w * n_regions + r] = run; run += t; }
+    region_tot[r] = run;
+}
+__global__ __launch_bounds__(MR_THREADS) void k_mphf_region_build(const uint64_t* __restrict__ items, const uint64_t* __restrict__ region_off, int wide, int level, uint64_t domain,
+                                                                   uint32_t* __restrict__ lbits, uint32_t* __restrict__ coll, uint64_t n_words32 /* of the level's array */,
+                                                                   uint64_t* __restrict__ next_keys, unsigned long long* __restrict__ next_n)
+{
+    extern __shared__ uint32_t s_b[];                              // [MR_WORDS] seen, [MR_WORDS] collided
+    uint32_t* s_seen = s_b; uint32_t* s_coll = s_b + MR_WORDS;
+    for (uint32_t w = threadIdx.x; w < 2 * MR_WORDS; w += MR_THREADS) s_b[w] = 0u;
+    __syncthreads();
+    const uint32_t r = blockIdx.x;
+    const uint64_t i0 = region_off[r], i1 = region_off[r + 1];
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += MR_THREADS) {
+        const uint64_t lo = wide ? items[2 * i] : items[i], hi = wide ? items[2 * i + 1] : 0;
+        const uint32_t rel = (uint32_t)((mphf_level_hash(lo, hi, wide, level) % domain) & ((1u << MR_BITS) - 1u));
+        const uint32_t bit = 1u << (rel & 31);
+        if (atomicOr(&s_seen[rel >> 5], bit) & bit) atomicOr(&s_coll[rel >> 5], bit);
+    }
+    __syncthreads();
+    const uint64_t w0 = (uint64_t)r * MR_WORDS;
+    for (uint32_t w = threadIdx.x; w < MR_WORDS; w += MR_THREADS) if (w0 + w < n_words32) { lbits[w0 + w] = s_seen[w]; coll[w0 + w] = s_coll[w]; }
+    // the keys whose slot collided go on to the next level: counted first (one reservation on the next list's cursor per WORKGROUP — a reservation per wave and
+    // round was 9e6 atomics on one address: 109 ms for level 0 of 5.8e8 keys), then written wave by wave through an LDS cursor
+    __shared__ uint32_t s_cnt[MR_THREADS / 64], s_n;
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto alive_of = [&](uint64_t i, uint64_t& lo, uint64_t& hi) -> bool {
+        lo = wide ? items[2 * i] : items[i]; hi = wide ? items[2 * i + 1] : 0;
+        const uint32_t rel = (uint32_t)((mphf_level_hash(lo, hi, wide, level) % domain) & ((1u << MR_BITS) - 1u));
+        return (s_coll[rel >> 5] >> (rel & 31)) & 1u;
+    };
+    uint32_t mine = 0;
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += MR_THREADS) { uint64_t lo, hi; mine += alive_of(i, lo, hi) ? 1u : 0u; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0) s_cnt[wave] = mine;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int w = 0; w < MR_THREADS / 64; w++) tot += s_cnt[w]; s_base = tot ? atomicAdd(next_n, (unsigned long long)tot) : 0ull; }
+    __syncthreads();
+    const unsigned long long base0 = s_base;
+    for (uint64_t ib = i0; ib < i1; ib += MR_THREADS) {
+        const uint64_t i = ib + threadIdx.x;
+        uint64_t lo = 0, hi = 0; bool alive = false;
+        if (i < i1) alive = alive_of(i, lo, hi);
+        const unsigned long long bal = __ballot(alive);
+        if (bal) {
+            uint32_t wb = 0;
+            if (lane == 0) wb = atomicAdd(&s_n, (uint32_t)__popcll(bal));
+            wb = __shfl(wb, 0, 64);
+            if (alive) {
+                const uint64_t at = base0 + wb + (uint64_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (wide) { next_keys[2 * at] = lo; next_keys[2 * at + 1] = hi; } else next_keys[at] = lo;
+            }
+        }
+    }
 }
 
 // lookup (BooPHF.h:787-822): first level whose bit is set at the key's slot -> rank; all 24 filtering levels miss -> the final list
@@ -241,8 +338,12 @@ struct gkc_mphf {
 
 // comm != nullptr: the keys are this rank's share of a key set spread over the communicator's ranks (in rank order); every rank builds the
 // complete function (level arrays combined per level, see gkc_mphf_build_solid_dist in gkc.h)
-static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t n_local, gkc_comm* comm = nullptr)
+static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t n_local, gkc_comm* comm = nullptr, bool ordered = false)
 {
+    // ordered: every level through the atomic / flag / stable-compaction kernels (the next lists stay in key order). Default: large levels of a single-rank build go
+    // through the region build (above), whose next lists come out in region order; gkc_mphf_build* rebuild `ordered` in the one case where that order would show.
+    const bool regions_env = !(getenv("GKC_MPHF_REGIONS") && atoi(getenv("GKC_MPHF_REGIONS")) == 0);
+    const uint64_t regions_min = getenv("GKC_MPHF_REGIONS_MIN") ? (uint64_t)atoll(getenv("GKC_MPHF_REGIONS_MIN")) : (1ull << 21);      // keys of a level from which it pays (tests lower it)
     uint64_t n = n_local;
     if (comm) {
         std::vector<uint64_t> ns(gkc_comm_world(comm));
@@ -264,16 +365,54 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
     m->total_words = words; m->total_ranks = nr;
     GKC_TRY(c->ensure(m->bits, (size_t)words * 8)); GKC_TRY(c->ensure(m->ranks, (size_t)nr * 8));
     GKC_HIP(c, hipMemsetAsync(m->bits.p, 0, (size_t)words * 8, c->stream));
-    DevBuf keysB, coll, flag, scratch, d_tot;
-    struct Guard { std::vector<DevBuf*> v; ~Guard() { for (DevBuf* b : v) b->release(); } } guard; guard.v = { &keysB, &coll, &flag, &scratch, &d_tot };
+    DevBuf keysB, coll, flag, scratch, d_tot, r_wg, r_off, r_items;
+    struct Guard { std::vector<DevBuf*> v; ~Guard() { for (DevBuf* b : v) b->release(); } } guard; guard.v = { &keysB, &coll, &flag, &scratch, &d_tot, &r_wg, &r_off, &r_items };
     GKC_TRY(c->ensure(coll, (size_t)m->nchar[0] * 8)); GKC_TRY(c->ensure(d_tot, 64));
     DevBuf* cur = &keysA; DevBuf* nxt = &keysB;
+    bool used_regions = false;
     uint64_t alive = n_local, offset = 0;      // alive: keys of THIS rank still unplaced; n - offset: keys of all ranks still unplaced
     for (int lv = 0; lv < MPHF_LEVELS; lv++) {
         uint64_t* lbits = (uint64_t*)m->bits.p + m->L.word0[lv];
         uint64_t* lranks = (uint64_t*)m->ranks.p + m->L.rank0[lv];
         const uint64_t global_alive = n - offset;
-        if (lv < MPHF_LEVELS - 1 && global_alive) {
+        const uint64_t n_regions64 = (m->L.domain[lv] + (1ull << MR_BITS) - 1) >> MR_BITS;
+        const bool by_region = !comm && !ordered && regions_env && lv < MPHF_LEVELS - 1 && alive >= regions_min && n_regions64 <= MR_MAX_REGIONS && alive < (1ull << 32);
+        if (by_region) {
+            used_regions = true;
+            const uint32_t n_regions = (uint32_t)n_regions64;
+            const uint32_t n_wgs = (uint32_t)std::min<uint64_t>(MR_WGS, (alive + MR_THREADS - 1) / MR_THREADS);
+            const uint64_t chunk = (alive + n_wgs - 1) / n_wgs;
+            GKC_TRY(c->ensure(r_wg, (size_t)n_wgs * n_regions * 4)); GKC_TRY(c->ensure(r_off, ((size_t)n_regions + 1) * 8)); GKC_TRY(c->ensure(r_items, (size_t)alive * kb));
+            GKC_TRY(c->ensure(*nxt, (size_t)alive * kb));                   // (the survivors are written before their number is known: ~28 % of `alive`)
+            static std::once_flag once;
+            std::call_once(once, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mphf_regions<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MR_MAX_REGIONS * 4));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mphf_regions<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MR_MAX_REGIONS * 4));
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mphf_region_build), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * MR_WORDS * 4));
+            });
+            GKC_HIP(c, hipMemsetAsync(coll.p, 0, (size_t)m->nchar[lv] * 8, c->stream));
+            GKC_HIP(c, hipMemsetAsync((uint64_t*)d_tot.p + 2, 0, 8, c->stream));
+            const bool dbg = getenv("GKC_MPHF_DEBUG") != nullptr;
+            hipEvent_t ev[5]; if (dbg) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], c->stream); }
+            hipLaunchKernelGGL((k_mphf_regions<false>), dim3(n_wgs), dim3(MR_THREADS), (size_t)n_regions * 4, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], chunk, n_regions,
+                               (uint32_t*)r_wg.p, (const uint64_t*)nullptr, (uint64_t*)nullptr);
+            if (dbg) (void)hipEventRecord(ev[1], c->stream);
+            hipLaunchKernelGGL(k_mr_wg_prefix, dim3((n_regions + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)r_wg.p, n_wgs, n_regions, (uint64_t*)r_off.p);
+            GKC_TRY(ms_scan(c, (uint64_t*)r_off.p, n_regions, (uint64_t*)r_off.p + n_regions, scratch));
+            if (dbg) (void)hipEventRecord(ev[2], c->stream);
+            hipLaunchKernelGGL((k_mphf_regions<true>), dim3(n_wgs), dim3(MR_THREADS), (size_t)n_regions * 4, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], chunk, n_regions,
+                               (uint32_t*)r_wg.p, (const uint64_t*)r_off.p, (uint64_t*)r_items.p);
+            if (dbg) (void)hipEventRecord(ev[3], c->stream);
+            hipLaunchKernelGGL(k_mphf_region_build, dim3(n_regions), dim3(MR_THREADS), (size_t)2 * MR_WORDS * 4, c->stream, (const uint64_t*)r_items.p, (const uint64_t*)r_off.p, wide, lv, m->L.domain[lv],
+                               (uint32_t*)lbits, (uint32_t*)coll.p, (uint64_t)m->nchar[lv] * 2, (uint64_t*)nxt->p, (unsigned long long*)((uint64_t*)d_tot.p + 2));
+            GKC_HIP(c, hipGetLastError());
+            if (dbg) {
+                (void)hipEventRecord(ev[4], c->stream); (void)hipEventSynchronize(ev[4]);
+                float t[4]; for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&t[i], ev[i], ev[i + 1]);
+                fprintf(stderr, "[gkc mphf] level %d: %llu keys, %u regions: count %.2f ms, prefix + scan %.2f, scatter %.2f, build %.2f\n", lv, (unsigned long long)alive, n_regions, t[0], t[1], t[2], t[3]);
+                for (auto& e : ev) (void)hipEventDestroy(e);
+            }
+        } else if (lv < MPHF_LEVELS - 1 && global_alive) {
             GKC_HIP(c, hipMemsetAsync(coll.p, 0, (size_t)m->nchar[lv] * 8, c->stream));
             if (alive) {
                 const unsigned grid = (unsigned)std::min<uint64_t>((alive + MPHF_THREADS - 1) / MPHF_THREADS, 256 * 32);
@@ -294,6 +433,15 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
         offset += placed;
         if (lv == MPHF_LEVELS - 1 || !global_alive) continue;
         // survivors of this level -> next list (stable)
+        if (by_region) {                                                  // the survivors are in the next list already
+            uint64_t left = 0;
+            GKC_HIP(c, hipMemcpyAsync(&left, (uint64_t*)d_tot.p + 2, 8, hipMemcpyDeviceToHost, c->stream));
+            GKC_HIP(c, hipStreamSynchronize(c->stream));
+            if (left != alive - placed) GKC_FAIL(c, GKC_ERR_HIP, "internal error: MPHF level %d (region build) placed %llu of %llu keys but %llu are left (duplicate keys?)", lv,
+                                                 (unsigned long long)placed, (unsigned long long)alive, (unsigned long long)left);
+            alive = left; std::swap(cur, nxt);
+            continue;
+        }
         if (placed == global_alive) { alive = 0; continue; }
         if (!alive) continue;
         GKC_TRY(c->ensure(flag, (size_t)(alive + 1) * 8));
@@ -328,6 +476,7 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
             GKC_HIP(c, hipMemcpy(m->final_keys.p, packed.data(), (size_t)tot * kb, hipMemcpyHostToDevice));
         }
     } else {
+        if (alive && used_regions) return GKC_MPHF_REBUILD_ORDERED;          // keys survived all filtering levels: their codes follow KEY order (see mphf_build_arrays)
         m->n_final = alive;
         if (alive) { GKC_TRY(c->ensure(m->final_keys, (size_t)alive * kb)); GKC_HIP(c, hipMemcpyAsync(m->final_keys.p, cur->p, (size_t)alive * kb, hipMemcpyDeviceToDevice, c->stream)); }
     }
@@ -351,7 +500,9 @@ static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8
     gkc_mphf* m = new gkc_mphf(); m->ctx = c; m->wide = k > 31; m->k = k; m->n_final = 0; gkc_ctx_child_add(c);
     const size_t kb = m->wide ? 16 : 8;
     DevBuf keys, tmp;
-    int rc = c->ensure(keys, (size_t)std::max<uint64_t>(n, 1) * kb);
+    int rc = GKC_OK;
+  for (int attempt = 0; attempt < 2; attempt++) {                        // (a second time only for keys that survived all levels of a region build: ordered rebuild)
+    rc = c->ensure(keys, (size_t)std::max<uint64_t>(n, 1) * kb);
     uint64_t done = 0;
     for (size_t i = 0; rc == GKC_OK && i < segs.size(); i++) {
         const uint8_t* src = segs[i].first; const uint64_t ni = segs[i].second;
@@ -367,7 +518,9 @@ static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8
         if (on_host) (void)hipStreamSynchronize(c->stream);
         done += ni;
     }
-    if (rc == GKC_OK) rc = mphf_build_from_list(c, m, keys, n, comm);
+    if (rc == GKC_OK) rc = mphf_build_from_list(c, m, keys, n, comm, attempt == 1 || getenv("GKC_MPHF_ORDERED") != nullptr);
+    if (rc != GKC_MPHF_REBUILD_ORDERED) break;
+  }
     (void)hipStreamSynchronize(c->stream);
     keys.release(); tmp.release();
     if (rc != GKC_OK) { gkc_mphf_destroy(m); return rc; }

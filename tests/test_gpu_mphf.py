@@ -34,6 +34,36 @@ def test_mphf_equals_boophf(gkc, k, n):
     dm.close()
 
 
+@pytest.mark.parametrize("k,n,rmin", [(31, 200000, 1000), (63, 120000, 500), (21, 60000, 64), (31, 3_000_000, None)])
+def test_mphf_region_build_equals_boophf(gkc, monkeypatch, k, n, rmin):
+    """Levels of >= GKC_MPHF_REGIONS_MIN keys (default 2^21) are built region by region in LDS (k_mphf_regions / k_mphf_region_build): same level arrays and rank samples as
+    the atomic path and as the oracle's BooPHF — the save() stream byte for byte —, same codes. The threshold is lowered so that several levels of a test-size key
+    set take the path (and the last ones the atomic path); 3e6 keys take it by default; the ordered rebuild (keys left after 24 levels: never on real sets) is forced
+    through GKC_MPHF_ORDERED and must give the same bytes."""
+    if rmin is not None:
+        monkeypatch.setenv("GKC_MPHF_REGIONS_MIN", str(rmin))
+    rng = np.random.default_rng(k * 7 + n)
+    raw = np.frombuffer(rng.bytes(16 * n), dtype=np.uint64).reshape(n, 2)
+    keys = sorted({(int(a) | (int(b) << 64)) & (4 ** k - 1) for a, b in raw})
+    c = gkc.Counter(0)
+    dm = gkc.Mphf(c, keys, k)
+    monkeypatch.setenv("GKC_MPHF_REGIONS", "0")
+    d0 = gkc.Mphf(c, keys, k)                                             # the atomic / flag / stable-compaction path
+    assert np.array_equal(dm.save(), d0.save())
+    monkeypatch.delenv("GKC_MPHF_REGIONS")
+    monkeypatch.setenv("GKC_MPHF_ORDERED", "1")
+    d1 = gkc.Mphf(c, keys, k)
+    assert np.array_equal(dm.save(), d1.save())
+    monkeypatch.delenv("GKC_MPHF_ORDERED")
+    sample = keys[:: max(1, len(keys) // 20000)]
+    codes = dm.lookup(sample)
+    assert np.array_equal(codes, d0.lookup(sample)) and len(set(codes.tolist())) == len(sample) and int(codes.max()) < len(keys)
+    if n <= 200000:
+        om = gko.Mphf(keys, k)
+        assert np.array_equal(dm.save(), om.save()) and np.array_equal(codes, om.lookup(sample))
+    dm.close(); d0.close(); d1.close()
+
+
 def test_mphf_of_solid_kmers_and_abundance_map(gkc):
     k, m, parts = 31, 10, 16
     reads = synth_reads(4000, 20000, 150, seed=21, n_rate=0.001)
