@@ -131,7 +131,7 @@ __global__ void k_mphf_compact(const uint64_t* __restrict__ keys, uint64_t n, in
 // disjoint word ranges) and appends the region's keys whose slot collided to the next level's list (one global atomic per wave and round). k_mphf_clear and the rank
 // scan then run as before. The next list comes out in region order instead of key order — nothing depends on it except the codes of keys that survive all 24
 // filtering levels, for which the caller rebuilds with the ordered path (probability ~1e-13 per key).
-constexpr uint32_t MR_BITS = 19, MR_WORDS = 1u << (MR_BITS - 5), MR_MAX_REGIONS = 8192, MR_WGS = 1024, MR_THREADS = 1024;
+constexpr uint32_t MR_BITS = 19, MR_WORDS = 1u << (MR_BITS - 5), MR_MAX_REGIONS = 16384, MR_WGS = 1024, MR_THREADS = 1024;
 template <bool SCATTER>
 __global__ __launch_bounds__(MR_THREADS) void k_mphf_regions(const uint64_t* __restrict__ keys, uint64_t n, int wide, int level, uint64_t domain, uint64_t chunk, uint32_t n_regions,
                                                               uint32_t* __restrict__ wg_cnt, const uint64_t* __restrict__ region_off, uint64_t* __restrict__ items)

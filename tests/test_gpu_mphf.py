@@ -64,8 +64,13 @@ def test_mphf_region_build_equals_boophf(gkc, monkeypatch, k, n, rmin):
     dm.close(); d0.close(); d1.close()
 
 
-def test_mphf_of_solid_kmers_and_abundance_map(gkc):
-    k, m, parts = 31, 10, 16
+@pytest.mark.parametrize("k,rmin", [(31, None), (31, 64), (63, 200), (21, 1000)])
+def test_mphf_of_solid_kmers_and_abundance_map(gkc, monkeypatch, k, rmin):
+    """rmin: GKC_MPHF_REGIONS_MIN lowered so that the build takes its by-region path on a test-size key set (k_mphf_region_build;
+    and the map of populate() is checked on what that build gives"""
+    if rmin is not None:
+        monkeypatch.setenv("GKC_MPHF_REGIONS_MIN", str(rmin))
+    m, parts = 10, 16
     reads = synth_reads(4000, 20000, 150, seed=21, n_rate=0.001)
     bases, offs = gko.pack_reads(reads)
     rep = simple_repart(m, parts)
@@ -76,7 +81,7 @@ def test_mphf_of_solid_kmers_and_abundance_map(gkc):
     order = []                                                            # getSolidKmers() order: dataset by dataset, ascending
     for p in range(parts):
         lo, hi, ab = ref.part(p)
-        order += [int(x) for x in lo]
+        order += [int(a) | (int(b) << 64) for a, b in zip(lo, hi)]
     dm = gkc.Mphf(c)
     om = gko.Mphf(order, k)
     assert dm.size == len(order) == ref.stats["kmers_nb_solid"]

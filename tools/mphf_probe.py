@@ -22,5 +22,10 @@ for tag, env in (("regions", None), ("regions", None), ("regions", None), ("atom
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = mp.save(); h = hash(s.tobytes())
     if ref is None: ref = h
-    print(tag, "%.1f ms" % (dt * 1e3), "same bytes" if h == ref else "DIFFERENT", flush=True)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    amap, above = mp.abundance_map()
+    torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
+    hm = hash(amap.tobytes())
+    if tag + "_map" not in globals(): globals()[tag + "_map"] = hm
+    print(tag, "build %.1f ms" % (dt * 1e3), "same bytes" if h == ref else "DIFFERENT", "| abundance map (incl. D2H of %d MB) %.1f ms" % (len(amap) >> 20, dt2 * 1e3), "map hash", hm & 0xFFFFFF, flush=True)
     mp.close()
