@@ -2000,16 +2000,18 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // Sliced batch (see SliceTables): a partition beyond GKC_SLICE_MIN k-mers (default 8e6: twice and more what the batches and the drop-in's Configuration aim
     // at, and where the bins of the record deduplication are full) is expanded by up to 16 workgroups, so that an entry is 2e6 .. 4e6 k-mers like a planned
     // partition; GKC_SLICES=0 switches it off (tests lower the threshold). The record deduplication (one workgroup per partition, bins for <= 8e5 records: on such
-    // partitions it costs more than it saves — 242 ms for 256 partitions of 1e8 reads) is skipped for a sliced batch.
+    // partitions it costs more than it saves — 242 ms for 256 partitions of 1e8 reads) is skipped for a batch most of whose k-mers sit in sliced partitions.
     // Measured, 1e8 reads, k = 31, two lanes (profiles/r04_sliced_partitions.txt): 256 partitions 600 -> 375 ms per step (expand_count 109 -> 19 ms, expand_scatter
     // 238 -> 90 ms single lane; what is left of the gap to the 4096-partition step, 203 ms, is the split levels: every 2^13-th of such a partition is 5700 keys,
     // beyond the sort tiers), 64 partitions 387 ms, 1024 partitions 346 -> 323 ms.
     const uint64_t slice_min = getenv("GKC_SLICE_MIN") ? (uint64_t)std::max(1, atoi(getenv("GKC_SLICE_MIN"))) : 8000000ull;
     const uint64_t slice_keys = std::max<uint64_t>(1, slice_min / 4);
     const bool slices_on = !(getenv("GKC_SLICES") && atoi(getenv("GKC_SLICES")) == 0);
-    bool sliced = false;
-    if (slices_on) for (uint32_t i = 0; i < nb; i++) sliced = sliced || part_keys[batch_parts[i]] > slice_min;
-    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0 && !sliced;
+    bool sliced = false; uint64_t heavy_keys = 0, batch_keys = 0;
+    if (slices_on) for (uint32_t i = 0; i < nb; i++) { const uint64_t np = part_keys[batch_parts[i]]; batch_keys += np; if (np > slice_min) { sliced = true; heavy_keys += np; } }
+    // (one heavy partition among a thousand planned ones — a repeat family under one minimizer — does not cost the batch its deduplication: its single dedupe workgroup
+    // hides behind the others; the step is skipped where most of the batch's k-mers sit in such partitions)
+    const bool dedupe = ((KW == 1 && RW == 2) || (KW == 2 && RW == 4 && k >= 32)) && dedupe_env != 0 && (dedupe_env == 1 || !c->dedupe_off) && nb > 0 && !(sliced && 2 * heavy_keys > batch_keys);
     // mean keys of a level-1 bucket, counted in k-mers BEFORE identical records are merged: with the merge on (8-byte keys: ~1.8x fewer keys on 30x reads) twice as
     // many — 12 sub-bucket bits instead of 13 for the partitions of the 1e8-read bench: first sort tier 46.8 -> 38.3 ms, the larger tiers +8, scatter -4: 220 -> 214 ms
     // (possible since the tagged sort carries 61 key bits: profiles/r04_weight_bits_experiment.txt)

@@ -204,20 +204,24 @@ def test_oversize_buckets_low_complexity(gkc):
 
 
 @pytest.mark.parametrize("k,m,parts,n_reads,skew,smin", [(31, 10, 1, 100_000, False, 1), (31, 9, 3, 160_000, False, 1_000_000), (63, 10, 2, 150_000, False, 1), (21, 8, 2, 120_000, False, 3_000_000),
-                                                         (31, 10, 5, 110_000, True, 2_000_000), (41, 10, 4, 130_000, True, 1), (63, 11, 3, 90_000, True, 1_500_000)])
+                                                         (31, 10, 5, 110_000, True, 2_000_000), (41, 10, 4, 130_000, True, 1), (63, 11, 3, 90_000, True, 1_500_000),
+                                                         (31, 10, 5, 110_000, 0.4, 3_000_000), (30, 9, 6, 120_000, 0.35, 2_500_000)])
 def test_sliced_partitions_few_huge(gkc, monkeypatch, k, m, parts, n_reads, skew, smin):
     """Several workgroups per partition: a partition far beyond the planned size is expanded by up to 16 workgroups, each taking a share of its
     records, with its own pair range + odd-key slot inside every sub-bucket (SliceTables in csrc/gkc_count.hip). GKC_SLICE_MIN makes partitions of 3e6 .. 1.2e7
     k-mers take the path that partitions beyond 1.6e7 k-mers take by default (16 slices with 1; 2 .. 8 with the larger thresholds; `skew`: one huge partition
-    beside small unsliced ones in the same batch). Records, statistics and histogram against the oracle; N's, ragged reads, low-complexity reads (split roots,
+    beside small unsliced ones in the same batch; a fraction: the sliced partition is a minority of the batch, which keeps its record deduplication). Records, statistics and histogram against the oracle; N's, ragged reads, low-complexity reads (split roots,
     giants) and copied reads included; then the same input with the slices switched off."""
     monkeypatch.setenv("GKC_SLICE_MIN", str(smin))
     reads = synth_reads(n_reads, n_reads * 5, 150, seed=3 * k + parts, n_rate=0.0005, ragged=True)
     reads += [b"A" * 150] * 200 + [b"ACACACACAC" * 15] * 200 + [b"G" * 150] * 30 + [reads[5]] * 40
     rep = simple_repart(m, parts)
-    if skew:
+    if skew is True:
         rep = (rep.astype(np.uint32) % (8 * (parts - 1))).astype(np.uint16)
         rep = np.where(rep < parts - 1, rep + 1, 0).astype(np.uint16)             # partition 0 takes 7/8 of the minimizers
+    elif skew:                                                                    # partition 0 takes the fraction `skew` of the minimizers: the only sliced partition of a batch
+        u = np.random.default_rng(11).random(len(rep))                            # that keeps its record deduplication (less than half of its k-mers are in sliced partitions)
+        rep = np.where(u < skew, 0, 1 + (rep.astype(np.uint32) % (parts - 1))).astype(np.uint16)
     device_vs_oracle(gkc, reads, k, m, parts, rep=rep)
     device_vs_oracle(gkc, reads, k, m, parts, rep=rep, batches=3, amin=2, amax=40)        # several segments (every slice takes its share of each), a solidity window
     monkeypatch.setenv("GKC_SLICES", "0")
