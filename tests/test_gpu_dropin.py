@@ -211,7 +211,7 @@ def check_pipeline(h5, tag):
 
 @needs_artefacts
 @pytest.mark.parametrize("tag", sorted(PIPELINE))
-@pytest.mark.parametrize("mode", ["resident", "from_storage", "single_queries"])
+@pytest.mark.parametrize("mode", ["resident", "from_storage", "single_queries", "resident_mphf_regions"])
 def test_bloom_and_mphf_through_the_boundary(tmp_path, tag, mode):
     """VERDICT r3 N2 / configs[4]: BloomFactory::createBloom hands out BloomDevice<T>, BloomAlgorithm::execute and MPHFAlgorithm::execute run on the device INSIDE the
     reference's dbgh5 (integration/gatb-core.device.patch), and the file is the unpatched reference's: /dsk/solid/*, /bloom/bloom, /dsk/mphf, and with the default
@@ -220,9 +220,12 @@ def test_bloom_and_mphf_through_the_boundary(tmp_path, tag, mode):
                       on the device), the debloom step asks contains8 of a partition's k-mers in one batched device query;
       from_storage    GATB_DEVICE_NO_RESIDENT=1: the reference's BloomBuilder iterates /dsk/solid and inserts into the BloomDevice one item at a time (blocks go to the
                       device), the MPHF is built from the keys of the Iterable (gkc_mphf_build), populate() runs on the CPU;
-      single_queries  GATB_DEVICE_NO_BATCHED_QUERIES=1: the debloom step's contains8 one k-mer at a time — served by the host twin, no launch per item."""
+      single_queries  GATB_DEVICE_NO_BATCHED_QUERIES=1: the debloom step's contains8 one k-mer at a time — served by the host twin, no launch per item;
+      resident_mphf_regions  the default with GKC_MPHF_REGIONS_MIN=200: the MPHF levels of these small key sets are built region by region in LDS, the path key sets
+                      of >= 2^21 k-mers take (csrc/gkc_mphf.hip k_mphf_region_build) — /dsk/mphf must still be the unpatched reference's bytes."""
     env = {"GATB_DEVICE_VERBOSE": "1"}
-    env.update({"from_storage": {"GATB_DEVICE_NO_RESIDENT": "1"}, "single_queries": {"GATB_DEVICE_NO_BATCHED_QUERIES": "1"}}.get(mode, {}))
+    env.update({"from_storage": {"GATB_DEVICE_NO_RESIDENT": "1"}, "single_queries": {"GATB_DEVICE_NO_BATCHED_QUERIES": "1"},
+                "resident_mphf_regions": {"GKC_MPHF_REGIONS_MIN": "200"}}.get(mode, {}))
     p, h5 = run_dbgh5(tag, str(tmp_path), env, pipeline=True)
     log = p.communicate(timeout=900)[0]
     assert p.returncode == 0, log[-3000:]
