@@ -231,6 +231,13 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
     import torch
     out = {}
     RB = c.rec_bytes                                          # 16 (k <= 31) / 32 (k <= 63): Kmer<span>::Count in memory
+    try:   # the sink and the library's staging buffer are page-locked: 1.6x the records; on a host that cannot spare twice that the leg is left out (it must not take the box down)
+        import psutil
+        avail = psutil.virtual_memory().available
+        if avail < 2 * 1.6 * distinct * RB:
+            return {"skipped": "page-locked sink + staging of %.0f GB on a host with %.0f GB available" % (1.6 * distinct * RB / 1e9, avail / 1e9)}
+    except ImportError:
+        pass
     t_alloc = time.perf_counter()
     try:
         sink = gkc.HostBuffer(int(distinct * RB * 1.01) + (64 << 20))
