@@ -224,44 +224,62 @@ def fastq_parse_leg(c, n_reads=1_000_000, L=150):
             "text_GBps": t.numel() / best / 1e9, "gbases_per_s": n_reads * L / best / 1e9, "ms": best * 1e3}
 
 
-def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, expect=None, parts=0, amins=(1, 2), host_to_host=True):
-    """SURVEY §8(d) wall: from the first push to the last partition's Count[] in (page-locked) host memory. Every Stage-B batch is copied into
-    the host sink on a copy stream while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns when everything has landed.
-    Reported beside `value` (which stops with the results in HBM), at abundance-min 1 (every distinct k-mer travels: PCIe-bound) and 2."""
-    import torch
-    out = {}
-    RB = c.rec_bytes                                          # 16 (k <= 31) / 32 (k <= 63): Kmer<span>::Count in memory
-    try:   # the sink and the library's staging buffer are page-locked: 1.6x the records; on a host that cannot spare twice that the leg is left out (it must not take the box down)
+def make_sink(c, gkc, distinct, world=1):
+    """page-locked host sink for every Count record of a pass (+1 %). The sink and the library's staging buffer are page-locked: 1.6x the records; on a host that
+    cannot spare twice that (per rank) it is not made (it must not take the box down). Returns (sink, None) or (None, {"skipped" | "error": why})."""
+    RB = c.rec_bytes
+    try:
         import psutil
-        avail = psutil.virtual_memory().available
+        avail = psutil.virtual_memory().available / max(1, world)
         if avail < 2 * 1.6 * distinct * RB:
-            return {"skipped": "page-locked sink + staging of %.0f GB on a host with %.0f GB available" % (1.6 * distinct * RB / 1e9, avail / 1e9)}
+            return None, {"skipped": "page-locked sink + staging of %.0f GB on a host with %.0f GB available per rank" % (1.6 * distinct * RB / 1e9, avail / 1e9)}
     except ImportError:
         pass
     t_alloc = time.perf_counter()
     try:
         sink = gkc.HostBuffer(int(distinct * RB * 1.01) + (64 << 20))
     except Exception as e:      # noqa
-        return {"error": "page-locked sink of %.1f GB: %s" % (distinct * RB / 1e9, e)}
-    out["sink_GB"] = sink.nbytes / 1e9; out["sink_alloc_s"] = time.perf_counter() - t_alloc
-    # what the box's PCIe link sustains device -> page-locked host (one 4 GB copy)
+        return None, {"error": "page-locked sink of %.1f GB: %s" % (distinct * RB / 1e9, e)}
+    sink.alloc_s = time.perf_counter() - t_alloc
+    return sink, None
+
+
+def pcie_probe(c, sink):
+    """what the box's PCIe link sustains device -> page-locked host (4 copies of 1 GB), GB/s"""
+    import torch
     probe = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
-    n_probe = min(4 << 30, sink.nbytes) // (1 << 30)
-    import ctypes as C_
+    n_probe = max(1, min(4 << 30, sink.nbytes) // (1 << 30))
     t0 = time.perf_counter()
     for i in range(n_probe):
-        c._chk(c.L.gkc_device_to_host(c.h, C_.c_void_p(sink._p.value + (i << 30)), probe.data_ptr(), 1 << 30))
-    pcie = n_probe * (1 << 30) / (time.perf_counter() - t0) / 1e9
+        c._chk(c.L.gkc_device_to_host(c.h, C.c_void_p(sink._p.value + (i << 30)), probe.data_ptr(), min(1 << 30, sink.nbytes)))
+    pcie = n_probe * min(1 << 30, sink.nbytes) / (time.perf_counter() - t0) / 1e9
     del probe
+    return pcie
+
+
+def host_landed_leg(c, gkc, step, sync, distinct, n_steps=5, n_steps_amin2=5, expect=None, parts=0, amins=(1, 2), host_to_host=True, sink=None):
+    """SURVEY §8(d) wall: from the first push to the last partition's Count[] in (page-locked) host memory. Every Stage-B batch is copied into
+    the host sink on a copy stream while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns when everything has landed.
+    Reported beside `value` (which stops with the results in HBM), at abundance-min 1 (every distinct k-mer travels: PCIe-bound) and 2."""
+    import torch
+    out = {}
+    RB = c.rec_bytes                                          # 16 (k <= 31) / 32 (k <= 63): Kmer<span>::Count in memory
+    if sink is None:
+        sink, why = make_sink(c, gkc, distinct)
+        if sink is None:
+            return why
+    out["sink_GB"] = sink.nbytes / 1e9; out["sink_alloc_s"] = sink.alloc_s
+    pcie = pcie_probe(c, sink)
     out["pcie_d2h_GBps"] = pcie
     c.set_host_sink(sink)
     for amin in amins:
         c.set_solidity(amin, 2147483647, 10000)
         step(); sync()                                        # the batch plan changes with the solidity window: one untimed step
         ns_ = n_steps_amin2 if amin == 2 else n_steps
+        per = []
         t0 = time.perf_counter()
         for _ in range(ns_):
-            step()
+            t1 = time.perf_counter(); step(); per.append((time.perf_counter() - t1) * 1e3)      # (gkc_finish_pass returns when the last batch has landed)
         sync()
         dt = (time.perf_counter() - t0) / ns_
         st = c.stats()
@@ -272,7 +290,8 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
         wire = st["sink_wire_bytes"] if packed else st["kmers_nb_solid"] * RB
         err = (c.L.gkc_last_error(c.h) or b"").decode()
         out["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s with every solid Count[] in page-locked host memory",
-                                          "ms_per_step": dt * 1e3, "steps": ns_, "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
+                                          "ms_per_step": dt * 1e3, "ms_per_step_median": float(np.median(per)), "ms_steps": [round(x, 1) for x in per], "steps": ns_,
+                                          "solid_records": st["kmers_nb_solid"], "bytes_landed": landed,
                                           "bytes_over_the_link": wire, "packed_on_the_wire": packed,
                                           "landed_GBps_over_the_step": landed / dt / 1e9, "link_GBps_over_the_step": wire / dt / 1e9, "frac_of_pcie": wire / dt / 1e9 / pcie,
                                           "sink_overflow": "sink" in err}
@@ -306,10 +325,14 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=2, ex
         for amin in (2, 1):
             c.set_solidity(amin, 2147483647, 10000)
             step2(); sync()
-            t0 = time.perf_counter(); step2(); step2(); sync(); dt = (time.perf_counter() - t0) / 2
+            per2 = []
+            t0 = time.perf_counter()
+            for _ in range(5):
+                t1 = time.perf_counter(); step2(); per2.append((time.perf_counter() - t1) * 1e3)
+            sync(); dt = (time.perf_counter() - t0) / 5
             st = c.stats()
             h2h["abundance_min_%d" % amin] = {"value": st["kmers_nb_distinct"] / dt, "unit": "distinct k-mers/s, pinned host bases in -> solid Count[] in pinned host memory",
-                                              "ms_per_step": dt * 1e3, "steps": 2, "count_bytes_out_GB": st["kmers_nb_solid"] * RB / 1e9}
+                                              "ms_per_step": dt * 1e3, "ms_per_step_median": float(np.median(per2)), "steps": 5, "count_bytes_out_GB": st["kmers_nb_solid"] * RB / 1e9}
         out["host_to_host"] = h2h
         del pin
     except StopIteration:
@@ -414,7 +437,10 @@ def main():
     else:
         runner = None
 
+    n_steps_run = [0]
+
     def step():
+        n_steps_run[0] += 1
         c.begin_pass(0)
         for b_, o_, nr, nb_ in chunks:
             c.push_reads_device(b_, o_, nr, nb_)
@@ -428,25 +454,83 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
     # per-kernel timers are HIP events on the context's own stream, accumulated inside the library
     names = ["scan_count", "scan_emit", "scan_refine", "dedupe_bin", "dedupe_sort", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "split_levels", "compact",
              "total_stage_a", "total_stage_b"]
-    base = {nme: c.timing(nme) for nme in names}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+
+    def timed_region(n_warm, n_steps):
+        """n_warm untimed steps, then EXACTLY n_steps steps bracketed by barrier + synchronize on both sides; max over ranks. Returns (seconds, per-step ms of this rank, kernel timers)"""
+        for _ in range(n_warm):
+            step()
+        sync()
+        base = {nme: c.timing(nme) for nme in names}
+        per = []
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            t1 = time.perf_counter(); step(); per.append((time.perf_counter() - t1) * 1e3)
+        sync()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt_], device=red_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt_ = float(t.item())
+        kt = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
+        return dt_, per, kt
+
+    # SURVEY 8(d): the wall of configs 2-4 runs from the first push to the last partition's Count[] in HOST memory at abundance-min 1. That is what `value` times
+    # (VERDICT r4 #1a): every Stage-B batch crosses PCIe packed into a page-locked sink while the next batches are counted (gkc_set_host_sink); gkc_finish_pass returns
+    # when the last record has landed. The same K steps with the records left in HBM are timed right after as `value_device_resident`.
+    # GKC_BENCH_VALUE=device (or a host that cannot page-lock the sink: reported) makes the HBM-resident figure `value`.
+    value_mode = os.environ.get("GKC_BENCH_VALUE", "host")
+    sink = None; sink_why = None
+    step(); sync()                                               # one untimed step: the allocator's blocks, and this rank's distinct k-mers (the size of the sink)
+    if value_mode == "host":
+        sink, sink_why = make_sink(c, gkc, c.stats()["kmers_nb_distinct"], world)
+        ok_all = 1 if sink is not None else 0
+        if world > 1:
+            t = torch.tensor([ok_all], device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok_all = int(t.item())
+        if not ok_all:
+            sink = None; value_mode = "device"
+            sys.stderr.write("[bench rank %d] no host sink (%s): `value` is the HBM-resident figure\n" % (rank, sink_why))
+    pcie_gbs = None; host_verification = None; landed = None
+    if value_mode == "host":
+        pcie_gbs = pcie_probe(c, sink)
+        c.set_host_sink(sink)
+        dt_host, per_host, ktime_host = timed_region(max(1, args.warmup), args.steps)        # (the batch plan changes with a sink: at least one untimed step)
+        st_h = c.stats()
+        wire = st_h["sink_wire_bytes"] if st_h.get("sink_wire_bytes", 0) > 0 else st_h["kmers_nb_solid"] * c.rec_bytes
+        err_ = (c.L.gkc_last_error(c.h) or b"").decode()
+        landed = {"ms_per_step": dt_host / args.steps * 1e3, "ms_per_step_median": float(np.median(per_host)), "ms_steps": [round(x, 1) for x in per_host], "steps": args.steps,
+                  "solid_records": st_h["kmers_nb_solid"], "bytes_landed": st_h["kmers_nb_solid"] * c.rec_bytes, "bytes_over_the_link": wire,
+                  "packed_on_the_wire": st_h.get("sink_wire_bytes", 0) > 0, "pcie_d2h_GBps": pcie_gbs,
+                  "link_GBps_over_the_step": wire / (dt_host / args.steps) / 1e9, "frac_of_pcie": wire / (dt_host / args.steps) / 1e9 / pcie_gbs,
+                  "sink_GB": sink.nbytes / 1e9, "sink_alloc_s": sink.alloc_s, "sink_overflow": "sink" in err_}
+        # outside the clock: what landed is what the device holds (first / middle / last partition this rank owns)
+        try:
+            same = True
+            own = list(runner.owned()) if runner is not None else list(range(parts))
+            for p_ in sorted({own[0], own[len(own) // 2], own[-1]}):
+                host_, n_ = c.wait_partition(0, p_)
+                if n_:
+                    same = same and host_ is not None and bool(np.array_equal(host_, c.partition_records(0, p_)))
+            landed["sink_spot_check"] = "first / middle / last owned partition: bytes in the sink == bytes on the device: %s" % same
+        except Exception as e:      # noqa
+            same = False; landed["sink_spot_check"] = "failed: %r" % (e,)
+        landed["sink_ok"] = bool(same and not landed["sink_overflow"])
+        if world == 1:                                           # ... and the device's records are the count of the input (several ranks: checked over all ranks below)
+            hv = verify_block(c, input_checksum(c, chunks), 1)
+            landed["verification"] = hv; landed["sink_ok"] = bool(landed["sink_ok"] and hv["verified"])
+        landed["verified"] = landed["sink_ok"]
+        if world > 1:
+            t = torch.tensor([1 if landed["sink_ok"] else 0], device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); landed["sink_ok"] = bool(int(t.item()))
+        c.set_host_sink(None)
+        dt, per_dev, ktime = timed_region(1, args.steps)             # the same K steps with the records left in HBM
+        dt_value, ktime_value = dt_host, ktime_host
+    else:
+        dt, per_dev, ktime = timed_region(args.warmup, args.steps)
+        dt_value, ktime_value = dt, ktime
     st = c.stats()
     distinct = st["kmers_nb_distinct"]; valid = st["kmers_nb_valid"]
     if world > 1:
         t = torch.tensor([distinct, valid], device=red_dev, dtype=torch.int64); dist.all_reduce(t); distinct, valid = int(t[0]), int(t[1])
-    ktime = {nme: ((c.timing(nme)[0] - base[nme][0]), (c.timing(nme)[1] - base[nme][1])) for nme in names}
     # OUTSIDE the clock: the records the last timed step left on the device are the count of the reads it was given (every rank: its reads in, the partitions it
     # owns out; over all ranks the two sides must meet)
     expect = input_checksum(c, chunks)
@@ -462,8 +546,8 @@ def main():
         verification = verify_block(c, expect, 1)
     all_verified = [verification["verified"]]
     exch = None
-    if runner is not None:                                     # per-rank exchange figures over warmup + timed steps (gkc_comm_get_stats)
-        cs = runner.stats(); n_st = max(1, args.steps + args.warmup)
+    if runner is not None:                                     # per-rank exchange figures over warmup + timed steps (gkc_comm_get_stats; every step run so far, timed or not)
+        cs = runner.stats(); n_st = max(1, n_steps_run[0])
         ps_, pr_, init_ms = runner.comm.peer_bytes(world)
         mine_x = {"rank": rank, "owned_partitions": len(runner.owned()), "exchanges_per_step": cs["n_exchanges"] / n_st,
                   "ms_transfer_per_step": cs["ms_transfer"] / n_st, "ms_transfer_per_exchange": cs["ms_transfer"] / max(1, cs["n_exchanges"]),
@@ -495,8 +579,11 @@ def main():
             os.environ["GKC_STAGEB_LANES"] = prev
 
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = distinct / (dt / args.steps)
+        ms_step = dt_value / args.steps * 1e3                   # the region `value` is quoted on (host-landed unless the line says otherwise)
+        value = distinct / (dt_value / args.steps)
+        ms_step_dev = dt / args.steps * 1e3                     # the same K steps with the records left in HBM
+        value_dev = distinct / (dt / args.steps)
+        ktime_dev = ktime; ktime = ktime_value
         nbar = (valid / world) / max(1, st["nb_superkmers"])
         d = distinct / max(1, valid)
         # dominant kernel = the one with the largest accumulated time; its algorithmic bytes per launch are stated in DESIGN.md §Kernels
@@ -522,15 +609,22 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload:
                 tot_b = sum(v_["hbm_bytes_per_step"] for n_, v_ in pt["kernels"].items() if n_.startswith("k_") and not n_.startswith("k_synth") and "checksum" not in n_)      # (the step's kernels: not the input generator, not the verification)
-                pipeline = {"counter_bytes_per_step": tot_b, "bytes_per_valid_kmer": tot_b / max(1, valid), "achieved": tot_b / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
-                            "frac": tot_b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "source": "profiles/pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE summed over every kernel of one step (separate single-lane PMC passes) / this run's ms_per_step"}
+                pipeline = {"counter_bytes_per_step": tot_b, "bytes_per_valid_kmer": tot_b / max(1, valid), "achieved": tot_b / (ms_step_dev * 1e-3) / 1e9, "unit": "GB/s",
+                            "frac": tot_b / (ms_step_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "source": "profiles/pmc_traffic.json: HBM bytes (FETCH_SIZE, x2 where tools/pmc_traffic.py says so, + WRITE_SIZE) summed over every kernel of one step "
+                                      "(separate single-lane PMC passes) / this run's ms_per_step_device_resident (the PCIe-bound host-landed step moves the same bytes in more time)"}
         except Exception:
             pipeline = None
         out = {
             "metric": "distinct k-mers/s at k=%d" % k, "value": value, "unit": "distinct k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if k <= 31 else "u128",
+            "value_definition": ("SURVEY 8(d) wall: reads resident in HBM -> every distinct k-mer's Count record (abundance-min 1) in page-locked HOST memory; the timed K steps are "
+                                 "host-landed steps (PCIe-bound: see `landed`)" if value_mode == "host" else
+                                 "records left in HBM (no host sink: %s)" % (sink_why if sink_why else "GKC_BENCH_VALUE=device")),
+            "ms_per_step_median": float(np.median(per_host if value_mode == "host" else per_dev)),
+            "value_device_resident": value_dev, "ms_per_step_device_resident": ms_step_dev, "ms_per_step_device_resident_median": float(np.median(per_dev)),
+            "landed": landed,
             "verified": verification["verified"], "verification": verification,
             "data": "synthetic (device generator, seeded; 150 bp reads, 30x, 1% substitutions)",
             "config": {"workload": workload,
@@ -542,7 +636,8 @@ def main():
                        "model_note": "SURVEY 8(d)'s FIXED accounting (an 8-pass LSD radix sort: 128 of its 160 bytes per k-mer): this build sorts with one MSD scatter and a "
                                      "register network, so model_GBps over-charges the bytes about 3.5x and can exceed the HBM peak; it is not a bandwidth. The measured "
                                      "whole-pipeline figure is roofline.pipeline (PMC bytes per step / step time)",
-                       "kernel_ms_per_step": {n_: round(ktime[n_][0] / args.steps, 3) for n_ in names}},
+                       "kernel_ms_per_step": {n_: round(ktime[n_][0] / args.steps, 3) for n_ in names},
+                       "kernel_ms_per_step_device_resident": {n_: round(ktime_dev[n_][0] / args.steps, 3) for n_ in names}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate single-lane passes; bytes per step / launches per step)" if traffic else None,
@@ -602,18 +697,17 @@ def main():
             out["exchange"] = {"transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if kind == "rccl" and red_dev == "cuda" else
                                ("%s%s; %d pushes per pass" % ("DRY RUN (GKC_BENCH_BACKEND=%s, the ranks share %d device(s)): " % (dist.get_backend(), torch.cuda.device_count()) if red_dev != "cuda" else "", kind, n_push)),
                                "per_rank": exch}
-        if world == 1 and not args.no_host_landed:
-            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps=2, n_steps_amin2=args.steps, expect=expect, parts=parts)
+        if landed is not None:
+            out["value_host_landed"] = value                   # (name kept from round 4: now the same number as `value`)
+            all_verified.append(landed["sink_ok"])
+        if world == 1 and not args.no_host_landed and sink is not None:
+            # the other host-landed legs, on the sink `value` used: abundance-min 2 (only the solid records travel) and PCIe at both ends; 5 timed steps each, medians beside the means
+            out["host_landed"] = host_landed_leg(c, gkc, step, sync, distinct, n_steps_amin2=5, expect=expect, parts=parts, amins=(2,), sink=sink)
             if "abundance_min_2" in out["host_landed"]:
-                out["host_landed"]["abundance_min_2"]["vs_value"] = out["host_landed"]["abundance_min_2"]["value"] / value
-            if "abundance_min_1" in out["host_landed"]:
-                # SURVEY 8(d)'s wall for configs 2-4 ends with the last partition's Count[] in HOST memory at abundance-min 1: that figure, beside `value` (results in HBM)
-                out["value_host_landed"] = out["host_landed"]["abundance_min_1"]["value"]
-                out["value_host_landed_note"] = ("SURVEY 8(d) wall: first push -> every distinct k-mer's Count record in page-locked host memory, abundance-min 1 (%.1f ms per step, PCIe-bound: "
-                                                 "%.2f of the link); `value` ends with the records in HBM" % (out["host_landed"]["abundance_min_1"]["ms_per_step"], out["host_landed"]["abundance_min_1"]["frac_of_pcie"]))
-            for a_ in ("abundance_min_1", "abundance_min_2"):
-                if a_ in out["host_landed"] and "verified" in out["host_landed"][a_]:
-                    all_verified.append(out["host_landed"][a_]["verified"])
+                out["host_landed"]["abundance_min_2"]["vs_value_device_resident"] = out["host_landed"]["abundance_min_2"]["value"] / value_dev
+                if "verified" in out["host_landed"]["abundance_min_2"]:
+                    all_verified.append(out["host_landed"]["abundance_min_2"]["verified"])
+        sink = None
         if world == 1 and k == 31 and not args.no_cpu_baseline:
             out["config"]["fastq_parse_on_device"] = fastq_parse_leg(c)
         if world == 1 and k == 31 and not args.no_bloom_mphf:
@@ -711,30 +805,31 @@ def main():
                 c63.begin_pass(0); c63.push_reads_device(b63, o63, n_reads, n_bases); c63.finish_pass()
             step63(); torch.cuda.synchronize()
             b63t = {nme: c63.timing(nme) for nme in names}
+            per63 = []
             t0 = time.perf_counter()
-            for _ in range(2):
-                step63()
+            for _ in range(5):
+                t1 = time.perf_counter(); step63(); per63.append((time.perf_counter() - t1) * 1e3)
             torch.cuda.synchronize()
-            dt63 = (time.perf_counter() - t0) / 2
+            dt63 = (time.perf_counter() - t0) / 5
             s63 = c63.stats()
             v63 = verify_block(c63, input_checksum(c63, [(b63, o63, n_reads, n_bases)]), 1); all_verified.append(v63["verified"])
             kt63 = {nme: ((c63.timing(nme)[0] - b63t[nme][0]), (c63.timing(nme)[1] - b63t[nme][1])) for nme in names}
-            alg63, dom63, dom63_ms, ach63, ln63 = kernel_roofline(kt63, 2, n_bases, s63, 63, s63["kmers_nb_valid"], s63["kmers_nb_distinct"])
+            alg63, dom63, dom63_ms, ach63, ln63 = kernel_roofline(kt63, 5, n_bases, s63, 63, s63["kmers_nb_valid"], s63["kmers_nb_distinct"])
             out["config"]["k63"] = {"workload": "k=63, %d synthetic 150 bp reads, single-pass count, m=%d, %d partitions (BASELINE configs[3])" % (n_reads, m, p63),
-                                    "steps": 2, "warmup": 1, "ms_per_step": dt63 * 1e3, "value": s63["kmers_nb_distinct"] / dt63, "unit": "distinct k-mers/s", "dtype": "u128",
+                                    "steps": 5, "warmup": 1, "ms_per_step": dt63 * 1e3, "ms_per_step_median": float(np.median(per63)), "value": s63["kmers_nb_distinct"] / dt63, "unit": "distinct k-mers/s (records left in HBM; host-landed: value_host_landed)", "dtype": "u128",
                                     "verified": v63["verified"], "verification": v63,
                                     "valid_kmers": s63["kmers_nb_valid"], "distinct_kmers": s63["kmers_nb_distinct"], "valid_kmers_per_s": s63["kmers_nb_valid"] / dt63,
-                                    "kernel_ms_per_step": {n_: round(kt63[n_][0] / 2, 3) for n_ in names},
+                                    "kernel_ms_per_step": {n_: round(kt63[n_][0] / 5, 3) for n_ in names},
                                     "roofline": {"bound": "hbm", "kernel": dom63, "achieved": ach63, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach63 / HBM_PEAK_GBS,
                                                  "traffic": None, "launches_per_step": int(ln63), "launch_ms": dom63_ms / ln63,
                                                  "algorithmic_bytes_per_launch": alg63[dom63] / ln63, "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2"))}}
             if not args.no_host_landed:
                 # SURVEY 8(d)'s wall for configs[3]: every distinct 63-mer's 32-byte Count record in page-locked host memory (abundance-min 1): 147 GB of records, 16 bytes
-                # per record on the link (csrc/gkc_sink.hip, 16-byte keys); one untimed + one timed step, verified like the others
+                # per record on the link (csrc/gkc_sink.hip, 16-byte keys); one untimed + five timed steps (mean and median), verified like the others
                 def sync63():
                     torch.cuda.synchronize()
                 try:
-                    hl63 = host_landed_leg(c63, gkc, step63, sync63, s63["kmers_nb_distinct"], n_steps=1, expect=input_checksum(c63, [(b63, o63, n_reads, n_bases)]), parts=p63,
+                    hl63 = host_landed_leg(c63, gkc, step63, sync63, s63["kmers_nb_distinct"], n_steps=5, expect=input_checksum(c63, [(b63, o63, n_reads, n_bases)]), parts=p63,
                                            amins=(1,), host_to_host=False)
                 except Exception as e:      # noqa
                     hl63 = {"error": repr(e)}

@@ -115,6 +115,9 @@ static int bg_join(gkc_ctx* c)
         } else {                                                                                   // ... or come back (gkc_segment_export, gkc_partition_superkmers after the pass)
             c->segments = std::move(c->b_segments); c->owned_arenas = std::move(c->b_arenas);
             for (hipEvent_t e : c->b_pending) c->pending_events.push_back(e);
+            // Stage B failed (GKC_ERR_NOMEM ...) and the context has not moved on: the pass is in progress again, exactly as after a failed gkc_finish_pass —
+            // gkc_finish_pass / gkc_finish_pass_async may be called again (gkc_count_pass: "a pass counted again")
+            if (c->stage_b_rc != GKC_OK) { c->pass = c->b_pass; c->in_pass = true; }
         }
         c->b_segments.clear(); c->b_arenas.clear(); c->b_pending.clear(); c->b_detached = false; c->b_moved_on = false;
     }
@@ -303,6 +306,7 @@ int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
             gkc_sink_reset(c);
             c->landed_events.clear(); c->sink_used = 0; c->sink_overflow = false;        // the host sink holds ONE pass: the previous pass's records are overwritten from here on
             for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; D.sink_batch = nullptr; }
+            if (c->sink) (void)gkc_sink_prepare(c);                      // a sink set before gkc_configure / a context configured again (key width, partitions): the staging buffer is re-sized here
         }
         for (uint32_t p = 0; p < c->nb_partitions; p++) c->datasets[(size_t)pass * c->nb_partitions + p] = Dataset();
         c->pass_stats[pass] = gkc_stats{}; c->pass_released[pass] = 0;
@@ -541,8 +545,13 @@ int gkc_set_host_sink(gkc_ctx* c, void* pinned, uint64_t cap_bytes)
     GKC_HIP(c, hipSetDevice(c->device));
     if (pinned && !c->copy_stream) GKC_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    gkc_sink_reset(c);
-    c->sink = pinned; c->sink_cap = pinned ? cap_bytes : 0; c->sink_used = 0; c->sink_overflow = false;
+    {   std::lock_guard<std::mutex> lk(c->mu);
+        for (hipEvent_t e : c->landed_events) (void)hipEventDestroy(e);
+        c->landed_events.clear();
+        gkc_sink_reset(c);                                               // (deletes the packed batches: no dataset may keep a handle of one)
+        for (Dataset& D : c->datasets) { D.h_counts = nullptr; D.landed = nullptr; D.sink_batch = nullptr; }
+    }
+    c->sink = pinned; c->sink_cap = pinned ? cap_bytes : 0; c->sink_used = 0; c->sink_overflow = false; c->sink_no6 = false;
     return gkc_sink_prepare(c);                                          // 8-byte keys: the page-locked staging buffer of the packed transfer (7/16 of the sink)
 }
 int gkc_wait_partition(gkc_ctx* c, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid)

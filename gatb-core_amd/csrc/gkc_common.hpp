@@ -10,6 +10,7 @@
 #include <vector>
 #include <chrono>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <condition_variable>
 #include <thread>
@@ -180,7 +181,7 @@ struct gkc_ctx {
     // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted
     void* sink = nullptr; uint64_t sink_cap = 0, sink_used = 0; bool sink_overflow = false;
     uint64_t sink_wire_bytes = 0;         // bytes the packed batches of the pass took on the link (gkc_stats.reserved[1])
-    bool sink_no6 = false;                // the packed transfer found too few abundances of 1 for its 6-byte entries to pay (gkc_sink.hip)
+    std::atomic<bool> sink_no6{false};                // the packed transfer found too few abundances of 1 for its 6-byte entries to pay (gkc_sink.hip)
     hipStream_t copy_stream = nullptr;
     gkc_unpacker* unpacker = nullptr;
     hipStream_t fetch_stream = nullptr;    // gkc_partition_counts: D2H of finished datasets, beside (not inside) the Stage-B lanes

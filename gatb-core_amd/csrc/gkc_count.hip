@@ -202,6 +202,75 @@ template <int KW> __device__ __forceinline__ uint32_t sub_index(typename KeyT<KW
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ one lane per GROUP of k-mers (round 5)
+// The walks above give a lane one RECORD: a record holds 1..28 k-mers (mean 11 on 150 bp reads), so a wave runs its k-mer loop as long as its longest record with
+// ~29 of its 64 lanes active per step — and a VALU instruction or an LDS atomic costs its slot whatever the number of active lanes (profiles/r02_lds_bench.txt).
+// Here a wave takes 64 records at a time and hands their k-mers out in TASKS of up to G consecutive k-mers of one record, one task per lane, 64 abreast:
+//   * lane l brings record l: prefix sum of ceil(nbK / G) over the wave -> first task P[l] of the record in the chunk, T tasks in all;
+//   * the record's nucleotide string goes to the wave's LDS stage, left-aligned, its weight in the low bits of the second word (below anything a window reaches);
+//   * a bit per task marks the tasks that START a record (one LDS atomic OR per record); task j = 64 it + lane finds its record as
+//     (records started before the 64-bit word `it`) + v_mbcnt(word) [+ its own bit] - 1: a wave-uniform word read and two VALU instructions, no search;
+//   * the task's first k-mer is a window of the string (one funnel shift) and its reverse complement is computed once (revcomp64); the <= G - 1 that follow roll
+//     like the per-record walk. Lane utilisation ~0.88 at G = 4 (the last task of a record may be short) instead of ~0.45.
+// (G = 1 with BOTH strings staged — the reverse complement as a window of the reversed record — was built first: 38 VALU + 5 LDS instructions per 64 k-mers, and
+// slower than the per-record walk, whose rolling step is 25 VALU for ~29 k-mers: the set-up per k-mer has to be shared by a few k-mers to pay.)
+// Same k-mers, same weights, another order of arrival (the sort does not care). Replaces the same reference loop: PartitionsCommand.cpp:944-1128.
+struct __attribute__((aligned(16))) WaveStage16 {
+    ulonglong2 rec[64];         // the record's string: {bits 127..64, (bits 63..0 >> 1) | weight - 1}
+    uint32_t bits[64];          // bit j: task j of the chunk is the first of its record (2048 bits)
+    uint16_t meta[64];          // P | nbK << 10
+};
+// all 64 lanes of the wave call it together; a lane without a record passes R0 = 0 (nbK = 0). f(canonical k-mer, weight - 1) once per k-mer.
+template <int G, class F>
+__device__ __forceinline__ void wave_each_kmer16(WaveStage16& S, const uint64_t R0, const uint64_t R1, const uint32_t k, const uint32_t wb, const int lane, F f)
+{
+    static_assert(G >= 2 && 64 * ((28 + G - 1) / G) < 1024, "P must fit 10 bits");
+    const uint32_t nbk = (uint32_t)(R0 >> 56), ntask = (nbk + G - 1) / G;
+    uint32_t incl = ntask;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (T == 0) return;
+    const uint32_t P = incl - ntask;
+    const uint64_t wmask = (1ull << wb) - 1ull, R1n = R1 & ~wmask;
+    S.rec[lane] = make_ulonglong2((R0 << 8) | (R1n >> 56), ((R1n << 8) >> 1) | (R1 & wmask));
+    S.meta[lane] = (uint16_t)(P | (nbk << 10));
+    if (lane < 32) reinterpret_cast<uint64_t*>(S.bits)[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (nbk) atomicOr(&S.bits[P >> 5], 1u << (P & 31u));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint32_t down = 64 - 2 * k, sh = 2 * (k - 1);
+    uint32_t base = 0;
+    for (uint32_t j0 = 0; j0 < T; j0 += 64) {
+        const uint64_t M = reinterpret_cast<const uint64_t*>(S.bits)[j0 >> 6];            // (a plain LDS read: a volatile one is compiled to a FLAT load)
+        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)M), mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(M >> 32));
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        const uint32_t own = (uint32_t)((((uint64_t)mhi << 32) | mlo) >> lane) & 1u;
+        const uint32_t r = base + below + own - 1u;
+        base += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+        const uint32_t j = j0 + (uint32_t)lane;
+        if (j < T) {
+            const uint32_t meta = S.meta[r];
+            const ulonglong2 A = S.rec[r];
+            const uint32_t i0 = G * (j - (meta & 0x3FFu)), left = (meta >> 10) - i0, cnt = left < (uint32_t)G ? left : (uint32_t)G;
+            const unsigned long long wq = A.y & wmask;
+            uint32_t s = 2 * i0;                                                    // <= 54: the weight bits (and the >> 1) stay below every window
+            uint64_t fw = ((A.x << s) | (A.y >> (63 - s))) >> down, rv = revcomp64(fw, k);
+            for (uint32_t u = 0; u < cnt; u++) {
+                f(fw < rv ? fw : rv, wq);
+                s += 2;
+                fw = ((A.x << s) | (A.y >> (63 - s))) >> down;
+                rv = (rv >> 2) | ((uint64_t)(((uint32_t)fw & 3u) ^ 2u) << sh);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                          // (the next chunk overwrites the stage)
+}
+#ifndef GKC_BAL_G
+#define GKC_BAL_G 4
+#endif
+
 constexpr int EXPAND_THREADS = 512;
 // A key on its way through the sort is the canonical k-mer shifted left by wb WEIGHT BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
 // of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. wb is chosen per batch (weight_bits_of): 2 .. 4 — the
@@ -251,7 +320,7 @@ struct TierLists {
     uint32_t cap1, cap2, cap3;
 };
 
-template <int KW, int RW>
+template <int KW, int RW, bool BAL /* one lane per k-mer (8-byte keys, 16-byte records) */>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                   uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
                                                                   TierLists T,
@@ -266,6 +335,7 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     __shared__ uint32_t s_wsum[EXPAND_THREADS / 64];
     __shared__ WgList s_big, s_wg, s_split;
     __shared__ uint32_t s_item;
+    __shared__ WaveStage16 s_stage[BAL ? EXPAND_THREADS / 64 : 1];
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1u);
@@ -281,6 +351,15 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const uint8_t* base = segs.rec[s];
+        if constexpr (BAL && KW == 1 && RW == 2) {
+            const int lane = threadIdx.x & 63;
+            WaveStage16& S = s_stage[threadIdx.x >> 6];
+            for (uint64_t rb = r0 + (threadIdx.x & ~63u); rb < r1; rb += EXPAND_THREADS) {        // (wave-uniform bounds: the 64 lanes walk the chunk's k-mers together)
+                uint64_t R[2] = {0, 0};
+                if (rb + lane < r1) load_rec<2>(base, rb + lane, R);
+                wave_each_kmer16<GKC_BAL_G>(S, R[0], R[1], k, 0u, lane, [&](uint64_t c, unsigned long long) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
+            }
+        } else
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
             if constexpr (KW == 2 && RW == 4) {
@@ -368,6 +447,7 @@ constexpr int PAIR_THREADS = 1024;
 // primitive only: EXCHANGES. A thread holding key h first swaps EMPTY into the slot: a key came out -> the two leave as a pair.
 // Nothing came out -> it swaps h in: EMPTY came out -> parked; a key came out (someone parked in between) -> it now holds
 // that key instead and starts over. Keys are conserved by every exchange, nobody waits on anybody; 1.5 exchanges per key.
+template <bool BAL /* one lane per k-mer: wave_each_kmer16 (the wave stages follow the cursors in the dynamic LDS) */>
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
                                                                        const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
@@ -393,30 +473,43 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+        auto emit = [&](uint64_t c, unsigned long long wq) {
+            const uint32_t q = (uint32_t)(c >> pd.shift);
+            unsigned long long h = (c << wb) | wq;                               // (bits beyond the 64th fall off: see above) never all ones
+            for (;;) {
+                const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
+                if (y != EMPTY) {
+                    const uint32_t p = atomicAdd(&s_cur[q], 2u);
+#ifdef GKC_EXP_NOSTORE
+                    if (c == 0x123456789ULL)
+#endif
+                    store16(out + p, y, h);
+                    break;
+                }
+                const unsigned long long z = atomicExch(&s_pend[q], h);
+                if (z == EMPTY) break;
+                h = z;
+            }
+        };
+        if constexpr (BAL) {
+            const int lane = threadIdx.x & 63;
+            WaveStage16& S = reinterpret_cast<WaveStage16*>(s_cur + nsub)[threadIdx.x >> 6];        // (nsub * 12 bytes: a multiple of 16)
+            const uint64_t rb0 = r0 + (threadIdx.x & ~63u);                                       // wave-uniform chunk bounds
+            ulonglong2 nx = rb0 + lane < r1 ? recs[rb0 + lane] : make_ulonglong2(0, 0);
+            for (uint64_t rb = rb0; rb < r1; rb += PAIR_THREADS) {
+                const ulonglong2 cur = nx;
+                nx = rb + PAIR_THREADS + lane < r1 ? recs[rb + PAIR_THREADS + lane] : make_ulonglong2(0, 0);      // next record in flight while this chunk is expanded
+                wave_each_kmer16<GKC_BAL_G>(S, cur.x, cur.y, k, wb, lane, emit);
+            }
+        } else {
         uint64_t r = r0 + threadIdx.x;
         ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
         for (; r < r1; r += PAIR_THREADS) {
             const uint64_t R[2] = {nx.x, nx.y};
             if (r + PAIR_THREADS < r1) nx = recs[r + PAIR_THREADS];                  // next record in flight while this one is expanded
             const unsigned long long wq = R[1] & ((1ull << wb) - 1ull);                              // the record's weight - 1 (below the nucleotides; 0 unless the records were deduplicated)
-            for_each_kmer16(R, k, [&](uint64_t c) {
-                const uint32_t q = (uint32_t)(c >> pd.shift);
-                unsigned long long h = (c << wb) | wq;                               // (bits beyond the 64th fall off: see above) never all ones
-                for (;;) {
-                    const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
-                    if (y != EMPTY) {
-                        const uint32_t p = atomicAdd(&s_cur[q], 2u);
-#ifdef GKC_EXP_NOSTORE
-                        if (c == 0x123456789ULL)
-#endif
-                        store16(out + p, y, h);
-                        break;
-                    }
-                    const unsigned long long z = atomicExch(&s_pend[q], h);
-                    if (z == EMPTY) break;
-                    h = z;
-                }
-            });
+            for_each_kmer16(R, k, [&](uint64_t c) { emit(c, wq); });
+        }
         }
     }
     __syncthreads();
@@ -2154,10 +2247,17 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             segs_b.rec = (const uint8_t* const*)B.dd_ptr.p; segs_b.rec_off = (const uint64_t*)B.dd_off.p; segs_b.n_seg = 1; segs_b.rec_end = (const uint64_t*)B.dd_end.p;
         }
     }
+    // GKC_BALANCED=1: one lane per group of <= 4 k-mers in the two expansion kernels (8-byte keys) instead of one lane per record. Built in round 5 (VERDICT r4 #1b), bit-exact,
+    // measured and NOT the default: expand_count 8.3 -> 10.5 ms, scatter 41 -> 41 ms single lane, the two-lane step 202-205 -> 203-208 ms (profiles/r05_balanced_expand.txt)
+    static const bool balanced = getenv("GKC_BALANCED") && atoi(getenv("GKC_BALANCED")) == 1;
     {   ScopedTimer tm(c, "expand_count");
         static const uint32_t cwgs_env = getenv("GKC_COUNT_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_COUNT_WGS"))) : 0u;
-        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(cwgs_env ? std::min(nv, cwgs_env) : nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
-                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
+        if (KW == 1 && RW == 2 && balanced)
+            hipLaunchKernelGGL((k_expand_count<KW, RW, KW == 1 && RW == 2>), dim3(cwgs_env ? std::min(nv, cwgs_env) : nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
+                               (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
+        else
+            hipLaunchKernelGGL((k_expand_count<KW, RW, false>), dim3(cwgs_env ? std::min(nv, cwgs_env) : nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
+                               (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
@@ -2166,10 +2266,17 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         // Measured, two lanes, 1e8 reads: one workgroup per partition 266-273 ms per step, 160-192 workgroups 249-251, 128: 252, 96: 256.
         static const uint32_t scatter_wgs = getenv("GKC_SCATTER_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCATTER_WGS"))) : 176u;
         if constexpr (KW == 1) {
-            const size_t lds_max = (size_t)MAX_SUB * 12, lds = ((size_t)12 << max_bits_b);          // parking slots + cursors of the batch's largest sub-bucket count
-            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
-            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), d_entries, segs_b, k,
-                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
+            const size_t stage = sizeof(WaveStage16) * (PAIR_THREADS / 64);                        // balanced walk: the waves' record stages (22 KB)
+            const size_t lds_max = (size_t)MAX_SUB * 12 + stage, lds = ((size_t)12 << max_bits_b);          // parking slots + cursors of the batch's largest sub-bucket count
+            static std::once_flag once; std::call_once(once, [&] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
+            if (balanced)
+                hipLaunchKernelGGL(k_expand_scatter_pair<true>, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds + stage, cur_stream(c), d_entries, segs_b, k,
+                                   (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
+            else
+                hipLaunchKernelGGL(k_expand_scatter_pair<false>, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), d_entries, segs_b, k,
+                                   (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });

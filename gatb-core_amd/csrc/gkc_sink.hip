@@ -223,6 +223,7 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts2(const uint64_t* __r
 
 // ------------------------------------------------------------------------------------------------ host side
 struct SinkBatch {
+    int users = 0;                               // workers between picking this batch and their last access to it (under gkc_unpacker::mu): a batch is deleted only at users == 0
     hipEvent_t copied = nullptr;                 // the batch's packed bytes are in the staging buffer
     hipEvent_t copy_start = nullptr;             // GKC_SINK_DEBUG: when the copy stream got to it
     const uint8_t* stage = nullptr;              // [bases: 8 x nblk, padded to 64][payload: nblk x PK_SLOT][exceptions: 16 x n_exc]
@@ -333,6 +334,7 @@ struct gkc_unpacker {
                     }
                     cv.wait(lk);
                 }
+                B->users++;                                                  // (gkc_sink_reset deletes a batch only when nobody is inside it any more)
             }
             if (!B->ready) {
                 (void)hipEventSynchronize(B->copied);
@@ -368,8 +370,9 @@ struct gkc_unpacker {
             }
             {   std::lock_guard<std::mutex> lk(mu);                              // every block of B has been taken: the next batch becomes the front
                 if (!queue.empty() && queue.front() == B && B->next.load() >= B->nblk) queue.pop_front();
+                B->users--;                                                      // the last access of this thread to B
             }
-            cv.notify_all();
+            cv.notify_all(); cv_done.notify_all();
         }
     }
 };
@@ -455,7 +458,7 @@ void gkc_sink_reset(gkc_ctx* c)
     gkc_unpacker* U = c->unpacker;
     if (!U) return;
     {   std::unique_lock<std::mutex> lk(U->mu);
-        U->cv_done.wait(lk, [&] { for (SinkBatch* B : U->all) if (!B->done.load()) return false; return true; });
+        U->cv_done.wait(lk, [&] { for (SinkBatch* B : U->all) if (!B->done.load() || B->users != 0) return false; return true; });
         U->queue.clear();
     }
     for (SinkBatch* B : U->all) { if (B->copied) (void)hipEventDestroy(B->copied); if (B->copy_start) (void)hipEventDestroy(B->copy_start); if (B->d_packed) c->dfree(B->d_packed); delete B; }

@@ -117,7 +117,9 @@ int gkc_finish_pass(gkc_ctx* ctx);
  *   gkc_wait_partition    : blocks until dataset (pass, part) is counted and, with a sink, has landed; *host_records points into the sink
  *                           (NULL without a sink / for what did not fit). Partitions complete in ascending order inside a batch, batches in
  *                           ascending order per lane: a consumer walking the partitions in order overlaps its work with Stage B.
- *   gkc_finish_pass_wait  : joins the worker; the pass is finished like after gkc_finish_pass. */
+ *   gkc_finish_pass_wait  : joins the worker; the pass is finished like after gkc_finish_pass. If Stage B FAILED on the worker (e.g. GKC_ERR_NOMEM) and the
+ *                           context has not begun another pass meanwhile, the pass is in progress again — as after a failed gkc_finish_pass — and
+ *                           gkc_finish_pass / gkc_finish_pass_async may be called again (the retry of gkc_count_pass). */
 int gkc_set_host_sink(gkc_ctx* ctx, void* pinned_host, uint64_t cap_bytes);     /* NULL: no sink */
 int gkc_finish_pass_async(gkc_ctx* ctx);
 int gkc_wait_partition(gkc_ctx* ctx, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid);
