@@ -2,6 +2,7 @@
 seeded inputs. Bit-exact: integer/byte work. Run on the GPU box with `pytest -m gpu`."""
 import ctypes
 import math
+import os
 
 import numpy as np
 import pytest
@@ -106,7 +107,7 @@ def test_fuzz_random_configurations(gkc, seed):
     device_vs_oracle(gkc, reads, k, m, parts, passes=passes, batches=batches, amin=amin, amax=amax, histo_max=histo_max, freq=freq)
 
 
-def test_balanced_walk_switch():
+def test_balanced_walk_switch(gkc):
     """GKC_BALANCED=1 (one lane per task of <= 4 k-mers in the two expansion kernels, csrc/gkc_count.hip wave_each_kmer16; measured and not the default:
     profiles/r05_balanced_expand.txt) stays bit-exact: the fuzz of tools/fuzz_soak.py (random k <= 63, partitions, passes, windows, low-complexity inserts)
     in a process of its own, since the switch is read once per process"""
