@@ -55,10 +55,65 @@ inline thread_local hipStream_t gkc_tl_stream = nullptr;
 // ------------------------------------------------------------------------------------------------ device buffer
 // Caching device allocator: hipMalloc/hipFree of multi-GB buffers cost tens of ms per GB on this platform (far more than
 // the kernels that use them), so freed blocks are kept and reused by later passes of the same shape.
+// Where the blocks come from (round 5): the first pass of a PROCESS used to spend 2-5 s in hipMalloc (10^8 reads: ~150 GB of buffers at ~22 ms per GB, erratic:
+// tools/malloc_bench) — more than ten times the kernels, and a dbgh5 run is one process, one pass. The HIP virtual-memory API maps physical memory ~20x cheaper
+// on these boxes (tools/vmm_probe: 512 MiB chunks created + mapped in 0.1-0.5 ms): a block of 64 MiB or more is an address range reserved with
+// hipMemAddressReserve and backed by hipMemCreate chunks of <= 1 GiB mapped read-write for this device; kernels, hipMemcpy and hipMemset see an ordinary
+// device pointer. GKC_VMM=0 keeps hipMalloc for everything; a context with a communicator (RCCL / IPC transports register their buffers) keeps hipMalloc as well
+// (DevPool::vmm_ok cleared by gkc_comm_create*): whether RCCL accepts VMM ranges as send / receive buffers cannot be checked on a one-GPU box.
+struct VmmBlock { size_t bytes = 0; std::vector<hipMemGenericAllocationHandle_t> handles; std::vector<size_t> sizes; };
 struct DevPool {
     std::recursive_mutex mu;                  // Stage B drives two host threads (two streams) through one pool
     std::multimap<size_t, void*> cache;       // free blocks by size
     std::map<void*, size_t> live;             // blocks handed out
+    std::map<void*, VmmBlock> vmm;            // blocks that are mapped ranges (handed out or parked)
+    int device = 0; bool vmm_ok = true; size_t vmm_gran = 0; int vmm_state = 0;      // 0: not probed, 1: usable, -1: not
+    static constexpr size_t VMM_MIN = (size_t)64 << 20, VMM_CHUNK = (size_t)1 << 30;
+    hipError_t raw_alloc(void** out, size_t want) {
+        if (vmm_state == 0) {
+            vmm_state = -1;
+            const char* e = getenv("GKC_VMM");
+            int sup = 0;
+            if (!(e && atoi(e) == 0) && hipDeviceGetAttribute(&sup, hipDeviceAttributeVirtualMemoryManagementSupported, device) == hipSuccess && sup) {
+                hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+                if (hipMemGetAllocationGranularity(&vmm_gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && vmm_gran) vmm_state = 1;
+            }
+            (void)hipGetLastError();
+        }
+        if (vmm_state != 1 || !vmm_ok || want < VMM_MIN) return hipMalloc(out, want);
+        const size_t total = (want + vmm_gran - 1) / vmm_gran * vmm_gran;
+        void* base = nullptr;
+        hipError_t e = hipMemAddressReserve(&base, total, 0, nullptr, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); return hipMalloc(out, want); }
+        hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+        VmmBlock B; B.bytes = total;
+        size_t off = 0;
+        while (off < total && e == hipSuccess) {
+            const size_t n = std::min(VMM_CHUNK / vmm_gran * vmm_gran, total - off);
+            hipMemGenericAllocationHandle_t h;
+            e = hipMemCreate(&h, n, &prop, 0);
+            if (e == hipSuccess) { e = hipMemMap((char*)base + off, n, 0, h, 0); if (e != hipSuccess) (void)hipMemRelease(h); }
+            if (e == hipSuccess) { B.handles.push_back(h); B.sizes.push_back(n); off += n; }
+        }
+        if (e == hipSuccess) { hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite; e = hipMemSetAccess(base, total, &acc, 1); }
+        if (e != hipSuccess) {                                   // (out of memory, mostly: the caller trims the parked blocks and asks again)
+            (void)hipGetLastError();
+            size_t o = 0; for (size_t i = 0; i < B.handles.size(); i++) { (void)hipMemUnmap((char*)base + o, B.sizes[i]); (void)hipMemRelease(B.handles[i]); o += B.sizes[i]; }
+            (void)hipMemAddressFree(base, total);
+            return e == hipErrorOutOfMemory ? e : hipErrorOutOfMemory;
+        }
+        vmm[base] = std::move(B);
+        *out = base;
+        return hipSuccess;
+    }
+    void raw_free(void* p) {
+        auto it = vmm.find(p);
+        if (it == vmm.end()) { (void)hipFree(p); return; }
+        (void)hipDeviceSynchronize();                            // (hipFree waits for the device as well: nothing may still be using the range)
+        size_t o = 0; for (size_t i = 0; i < it->second.handles.size(); i++) { (void)hipMemUnmap((char*)p + o, it->second.sizes[i]); (void)hipMemRelease(it->second.handles[i]); o += it->second.sizes[i]; }
+        (void)hipMemAddressFree(p, it->second.bytes);
+        vmm.erase(it);
+    }
     size_t cached_bytes = 0;
     uint64_t n_malloc = 0, n_fail = 0, n_trim = 0; double malloc_ms = 0;   // diagnostics (GKC_POOL_DEBUG)
     // size classes: 256 B granules below 2 MB, 2 MB granules up to 64 MB, then 16 classes per octave (<= 6.25 % slack) so that the
@@ -79,7 +134,7 @@ struct DevPool {
         }
         void* p = nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t e = hipMalloc(&p, want);
+        hipError_t e = raw_alloc(&p, want);
         n_malloc++;
         if (e != hipSuccess) {
             // out of memory: give parked blocks back, largest first, until the request fits. (Handing out a parked block that is merely
@@ -89,12 +144,14 @@ struct DevPool {
             if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] hipMalloc of %.2f GB failed; parked %.2f GB in %zu blocks\n", (double)want / 1e9, (double)cached_bytes / 1e9, cache.size());
             while (e != hipSuccess && !cache.empty()) {
                 auto last = std::prev(cache.end());
-                (void)hipFree(last->second); cached_bytes -= last->first; cache.erase(last);
-                e = hipMalloc(&p, want);
+                raw_free(last->second); cached_bytes -= last->first; cache.erase(last);
+                e = raw_alloc(&p, want);
                 if (e != hipSuccess) (void)hipGetLastError();
             }
         }
-        malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const double ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        malloc_ms += ms_;
+        if (ms_ > 20.0 && getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] %.2f GB took %.1f ms (%s)\n", (double)want / 1e9, ms_, vmm.count(p) ? "mapped chunks" : "hipMalloc");
         *err = e;
         if (e != hipSuccess) return nullptr;
         live[p] = want;
@@ -106,11 +163,11 @@ struct DevPool {
         if (gkc_tl_stream) (void)hipStreamSynchronize(gkc_tl_stream);
         std::lock_guard<std::recursive_mutex> lk(mu);
         auto it = live.find(p);
-        if (it == live.end()) { (void)hipFree(p); return; }
+        if (it == live.end()) { raw_free(p); return; }
         cache.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
     }
-    void trim() { std::lock_guard<std::recursive_mutex> lk(mu); for (auto& kv : cache) (void)hipFree(kv.second); cache.clear(); cached_bytes = 0; }
-    void destroy() { std::lock_guard<std::recursive_mutex> lk(mu); trim(); for (auto& kv : live) (void)hipFree(kv.first); live.clear(); }
+    void trim() { std::lock_guard<std::recursive_mutex> lk(mu); for (auto& kv : cache) raw_free(kv.second); cache.clear(); cached_bytes = 0; }
+    void destroy() { std::lock_guard<std::recursive_mutex> lk(mu); trim(); for (auto& kv : live) raw_free(kv.first); live.clear(); }
 };
 
 struct DevBuf {

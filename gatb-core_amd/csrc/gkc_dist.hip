@@ -409,6 +409,9 @@ int gkc_comm_create_rccl(gkc_ctx* c, const uint8_t id[GKC_COMM_ID_BYTES], int wo
     m->init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count();
     if (r != ncclSuccess) { c->set_error(GKC_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); gkc_comm_destroy(m); *out = nullptr; return GKC_ERR_HIP; }
     m->rccl = true;
+    // several GPUs: the blocks RCCL sends from / receives into come from hipMalloc as in rounds 1-4 (whether it takes hipMemCreate-mapped ranges as user buffers
+    // could not be checked on a one-GPU box; GKC_VMM_WITH_RCCL=1 to try). What the pool already handed out stays valid.
+    if (world > 1 && !(getenv("GKC_VMM_WITH_RCCL") && atoi(getenv("GKC_VMM_WITH_RCCL")) == 1)) { std::lock_guard<std::recursive_mutex> lk(c->pool.mu); c->pool.vmm_ok = false; }
     return GKC_OK;
 }
 int gkc_comm_create_transport(gkc_ctx* c, const gkc_transport* t, int world, int rank, gkc_comm** out)

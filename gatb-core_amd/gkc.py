@@ -17,7 +17,7 @@ _LIB = None
 SYMBOLS = [
     "gkc_create", "gkc_destroy", "gkc_last_error", "gkc_version", "gkc_configure", "gkc_set_solidity",
     "gkc_set_max_superkmer", "gkc_begin_pass", "gkc_push_reads", "gkc_push_reads_device", "gkc_finish_pass",
-    "gkc_partition_info", "gkc_partition_counts", "gkc_partition_counts_device", "gkc_histogram", "gkc_get_stats",
+    "gkc_partition_info", "gkc_partition_counts", "gkc_partition_counts_range", "gkc_partition_counts_device", "gkc_histogram", "gkc_get_stats",
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_query_solid", "gkc_bloom_contains",
@@ -96,6 +96,7 @@ def lib():
         "gkc_finish_pass": (C.c_int, [vp]),
         "gkc_partition_info": (C.c_int, [vp, u32, u32, P(u64), P(u64), P(u64)]),
         "gkc_partition_counts": (C.c_int, [vp, u32, u32, vp, u64, P(u64)]),
+        "gkc_partition_counts_range": (C.c_int, [vp, u32, u32, u64, u64, vp]),
         "gkc_partition_counts_device": (C.c_int, [vp, u32, u32, P(vp), P(u64)]),
         "gkc_histogram": (C.c_int, [vp, vp, u32]),
         "gkc_get_stats": (C.c_int, [vp, P(Stats)]),
@@ -340,6 +341,12 @@ class Counter:
         n = C.c_uint64()
         self._chk(self.L.gkc_partition_counts(self.h, pass_, part, _p(out), ns, C.byref(n)))
         return out[: ns * self.rec_bytes]
+
+    def partition_records_range(self, pass_, part, first, n):
+        """records [first, first + n) of the dataset (gkc_partition_counts_range)"""
+        out = np.zeros(max(1, n * self.rec_bytes), np.uint8)
+        self._chk(self.L.gkc_partition_counts_range(self.h, pass_, part, first, n, _p(out)))
+        return out[: n * self.rec_bytes]
 
     def partition(self, pass_, part):
         """-> (lo uint64[], hi uint64[], abundance int32[])"""

@@ -132,6 +132,9 @@ int gkc_partition_info(gkc_ctx* ctx, uint32_t pass, uint32_t part,
                        uint64_t* n_solid, uint64_t* n_distinct, uint64_t* n_kmers);
 int gkc_partition_counts(gkc_ctx* ctx, uint32_t pass, uint32_t part, void* out_counts, uint64_t cap_records,
                          uint64_t* n_solid);
+/* records [first, first + n) of the dataset into `out` — for a consumer that moves a partition through page-locked buffers smaller than the partition
+ * (integration/gatb_device/DeviceCounting.hpp: a ring of 4 MiB slots between the link and the .h5 file). Same stream and ordering as gkc_partition_counts. */
+int gkc_partition_counts_range(gkc_ctx* ctx, uint32_t pass, uint32_t part, uint64_t first, uint64_t n, void* out_counts);
 /* device pointer to the same records (valid until gkc_begin_pass of the same pass index or gkc_destroy) */
 int gkc_partition_counts_device(gkc_ctx* ctx, uint32_t pass, uint32_t part, const void** d_counts, uint64_t* n_solid);
 

@@ -26,9 +26,13 @@
 
 #include <gkc.h>
 #include <gatb_device/DeviceContext.hpp>
+#include <gatb_device/SolidSinkDirect.hpp>
 
 #include <vector>
 #include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <list>
 #include <atomic>
 #include <thread>
 #include <memory>
@@ -75,6 +79,7 @@ public:
         device::DeviceContext::singleton().setResident (device::DeviceContext::Resident());      /* a new count: what an earlier one left in HBM is going away */
         _plan = plan;  _nbPartitions = config._nb_partitions;  _kmerSize = config._kmerSize;
         _waitS = _handOverS = 0;
+        if (plan.on)  { prepareRing (config._nbCores); }                  /* (page-locked once, before anything runs on the device) */
         const u_int64_t nbMinims = (u_int64_t)1 << (2 * config._minim_size);
         std::vector<uint16_t> table (nbMinims);
         for (u_int64_t m = 0; m < nbMinims; m++)  { table[m] = (uint16_t) repartitor (m); }
@@ -311,6 +316,8 @@ public:
     void joinPass (size_t pass, size_t nbPasses)
     {
         if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); }
+        if (hasRing())  { drainWriter(); }                                /* every Count[] of the pass is in the file */
+        if (pass + 1 == nbPasses)  { freeRing(); }
         if (pass + 1 == nbPasses  &&  _plan.on  &&  (_comm == 0  ||  _rank == 0))
         {
             gkc_stats st;  check (gkc_get_stats (_ctx, &st));
@@ -318,6 +325,8 @@ public:
             r.on = true;  r.nbSolid = st.kmers_nb_solid;  r.kmerSize = (uint32_t) _kmerSize;  r.keyBytes = _kmerSize <= 31 ? 8 : 16;
             device::DeviceContext::singleton().setResident (r);
         }
+        if (getenv ("GATB_DEVICE_VERBOSE") != 0  &&  _writerBytes > 0)
+            fprintf (stderr, "[device counting] the file's writer thread: %.2f GB in %.2f s of pwrite (%.2f GB/s while writing)\n", _writerBytes / 1e9, _writerBusyS, _writerBytes / 1e9 / std::max (1e-9, _writerBusyS));
         if (getenv ("GATB_DEVICE_VERBOSE") != 0)
         {
             double a = 0, b = 0;  uint64_t n = 0;
@@ -357,10 +366,58 @@ public:
         _progressDebt -= owed;
         return n - owed;
     }
+    /** The ring between the link and the result file (bulk mode): `slots` page-locked buffers of SLOT_BYTES in ONE allocation made before the reads are scanned
+     *  (page-locking memory while Stage B runs stalls its launches: measured, 0.2 -> 2-4 s), and ONE writer thread. A partition command makes its dataset
+     *  (SolidSinkDirect::prepare), then moves its Count[] piece by piece: take a slot, gkc_partition_counts_range into it (DMA at the link's rate; pageable memory is
+     *  staged by the runtime at ~3.4 GB/s with 256 threads asking at once), queue {slot, file offset}; the writer pwrite()s the pieces in the order they were queued
+     *  and gives the slots back. One writer because that is what one file takes fastest (tools/filewrite_probe: 9.1 GB/s against 3-4 GB/s with several). */
+    enum { SLOT_BYTES = 4 << 20 };
+    void prepareRing (size_t nbCores)
+    {
+        if (_ring != 0  ||  getenv ("GATB_DEVICE_NO_RING") != 0)  { return; }
+        size_t slots = 256;                                              /* 1 GiB: a whole group of nb-cores partition commands queues its records and returns while the writer is still at it */
+        (void) nbCores;
+        if (getenv ("GATB_DEVICE_RING_SLOTS") != 0)  { slots = std::max (1, atoi (getenv ("GATB_DEVICE_RING_SLOTS"))); }
+        void* p = 0;
+        if (gkc_host_alloc (&p, (uint64_t) slots * SLOT_BYTES) != GKC_OK)  { return; }      /* no page-locked memory: the commands fetch into pageable memory */
+        std::lock_guard<std::mutex> guard (_ringLock);
+        _ring = p;  _ringFree.clear();
+        for (size_t i = 0; i < slots; i++)  { _ringFree.push_back ((char*) p + i * (size_t) SLOT_BYTES); }
+        _writerStop = false;  _writerError.clear();  _jobsPending = 0;
+        _writer = std::thread ([this] { writerLoop(); });
+    }
+    bool  hasRing ()  { return _ring != 0; }
+    void* takeSlot ()  { std::unique_lock<std::mutex> lk (_ringLock);  _ringCv.wait (lk, [this] { return !_ringFree.empty(); });  void* p = _ringFree.back();  _ringFree.pop_back();  return p; }
+    void  giveSlot (void* p)  { { std::lock_guard<std::mutex> guard (_ringLock);  _ringFree.push_back (p); }  _ringCv.notify_one(); }
+    /** `bytes` of a slot to `offset` of the file `path`; the writer gives the slot back */
+    void  queueWrite (const std::string& path, uint64_t offset, void* slot, size_t bytes)
+    {
+        { std::lock_guard<std::mutex> guard (_ringLock);  WriteJob j;  j.path = &pathOf (path);  j.offset = offset;  j.slot = slot;  j.bytes = bytes;  _jobs.push_back (j);  _jobsPending++; }
+        _jobCv.notify_one();
+    }
+    /** everything queued is in the file (throws what the writer met) */
+    void  drainWriter ()
+    {
+        std::unique_lock<std::mutex> lk (_ringLock);
+        _idleCv.wait (lk, [this] { return _jobsPending == 0; });
+        if (!_writerError.empty())  { const std::string e = _writerError;  _writerError.clear();  throw system::Exception ("%s", e.c_str()); }
+    }
+    void  freeRing ()
+    {
+        if (_writer.joinable())
+        {
+            { std::lock_guard<std::mutex> guard (_ringLock);  _writerStop = true; }
+            _jobCv.notify_all();  _writer.join();
+        }
+        std::lock_guard<std::mutex> guard (_ringLock);
+        if (_ring)  { gkc_host_free (_ring); }
+        _ring = 0;  _ringFree.clear();  _paths.clear();
+    }
+
     /** called by every partition command: seconds it waited for Stage B / spent handing its records over */
     void addCommandTimes (double waitS, double handOverS)  { std::lock_guard<std::mutex> guard (_timesLock);  _waitS += waitS;  _handOverS += handOverS; }
 
-    ~DeviceSession ()  { for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); } }      /* (the context is the process's: DeviceContext) */
+    ~DeviceSession ()  { freeRing();  for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); } }      /* (the context is the process's: DeviceContext) */
 
 private:
     DeviceSession () : _ctx(0), _comm(0), _ranks(1), _rank(0), _nbExchanges(1), _exchangesDone(0), _readsPerExchange(1), _pushedReads(0), _nbPartitions(0) {}
@@ -385,6 +442,43 @@ private:
     u_int64_t _progressReported = 0, _progressDebt = 0;
     std::mutex _timesLock;
     double    _waitS = 0, _handOverS = 0;
+    struct WriteJob  { const std::string* path;  uint64_t offset;  void* slot;  size_t bytes; };
+    const std::string& pathOf (const std::string& p)  { for (std::list<std::string>::iterator it = _paths.begin(); it != _paths.end(); ++it) { if (*it == p) { return *it; } }  _paths.push_back (p);  return _paths.back(); }      /* (under _ringLock) */
+    void writerLoop ()
+    {
+        int fd = -1;  const std::string* open_ = 0;
+        for (;;)
+        {
+            WriteJob j;
+            {
+                std::unique_lock<std::mutex> lk (_ringLock);
+                _jobCv.wait (lk, [this] { return _writerStop  ||  !_jobs.empty(); });
+                if (_jobs.empty())  { break; }
+                j = _jobs.front();  _jobs.pop_front();
+            }
+            std::string error;
+            try
+            {
+                if (j.path != open_)  { if (fd >= 0) { ::close (fd); }  fd = ::open (j.path->c_str(), O_WRONLY);  open_ = j.path;
+                                         if (fd < 0)  { open_ = 0;  throw system::Exception ("device sink: open (%s): %s", j.path->c_str(), strerror (errno)); } }
+                const double w0 = wallNow();
+                SolidSinkDirect<char>::writeAt (fd, j.offset, j.slot, j.bytes);
+                _writerBusyS += wallNow() - w0;  _writerBytes += j.bytes;
+            }
+            catch (system::Exception& e)  { error = e.getMessage(); }
+            giveSlot (j.slot);
+            { std::lock_guard<std::mutex> guard (_ringLock);  if (!error.empty()  &&  _writerError.empty()) { _writerError = error; }  _jobsPending--; }
+            _idleCv.notify_all();
+        }
+        if (fd >= 0)  { ::close (fd); }
+    }
+    std::mutex _ringLock;  std::condition_variable _ringCv, _jobCv, _idleCv;
+    void*     _ring = 0;
+    std::vector<void*> _ringFree;
+    std::deque<WriteJob> _jobs;  size_t _jobsPending = 0;  bool _writerStop = false;  std::string _writerError;
+    std::list<std::string> _paths;
+    double    _writerBusyS = 0;  u_int64_t _writerBytes = 0;       /* (written by the writer thread, read after drainWriter) */
+    std::thread _writer;
 };
 
 /********************************************************************************/
@@ -483,6 +577,7 @@ public:
         CountProcessorDump<span>*        dump  = dynamic_cast<CountProcessorDump<span>*>        (items[2]);
         if (histo == 0  ||  solid == 0  ||  dump == 0  ||  histo->getHistogram() == 0)  { return plan; }
         plan.on = true;
+        if (dump->getSolidCounts() != 0)  { SolidSinkDirect<Count>::closeHandles (*dump->getSolidCounts()); }      /* (what the direct sink needs of the partition before the commands run) */
         plan.abundanceMin = (int32_t) config._abundance[0].getBegin();
         plan.abundanceMax = (int32_t) config._abundance[0].getEnd();
         plan.histoMax     = (uint32_t) histo->getHistogram()->getLength();
@@ -530,19 +625,6 @@ public:
         dev.check (gkc_wait_partition (dev.ctx(), this->_pass_num, this->_parti_num, &landed, &nbSolid));
         const double t1 = now();
 
-        /* the device record width follows k (16 bytes for k <= 31, 32 bytes above) */
-        const size_t recBytes = this->_kmerSize <= 31 ? 16 : 32;
-        std::unique_ptr<unsigned char[]> fetched;                 /* (not a vector: no zero-fill of a block that is overwritten at once) */
-        const unsigned char* recs = (const unsigned char*) landed;
-        if (recs == 0  &&  nbSolid > 0)
-        {
-            fetched.reset (new unsigned char [nbSolid * recBytes]);
-            uint64_t got = 0;
-            dev.check (gkc_partition_counts (dev.ctx(), this->_pass_num, this->_parti_num, fetched.get(), nbSolid, &got));
-            recs = fetched.get();
-        }
-        const double t2 = now();
-
         CountProcessorDump<span>* dump = 0;
         if (dev.plan().on)
         {
@@ -550,14 +632,57 @@ public:
             if (items.size() == 3)  { dump = dynamic_cast<CountProcessorDump<span>*> (items[2]); }
         }
 
-        if (dump != 0  &&  dump->getSolidCounts() != 0)
+        /* the device record width follows k (16 bytes for k <= 31, 32 bytes above) */
+        const size_t recBytes = this->_kmerSize <= 31 ? 16 : 32;
+        const size_t actualPartId = this->_parti_num + this->_pass_num * dev.nbPartitions();      /* CountProcessorDump.hpp:131 */
+        const bool   bulk = dump != 0  &&  dump->getSolidCounts() != 0;
+        double fetchS = 0;
+        bool   written = false;
+
+        /* Bulk mode, HDF5 storage, the device layout IS Abundance<Type,int32> (Abundance.hpp:68-129): the partition's dataset is made at its final size and the
+         * records go from the device through the page-locked slots of the session's ring to the file's writer thread (SolidSinkDirect.hpp, DeviceSession::prepareRing) —
+         * no block of the partition's size on the host, no H5Dwrite under the storage's lock */
+        if (bulk  &&  landed == 0  &&  nbSolid > 0  &&  sizeof(Count) == recBytes  &&  dev.hasRing())
         {
-            /* one block per partition straight into the partition's collection (for HDF5 storage: one H5Dwrite, synchronized inside) */
-            const size_t actualPartId = this->_parti_num + this->_pass_num * dev.nbPartitions();      /* CountProcessorDump.hpp:131 */
-            tools::collections::Collection<Count>& coll = (*dump->getSolidCounts()) [actualPartId];
-            if (nbSolid > 0)
+            uint64_t address = 0;  std::string path;
+            if (SolidSinkDirect<Count>::prepare ((*dump->getSolidCounts()) [actualPartId], (size_t) nbSolid, address, path))
             {
-                if (sizeof(Count) == recBytes)  { coll.insert ((const Count*) recs, (size_t) nbSolid); }     /* the device layout IS Abundance<Type,int32> (Abundance.hpp:68-129) */
+                const uint64_t per = (uint64_t) DeviceSession::SLOT_BYTES / recBytes;
+                for (uint64_t first = 0; first < nbSolid; first += per)
+                {
+                    const uint64_t n = std::min<uint64_t> (per, nbSolid - first);
+                    struct Slot  { DeviceSession& dev;  void* p;  Slot (DeviceSession& d) : dev(d), p(d.takeSlot()) {}  ~Slot ()  { if (p) { dev.giveSlot (p); } } }  slot (dev);
+                    const double f0 = now();
+                    dev.check (gkc_partition_counts_range (dev.ctx(), this->_pass_num, this->_parti_num, first, n, slot.p));
+                    fetchS += now() - f0;
+                    dev.queueWrite (path, address + first * recBytes, slot.p, (size_t) (n * recBytes));
+                    slot.p = 0;                                          /* (the writer gives it back) */
+                }
+                written = true;
+            }
+        }
+
+        std::unique_ptr<unsigned char[]> fetched;                 /* (not a vector: no zero-fill of a block that is overwritten at once) */
+        const unsigned char* recs = (const unsigned char*) landed;
+        if (!written  &&  recs == 0  &&  nbSolid > 0)
+        {
+            fetched.reset (new unsigned char [nbSolid * recBytes]);
+            uint64_t got = 0;
+            const double f0 = now();
+            dev.check (gkc_partition_counts (dev.ctx(), this->_pass_num, this->_parti_num, fetched.get(), nbSolid, &got));
+            fetchS += now() - f0;
+            recs = fetched.get();
+        }
+        const double t2 = t1 + fetchS;
+
+        if (bulk)
+        {
+            /* one block per partition into the partition's collection: the direct sink when the records are in host memory already (a host sink is set) or the ring
+             * is absent; otherwise the collection's own insert (HDF5: one H5Dwrite under the storage's lock; file storage: BagFile) */
+            tools::collections::Collection<Count>& coll = (*dump->getSolidCounts()) [actualPartId];
+            if (!written  &&  nbSolid > 0)
+            {
+                if (sizeof(Count) == recBytes)  { if (!SolidSinkDirect<Count>::insert (coll, (const Count*) recs, (size_t) nbSolid))  { coll.insert ((const Count*) recs, (size_t) nbSolid); } }
                 else
                 {
                     std::vector<Count> block (nbSolid);

@@ -74,12 +74,21 @@ def main():
             os.remove(out + ".h5")
             return v
 
+        # a freshly leased box pays ~26 ms per GB the FIRST time a region of its VRAM is allocated after boot (tools/alloc_probe: 128 GB of hipMalloc 3.4-3.9 s in the first
+        # process, 2 ms in the next): every dbgh5 run below would carry 2-4 s of that inside its device_stage_b. One process touches the VRAM first, so the runs
+        # measure the software (a machine that has been up for a while behaves like this all the time).
+        probe = os.path.join(ROOT, "tools", "alloc_probe", "alloc_probe")
+        if os.path.exists(probe) and not os.environ.get("DROPIN_NO_VRAM_TOUCH"):
+            r = subprocess.run([probe, "malloc", "16", "16"], capture_output=True, text=True)
+            print("# VRAM touched once before the runs (tools/alloc_probe malloc 16 16): " + " | ".join(r.stdout.strip().splitlines()[:2]))
         if mode in ("count", "all"):
             print("# DSK step alone: %d synthetic 150 bp reads (30x, 1%% substitutions) as FASTA in %s, k=31, abundance-min %s, -nb-cores %d, %s" % (n, work, amin, cores, " ".join(count_only)))
             print("# %-86s %8s %8s %9s %10s %6s %6s %9s %9s %9s %9s %12s %12s" % ("run", "wall s", "dsk s", "fill_part", "fill_solid", "parts", "passes", "dev A s", "dev B s", "dev wait", "hand-over", "distinct", "solid"))
             ref_counts = None
             runs = [] if skip_ref else [("reference (unpatched dbgh5), -max-memory 5000 (its default)", os.path.join(REF, "dbgh5"), {}, "5000")]
             runs += [("patched (default: Configuration from the HBM, text parsed on the device, bulk), -max-memory 5000", DEV, {}, "5000"),
+                     ("patched, round 4's sink: BagHDF5Patch::insert under the storage lock (GATB_DEVICE_NO_DIRECT_SINK=1), -max-memory 5000", DEV, {"GATB_DEVICE_NO_DIRECT_SINK": "1"}, "5000"),
+                     ("patched, direct sink without the page-locked ring: pageable fetch (GATB_DEVICE_NO_RING=1), -max-memory 5000", DEV, {"GATB_DEVICE_NO_RING": "1"}, "5000"),
                      ("patched (default), -max-memory 200000", DEV, {}, "200000"),
                      ("patched, the REFERENCE's Configuration, -max-memory 5000", DEV, {"GATB_DEVICE_REFERENCE_CONFIG": "1"}, "5000"),
                      ("patched, the REFERENCE's Configuration, -max-memory 200000 (few huge partitions)", DEV, {"GATB_DEVICE_REFERENCE_CONFIG": "1"}, "200000"),
