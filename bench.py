@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--partitions", type=int, default=0, help="0 = auto (about 4M k-mers per partition)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bloom-mphf", action="store_true", help="skip the Bloom + MPHF block (BASELINE configs[4] on one GPU's share)")
+    ap.add_argument("--no-freq-order", action="store_true", help="skip the block with minimizers in frequency order (the mode GraphUnitigs forces)")
+    ap.add_argument("--no-skewed", action="store_true", help="skip the block on the repeat-rich genome with low-complexity reads")
     ap.add_argument("--no-k63", action="store_true", help="skip the second block (BASELINE configs[3]: k=63 at the same size)")
     ap.add_argument("--no-host-landed", action="store_true", help="skip the host-landed / host-to-host legs (results streamed into page-locked host memory)")
     ap.add_argument("--no-two-pass", action="store_true", help="skip the two-pass block (Stage A of pass 1 overlapped with Stage B of pass 0)")
@@ -788,6 +790,75 @@ def main():
             blk2["note"] = "serial = A0 B0 A1 B1; overlapped = A0 (B0 | A1) B1: the first Stage A and the last Stage B have nothing to hide behind"
             out["config"]["two_pass_overlap"] = blk2
             c = c2                                              # (the later blocks only free the reads through it)
+        if world == 1 and k == 31 and not args.no_freq_order:
+            # The mode GraphUnitigs forces (GraphUnitigs.cpp:861-870: -minimizer-type 1 -repartition-type 1; Model.hpp:957-973 order): minimizers by increasing frequency
+            # of the canonical m-mers of a sample of the reads (RepartitionAlgorithm.cpp:311-380: the first reads; here 10^6 of them, counted on the device by
+            # gkc_count_mmers; rank = position in the (count, value) order, unseen m-mers 4^m, the largest m-mer keeps 4^m - 1), same reads, same size. A clearly
+            # labelled block; records left in HBM, 5 timed steps after one untimed.
+            if c is not None:
+                c.close()
+            c = gkc.Counter(local)
+            n_s = min(n_reads, 1_000_000)
+            hb = c.device_to_host(chunks[0][0], n_s * L); ho = np.arange(n_s + 1, dtype=np.uint64) * np.uint64(L)
+            t0 = time.perf_counter(); cnts = c.count_mmers(m, hb, ho); t_cnt = time.perf_counter() - t0
+            idx = np.nonzero(cnts)[0]; order_ = idx[np.lexsort((idx, cnts[idx]))]
+            freq = np.full(4 ** m, 4 ** m, dtype=np.uint32); freq[order_] = np.arange(len(order_), dtype=np.uint32); freq[-1] = 4 ** m - 1
+            del hb
+            c.configure(k, m, parts, rep, freq_order=freq)
+            def step_f():
+                c.begin_pass(0)
+                for b_, o_, nr, nb_ in chunks:
+                    c.push_reads_device(b_, o_, nr, nb_)
+                c.finish_pass()
+            step_f(); torch.cuda.synchronize()
+            bft = {nme: c.timing(nme) for nme in names}
+            perf_ = []
+            t0 = time.perf_counter()
+            for _ in range(5):
+                t1 = time.perf_counter(); step_f(); perf_.append((time.perf_counter() - t1) * 1e3)
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t0) / 5
+            sf = c.stats()
+            vf = verify_block(c, expect, 1); all_verified.append(vf["verified"])
+            ktf = {n_: round((c.timing(n_)[0] - bft[n_][0]) / 5, 3) for n_ in names}
+            out["config"]["freq_order"] = {
+                "workload": "k=%d, %d reads, minimizers in FREQUENCY order (-minimizer-type 1: what GraphUnitigs forces), m=%d, %d partitions, order table from the canonical m-mer counts of the first %d reads" % (k, n_reads, m, parts, n_s),
+                "steps": 5, "warmup": 1, "ms_per_step": dtf * 1e3, "ms_per_step_median": float(np.median(perf_)), "value": sf["kmers_nb_distinct"] / dtf, "unit": "distinct k-mers/s (records left in HBM)",
+                "vs_lexi_device_resident": (sf["kmers_nb_distinct"] / dtf) / value_dev, "verified": vf["verified"], "verification": vf,
+                "distinct_kmers": sf["kmers_nb_distinct"], "nb_superkmers": sf["nb_superkmers"], "mean_kmers_per_superkmer": sf["kmers_nb_valid"] / max(1, sf["nb_superkmers"]),
+                "kernel_ms_per_step": ktf, "scan_count_vs_lexi": ktf["scan_count"] / max(1e-9, ktime_dev["scan_count"][0] / args.steps),
+                "stage_a_vs_lexi": ktf["total_stage_a"] / max(1e-9, ktime_dev["total_stage_a"][0] / args.steps),
+                "count_mmers_of_the_sample_ms": t_cnt * 1e3}
+        if world == 1 and k == 31 and not args.no_skewed:
+            # A repeat-rich input at full size: the same generator over a genome with 50 repeat families (~9 % of the bases, ~300 copies each, 0.5 % diverged)
+            # and 1 % low-complexity reads (GKC_SYNTH_SKEWED, include/gkc.h) — k-mers at 10^4 copies, sub-buckets of 10^8 identical keys, partitions of very different
+            # sizes: what the reference answers with PartitionsCommand.cpp:505-545. Same k, reads, partitions as the headline; records left in HBM; 5 timed steps.
+            if c is not None:
+                for b_, o_, _, _ in chunks:
+                    c.device_free(b_); c.device_free(o_)
+                chunks.clear(); c.close()
+            c = gkc.Counter(local); c.configure(k, m, parts, rep)
+            bs_, os_ = c.synth_reads_device(2, n_reads, L, genome, 10000, profile=1)
+            exp_s = input_checksum(c, [(bs_, os_, n_reads, n_bases)])
+            def step_s():
+                c.begin_pass(0); c.push_reads_device(bs_, os_, n_reads, n_bases); c.finish_pass()
+            step_s(); torch.cuda.synchronize()
+            bst = {nme: c.timing(nme) for nme in names}
+            pers_ = []
+            t0 = time.perf_counter()
+            for _ in range(5):
+                t1 = time.perf_counter(); step_s(); pers_.append((time.perf_counter() - t1) * 1e3)
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / 5
+            ss = c.stats()
+            vs = verify_block(c, exp_s, 1); all_verified.append(vs["verified"])
+            kts = {n_: round((c.timing(n_)[0] - bst[n_][0]) / 5, 3) for n_ in names}
+            out["config"]["skewed"] = {
+                "workload": "k=%d, %d reads over a genome with repeat families + 1 %% low-complexity reads (GKC_SYNTH_SKEWED), m=%d, %d partitions" % (k, n_reads, m, parts),
+                "steps": 5, "warmup": 1, "ms_per_step": dts * 1e3, "ms_per_step_median": float(np.median(pers_)), "value": ss["kmers_nb_distinct"] / dts, "unit": "distinct k-mers/s (records left in HBM)",
+                "valid_kmers_per_s": ss["kmers_nb_valid"] / dts, "ms_per_step_vs_uniform": dts * 1e3 / ms_step_dev, "verified": vs["verified"], "verification": vs,
+                "distinct_kmers": ss["kmers_nb_distinct"], "nb_superkmers": ss["nb_superkmers"], "oversize_buckets": ss.get("oversize_buckets"), "kernel_ms_per_step": kts}
+            c.device_free(bs_); c.device_free(os_)
         if world == 1 and k == 31 and not args.no_k63:
             # BASELINE configs[3] (k=63, LargeInt<2> 128-bit k-mer path, same reads per GPU) timed by the same driver run: a second, clearly labelled block —
             # `value` above stays the k=31 figure of configs[1]

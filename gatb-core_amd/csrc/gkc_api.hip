@@ -15,7 +15,27 @@ __device__ __host__ __forceinline__ uint64_t synth_rnd(uint64_t seed, uint64_t s
 {
     return mix64(mix64(seed ^ (stream << 56)) + idx);
 }
-__global__ void k_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, uint32_t sub_ppm,
+// base at a position of the synthetic genome. profile 0: uniform. profile 1 (GKC_SYNTH_SKEWED): repeat families — the genome is cut into slots of 8192 bases, a quarter of
+// the slots start with a copy of one of 50 family sequences of 1000..5000 bases (about 300 copies per family at 5e8 bases, ~9 % of the genome), every copy diverged
+// from its family by 0.5 % substitutions; the rest is uniform
+__device__ __host__ __forceinline__ uint32_t synth_genome_code(uint64_t seed, uint64_t pos, uint32_t profile)
+{
+    if (profile == 1) {
+        const uint64_t slot = pos >> 13, in = pos & 8191;
+        const uint64_t h = synth_rnd(seed, 4, slot);
+        if ((h & 3) == 0) {
+            const uint64_t f = (h >> 8) % 50, len = 1000 + synth_rnd(seed, 5, f) % 4001;
+            if (in < len) {
+                uint32_t code = (uint32_t)(synth_rnd(seed, 6, f * 8192 + in) & 3);
+                const uint64_t d = synth_rnd(seed, 7, pos);
+                if (d % 1000 < 5) code = (code + 1 + (uint32_t)((d >> 32) % 3)) & 3;
+                return code;
+            }
+        }
+    }
+    return (uint32_t)(synth_rnd(seed, 1, pos) & 3);
+}
+__global__ void k_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, uint32_t sub_ppm, uint32_t profile,
                               uint8_t* __restrict__ bases, uint64_t* __restrict__ offsets)
 {
     const uint64_t total = n_reads * read_len;
@@ -25,8 +45,12 @@ __global__ void k_synth_reads(uint64_t seed, uint64_t first_read, uint64_t n_rea
         const uint64_t u = synth_rnd(seed, 2, first_read + i);
         const uint64_t start = (u >> 1) % span;
         uint32_t code;
-        if (u & 1) code = (uint32_t)(synth_rnd(seed, 1, start + read_len - 1 - j) & 3) ^ 2u;   // reverse complement
-        else       code = (uint32_t)(synth_rnd(seed, 1, start + j) & 3);
+        if (u & 1) code = synth_genome_code(seed, start + read_len - 1 - j, profile) ^ 2u;   // reverse complement
+        else       code = synth_genome_code(seed, start + j, profile);
+        if (profile == 1) {                                         // 1 % of the reads are low complexity: a unit of 1..3 bases repeated (poly-A, (AC)n, (ACG)n ...)
+            const uint64_t hl = synth_rnd(seed, 8, first_read + i);
+            if (hl % 100 == 0) { const uint32_t ul = 1 + (uint32_t)((hl >> 8) % 3); code = (uint32_t)(hl >> (16 + 2 * (j % ul))) & 3; }
+        }
         const uint64_t v = synth_rnd(seed, 3, first_read * read_len + g);
         if ((v % 1000000ULL) < sub_ppm) code = (code + 1 + (uint32_t)((v >> 32) % 3)) & 3;
         bases[g] = (uint8_t)("ACTG"[code]);
@@ -714,7 +738,13 @@ int gkc_segments_clear(gkc_ctx* c)
 int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len,
                            uint32_t sub_ppm, char** d_bases, uint64_t** d_offsets)
 {
+    return gkc_synth_reads_profile_device(c, seed, first_read, n_reads, read_len, genome_len, sub_ppm, GKC_SYNTH_UNIFORM, d_bases, d_offsets);
+}
+int gkc_synth_reads_profile_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len,
+                                   uint32_t sub_ppm, uint32_t profile, char** d_bases, uint64_t** d_offsets)
+{
     if (!c || !d_bases || !d_offsets) return GKC_ERR_ARG;
+    if (profile > GKC_SYNTH_SKEWED) GKC_FAIL(c, GKC_ERR_ARG, "unknown generator profile %u", profile);
     if (read_len == 0 || genome_len < read_len) GKC_FAIL(c, GKC_ERR_ARG, "genome_len must be >= read_len > 0");
     GKC_HIP(c, hipSetDevice(c->device));
     void *b = nullptr, *o = nullptr;
@@ -722,7 +752,7 @@ int gkc_synth_reads_device(gkc_ctx* c, uint64_t seed, uint64_t first_read, uint6
     if (hipMalloc(&b, nb + 64) != hipSuccess) GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of %zu bases failed", nb);
     if (hipMalloc(&o, (size_t)(n_reads + 1) * 8) != hipSuccess) { (void)hipFree(b); GKC_FAIL(c, GKC_ERR_NOMEM, "hipMalloc of offsets failed"); }
     const unsigned grid = (unsigned)std::min<uint64_t>((nb + 255) / 256 + 1, 256 * 32);
-    hipLaunchKernelGGL(k_synth_reads, dim3(grid), dim3(256), 0, c->stream, seed, first_read, n_reads, read_len, genome_len, sub_ppm, (uint8_t*)b, (uint64_t*)o);
+    hipLaunchKernelGGL(k_synth_reads, dim3(grid), dim3(256), 0, c->stream, seed, first_read, n_reads, read_len, genome_len, sub_ppm, profile, (uint8_t*)b, (uint64_t*)o);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipFree(b); (void)hipFree(o); GKC_FAIL(c, GKC_ERR_HIP, "synth kernel failed: %s", hipGetErrorString(e)); }

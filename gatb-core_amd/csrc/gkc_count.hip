@@ -271,6 +271,38 @@ __device__ __forceinline__ void wave_each_kmer16(WaveStage16& S, const uint64_t 
 #define GKC_BAL_G 4
 #endif
 
+
+// ------------------------------------------------------------------------------------------------ same-address relief (round 5)
+// A low-complexity read (poly-A, (AC)n) or a repeat family at hundreds of copies sends 10^5 .. 10^7 keys of ONE k-mer through Stage B: every lane of a wave then
+// asks for the same LDS counter, the same parking slot, the same global cursor, and same-address atomics are served one lane at a time (1e8 reads with 1 % such
+// reads: k_expand_scatter_pair 1.08 s, k_giant_scatter 0.55 s, k_deep_split 0.29 s per step instead of 42 / 0.2 / 9 ms — profiles/r05_skewed_input.txt). When at least
+// SAME_MIN lanes of the wave want what its first active lane wants, ONE lane asks for all of them (the others take their place by their rank among those lanes);
+// the rest of the wave, and every wave of ordinary input (6 scalar instructions to find out), goes on as before.
+constexpr int SAME_MIN = 8;
+__device__ __forceinline__ uint32_t rank_in(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+// ctr[idx] += 1 for every active lane
+__device__ __forceinline__ void wave_add1(uint32_t* ctr, uint32_t idx)
+{
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+    const uint64_t same = __ballot(idx == lead);
+    if (__popcll(same) >= SAME_MIN && idx == lead) { if (rank_in(same) == 0) atomicAdd(&ctr[lead], (uint32_t)__popcll(same)); }
+    else atomicAdd(&ctr[idx], 1u);
+}
+// slot = ctr[idx]++ for every active lane
+__device__ __forceinline__ uint32_t wave_take1(uint32_t* ctr, uint32_t idx)
+{
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+    const uint64_t same = __ballot(idx == lead);
+    if (__popcll(same) >= SAME_MIN && idx == lead) {
+        const uint32_t r = rank_in(same);
+        uint32_t base = 0;
+        if (r == 0) base = atomicAdd(&ctr[lead], (uint32_t)__popcll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(same));
+        return base + r;
+    }
+    return atomicAdd(&ctr[idx], 1u);
+}
+
 constexpr int EXPAND_THREADS = 512;
 // A key on its way through the sort is the canonical k-mer shifted left by wb WEIGHT BITS with (multiplicity - 1) of its super-k-mer record below it: identical records
 // of a partition may be merged before the expansion (k_dedupe_*), their k-mers then count `weight` times. wb is chosen per batch (weight_bits_of): 2 .. 4 — the
@@ -357,15 +389,15 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
             for (uint64_t rb = r0 + (threadIdx.x & ~63u); rb < r1; rb += EXPAND_THREADS) {        // (wave-uniform bounds: the 64 lanes walk the chunk's k-mers together)
                 uint64_t R[2] = {0, 0};
                 if (rb + lane < r1) load_rec<2>(base, rb + lane, R);
-                wave_each_kmer16<GKC_BAL_G>(S, R[0], R[1], k, 0u, lane, [&](uint64_t c, unsigned long long) { atomicAdd(&s_hist[(uint32_t)(c >> pd.shift)], 1u); });
+                wave_each_kmer16<GKC_BAL_G>(S, R[0], R[1], k, 0u, lane, [&](uint64_t c, unsigned long long) { wave_add1(s_hist, (uint32_t)(c >> pd.shift)); });
             }
         } else
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
             if constexpr (KW == 2 && RW == 4) {
-                if (k >= 32) for_each_sub32(R, k, pd.sub_bits, [&](uint32_t sb) { atomicAdd(&s_hist[sb], 1u); });
-                else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[sub_index<KW>(c, pd.shift)], 1u); });
-            } else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { atomicAdd(&s_hist[sub_index<KW>(c, pd.shift)], 1u); });
+                if (k >= 32) for_each_sub32(R, k, pd.sub_bits, [&](uint32_t sb) { wave_add1(s_hist, sb); });
+                else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { wave_add1(s_hist, sub_index<KW>(c, pd.shift)); });
+            } else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { wave_add1(s_hist, sub_index<KW>(c, pd.shift)); });
         }
     }
     __syncthreads();
@@ -473,9 +505,34 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
+        unsigned long long* const s_comb0 = s_pend + (((size_t)nsub * 12 + 15) / 16) * 2;                   // behind the cursors, 16-byte aligned
+        unsigned long long* const s_comb = s_comb0 + (size_t)(threadIdx.x >> 6) * 64;                         // this wave's 64 words
         auto emit = [&](uint64_t c, unsigned long long wq) {
             const uint32_t q = (uint32_t)(c >> pd.shift);
             unsigned long long h = (c << wb) | wq;                               // (bits beyond the 64th fall off: see above) never all ones
+            // same-address relief (see wave_add1): >= SAME_MIN lanes of the wave with keys for ONE sub-bucket (one k-mer at 10^6 copies) pair up among themselves —
+            // keys into the wave's LDS words by rank, one reservation for all the pairs, lane r < pairs stores words 2r, 2r + 1; an odd last lane takes the usual way
+            {
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+                const uint64_t same = __ballot(q == lead);
+                const uint32_t ns = (uint32_t)__popcll(same);
+                if (ns >= (uint32_t)SAME_MIN) {
+                    bool done = false;
+                    if (q == lead) {
+                        const uint32_t r = rank_in(same), np = ns >> 1;
+                        s_comb[r] = h;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        uint32_t base = 0;
+                        if (r == 0) base = atomicAdd(&s_cur[lead], 2u * np);
+                        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(same));
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (r < np) store16(out + base + 2 * r, s_comb[2 * r], s_comb[2 * r + 1]);
+                        done = !((ns & 1u) && r == ns - 1u);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (the words are reused by the wave's next group)
+                    }
+                    if (done) return;
+                }
+            }
             for (;;) {
                 const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
                 if (y != EMPTY) {
@@ -493,7 +550,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         };
         if constexpr (BAL) {
             const int lane = threadIdx.x & 63;
-            WaveStage16& S = reinterpret_cast<WaveStage16*>(s_cur + nsub)[threadIdx.x >> 6];        // (nsub * 12 bytes: a multiple of 16)
+            WaveStage16& S = reinterpret_cast<WaveStage16*>(s_comb0 + PAIR_THREADS)[threadIdx.x >> 6];        // (behind the waves' pairing words)
             const uint64_t rb0 = r0 + (threadIdx.x & ~63u);                                       // wave-uniform chunk bounds
             ulonglong2 nx = rb0 + lane < r1 ? recs[rb0 + lane] : make_ulonglong2(0, 0);
             for (uint64_t rb = rb0; rb < r1; rb += PAIR_THREADS) {
@@ -568,6 +625,28 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
                 const uint32_t q = sub_index<2>(c, pd.shift);
                 const u128 st = (c << wb) | (u128)wq;                                    // (bits beyond the 128th fall off) never all ones
                 uint64_t h_lo = (uint64_t)st, h_hi = (uint64_t)(st >> 64);
+                {   // same-address relief, as in k_expand_scatter_pair — without LDS words (the parking table of 8192 sub-buckets takes the CU's whole LDS, and the partitions
+                    // that need this are the ones with 8192): a lane's partner is the NEXT lane of the group, its key comes over by ds_bpermute
+                    const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+                    const uint64_t same = __ballot(q == lead);
+                    const uint32_t ns = (uint32_t)__popcll(same);
+                    if (ns >= (uint32_t)SAME_MIN) {
+                        bool done = false;
+                        if (q == lead) {
+                            const int lane = threadIdx.x & 63;
+                            const uint32_t r = rank_in(same), np = ns >> 1;
+                            const uint64_t above = same & ~((2ull << lane) - 1ull);
+                            const int pl = above ? (int)__builtin_ctzll(above) : lane;
+                            const uint64_t p_lo = (uint64_t)__shfl((unsigned long long)h_lo, pl, 64), p_hi = (uint64_t)__shfl((unsigned long long)h_hi, pl, 64);
+                            uint32_t base = 0;
+                            if (r == 0) base = atomicAdd(&s_cur[lead], 2u * np);
+                            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(same));
+                            if (!(r & 1u) && r + 1u < ns) { out[base + r] = make_ulonglong2(h_lo, h_hi); out[base + r + 1] = make_ulonglong2(p_lo, p_hi); }
+                            done = !((ns & 1u) && r == ns - 1u);
+                        }
+                        if (done) return;
+                    }
+                }
                 for (;;) {
                     uint64_t y_lo, y_hi;
                     lds_xchg128(&s_pend[2 * (size_t)q], EMPTY, EMPTY, y_lo, y_hi);
@@ -1221,9 +1300,9 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
 #pragma unroll
                 for (int u = 0; u < DEEP_MLP; u++) v[u] = src[i + u * DEEP_THREADS];
 #pragma unroll
-                for (int u = 0; u < DEEP_MLP; u++) atomicAdd(&s_cnt[(uint32_t)(v[u] >> shift) & mask], 1u);
+                for (int u = 0; u < DEEP_MLP; u++) wave_add1(s_cnt, (uint32_t)(v[u] >> shift) & mask);
             }
-            for (; i < d.n; i += DEEP_THREADS) atomicAdd(&s_cnt[(uint32_t)(src[i] >> shift) & mask], 1u);
+            for (; i < d.n; i += DEEP_THREADS) wave_add1(s_cnt, (uint32_t)(src[i] >> shift) & mask);
         }
         __syncthreads();
         // exclusive scan of the piece sizes -> first slot of every piece
@@ -1320,9 +1399,9 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep_split(typename KeyT<KW>::
 #pragma unroll
                 for (int u = 0; u < DEEP_MLP; u++) v[u] = src[i + u * DEEP_THREADS];
 #pragma unroll
-                for (int u = 0; u < DEEP_MLP; u++) { const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(v[u] >> shift) & mask], 1u); dst[slot] = v[u]; }
+                for (int u = 0; u < DEEP_MLP; u++) { const uint32_t slot = wave_take1(s_cur, (uint32_t)(v[u] >> shift) & mask); dst[slot] = v[u]; }
             }
-            for (; i < d.n; i += DEEP_THREADS) { const key_t key = src[i]; const uint32_t slot = atomicAdd(&s_cur[(uint32_t)(key >> shift) & mask], 1u); dst[slot] = key; }
+            for (; i < d.n; i += DEEP_THREADS) { const key_t key = src[i]; const uint32_t slot = wave_take1(s_cur, (uint32_t)(key >> shift) & mask); dst[slot] = key; }
         }
     }
 }
@@ -1384,7 +1463,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_hist(const typename Key
 #pragma unroll
         for (int u = 0; u < GIANT_MLP; u++) { const uint32_t i = c0 + u * GIANT_THREADS + threadIdx.x; v[u] = i < n ? src[i] : (key_t)0; }
 #pragma unroll
-        for (int u = 0; u < GIANT_MLP; u++) if (c0 + u * GIANT_THREADS + threadIdx.x < n) atomicAdd(&s_cnt[(uint32_t)(v[u] >> P.shift) & mask], 1u);
+        for (int u = 0; u < GIANT_MLP; u++) if (c0 + u * GIANT_THREADS + threadIdx.x < n) wave_add1(s_cnt, (uint32_t)(v[u] >> P.shift) & mask);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nsub; i += GIANT_THREADS) { const uint32_t h = s_cnt[i]; if (h) atomicAdd(&G.ghist[(size_t)y * MAX_SUB + i], h); }
@@ -1489,7 +1568,7 @@ __global__ __launch_bounds__(GIANT_THREADS) void k_giant_scatter(const typename 
 #pragma unroll
         for (int u = 0; u < GIANT_MLP; u++) { const uint32_t i = c0 + u * GIANT_THREADS + threadIdx.x; v[u] = i < n ? src[i] : (key_t)0; }
 #pragma unroll
-        for (int u = 0; u < GIANT_MLP; u++) if (c0 + u * GIANT_THREADS + threadIdx.x < n) { const uint32_t slot = atomicAdd(&cur[(uint32_t)(v[u] >> P.shift) & mask], 1u); dst[slot] = v[u]; }
+        for (int u = 0; u < GIANT_MLP; u++) if (c0 + u * GIANT_THREADS + threadIdx.x < n) { const uint32_t slot = wave_take1(cur, (uint32_t)(v[u] >> P.shift) & mask); dst[slot] = v[u]; }
     }
 }
 
@@ -1886,7 +1965,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
             for (uint64_t r = r0 + t; r < r1; r += DD_THREADS) {
                 DRec<RW> R = dd_load<RW>(recs + r * RW);
                 dd_canonical(R, k);
-                atomicAdd(&s_cnt[lg ? (uint32_t)(dd_hash64<RW>(R) >> hsh) : 0u], 1u);
+                wave_add1(s_cnt, lg ? (uint32_t)(dd_hash64<RW>(R) >> hsh) : 0u);
             }
         }
         __syncthreads();
@@ -1912,7 +1991,7 @@ __global__ __launch_bounds__(DD_THREADS) void k_dedupe_bin(const PartDesc* __res
             for (uint64_t r = r0 + t; r < r1; r += DD_THREADS) {
                 DRec<RW> R = dd_load<RW>(recs + r * RW);
                 dd_canonical(R, k);
-                const uint32_t slot = atomicAdd(&s_cnt[lg ? (uint32_t)(dd_hash64<RW>(R) >> hsh) : 0u], 1u);
+                const uint32_t slot = wave_take1(s_cnt, lg ? (uint32_t)(dd_hash64<RW>(R) >> hsh) : 0u);
                 dd_store<RW>(out + (uint64_t)slot * RW, R);
             }
         }
@@ -2018,13 +2097,45 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
             uint32_t x = nout;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-            const uint32_t total = kpl ? (uint32_t)__builtin_amdgcn_readlane((int)x, 63) : n;
+            uint32_t total = kpl ? (uint32_t)__builtin_amdgcn_readlane((int)x, 63) : n;
             // my turn? (the bins of a partition are handed to the waves in order: the wave of bin - 1 is another wave of this workgroup)
             while (s_next != bin) __builtin_amdgcn_s_sleep(1);
             const uint32_t pos0 = s_pos;
-            if (!kpl && n) {
-                // one record, or more than the wave's registers hold (one record copied thousands of times: low-complexity reads): moved left, chunk by chunk,
-                // BEFORE the next bin may place its output (which may reach into this bin's old range)
+            if (!kpl && n > (uint32_t)SLOTS) {
+                // More than the wave's registers hold: one record copied 10^5 .. 10^7 times (the super-k-mers of poly-A / (AC)n reads, of a repeat family at hundreds of
+                // copies: every copy hashes into this bin). Round 5: the bin is deduplicated CHUNK by chunk of SLOTS records — each chunk sorted and merged like a bin of
+                // its own, its output placed behind the output of the chunk before (always left of the chunk's own records: in place). Up to round 4 such a bin was moved
+                // as it was: 1e8 reads with 1 % low-complexity reads then sent 2e7 keys of ONE k-mer through one parking slot of the scatter and one cursor of the
+                // giant split (k_expand_scatter_pair 1.08 s, k_giant_scatter 0.55 s, k_deep_split 0.29 s per step: profiles/r05_skewed_input.txt).
+                uint32_t pos = pos0;
+                for (uint32_t i0 = 0; i0 < n; i0 += SLOTS) {
+                    const uint32_t nc = min((uint32_t)SLOTS, n - i0);
+                    DRec<RW> cin[KM];
+#pragma unroll
+                    for (int r = 0; r < KM; r++) { const uint32_t i = r * 64 + lane; if (i < nc) cin[r] = dd_load<RW>(part + (size_t)(s0 + i0 + i) * RW); }
+                    if (nc < 2) { if (lane == 0) dd_store<RW>(part + (size_t)pos * RW, cin[0]); pos += nc; continue; }
+                    DRec<RW> crec[KM]; uint32_t ccnt[KM];
+                    const uint32_t cn = dd_sort_bin<RW, KM>(cin, nc, lane, s_win[wave], crec, ccnt, ik, WCAP);
+                    uint32_t cx = cn;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(cx, d, 64); if (lane >= d) cx += y; }
+                    uint32_t cp = pos + cx - cn;
+#pragma unroll
+                    for (int r = 0; r < KM; r++) if (ccnt[r]) {
+                        const uint32_t nbk = (uint32_t)(crec[r].w[0] >> 56);
+                        for (uint32_t c = ccnt[r]; c; ) {
+                            const uint32_t w = c < WCAP ? c : WCAP;
+                            DRec<RW> o = crec[r]; o.w[RW - 1] |= (uint64_t)(w - 1);
+                            dd_store<RW>(part + (size_t)cp * RW, o); cp++;
+                            ok += nbk; c -= w;
+                        }
+                    }
+                    pos += (uint32_t)__builtin_amdgcn_readlane((int)cx, 63);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                 // (the next chunk reuses the wave's LDS window)
+                }
+                total = pos - pos0;
+            } else if (!kpl && n) {
+                // one record: moved left BEFORE the next bin may place its output (which may reach into this bin's old range)
                 for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                     DRec<RW> q;
                     if (i0 + lane < n) q = dd_load<RW>(part + (size_t)(s0 + i0 + lane) * RW);
@@ -2267,7 +2378,8 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         static const uint32_t scatter_wgs = getenv("GKC_SCATTER_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCATTER_WGS"))) : 176u;
         if constexpr (KW == 1) {
             const size_t stage = sizeof(WaveStage16) * (PAIR_THREADS / 64);                        // balanced walk: the waves' record stages (22 KB)
-            const size_t lds_max = (size_t)MAX_SUB * 12 + stage, lds = ((size_t)12 << max_bits_b);          // parking slots + cursors of the batch's largest sub-bucket count
+            const size_t comb = (size_t)PAIR_THREADS * 8 + 16;                                            // 64 pairing words per wave (same-address relief)
+            const size_t lds_max = (size_t)MAX_SUB * 12 + comb + stage, lds = ((size_t)12 << max_bits_b) + comb;          // parking slots + cursors of the batch's largest sub-bucket count
             static std::once_flag once; std::call_once(once, [&] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });

@@ -21,7 +21,7 @@ SYMBOLS = [
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
     "gkc_bloom_insert", "gkc_bloom_insert_device", "gkc_bloom_insert_solid", "gkc_bloom_query_solid", "gkc_bloom_contains",
-    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_device_free", "gkc_host_alloc", "gkc_host_free", "gkc_release_pass", "gkc_device_memory",
+    "gkc_bloom_contains8", "gkc_bloom_get_array", "gkc_bloom_set_array", "gkc_bloom_device_array", "gkc_synth_reads_device", "gkc_synth_reads_profile_device", "gkc_device_free", "gkc_host_alloc", "gkc_host_free", "gkc_release_pass", "gkc_device_memory",
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
@@ -120,6 +120,7 @@ def lib():
         "gkc_bloom_set_array": (C.c_int, [vp, vp, u64]),
         "gkc_bloom_device_array": (C.c_int, [vp, P(vp), P(u64)]),
         "gkc_synth_reads_device": (C.c_int, [vp, u64, u64, u64, u32, u64, u32, P(vp), P(vp)]),
+        "gkc_synth_reads_profile_device": (C.c_int, [vp, u64, u64, u64, u32, u64, u32, u32, P(vp), P(vp)]),
         "gkc_device_free": (C.c_int, [vp, vp]),
         "gkc_host_alloc": (C.c_int, [P(vp), u64]),
         "gkc_host_free": (C.c_int, [vp]),
@@ -198,18 +199,40 @@ def synth_rnd_np(seed, stream, idx):
         return mix64_np(base + np.asarray(idx, dtype=np.uint64))
 
 
-def synth_reads_np(seed, n_reads, read_len, genome_len, sub_ppm, first_read=0):
-    """numpy twin of the k_synth_reads kernel (csrc/gkc_api.hip): -> (bases uint8[n*L], offsets uint64[n+1])"""
+def synth_genome_np(seed, pos, profile=0):
+    """numpy twin of synth_genome_code (csrc/gkc_api.hip): 2-bit codes of the genome at `pos`"""
+    pos = np.asarray(pos, dtype=np.uint64)
+    code = (synth_rnd_np(seed, 1, pos) & np.uint64(3)).astype(np.uint32)
+    if profile == 1:
+        slot = pos >> np.uint64(13); inn = pos & np.uint64(8191)
+        h = synth_rnd_np(seed, 4, slot)
+        f = (h >> np.uint64(8)) % np.uint64(50)
+        ln = np.uint64(1000) + synth_rnd_np(seed, 5, f) % np.uint64(4001)
+        rep = ((h & np.uint64(3)) == 0) & (inn < ln)
+        fc = (synth_rnd_np(seed, 6, f * np.uint64(8192) + inn) & np.uint64(3)).astype(np.uint32)
+        d = synth_rnd_np(seed, 7, pos)
+        fc = np.where(d % np.uint64(1000) < np.uint64(5), (fc + 1 + ((d >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, fc)
+        code = np.where(rep, fc, code)
+    return code
+
+
+def synth_reads_np(seed, n_reads, read_len, genome_len, sub_ppm, first_read=0, profile=0):
+    """numpy twin of the k_synth_reads kernel (csrc/gkc_api.hip): -> (bases uint8[n*L], offsets uint64[n+1]); profile 1 = GKC_SYNTH_SKEWED"""
     i = np.repeat(np.arange(first_read, first_read + n_reads, dtype=np.uint64), read_len)
     j = np.tile(np.arange(read_len, dtype=np.uint64), n_reads)
-    g = i * np.uint64(read_len) + j
+    g = (i - np.uint64(first_read)) * np.uint64(read_len) + j
     u = synth_rnd_np(seed, 2, i)
     start = (u >> np.uint64(1)) % np.uint64(genome_len - read_len + 1)
     rev = (u & np.uint64(1)).astype(bool)
     pos = np.where(rev, start + np.uint64(read_len - 1) - j, start + j)
-    code = (synth_rnd_np(seed, 1, pos) & np.uint64(3)).astype(np.uint32)
+    code = synth_genome_np(seed, pos, profile)
     code = np.where(rev, code ^ 2, code)
-    v = synth_rnd_np(seed, 3, g)
+    if profile == 1:
+        hl = synth_rnd_np(seed, 8, i)
+        ul = np.uint64(1) + (hl >> np.uint64(8)) % np.uint64(3)
+        lc = ((hl >> (np.uint64(16) + np.uint64(2) * (j % ul))) & np.uint64(3)).astype(np.uint32)
+        code = np.where(hl % np.uint64(100) == 0, lc, code)
+    v = synth_rnd_np(seed, 3, np.uint64(first_read) * np.uint64(read_len) + g)
     sub = (v % np.uint64(1000000)) < np.uint64(sub_ppm)
     code = np.where(sub, (code + 1 + ((v >> np.uint64(32)) % np.uint64(3)).astype(np.uint32)) & 3, code)
     bases = np.frombuffer(b"ACTG", dtype=np.uint8)[code]
@@ -453,9 +476,10 @@ class Counter:
         self.device_free(b.value); self.device_free(o.value)
         return bases, offs, cons.value
 
-    def synth_reads_device(self, seed, n_reads, read_len, genome_len, sub_ppm, first_read=0):
+    def synth_reads_device(self, seed, n_reads, read_len, genome_len, sub_ppm, first_read=0, profile=0):
+        """profile 1 = GKC_SYNTH_SKEWED: repeat families in the genome + 1 % low-complexity reads (include/gkc.h)"""
         b = C.c_void_p(); o = C.c_void_p()
-        self._chk(self.L.gkc_synth_reads_device(self.h, seed, first_read, n_reads, read_len, genome_len, sub_ppm, C.byref(b), C.byref(o)))
+        self._chk(self.L.gkc_synth_reads_profile_device(self.h, seed, first_read, n_reads, read_len, genome_len, sub_ppm, profile, C.byref(b), C.byref(o)))
         return b.value, o.value
 
     def device_free(self, p):

@@ -307,6 +307,14 @@ int gkc_bloom_allreduce_or(gkc_bloom* b, gkc_comm* comm);
  * ------------------------------------------------------------------------------------------------------------- */
 int gkc_synth_reads_device(gkc_ctx* ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                            uint64_t genome_len, uint32_t sub_rate_ppm, char** d_bases, uint64_t** d_offsets);
+/* The same generator over a REPEAT-RICH genome with low-complexity reads (full-size parity and bench of the paths the reference answers skew with:
+ * PartitionsCommand.cpp:505-545, TempCountFileMerger :217-360). GKC_SYNTH_SKEWED: the genome is cut into slots of 8192 bases; a quarter of them start with a copy
+ * of one of 50 family sequences of 1000..5000 bases (about genome_len / 1.6e6 copies per family, ~9 % of the bases; every copy 0.5 % diverged), the rest is
+ * uniform; 1 % of the reads are a unit of 1..3 bases repeated (poly-A, (AC)n, (ACG)n ...) before the substitutions. Twin: gkc.py synth_reads_np(profile=1). */
+#define GKC_SYNTH_UNIFORM 0u
+#define GKC_SYNTH_SKEWED  1u
+int gkc_synth_reads_profile_device(gkc_ctx* ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                   uint64_t genome_len, uint32_t sub_rate_ppm, uint32_t profile, char** d_bases, uint64_t** d_offsets);
 /* ---- MPHF + abundance map ------------------------------------------------------------------------------
  * Replaces MPHFAlgorithm::execute / populate (kmer/impl/MPHFAlgorithm.cpp:150-275) and the BooPHF build behind it
  * (thirdparty/BooPHF/BooPHF.h:734-1108 as instantiated by tools/collections/impl/BooPHF.hpp:236-300: jenkins64 hasher seeded by

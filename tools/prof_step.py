@@ -8,11 +8,12 @@ gkc = ge.load().gkc
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
+profile = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # 1 = GKC_SYNTH_SKEWED
 c = gkc.Counter(0)
 rep = bench.repart_for_bench(10, parts)
 c.configure(k, 10, parts, rep)
-db, do = c.synth_reads_device(2, n, 150, n * 5, 10000)
-names = ["scan_count", "scan_emit", "scan_refine", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "bucket_sort_deep", "split_levels", "compact",
+db, do = c.synth_reads_device(2, n, 150, n * 5, 10000, profile=profile)
+names = ["scan_count", "scan_emit", "scan_refine", "dedupe_bin", "dedupe_sort", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "bucket_sort_deep", "split_levels", "compact",
          "total_stage_a", "total_stage_b"]
 for it in range(3):
     base = {x: c.timing(x) for x in names}
