@@ -272,6 +272,77 @@ __global__ __launch_bounds__(BR_THREADS) void k_bloom_region_build(BloomParams B
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ contains8 by region (round 5)
+// k_bloom_contains8 gathers: per k-mer 2 sides x (7 dependent bit tests of the present neighbour + ~2 of each absent one) = ~25 scattered 4-byte reads of an array
+// far beyond the caches — 5.8e8 solid k-mers: 273 ms against 28 ms for their insert. The insert's trick works for the query as well: the eight neighbours of a k-mer
+// are two groups of four that share a canonical (k-2)-mer core, hence one root position each, and every bit of a group lies in [root, root + 16 + 4096): a QUERY ITEM per
+// (k-mer, side) is bucketed by the 2^20-bit region of its root (same count / prefix / scatter passes as the insert), one workgroup per region copies its 128 KB of the
+// array (+ the fringe) into LDS with coalesced loads, answers its items from there, and writes each item's four answers as one byte at (side, k-mer index); a last pass puts
+// the two nibbles of a k-mer together. Replaces the same reference loop (DebloomMinimizerAlgorithm.cpp:201: contains8 of every solid k-mer; Bloom.hpp:645-811).
+struct BloomQ { uint64_t key64; uint32_t rel; uint32_t idx; };      // core (hash input of the offsets); root inside the region | the side's own end nucleotide << 20; 2 * k-mer index + side
+template <bool SCATTER>
+__global__ __launch_bounds__(BR_THREADS) void k_bloom_q_regions(BloomParams B, BSegTable T, uint64_t chunk, uint32_t n_regions, uint32_t* __restrict__ wg_cnt,
+                                                                 const uint32_t* __restrict__ region_off, BloomQ* __restrict__ items)
+{
+    extern __shared__ uint32_t s_r[];                              // [n_regions] count / cursor
+    for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS)
+        s_r[r] = SCATTER ? region_off[r] + wg_cnt[(uint64_t)blockIdx.x * n_regions + r] : 0u;
+    __syncthreads();
+    const uint32_t k = B.k;
+    const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(T.total, i0 + chunk);
+    for (uint64_t g = i0 + threadIdx.x; g < i1; g += BR_THREADS) {
+        const u128 x = load_key(bseg_item(T, g), B.wide);
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const u128 elem = side == 0 ? ((x << 2) & kmask128(k)) : (x >> 2);      // (the neighbour without its new nucleotide: Bloom.hpp:660, :735)
+            u128 core; uint64_t racine;
+            neighbor_root(B, elem, core, racine);
+            const uint32_t slot = atomicAdd(&s_r[(uint32_t)(racine >> BR_BITS)], 1u);
+            if (SCATTER) {
+                const uint32_t nt = side == 0 ? ((uint32_t)(elem >> (2 * (k - 1))) & 3u) : ((uint32_t)elem & 3u);
+                BloomQ it; it.key64 = (uint64_t)core; it.rel = (uint32_t)(racine & ((1u << BR_BITS) - 1)) | (nt << BR_BITS); it.idx = (uint32_t)(2 * g + side);
+                items[slot] = it;
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < n_regions; r += BR_THREADS) wg_cnt[(uint64_t)blockIdx.x * n_regions + r] = s_r[r];
+    }
+}
+__global__ __launch_bounds__(BR_THREADS) void k_bloom_region_query8(BloomParams B, uint64_t n_words, const BloomQ* __restrict__ items, const uint32_t* __restrict__ region_off,
+                                                                     uint8_t* __restrict__ sides /* [2][total] */, uint64_t total)
+{
+    extern __shared__ uint32_t s_img[];                            // [BR_WORDS + BR_FRINGE_WORDS] this region's bits + what the offsets reach of the next one
+    constexpr uint32_t NW = BR_WORDS + BR_FRINGE_WORDS;
+    const uint32_t r = blockIdx.x, i0 = region_off[r], i1 = region_off[r + 1];
+    if (i0 == i1) return;
+    const uint64_t w0 = (uint64_t)r * BR_WORDS;
+    for (uint32_t i = threadIdx.x; i < NW; i += BR_THREADS) s_img[i] = w0 + i < n_words ? B.words[w0 + i] : 0u;
+    __syncthreads();
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += BR_THREADS) {
+        const BloomQ it = items[i];
+        const uint32_t rel = it.rel & ((1u << BR_BITS) - 1), nt = it.rel >> BR_BITS, side = it.idx & 1u;
+        uint32_t tab[10];
+        for (uint32_t h = 1; h < B.nb_hash; h++) tab[h] = (uint32_t)(simplehash16_dev(it.key64, (int)h, B.wide) & 4095);
+        uint32_t res = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t pre = side == 0 ? nt << 2 : j << 2, suf = side == 0 ? j : nt;
+            const uint32_t h0 = rel + d_cano2[(pre + suf) & 15];
+            bool ok = (s_img[h0 >> 5] >> (h0 & 31)) & 1u;
+            for (uint32_t h = 1; ok && h < B.nb_hash; h++) { const uint32_t q = h0 + tab[h]; ok = (s_img[q >> 5] >> (q & 31)) & 1u; }
+            res |= (uint32_t)ok << j;
+        }
+        sides[(uint64_t)side * total + (it.idx >> 1)] = (uint8_t)res;
+    }
+}
+__global__ void k_bloom_join_sides(const uint8_t* __restrict__ sides, uint64_t total, uint8_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint8_t)(sides[i] | (sides[total + i] << 4));
+}
+
 // ------------------------------------------------------------------------------------------------ C-ABI
 static BloomParams params_of(const gkc_bloom* b)
 {
@@ -433,6 +504,45 @@ int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* c)
     GKC_HIP(c, hipStreamSynchronize(c->stream));
     return GKC_OK;
 }
+
+// contains8 of up to 16 device arrays of k-mers (total < 2^31), answers in array order into d_out[total]: by region when the array has few enough regions, else false
+static int bloom_contains8_regions(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, uint32_t stride, uint8_t* d_out, bool* handled)
+{
+    gkc_ctx* c = b->ctx;
+    *handled = false;
+    uint64_t total = 0; for (uint32_t i = 0; i < n_segs; i++) total += segs[i].n;
+    const uint64_t n_bits = b->tai + 1;
+    const uint32_t n_regions = (uint32_t)std::min<uint64_t>((n_bits + (1u << BR_BITS) - 1) >> BR_BITS, 0xffffffffu);
+    const uint64_t min_items = getenv("GKC_BLOOM_QUERY_REGIONS_MIN") ? (uint64_t)atoll(getenv("GKC_BLOOM_QUERY_REGIONS_MIN")) : 2000000ull;      // (tests lower it: the bucketing passes do not pay for a few k-mers)
+    if (!total || total < min_items || n_regions > BR_MAX_REGIONS || total >= (1ULL << 31) || n_segs > 16 || b->kind != 2 || getenv("GKC_BLOOM_GATHER") != nullptr) return GKC_OK;
+    BSegTable T{}; T.n = n_segs; T.stride = stride; T.total = total;
+    { uint64_t first = 0; for (uint32_t i = 0; i < n_segs; i++) { T.s[i] = segs[i]; T.s[i].first = first; first += segs[i].n; } }
+    const uint32_t n_wgs = (uint32_t)std::min<uint64_t>(BR_WGS, (total + BR_THREADS - 1) / BR_THREADS);
+    const uint64_t chunk = (total + n_wgs - 1) / n_wgs;
+    DevBuf d_wg, d_tot, d_off, d_items, d_sides;
+    struct Guard { DevBuf *a, *b2, *c2, *d, *e; ~Guard() { a->release(); b2->release(); c2->release(); d->release(); e->release(); } } guard{&d_wg, &d_tot, &d_off, &d_items, &d_sides};
+    GKC_TRY(c->ensure(d_wg, (size_t)n_wgs * n_regions * 4)); GKC_TRY(c->ensure(d_tot, (size_t)n_regions * 4)); GKC_TRY(c->ensure(d_off, ((size_t)n_regions + 1) * 4));
+    GKC_TRY(c->ensure(d_items, (size_t)total * 2 * sizeof(BloomQ))); GKC_TRY(c->ensure(d_sides, (size_t)total * 2));
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_q_regions<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_q_regions<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BR_MAX_REGIONS * 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bloom_region_query8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BR_WORDS + BR_FRINGE_WORDS) * 4));
+        attr_set = true;
+    }
+    const BloomParams P = params_of(b);
+    hipLaunchKernelGGL((k_bloom_q_regions<false>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)nullptr, (BloomQ*)nullptr);
+    hipLaunchKernelGGL(k_bloom_wg_prefix, dim3((n_regions + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d_wg.p, n_wgs, n_regions, (uint32_t*)d_tot.p);
+    hipLaunchKernelGGL(k_bloom_region_scan, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)d_tot.p, n_regions, (uint32_t*)d_off.p);
+    hipLaunchKernelGGL((k_bloom_q_regions<true>), dim3(n_wgs), dim3(BR_THREADS), (size_t)n_regions * 4, c->stream, P, T, chunk, n_regions, (uint32_t*)d_wg.p, (const uint32_t*)d_off.p, (BloomQ*)d_items.p);
+    hipLaunchKernelGGL(k_bloom_region_query8, dim3(n_regions), dim3(BR_THREADS), (size_t)(BR_WORDS + BR_FRINGE_WORDS) * 4, c->stream, P, (uint64_t)(b->bits.bytes / 4), (const BloomQ*)d_items.p,
+                       (const uint32_t*)d_off.p, (uint8_t*)d_sides.p, total);
+    hipLaunchKernelGGL(k_bloom_join_sides, dim3((unsigned)std::min<uint64_t>((total + 255) / 256, 256 * 16)), dim3(256), 0, c->stream, (const uint8_t*)d_sides.p, total, d_out);
+    GKC_HIP(c, hipGetLastError());
+    GKC_HIP(c, hipStreamSynchronize(c->stream));                   // the scratch buffers go back to the pool
+    *handled = true;
+    return GKC_OK;
+}
 static int bloom_query(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out, bool c8)
 {
     if (!b) return GKC_ERR_ARG;
@@ -447,7 +557,10 @@ static int bloom_query(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stri
     if (e == hipSuccess) {
         ScopedTimer tm(c, c8 ? "bloom_contains8" : "bloom_contains");
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256 * 16);
-        if (c8) hipLaunchKernelGGL(k_bloom_contains8, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d.p, n, stride, (uint8_t*)o.p);
+        bool by_region = false;
+        if (c8) { BSeg sg{ (const uint8_t*)d.p, n, 0 }; (void)hipStreamSynchronize(c->stream); if (bloom_contains8_regions(b, &sg, 1, stride, (uint8_t*)o.p, &by_region) != GKC_OK) by_region = false; }
+        if (by_region) {}
+        else if (c8) hipLaunchKernelGGL(k_bloom_contains8, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d.p, n, stride, (uint8_t*)o.p);
         else    hipLaunchKernelGGL(k_bloom_contains, dim3(grid), dim3(256), 0, c->stream, params_of(b), (const uint8_t*)d.p, n, stride, (uint8_t*)o.p);
         e = hipGetLastError();
     }
@@ -485,8 +598,18 @@ int gkc_bloom_query_solid(gkc_bloom* b, gkc_ctx* c, int neighbors8, uint8_t* d_o
     {   ScopedTimer tm(c, neighbors8 ? "bloom_contains8" : "bloom_contains");
         uint64_t done = 0;
         const uint8_t* run_p = nullptr; uint64_t run_n = 0;                // consecutive datasets of one Stage-B batch form one array
+        bool by_region = false;
+        if (neighbors8) {                                                  // all arrays at once, bucketed by region of the Bloom array (<= 16 arrays, < 2^31 k-mers: else the gathers below)
+            std::vector<BSeg> segs;
+            for (const Dataset& D : c->datasets) {
+                if (!D.done || !D.n_solid) continue;
+                if (!segs.empty() && (const uint8_t*)D.d_counts == segs.back().p + segs.back().n * stride) { segs.back().n += D.n_solid; continue; }
+                segs.push_back(BSeg{ (const uint8_t*)D.d_counts, D.n_solid, 0 });
+            }
+            if (segs.size() <= 16 && bloom_contains8_regions(b, segs.data(), (uint32_t)segs.size(), stride, d_out, &by_region) != GKC_OK) by_region = false;
+        }
         auto flush = [&]() {
-            if (!run_n) return;
+            if (!run_n || by_region) return;
             const unsigned grid = (unsigned)std::min<uint64_t>((run_n + 255) / 256, 256 * 16);
             if (neighbors8) hipLaunchKernelGGL(k_bloom_contains8, dim3(grid), dim3(256), 0, c->stream, params_of(b), run_p, run_n, stride, d_out + done);
             else            hipLaunchKernelGGL(k_bloom_contains, dim3(grid), dim3(256), 0, c->stream, params_of(b), run_p, run_n, stride, d_out + done);

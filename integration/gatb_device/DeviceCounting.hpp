@@ -307,7 +307,7 @@ public:
     void finishPass (size_t pass)
     {
         _finishWall = wallNow();
-        if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  return; }
+        if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  _stageBPending = true;  return; }
         check (gkc_finish_pass (_ctx));
         check (gkc_gather_results (_ctx, _comm, 0));
     }
@@ -315,7 +315,9 @@ public:
      *  device) and they stay in HBM: BloomAlgorithm / MPHFAlgorithm find them there (DeviceContext::residentMatches) */
     void joinPass (size_t pass, size_t nbPasses)
     {
-        if (_comm == 0)  { check (gkc_finish_pass_wait (_ctx)); }
+        /* (fillSolidKmers_aux runs once per processor of the run — two with -abundance-min auto, SortingCountAlgorithm.cpp:1388-1393 — over the same device results:
+         *  Stage B is joined by the first) */
+        if (_comm == 0  &&  _stageBPending)  { _stageBPending = false;  check (gkc_finish_pass_wait (_ctx)); }
         if (hasRing())  { drainWriter(); }                                /* every Count[] of the pass is in the file */
         if (pass + 1 == nbPasses)  { freeRing(); }
         if (pass + 1 == nbPasses  &&  _plan.on  &&  (_comm == 0  ||  _rank == 0))
@@ -439,6 +441,7 @@ private:
     size_t    _nbPartitions;
     size_t    _kmerSize = 0;
     double    _finishWall = 0;
+    bool      _stageBPending = false;
     u_int64_t _progressReported = 0, _progressDebt = 0;
     std::mutex _timesLock;
     double    _waitS = 0, _handOverS = 0;

@@ -30,7 +30,10 @@ needs_artefacts = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists
 CASES = {"k21_freq_4parts": (["-minimizer-type", "1", "-repartition-type", "1"], "1", "1"),
          "k21_default_parts": ([], "1", "1"),
          "k31_2parts_mphf": ([], "2000", "2"),
-         "k63_neighbor_mphf": ([], "2000", "1")}        # span 64: 32-byte Count records through the bulk insert (DeviceCounting.hpp: sizeof(Count) == recBytes)
+         "k63_neighbor_mphf": ([], "2000", "1"),        # span 64: 32-byte Count records through the bulk insert (DeviceCounting.hpp: sizeof(Count) == recBytes)
+         "k31_auto_parts": ([], "1", "1")}              # -abundance-min auto: the cut-off processor + a proxy = TWO processors (SortingCountAlgorithm.cpp:418-444): no bulk plan,
+                                                        # every record through process(); the cut-off (Histogram::compute_threshold) and the solid set must be the reference's
+ABUNDANCE_MIN = {"k31_auto_parts": "auto"}
 
 # the steps BEHIND the counting step (BASELINE configs[4]: Bloom + MPHF, and what dbgh5 builds on them), flags as the fixture's reference run had them:
 #   *_neighbor_mphf  -bloom neighbor -debloom none -branching-nodes none (MPHF on)
@@ -60,6 +63,8 @@ def check_h5(h5, tag):
         assert list(zip(vals, ab)) == parts[p], "/dsk/solid/%d differs from the unpatched reference's" % p
     hist = dump_dataset(h5, "/histogram/histogram", "FILE"); hist = hist[:len(hist) // 12 * 12].reshape(-1, 12)
     assert np.array_equal(hist[:, 4:].copy().view("<u8")[:, 0], z["histogram_abundance"]), "histogram differs"
+    assert int(dump_dataset(h5, "/histogram/cutoff", "LE").view("<u8")[0]) == int(z["cutoff"]), "cut-off differs"
+    assert int(dump_dataset(h5, "/histogram/nbsolidsforcutoff", "LE").view("<u8")[0]) == int(z["nbsolidsforcutoff"]), "nbsolidsforcutoff differs"
 
 
 def fasta_to_fastq(text):
@@ -89,7 +94,7 @@ def run_dbgh5(tag, outdir, env_extra=None, out_name=None, fastq=False, pipeline=
     if not os.path.exists(fa):
         open(fa, "wb").write(fasta_to_fastq(bytes(z["fasta"])) if fastq else bytes(z["fasta"]))
     out = os.path.join(outdir, out_name or (tag + "_dev"))
-    cmd = [EXE, "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", outdir, "-nb-cores", cores,
+    cmd = [EXE, "-in", fa, "-kmer-size", str(k), "-abundance-min", ABUNDANCE_MIN.get(tag, "2"), "-out", out, "-out-tmp", outdir, "-nb-cores", cores,
            "-max-memory", mem, "-verbose", "0"] + ([] if pipeline else COUNT_ONLY) + extra
     # GATB_DEVICE_REFERENCE_CONFIG: partitions and passes as the reference derives them from -max-memory / -nb-cores (the fixtures' layout); without it the patched
     # ConfigurationAlgorithm sizes them from the HBM of the device (test_configuration_sized_from_the_device below)

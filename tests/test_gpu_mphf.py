@@ -106,3 +106,59 @@ def test_mphf_reference_check1(gkc):
     assert len(amap) == 130 and set(amap.tolist()) == {1}
     keys = sorted(c.all_counts().keys())
     assert sorted(dm.lookup(keys).tolist()) == list(range(130))
+
+
+def test_bloom_and_mphf_at_share_size(gkc, monkeypatch):
+    """BASELINE configs[4] at one GPU's share (Bloom + MPHF at 5.8e8 solid k-mers were checked only inside bench.py): k = 31, 1e8 reads, abundance-min 2.
+    Bloom (neighbor kind, 11 bits per k-mer, 7 hashes): the region build == the atomic build, byte for byte; no false negative; contains8 by region == contains8 by gathers
+    for every solid k-mer. MPHF: the region-build stream == the atomic-path stream; every cell of the abundance map written (the codes are a bijection onto [0, n)).
+    Against the oracle on the first 1e6 solid k-mers: every bit the oracle's hash functions set for them is set in the device's array (the same functions at an array of
+    6.4e9 bits), and the oracle's contains8 over the device's array gives the device's answers; their MPHF codes are distinct and below n."""
+    import torch
+    k, m, L, n, parts = 31, 10, 150, 100_000_000, 4096
+    c = gkc.Counter(0); c.configure(k, m, parts, simple_repart(m, parts)); c.set_solidity(2, 2147483647, 10000)
+    db, do = c.synth_reads_device(2, n, L, n * 5, 10000)
+    c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+    c.device_free(db); c.device_free(do)
+    ns = c.stats()["kmers_nb_solid"]
+    assert ns >= 500_000_000
+    bits = ns * 11
+    bl = gkc.Bloom(c, "neighbor", bits, 7, k); bl.insert_solid()
+    a_reg = bl.array()
+    monkeypatch.setenv("GKC_BLOOM_ATOMIC", "1")
+    bl0 = gkc.Bloom(c, "neighbor", bits, 7, k); bl0.insert_solid()
+    assert np.array_equal(a_reg, bl0.array())
+    bl0.close(); monkeypatch.delenv("GKC_BLOOM_ATOMIC")
+    nq, npos = bl.query_solid(False)
+    assert nq == npos == ns                                                # no false negative
+    o_reg = torch.zeros(ns, dtype=torch.uint8, device="cuda"); o_gat = torch.zeros(ns, dtype=torch.uint8, device="cuda")
+    r_reg = bl.query_solid(True, d_out=o_reg.data_ptr())
+    monkeypatch.setenv("GKC_BLOOM_GATHER", "1")
+    r_gat = bl.query_solid(True, d_out=o_gat.data_ptr())
+    monkeypatch.delenv("GKC_BLOOM_GATHER")
+    assert r_reg == r_gat and bool(torch.equal(o_reg, o_gat))
+    keys = []; p = 0
+    while len(keys) < 1_000_000:
+        lo, hi, ab = c.partition(0, p); keys += lo.tolist(); p += 1
+    ob = gko.Bloom("neighbor", bits, 7, k)
+    oa = np.ctypeslib.as_array(gko.lib().gko_bloom_array(ob._h), shape=(ob.nbytes,))
+    assert ob.nbytes == bl.nbytes
+    ob.insert(keys)
+    assert np.array_equal(oa & a_reg, oa)                                  # the oracle's bits of these k-mers are set in the device's array
+    oa[:] = a_reg                                                         # ... and over the device's array the oracle answers what the device answered
+    assert bool(ob.contains(keys).all())
+    assert np.array_equal(ob.contains8(keys), o_reg[: len(keys)].cpu().numpy())
+    del o_reg, o_gat, ob, oa
+    bl.close()
+    mp = gkc.Mphf(c)
+    assert mp.size == ns
+    s_reg = mp.save()
+    amap, above = mp.abundance_map()
+    assert len(amap) == ns and bool((amap != 0).all())                    # every cell written: n keys, n cells, none twice
+    codes = mp.lookup(keys[:200_000])
+    assert len(set(codes.tolist())) == 200_000 and int(codes.max()) < ns
+    monkeypatch.setenv("GKC_MPHF_REGIONS", "0")
+    mp0 = gkc.Mphf(c)
+    assert np.array_equal(s_reg, mp0.save())
+    assert np.array_equal(codes, mp0.lookup(keys[:200_000]))
+    mp.close(); mp0.close()

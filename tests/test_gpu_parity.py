@@ -345,6 +345,16 @@ def test_bloom_query_of_the_solid_set_on_the_device(gkc, k):
     assert nq == len(keys) and npos == int(sum(bin(int(x)).count("1") for x in exp8))
     nq1, npos1 = db.query_solid(neighbors8=False)
     assert nq1 == len(keys) and npos1 == len(keys)                      # no false negatives
+    # round 5: contains8 BY REGION of the array (what 2e6 k-mers and more get; the threshold lowered here): the same answers k-mer by k-mer, and over the resident set
+    exp8 = np.asarray(exp8, dtype=np.uint8)
+    assert np.array_equal(db.contains8(keys), exp8)                     # (the gathers)
+    os.environ["GKC_BLOOM_QUERY_REGIONS_MIN"] = "1"
+    try:
+        assert np.array_equal(db.contains8(keys), exp8)
+        nq2, npos2 = db.query_solid(neighbors8=True)
+        assert (nq2, npos2) == (nq, npos)
+    finally:
+        del os.environ["GKC_BLOOM_QUERY_REGIONS_MIN"]
     db.close()
 
 

@@ -37,11 +37,17 @@ def freq_order_of(z, m):
     return raw[:4 * 4 ** m].view("<u4").copy()
 
 
-def oracle_run(z, k, m, nbpart, table):
+def oracle_run(z, k, m, nbpart, table, auto=False):
     bases, offs = gko.fastx_parse(bytes(z["fasta"]))
     # partition membership depends on the table and, in frequency mode, on the order (freq_order[c], c) of the reference's own minimFrequency;
     # the one-partition frequency fixture (k21_freq) has no stored order: every minimizer maps to partition 0 whatever the order
-    return gko.Dsk(bases, offs, k, m, nbpart, table, abundance_min=2, freq_order=freq_order_of(z, m))
+    amin = 2
+    if auto:
+        # -abundance-min auto (SortingCountAlgorithm.cpp:418-444, CountProcessorCutoff.hpp:88-99): a first count feeds the histogram, Histogram::compute_threshold with a
+        # floor of 3 gives the cut-off, and that cut-off is the abundance-min of the count whose records are written
+        h0 = gko.Dsk(bases, offs, k, m, nbpart, table, abundance_min=1, freq_order=freq_order_of(z, m)).histogram()
+        amin = int(gko.histogram_cutoff(h0, 3)[0])
+    return gko.Dsk(bases, offs, k, m, nbpart, table, abundance_min=amin, freq_order=freq_order_of(z, m))
 
 
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(p)[:-4] for p in FIX])
@@ -51,7 +57,7 @@ def test_oracle_equals_reference_run(path):
         assert nbpart == 1
     if "4parts" in path:
         assert nbpart == 4 and freq_order_of(z, m) is not None and min(len(p) for p in parts) > 0     # frequency order really decides membership here
-    d = oracle_run(z, k, m, nbpart, table)
+    d = oracle_run(z, k, m, nbpart, table, auto="_auto" in path)
     assert d.stats["kmers_nb_solid"] == int(z["nb_solid_kmers"]) == sum(len(p) for p in parts)
     for p in range(nbpart):
         lo, hi, ab = d.part(p)

@@ -42,13 +42,13 @@ def attr(h5, path):
     return m.group(1) if m else None
 
 
-def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1, max_memory=2000, want_freq=False, want_graph=False):
+def run(tag, reads, k, extra, want_bloom=False, want_mphf=False, cores=1, max_memory=2000, want_freq=False, want_graph=False, amin="2"):
     with tempfile.TemporaryDirectory() as td:
         fa = os.path.join(td, "in.fa")
         text = "".join(">r%d\n%s\n" % (i, r.decode()) for i, r in enumerate(reads))
         open(fa, "w").write(text)
         out = os.path.join(td, "ref")
-        cmd = [os.path.join(BIN, "dbgh5"), "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", td, "-nb-cores", str(cores),
+        cmd = [os.path.join(BIN, "dbgh5"), "-in", fa, "-kmer-size", str(k), "-abundance-min", amin, "-out", out, "-out-tmp", td, "-nb-cores", str(cores),
                "-max-memory", str(max_memory), "-verbose", "0"] + extra
         subprocess.run(cmd, check=True, capture_output=True)
         h5 = out + ".h5"
@@ -138,6 +138,9 @@ if __name__ == "__main__":
     run("k31_defaults", reads, 31, [], want_bloom=True, want_mphf=True, want_graph=True)
     run("k63_defaults", reads[:300], 63, [], want_bloom=True, want_mphf=True, want_graph=True)
     run("k21_defaults_parts", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21, [], want_bloom=True, want_mphf=True, want_graph=True, max_memory=1)
+    # -abundance-min auto (SortingCountAlgorithm.cpp:418-444: the cut-off processor + a proxy, TWO processors; the threshold is Histogram::compute_threshold's,
+    # Histogram.cpp:61-190): 30x reads, several partitions
+    run("k31_auto_parts", synth_reads(6000, 30000, 150, seed=45), 31, count_only, max_memory=1, amin="auto")
     run_unitigs("k21_freq_4parts_unitigs", synth_reads(6000, 30000, 150, seed=43, n_rate=0.002), 21)
     if CHECK:
         for f in sorted(os.listdir(OUT)):
