@@ -696,7 +696,9 @@ def main():
                 sl["frac_from_counters"] = sl["hbm_GBps_from_counters"] / HBM_PEAK_GBS
         if exch is not None:
             kind = gdist.LAST_COMM_KIND or "rccl"
-            out["exchange"] = {"transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if kind == "rccl" and red_dev == "cuda" else
+            tot_sent = sum(x_["bytes_sent_per_step"] for x_ in exch)
+            out["exchange"] = {"bytes_per_kmer": tot_sent / max(1, valid), "bytes_per_kmer_note": "bytes all ranks sent per step / valid k-mers of the job: 16-byte records, (world - 1) / world of them leave their rank",
+                               "transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if kind == "rccl" and red_dev == "cuda" else
                                ("%s%s; %d pushes per pass" % ("DRY RUN (GKC_BENCH_BACKEND=%s, the ranks share %d device(s)): " % (dist.get_backend(), torch.cuda.device_count()) if red_dev != "cuda" else "", kind, n_push)),
                                "per_rank": exch}
         if landed is not None:
@@ -954,7 +956,12 @@ def main():
                 "x8_if_the_exchange_were_free": 8 * s8["kmers_nb_distinct"] / dt8,
                 "valid_kmers": s8["kmers_nb_valid"], "distinct_kmers": s8["kmers_nb_distinct"],
                 "kernel_ms_per_step": {n_: round((c8.timing(n_)[0] - b8t[n_][0]) / 3, 3) for n_ in names},
-                "exchange": {"exchanges_per_step": cs8["n_exchanges"] / 4, "ms_host_per_step": cs8["ms_host"] / 4, "ms_transfer_per_step": cs8["ms_transfer"] / 4}}
+                "exchange": {"exchanges_per_step": cs8["n_exchanges"] / 4, "ms_host_per_step": cs8["ms_host"] / 4, "ms_transfer_per_step": cs8["ms_transfer"] / 4,
+                             # what an owner-routed k-mer costs on xGMI: the exchange ships the device's fixed 16-byte records; the reference's wire format (Model.hpp:1386-1471:
+                             # 1 byte + ceil((k + nbK - 1) / 4) per super-k-mer) would be 25 % fewer bytes for one more pass over the records
+                             "bytes_per_kmer": s8["nb_superkmers"] * 16 / max(1, s8["kmers_nb_valid"]),
+                             "bytes_per_kmer_reference_wire_format": (s8["nb_superkmers"] * 1.375 + (s8["kmers_nb_valid"] + s8["nb_superkmers"] * (k - 1)) / 4.0) / max(1, s8["kmers_nb_valid"]),
+                             "sent_fraction_at_8_ranks": 7.0 / 8.0}}
             for b_, o_, _, _ in ch8:
                 c8.device_free(b_); c8.device_free(o_)
             c8.close()

@@ -259,16 +259,32 @@ struct FileBox {
             if (gen == 0) remove_matching(dir, { "session.", "join.", "go." });
             std::random_device rd; nonce = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)getpid() << 20) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
             if (!write_file(session, &nonce, 8)) return false;
-        } else if (!read_file(session, &nonce, 8, timeout_s)) return false;
-        char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)nonce);
-        tag = std::to_string(gen) + "." + hex;
+        }
+        auto tag_of = [&](uint64_t nn) { char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)nn); return std::to_string(gen) + "." + hex; };
         uint8_t one = 1;
         if (rank == 0) {
+            tag = tag_of(nonce);
             for (int r = 1; r < world; r++) { if (!read_file(dir + "/join." + tag + "." + std::to_string(r), &one, 1, timeout_s)) return false; (void)unlink((dir + "/join." + tag + "." + std::to_string(r)).c_str()); }
             return write_file(dir + "/go." + tag, &one, 1);
         }
-        if (!write_file(dir + "/join." + tag + "." + std::to_string(rank), &one, 1)) return false;
-        return read_file(dir + "/go." + tag, &one, 1, timeout_s);
+        // A joining rank may start before rank 0 has cleaned the directory: the session file it finds can be what a crashed run left. It therefore (i) ignores a
+        // session file older than the time limit (its rank 0 has given up long ago), (ii) keeps re-reading the file while it waits for go.<tag> and joins again when the
+        // nonce changes — the live rank 0 overwrites session.<generation> when it arrives.
+        const auto t0 = std::chrono::steady_clock::now();
+        bool joined = false; uint64_t joined_nonce = 0;
+        for (;;) {
+            struct stat st; uint64_t seen = 0;
+            if (stat(session.c_str(), &st) == 0 && (double)(time(nullptr) - st.st_mtime) <= timeout_s && read_file(session, &seen, 8, 0.0)) {
+                if (!joined || seen != joined_nonce) {
+                    tag = tag_of(seen);
+                    if (!write_file(dir + "/join." + tag + "." + std::to_string(rank), &one, 1)) return false;
+                    joined = true; joined_nonce = seen;
+                }
+                if (read_file(dir + "/go." + tag, &one, 1, 0.0)) return true;
+            }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+            usleep(1000);
+        }
     }
     static bool read_file(const std::string& path, void* data, size_t n, double timeout_s) {
         const auto t0 = std::chrono::steady_clock::now();

@@ -140,7 +140,15 @@ public:
     int       ranks () const { return _ranks; }
     int       rank  () const { return _rank;  }
 
-    void beginPass (size_t pass)  { check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0;  _progressReported = 0; }      /* (a debt of a refused text pass stays) */
+    void beginPass (size_t pass)
+    {
+        /* Several passes: the device results of the pass before have been handed to every processor (fillSolidKmers of that pass is over) and go back to the allocator —
+         * DeviceConfiguration sizes a pass for ITS records + ITS Count records, not for the Count records of all passes so far. What BloomAlgorithm /
+         * MPHFAlgorithm need later they then read from the storage (DeviceContext::Resident is only set by a one-pass count). */
+        if (pass > 0  &&  pass != _releasedBelow)  { for (size_t q = _releasedBelow; q < pass; q++) { check (gkc_release_pass (_ctx, (uint32_t) q)); }  _releasedBelow = pass; }
+        if (pass == 0)  { _releasedBelow = 0; }
+        check (gkc_begin_pass (_ctx, (uint32_t)pass));  _pushedReads = 0;  _exchangesDone = 0;  _progressReported = 0;      /* (a debt of a refused text pass stays) */
+    }
 
     /** one block of reads to Stage A (the caller holds the packers' lock: one thread drives the context at a time); multi-rank: the exchanges that are due */
     void push (const char* bases, const uint64_t* offsets, uint64_t nbReads)
@@ -320,7 +328,7 @@ public:
         if (_comm == 0  &&  _stageBPending)  { _stageBPending = false;  check (gkc_finish_pass_wait (_ctx)); }
         if (hasRing())  { drainWriter(); }                                /* every Count[] of the pass is in the file */
         if (pass + 1 == nbPasses)  { freeRing(); }
-        if (pass + 1 == nbPasses  &&  _plan.on  &&  (_comm == 0  ||  _rank == 0))
+        if (pass + 1 == nbPasses  &&  nbPasses == 1  &&  _plan.on  &&  (_comm == 0  ||  _rank == 0))
         {
             gkc_stats st;  check (gkc_get_stats (_ctx, &st));
             device::DeviceContext::Resident r;
@@ -442,6 +450,7 @@ private:
     size_t    _kmerSize = 0;
     double    _finishWall = 0;
     bool      _stageBPending = false;
+    size_t    _releasedBelow = 0;          /**< passes [0, _releasedBelow) have been released on the device */
     u_int64_t _progressReported = 0, _progressDebt = 0;
     std::mutex _timesLock;
     double    _waitS = 0, _handOverS = 0;

@@ -249,6 +249,35 @@ def test_bloom_and_mphf_through_the_boundary(tmp_path, tag, mode):
         assert (queried > 0) == (mode != "single_queries"), log[-3000:]
 
 
+@needs_artefacts
+def test_several_passes_release_the_earlier_ones(tmp_path):
+    """a run of several passes must not keep the Count records of every pass in HBM (DeviceConfiguration sizes a pass for its own). The reference's Configuration
+    with -max-disk 1 cuts this input into several passes (ConfigurationAlgorithm.cpp:350); the binding releases pass p - 1 when pass p begins (gkc_release_pass), nothing is
+    resident at the end, BloomAlgorithm reads /dsk/solid from the storage: the SET of solid records over all nb_partitions x nb_passes datasets and /bloom/bloom are the
+    one-pass fixture's."""
+    tag = "k21_defaults_parts"                                                       # 6000 reads: 6 MB of k-mers, two passes at -max-disk 1
+    z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    fa = os.path.join(str(tmp_path), tag + ".fa"); open(fa, "wb").write(bytes(z["fasta"]))
+    out = os.path.join(str(tmp_path), "mp")
+    cmd = [EXE, "-in", fa, "-kmer-size", str(k), "-abundance-min", "2", "-out", out, "-out-tmp", str(tmp_path), "-nb-cores", "1", "-max-memory", "2000", "-max-disk", "1", "-verbose", "0"]      # (the fixture's flags: dbgh5's defaults)
+    env = dict(os.environ); env["GATB_DEVICE_REFERENCE_CONFIG"] = "1"; env["GATB_DEVICE_VERBOSE"] = "1"
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    log = r.stdout + r.stderr
+    assert r.returncode == 0, log[-3000:]
+    import re
+    passes = {int(x) for x in re.findall(r"\[device counting\] pass (\d+),", log)}
+    assert len(passes) >= 2, log[-3000:]
+    assert "gkc_bloom_insert_solid" not in log, log[-3000:]                           # nothing resident after a run of several passes: inserted from the storage
+    h5 = out + ".h5"
+    nds = int(subprocess.run([H5DUMP, "-a", "/dsk/solid/nb_partitions", h5], capture_output=True, text=True).stdout.split('(0): "')[1].split('"')[0])
+    got = []
+    for p_ in range(nds):
+        raw = dump_dataset(h5, "/dsk/solid/%d" % p_, "FILE"); n = len(raw) // 12; raw = raw[:n * 12].reshape(n, 12)
+        got += list(zip([int.from_bytes(bytes(r_), "little") for r_ in raw[:, :8]], raw[:, 8:].copy().view("<u4")[:, 0].tolist()))
+    assert sorted(got) == sorted(x for p_ in parts for x in p_)
+    assert np.array_equal(dump_dataset(h5, "/bloom/bloom", "LE"), z["bloom"])
+
+
 UNITIGS = os.path.join(ROOT, "integration", "_build", "unitigs_check")            # GraphUnitigs linked WITH the patched units: counts on the device
 UNITIGS_REF = os.path.join(ROOT, "integration", "_build", "ref", "unitigs_check")  # GraphUnitigs of the unpatched library: the consumer of an .h5
 
