@@ -40,6 +40,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <zlib.h>
 #include <gatb/bank/impl/BankFasta.hpp>
 #include <gatb/bank/impl/BankComposite.hpp>
 #include <string>
@@ -175,7 +176,9 @@ public:
             const std::string name = fasta->getId();
             FILE* f = fopen (name.c_str(), "rb");  if (f == 0)  { return false; }
             unsigned char magic[2] = {0, 0};  const size_t got = fread (magic, 1, 2, f);  fclose (f);
-            if (got == 2  &&  magic[0] == 0x1f  &&  magic[1] == 0x8b)  { return false; }      /* gzip: the reference's reader inflates it (BankFasta.cpp:425-483) */
+            /* gzip (BankFasta.cpp:425-483 inflates it inside the locked reader): one rank inflates it on a thread of its own into the same text path (pushTextFiles);
+             * several ranks cannot cut a deflate stream into byte ranges: iterated */
+            if (got == 2  &&  magic[0] == 0x1f  &&  magic[1] == 0x8b  &&  (singleton().ranks() > 1  ||  getenv ("GATB_DEVICE_NO_GZ") != 0))  { return false; }
             files.push_back (name);
             return true;
         }
@@ -259,23 +262,57 @@ public:
                 for (size_t r = 0; r < readers.size(); r++)  { readers[r].join(); }
                 return !failed.load();
             };
+            /* a gzipped file (one rank): the text comes out of zlib on the prefetch thread — CHUNK bytes of text at a time, while the chunk before is parsed and scanned
+             * on the device; where the text ends is only known when gzread returns less than asked, so the chunks go to the parser as "not the last" and what the last
+             * one leaves (a record without its newline) is pushed as the final piece */
+            unsigned char magic[2] = {0, 0};
+            const bool gz = pread (fd, magic, 2, 0) == 2  &&  magic[0] == 0x1f  &&  magic[1] == 0x8b;
+            gzFile zf = 0;
+            if (gz)
+            {
+                zf = gzopen (files[fi].c_str(), "rb");
+                if (zf == 0)  { ::close (fd);  throw system::Exception ("device counting: cannot open %s through zlib", files[fi].c_str()); }
+                gzbuffer (zf, 1 << 20);
+                if (getenv ("GATB_DEVICE_VERBOSE") != 0)  { fprintf (stderr, "[device counting] %s: gzipped text, inflated on a host thread into the device parser\n", files[fi].c_str()); }
+                size = ~(uint64_t)0;  off = 0;
+            }
+            auto inflate = [zf] (char* dst, uint64_t n, uint64_t& got) -> bool      /* up to n bytes of text; got < n: the end */
+            {
+                got = 0;
+                while (got < n)
+                {
+                    const int g = gzread (zf, dst + got, (unsigned) std::min<uint64_t> (n - got, (uint64_t)1 << 30));
+                    if (g < 0)  { return false; }
+                    if (g == 0)  { break; }
+                    got += (uint64_t) g;
+                }
+                return true;
+            };
             /* two buffers: the next chunk is read (behind PAD bytes of room for what the parser leaves of this one) while this one is parsed and scanned */
             int cur = 0;
-            uint64_t have = std::min<uint64_t> ((uint64_t)CHUNK, size - off);
+            uint64_t have = gz ? 0 : std::min<uint64_t> ((uint64_t)CHUNK, size - off);
             char* ptr = _text[cur] + PAD;
-            bool ok = true, readError = have > 0 && !fill (ptr, off, have);
-            off += have;
+            bool ok = true, readError = gz ? !inflate (ptr, (uint64_t)CHUNK, have) : (have > 0 && !fill (ptr, off, have));
+            bool gzEnd = gz && have < (uint64_t)CHUNK;
+            if (!gz)  { off += have; }
             while (ok  &&  !readError  &&  have > 0)
             {
-                const uint64_t next = std::min<uint64_t> ((uint64_t)CHUNK, size - off);
+                uint64_t next = gz ? (gzEnd ? 0 : (uint64_t)CHUNK) : std::min<uint64_t> ((uint64_t)CHUNK, size - off);
                 std::atomic<bool> nextFailed (false);
+                std::atomic<uint64_t> nextGot (0);
                 std::thread prefetch;
-                if (next > 0)  { char* dst = _text[cur ^ 1] + PAD;  const uint64_t from = off;  prefetch = std::thread ([&fill, &nextFailed, dst, from, next] { nextFailed = !fill (dst, from, next); }); }
+                if (next > 0)
+                {
+                    char* dst = _text[cur ^ 1] + PAD;  const uint64_t from = off;
+                    if (gz)  { prefetch = std::thread ([&inflate, &nextFailed, &nextGot, dst, next] { uint64_t g = 0;  nextFailed = !inflate (dst, next, g);  nextGot = g; }); }
+                    else     { prefetch = std::thread ([&fill, &nextFailed, dst, from, next] { nextFailed = !fill (dst, from, next); }); }
+                }
                 const int final = next == 0 ? 1 : 0;
                 uint64_t consumed = 0;
                 const int rc = gkc_push_fastx (_ctx, ptr, have, final, &consumed);
                 if (prefetch.joinable())  { prefetch.join(); }
                 readError = nextFailed.load();
+                if (gz  &&  next > 0)  { next = nextGot.load();  gzEnd = next < (uint64_t)CHUNK; }      /* (next == 0: the text ended exactly at the chunk: what is left goes out as the final piece below) */
                 const uint64_t left = final ? 0 : have - consumed;
                 if (rc == GKC_ERR_FORMAT  ||  (rc == GKC_OK  &&  left > (uint64_t)PAD))  { ok = false;  break; }      /* (or a record larger than the room: a genome, not reads) */
                 if (rc != GKC_OK)  { ::close (fd);  check (rc); }
@@ -292,11 +329,21 @@ public:
                 {
                     check (gkc_exchange (_ctx, _comm));  _exchangesDone++;
                 }
-                if (next == 0)  { break; }
+                if (next == 0)
+                {
+                    if (!final  &&  left > 0)                              /* gz: the text ended with the chunk just pushed as "not the last": its tail is the final piece */
+                    {
+                        uint64_t c2 = 0;
+                        const int rc2 = gkc_push_fastx (_ctx, ptr + consumed, left, 1, &c2);
+                        if (rc2 == GKC_ERR_FORMAT)  { ok = false; }  else if (rc2 != GKC_OK)  { if (zf) { gzclose (zf); }  ::close (fd);  check (rc2); }
+                    }
+                    break;
+                }
                 char* nptr = _text[cur ^ 1] + PAD - left;
                 if (left > 0)  { memcpy (nptr, ptr + consumed, left); }
-                ptr = nptr;  have = left + next;  off += next;  cur ^= 1;
+                ptr = nptr;  have = left + next;  if (!gz) { off += next; }  cur ^= 1;
             }
+            if (zf)  { gzclose (zf); }
             ::close (fd);
             if (readError)  { throw system::Exception ("device counting: read error in %s", files[fi].c_str()); }
             if (!ok)
