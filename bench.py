@@ -647,6 +647,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg[dom] / launches_per_step,
                          "stage_b_lanes": int(os.environ.get("GKC_STAGEB_LANES", "2")), "pipeline": pipeline},
         }
+        # the same kernel over the K steps that leave the records in HBM (no pack kernels, no copy stream beside it): `frac` above belongs to the region `value` is quoted on
+        if value_mode == "host" and ktime_dev[dom][0] > 0:
+            d_ms = ktime_dev[dom][0] / max(1, args.steps); d_l = max(1, ktime_dev[dom][1] // max(1, args.steps))
+            out["roofline"]["device_resident_region"] = {"launch_ms": d_ms / d_l, "launches_per_step": int(d_l), "achieved": alg[dom] / (d_ms * 1e-3) / 1e9,
+                                                         "frac": alg[dom] / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                         "note": "same kernel, same algorithmic bytes, HIP events over the K steps of value_device_resident"}
         # Stage B merges identical super-k-mer records before the expansion: every k-mer is still counted (the algorithmic bytes above are per k-mer of the
         # input), but the kernels after it move fewer keys. Both figures are reported: `frac` on the algorithmic bytes, `frac_on_moved_bytes` on what
         # the dominant kernel really reads and writes

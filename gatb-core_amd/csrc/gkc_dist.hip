@@ -42,6 +42,7 @@ struct gkc_comm {
     double init_ms = 0;                        // wall of ncclCommInitRank (RCCL) / of the session handshake (file mailbox)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;      // transfer intervals not yet added to stats.ms_transfer
     DevBuf ag_send, ag_recv;                   // staging of the host all-gather (RCCL)
+    bool ipc = false;                          // transport communicator whose device messages go peer to peer through IPC memory handles (gkc_comm_enable_ipc)
 };
 
 // RCCL is bound at run time, when the first RCCL communicator is asked for: a single-GPU host without librccl loads libgkc_hip.so all the same
@@ -116,6 +117,66 @@ int gkc_comm_agree(gkc_comm* m, int local_rc, const char* where)
     return GKC_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ device-to-device fallback transport (round 5)
+// When RCCL refuses the communicator (gatb_core_amd/dist.py make_comm: every rank falls back together) the host-staged transport keeps the run alive at the price of
+// two PCIe crossings and a TCP copy per message. This one keeps the bytes on the devices: every receive buffer is published as (hipIpcMemHandle of its allocation,
+// offset, length) through the transport's HOST all-gather, the SENDER opens the handle and copies device to device (peer access over xGMI between GPUs of a node;
+// a plain copy when the ranks share a GPU), a second all-gather tells everybody that what was sent to them has landed. Handles are opened per exchange and closed
+// after it: the allocator of the peer may hand the block to something else later. Needs hipMalloc'ed blocks (an IPC handle names a whole allocation): the pool's
+// mapped ranges are switched off for the context (gkc_comm_enable_ipc).
+struct IpcEntry { int32_t src; uint32_t pad; uint64_t offset, bytes; hipIpcMemHandle_t handle; };
+static int sendrecv_ipc(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st)
+{
+    gkc_ctx* c = m->ctx;
+    const int W = m->world;
+    // my receive table
+    std::vector<IpcEntry> mine(recvs.size());
+    for (size_t i = 0; i < recvs.size(); i++) {
+        IpcEntry& e = mine[i]; memset(&e, 0, sizeof e);
+        e.src = recvs[i].peer; e.bytes = recvs[i].n_bytes;
+        hipDeviceptr_t base = nullptr; size_t span = 0;
+        if (recvs[i].n_bytes) {
+            if (hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)recvs[i].d_ptr) != hipSuccess || hipIpcGetMemHandle(&e.handle, (void*)base) != hipSuccess) {
+                (void)hipGetLastError(); e.src = -2;                      // (published all the same: the ranks fail together below)
+            } else e.offset = (uint64_t)((const uint8_t*)recvs[i].d_ptr - (const uint8_t*)base);
+        }
+    }
+    uint32_t n_mine = (uint32_t)mine.size(); std::vector<uint32_t> n_all((size_t)W, 0);
+    GKC_TRY(gkc_comm_allgather_host(m, &n_mine, 4, n_all.data()));
+    uint32_t n_max = 1; for (int r = 0; r < W; r++) n_max = std::max(n_max, n_all[r]);
+    std::vector<IpcEntry> padded(n_max), all((size_t)W * n_max);
+    memset(padded.data(), 0, padded.size() * sizeof(IpcEntry)); if (n_mine) memcpy(padded.data(), mine.data(), (size_t)n_mine * sizeof(IpcEntry));
+    GKC_TRY(gkc_comm_allgather_host(m, padded.data(), (uint64_t)n_max * sizeof(IpcEntry), all.data()));
+    int rc = GKC_OK; std::string why;
+    for (int r = 0; r < W && rc == GKC_OK; r++) for (uint32_t i = 0; i < n_all[r]; i++) if (all[(size_t)r * n_max + i].src == -2) { rc = GKC_ERR_HIP; why = "rank " + std::to_string(r) + " could not export a receive buffer (hipIpcGetMemHandle)"; break; }
+    // my sends: the j-th message to peer p goes to the j-th entry of p's table whose source is me
+    std::vector<std::pair<hipIpcMemHandle_t, void*>> opened;
+    auto open_handle = [&](const hipIpcMemHandle_t& h) -> void* {
+        for (auto& o : opened) if (memcmp(&o.first, &h, sizeof h) == 0) return o.second;
+        void* p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        opened.push_back({h, p}); return p;
+    };
+    std::vector<uint32_t> cursor((size_t)W, 0);
+    for (size_t j = 0; j < sends.size() && rc == GKC_OK; j++) {
+        const int p = sends[j].peer;
+        if (p < 0 || p >= W) { rc = GKC_ERR_ARG; why = "send to a rank outside the communicator"; break; }
+        const IpcEntry* e = nullptr;
+        while (cursor[p] < n_all[p]) { const IpcEntry& x = all[(size_t)p * n_max + cursor[p]++]; if (x.src == m->rank) { e = &x; break; } }
+        if (!e || e->bytes != sends[j].n_bytes) { rc = GKC_ERR_HIP; why = "the receive posted by rank " + std::to_string(p) + " does not match the send"; break; }
+        if (!e->bytes) continue;
+        void* base = open_handle(e->handle);
+        if (!base) { rc = GKC_ERR_HIP; why = "hipIpcOpenMemHandle of a buffer of rank " + std::to_string(p) + " failed"; break; }
+        if (hipMemcpyAsync((uint8_t*)base + e->offset, sends[j].d_ptr, (size_t)e->bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipGetLastError(); rc = GKC_ERR_HIP; why = "device-to-device copy failed"; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == GKC_OK) { (void)hipGetLastError(); rc = GKC_ERR_HIP; why = "device-to-device copy failed"; }
+    for (auto& o : opened) (void)hipIpcCloseMemHandle(o.second);
+    if (rc != GKC_OK) c->set_error(rc, "IPC transport: %s", why.c_str());
+    // everybody's copies have landed (or everybody learns that somebody failed)
+    return gkc_comm_agree(m, rc, "the device-to-device exchange");
+}
+
 int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st)
 {
     gkc_ctx* c = m->ctx;
@@ -138,6 +199,7 @@ int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std
         return GKC_OK;
     }
     GKC_HIP(c, hipStreamSynchronize(st));
+    if (m->ipc) return sendrecv_ipc(m, s2, r2, st);
     if (m->t.sendrecv_device(m->t.user, s2.data(), (uint32_t)s2.size(), r2.data(), (uint32_t)r2.size()) != 0) GKC_FAIL(c, GKC_ERR_HIP, "transport send/recv failed");
     return GKC_OK;
 }
@@ -435,6 +497,14 @@ int gkc_comm_create_transport(gkc_ctx* c, const gkc_transport* t, int world, int
     if (!t || !t->allgather_host || !t->sendrecv_device) return GKC_ERR_ARG;
     GKC_TRY(comm_new(c, world, rank, out));
     (*out)->t = *t;
+    return GKC_OK;
+}
+int gkc_comm_enable_ipc(gkc_comm* m, int on)
+{
+    if (!m) return GKC_ERR_ARG;
+    if (m->rccl) { m->ctx->set_error(GKC_ERR_ARG, "gkc_comm_enable_ipc: an RCCL communicator moves its messages itself"); return GKC_ERR_ARG; }
+    m->ipc = on != 0;
+    if (m->ipc) { std::lock_guard<std::recursive_mutex> lk(m->ctx->pool.mu); m->ctx->pool.vmm_ok = false; }      // an IPC handle names a hipMalloc allocation
     return GKC_OK;
 }
 int gkc_comm_create_files(gkc_ctx* c, const char* directory, int world, int rank, gkc_comm** out)

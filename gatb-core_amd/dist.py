@@ -13,6 +13,8 @@ MPHF levels. This module only provides what a Python launcher adds on top:
   * DistributedCounter: per pass begin -> [push -> exchange]* -> finish, and the owner ranges afterwards;
   * owner_ranges / exchange_buckets: the host-side twins the CPU tests drive (gkc_exchange_plan is the library's planning function).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -61,7 +63,29 @@ class HostStagedTransport:
             self.c.host_to_device(ptr, t.numpy())
 
 
-LAST_COMM_KIND = None       # "rccl" | "host-staged" | "host-staged (fallback: <why>)": what make_comm gave this process last (bench.py reports it)
+LAST_COMM_KIND = None       # "rccl" | "host-staged" | "device-to-device IPC (...)" | "host-staged (fallback: <why>)": what make_comm gave this process last (bench.py reports it)
+
+
+def _staged_comm(counter, group, world, rank, ipc):
+    """transport communicator over a gloo group; ipc: its device messages go device to device through IPC memory handles (gkc_comm_enable_ipc) — checked by a small
+    exchange over the real peers before it is trusted; if any rank fails, all of them go back to staging through the host. Returns (comm, used_ipc)."""
+    comm = gkc.Comm.transport(counter, HostStagedTransport(counter, group), world, rank)
+    if not ipc or world < 2:
+        return comm, False
+    why = None
+    try:
+        comm.enable_ipc(True)
+        bad, _ = comm.selftest(1 << 20)
+        if bad:
+            why = "%d wrong words" % bad
+    except Exception as e:      # noqa
+        why = str(e)[:200]
+    votes = [None] * world
+    dist.all_gather_object(votes, why, group=group)
+    if any(votes):
+        comm.enable_ipc(False)
+        return comm, False
+    return comm, True
 
 
 def make_comm(counter, group=None, try_rccl=None):
@@ -93,10 +117,12 @@ def make_comm(counter, group=None, try_rccl=None):
             return comm
         # (a communicator that did open on this rank is left alone: destroying half of a broken clique may hang)
         staged_group = dist.new_group(backend="gloo") if is_nccl else group
-        LAST_COMM_KIND = "host-staged (fallback: RCCL communicator refused on %d of %d ranks; %s)" % (len(bad), world, bad[0])
-        return gkc.Comm.transport(counter, HostStagedTransport(counter, staged_group), world, rank)
-    LAST_COMM_KIND = "host-staged"
-    return gkc.Comm.transport(counter, HostStagedTransport(counter, group), world, rank)
+        comm, used = _staged_comm(counter, staged_group, world, rank, ipc=os.environ.get("GKC_NO_IPC") is None)
+        LAST_COMM_KIND = "%s (fallback: RCCL communicator refused on %d of %d ranks; %s)" % ("device-to-device IPC copies, host all-gathers over gloo" if used else "host-staged", len(bad), world, bad[0])
+        return comm
+    comm, used = _staged_comm(counter, group, world, rank, ipc=os.environ.get("GKC_IPC") == "1")
+    LAST_COMM_KIND = "device-to-device IPC copies, host all-gathers over gloo" if used else "host-staged"
+    return comm
 
 
 class DistributedCounter:

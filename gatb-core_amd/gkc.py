@@ -25,7 +25,7 @@ SYMBOLS = [
     "gkc_fastx_parse_device", "gkc_push_fastx", "gkc_mphf_build", "gkc_mphf_build_solid", "gkc_mphf_destroy", "gkc_mphf_size",
     "gkc_mphf_lookup", "gkc_mphf_save_size", "gkc_mphf_save", "gkc_mphf_abundance_map",
     "gkc_device_to_host", "gkc_kmer_checksum_device", "gkc_result_checksum", "gkc_sample_minimizers", "gkc_count_mmers",
-    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_gather_results", "gkc_comm_loopback", "gkc_comm_selftest", "gkc_comm_peer_bytes", "gkc_comm_destroy", "gkc_comm_set_owners",
+    "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_comm_enable_ipc", "gkc_gather_results", "gkc_comm_loopback", "gkc_comm_selftest", "gkc_comm_peer_bytes", "gkc_comm_destroy", "gkc_comm_set_owners",
     "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
     "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
     "gkc_sample_exact", "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
@@ -142,6 +142,7 @@ def lib():
         "gkc_comm_create_rccl": (C.c_int, [vp, vp, C.c_int, C.c_int, P(vp)]),
         "gkc_comm_create_transport": (C.c_int, [vp, P(Transport), C.c_int, C.c_int, P(vp)]),
         "gkc_comm_create_files": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, P(vp)]),
+        "gkc_comm_enable_ipc": (C.c_int, [vp, C.c_int]),
         "gkc_gather_results": (C.c_int, [vp, vp, C.c_int]),
         "gkc_comm_loopback": (C.c_int, [vp, vp, u64, P(u64), P(C.c_double)]),
         "gkc_comm_selftest": (C.c_int, [vp, vp, u64, P(u64), P(C.c_double)]),
@@ -585,6 +586,10 @@ class Comm:
         h = C.c_void_p()
         counter._chk(counter.L.gkc_comm_create_files(counter.h, str(directory).encode(), world, rank, C.byref(h)))
         return cls(counter, h)
+
+    def enable_ipc(self, on=True):
+        """device messages of a transport communicator go device to device through IPC memory handles (gkc_comm_enable_ipc)"""
+        self.c._chk(self.L.gkc_comm_enable_ipc(self.h, 1 if on else 0))
 
     def loopback(self, n_bytes):
         """this rank sends n_bytes to itself through the communicator's send / receive path (chunked like gkc_exchange) -> (mismatching words, ms)"""

@@ -216,6 +216,10 @@ int  gkc_comm_create_transport(gkc_ctx* ctx, const gkc_transport* t, int world, 
  * through host memory, one file per message). For ranks RCCL cannot connect — two processes sharing one GPU in the tests (RCCL refuses a duplicate device),
  * hosts without xGMI — and for launchers that have nothing but a shared file system. Development / test transport: bandwidth is that of the file system. */
 int  gkc_comm_create_files(gkc_ctx* ctx, const char* directory, int world, int rank, gkc_comm** out);
+/* A transport communicator (gkc_comm_create_transport / _files) whose DEVICE messages stay on the devices: every receive buffer is published as an IPC memory handle
+ * through the transport's host all-gather and the sender copies device to device (xGMI peer copy between the GPUs of a node). What a launcher falls back to when RCCL
+ * refuses the communicator: the host side of the transport is then only used for a few hundred bytes per exchange. Call before the first push on every rank. */
+int  gkc_comm_enable_ipc(gkc_comm* comm, int on);
 void gkc_comm_destroy(gkc_comm* comm);
 /* Owner ranges: rank r owns partitions [first[r], first[r+1]); first[0] = 0, first[world] = nb_partitions. By default the first
  * exchange of a pass balances them by the k-mers per partition all ranks report ("balanced by weight"); gkc_comm_set_owners

@@ -21,9 +21,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, k, parts, amin, q, try_rccl=False):
+def _rank_main(rank, world, port, k, parts, amin, q, try_rccl=False, ipc=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if ipc:
+        os.environ["GKC_IPC"] = "1"                       # the gloo-backed transport with device-to-device copies through IPC memory handles (gkc_comm_enable_ipc)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pkg = ge.load(); gkc = pkg.gkc
@@ -38,7 +40,15 @@ def _rank_main(rank, world, port, k, parts, amin, q, try_rccl=False):
         dc = gd.DistributedCounter(c, rank, world, parts, try_rccl=try_rccl)
         # try_rccl: both ranks first ask the library for an RCCL communicator (refused: two ranks on one device), agree on the refusal and fall back to the host-staged
         # transport — the path a multi-GPU run takes if RCCL inside libgkc_hip.so does not come up between real peers (gatb-core_amd/dist.py:make_comm)
-        assert gd.LAST_COMM_KIND == "host-staged" if not try_rccl else gd.LAST_COMM_KIND.startswith("host-staged (fallback: RCCL communicator refused on 2 of 2 ranks"), gd.LAST_COMM_KIND
+        # ... which since round 5 keeps the records on the devices where it can: the fallback first tries device-to-device copies through IPC memory handles (checked by a
+        # small exchange between the ranks) and only then stages through the host
+        kind = gd.LAST_COMM_KIND
+        if try_rccl:
+            assert "(fallback: RCCL communicator refused on 2 of 2 ranks" in kind and kind.startswith(("device-to-device IPC", "host-staged")), kind
+        elif ipc:
+            assert kind.startswith("device-to-device IPC"), kind     # two processes on one GPU can open each other's allocations (dmabuf IPC)
+        else:
+            assert kind == "host-staged", kind
         bad, _ = dc.comm.selftest(3 << 20)                   # every rank sends a keyed pattern to every other rank and checks what it gets (what bench.py --gpus N does first)
         assert bad == 0
         c.begin_pass(0)
@@ -63,18 +73,18 @@ def _rank_main(rank, world, port, k, parts, amin, q, try_rccl=False):
         # MPHF + abundance map over all ranks
         mp_ = gkc.Mphf(c, comm=dc.comm)
         amap, above = mp_.abundance_map()
-        q.put((rank, first.tolist(), owned, st, cs, bl.array(), mp_.save(), amap, above, mp_.size))
+        q.put((rank, first.tolist(), owned, st, cs, bl.array(), mp_.save(), amap, above, mp_.size, kind))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,parts,amin,try_rccl", [(31, 12, 2, False), (41, 8, 1, False), (31, 12, 2, True)])
-def test_two_ranks_one_gpu_end_to_end(k, parts, amin, try_rccl):
+@pytest.mark.parametrize("k,parts,amin,try_rccl,ipc", [(31, 12, 2, False, False), (41, 8, 1, False, False), (31, 12, 2, True, False), (31, 12, 2, False, True), (63, 8, 1, False, True)])
+def test_two_ranks_one_gpu_end_to_end(k, parts, amin, try_rccl, ipc):
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, k, parts, amin, q, try_rccl)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, k, parts, amin, q, try_rccl, ipc)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     [p.join(timeout=120) for p in procs]
@@ -89,6 +99,8 @@ def test_two_ranks_one_gpu_end_to_end(k, parts, amin, try_rccl):
     first = res[0][1]
     assert res[1][1] == first and first[0] == 0 and first[-1] == parts and 0 < first[1] < parts      # both ranks agree; both own something
     seen = 0
+    if try_rccl:
+        print("fallback transport after the RCCL refusal:", res[0][10])
     for rank, _, owned, st, cs, *_ in res:
         assert sorted(owned) == list(range(first[rank], first[rank + 1]))
         for p, (lo, hi, ab) in owned.items():
