@@ -1,5 +1,5 @@
 """profiles/pmc_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as the guide prescribes).
-usage: pmc_traffic.py fetch.db write.db '<workload string>' out.json
+usage: pmc_traffic.py fetch.db write.db '<workload string>' out.json [steps the profiled command ran: default 1]
 Units: FETCH_SIZE/WRITE_SIZE are KiB per dispatch. gfx950 correction (MI355X_MICROARCH.md §HBM, calibrated for this library's access patterns in
 profiles/r05_fetch_size_calibration.txt): FETCH_SIZE reports half of the bytes of coalesced reads (16 / 8 / 4 bytes per lane, wave-contiguous runs) -> read bytes = 2 * FETCH_SIZE * 1024
 for the streaming kernels; per-lane gathers are counted one 64-byte line per read at face value -> 1 * FETCH_SIZE * 1024 for the kernels listed in GATHER; byte-per-lane loads are not
@@ -23,6 +23,7 @@ def read_factor(name):
     return 1 if name.startswith(GATHER) else 2
 
 
+STEPS = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 f = per_kernel(sys.argv[1], "FETCH_SIZE"); w = per_kernel(sys.argv[2], "WRITE_SIZE")
 for k_ in list(f):
     if k_.startswith(UNCOUNTED):
@@ -34,6 +35,6 @@ for k in sorted(set(f) | set(w)):
     rf = read_factor(k)
     res["kernels"][k] = {"dispatches": int(max(fn, wn)), "read_factor": rf, "read_bytes_total": rf * fv * 1024, "write_bytes_total": wv * 1024,
                          "hbm_bytes_per_launch": (rf * fv * 1024 + wv * 1024) / max(fn, wn),
-                         "hbm_bytes_per_step": rf * fv * 1024 + wv * 1024}          # the PMC passes run exactly one step (--steps 1 --warmup 0)
+                         "hbm_bytes_per_step": (rf * fv * 1024 + wv * 1024) / STEPS}
 json.dump(res, open(sys.argv[4], "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in res["kernels"].items()}, indent=0))
