@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """bench.py — one "step" = one full pass of the DSK hot path (Stage A scan+bucket, Stage B expand+sort+count) over one
-batch of synthetic 150 bp reads that is already resident in HBM when the timed region starts.
+batch of synthetic 150 bp reads that is already resident in HBM when the timed region starts. `value` follows SURVEY 8(d): the clock
+of a step stops when every distinct k-mer's Count record (abundance-min 1) is in page-locked HOST memory (the batches cross PCIe
+packed while later batches are counted); `value_device_resident` is the same K steps with the records left in HBM.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched by torch.distributed.run, one rank per GPU).
 Rank 0 prints ONE JSON line. metric = BASELINE.json's "distinct k-mers/s at k=31".
