@@ -34,6 +34,13 @@ def test_device_equals_reference_run(gkc, path):
     c.begin_pass(0)
     assert c.push_fastx(bytes(z["fasta"])) == len(z["fasta"])      # the text is parsed on the device
     c.finish_pass()
+    if "_auto" in path:
+        # -abundance-min auto (SortingCountAlgorithm.cpp:418-444, CountProcessorCutoff.hpp:88-99): the cut-off of the first count's histogram (Histogram::compute_threshold
+        # with a floor of 3; the host-side rule, here the oracle's restatement of it applied to the DEVICE's histogram) is the abundance-min of the count that is written
+        from oracle import gko
+        amin = int(gko.histogram_cutoff(c.histogram(), 3)[0])
+        c.set_solidity(amin, 2147483647, 10000)
+        c.begin_pass(0); c.push_fastx(bytes(z["fasta"])); c.finish_pass()
     assert c.stats()["kmers_nb_solid"] == int(z["nb_solid_kmers"])
     for p in range(nbpart):
         lo, hi, ab = c.partition(0, p)
