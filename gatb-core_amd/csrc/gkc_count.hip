@@ -280,6 +280,17 @@ __device__ __forceinline__ void wave_each_kmer16(WaveStage16& S, const uint64_t 
 // the rest of the wave, and every wave of ordinary input (6 scalar instructions to find out), goes on as before.
 constexpr int SAME_MIN = 8;
 __device__ __forceinline__ uint32_t rank_in(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); }
+// Do many lanes of the wave ask for one thing? (>= SAME_MIN lanes agree with the first or with the last active lane.) The expansion kernels ask once per RECORD, with the
+// sub-bucket of its first k-mer — all active lanes are in the first step of their record then — and run the per-k-mer relief only for the records of a wave that says yes:
+// ordinary input pays the check once per ~11 k-mers (the per-k-mer check alone cost k_expand_count 8.3 -> 11.7 ms).
+__device__ __forceinline__ bool wave_same_hint(uint32_t idx)
+{
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+    if (__popcll(__ballot(idx == lead)) >= SAME_MIN) return true;
+    const uint64_t act = __ballot(true);
+    const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)idx, 63 - (int)__builtin_clzll(act));
+    return __popcll(__ballot(idx == tail)) >= SAME_MIN;
+}
 // ctr[idx] += 1 for every active lane
 __device__ __forceinline__ void wave_add1(uint32_t* ctr, uint32_t idx)
 {
@@ -395,9 +406,14 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
             if constexpr (KW == 2 && RW == 4) {
-                if (k >= 32) for_each_sub32(R, k, pd.sub_bits, [&](uint32_t sb) { wave_add1(s_hist, sb); });
-                else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { wave_add1(s_hist, sub_index<KW>(c, pd.shift)); });
-            } else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { wave_add1(s_hist, sub_index<KW>(c, pd.shift)); });
+                bool first = true, armed = false;                                 // (same-address relief armed per record: wave_same_hint)
+                auto add = [&](uint32_t sb) { if (first) { first = false; armed = wave_same_hint(sb); } if (armed) wave_add1(s_hist, sb); else atomicAdd(&s_hist[sb], 1u); };
+                if (k >= 32) for_each_sub32(R, k, pd.sub_bits, [&](uint32_t sb) { add(sb); });
+                else for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { add(sub_index<KW>(c, pd.shift)); });
+            } else {
+                bool first = true, armed = false;
+                for_each_kmer_fast<KW, RW>(R, k, [&](key_t c) { const uint32_t sb = sub_index<KW>(c, pd.shift); if (first) { first = false; armed = wave_same_hint(sb); } if (armed) wave_add1(s_hist, sb); else atomicAdd(&s_hist[sb], 1u); });
+            }
         }
     }
     __syncthreads();
@@ -507,12 +523,14 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
         unsigned long long* const s_comb0 = s_pend + (((size_t)nsub * 12 + 15) / 16) * 2;                   // behind the cursors, 16-byte aligned
         unsigned long long* const s_comb = s_comb0 + (size_t)(threadIdx.x >> 6) * 64;                         // this wave's 64 words
+        bool rec_first = true, armed = BAL;                                      // same-address relief armed per record (wave_same_hint); the balanced walk has no record steps: always
         auto emit = [&](uint64_t c, unsigned long long wq) {
             const uint32_t q = (uint32_t)(c >> pd.shift);
             unsigned long long h = (c << wb) | wq;                               // (bits beyond the 64th fall off: see above) never all ones
+            if (!BAL && rec_first) { rec_first = false; armed = wave_same_hint(q); }
             // same-address relief (see wave_add1): >= SAME_MIN lanes of the wave with keys for ONE sub-bucket (one k-mer at 10^6 copies) pair up among themselves —
             // keys into the wave's LDS words by rank, one reservation for all the pairs, lane r < pairs stores words 2r, 2r + 1; an odd last lane takes the usual way
-            {
+            if (armed) {
                 const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
                 const uint64_t same = __ballot(q == lead);
                 const uint32_t ns = (uint32_t)__popcll(same);
@@ -565,6 +583,7 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
             const uint64_t R[2] = {nx.x, nx.y};
             if (r + PAIR_THREADS < r1) nx = recs[r + PAIR_THREADS];                  // next record in flight while this one is expanded
             const unsigned long long wq = R[1] & ((1ull << wb) - 1ull);                              // the record's weight - 1 (below the nucleotides; 0 unless the records were deduplicated)
+            rec_first = true;
             for_each_kmer16(R, k, [&](uint64_t c) { emit(c, wq); });
         }
         }
@@ -621,11 +640,13 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair2(const Par
             const uint64_t R[4] = {nx0.x, nx0.y, nx1.x, nx1.y};
             if (r + PAIR_THREADS < r1) { nx0 = recs[2 * (r + PAIR_THREADS)]; nx1 = recs[2 * (r + PAIR_THREADS) + 1]; }   // next record in flight
             const uint64_t wq = R[3] & ((1ull << wb) - 1ull);                                                   // the record's weight - 1
+            bool rec_first = true, armed = false;                                                                // same-address relief armed per record (wave_same_hint)
             for_each_kmer32(R, k, [&](u128 c) {
                 const uint32_t q = sub_index<2>(c, pd.shift);
                 const u128 st = (c << wb) | (u128)wq;                                    // (bits beyond the 128th fall off) never all ones
                 uint64_t h_lo = (uint64_t)st, h_hi = (uint64_t)(st >> 64);
-                {   // same-address relief, as in k_expand_scatter_pair — without LDS words (the parking table of 8192 sub-buckets takes the CU's whole LDS, and the partitions
+                if (rec_first) { rec_first = false; armed = wave_same_hint(q); }
+                if (armed) {   // same-address relief, as in k_expand_scatter_pair — without LDS words (the parking table of 8192 sub-buckets takes the CU's whole LDS, and the partitions
                     // that need this are the ones with 8192): a lane's partner is the NEXT lane of the group, its key comes over by ds_bpermute
                     const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
                     const uint64_t same = __ballot(q == lead);
@@ -2086,76 +2107,63 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
 #pragma unroll
             for (int r = 0; r < KM; r++) in[r] = nx[r];
             fetch(bin + DDS_WAVES);
-            DRec<RW> rec[KM]; uint32_t cnt[KM];
+            // A bin beyond the wave's registers — one record copied 10^5 .. 10^7 times: the super-k-mers of poly-A / (AC)n reads, of a repeat family at hundreds of copies (every
+            // copy hashes into this bin) — is deduplicated CHUNK by chunk of SLOTS records (round 5): each chunk sorted and merged like a bin of its own by the code below, its
+            // output placed behind the output of the chunk before (always left of the chunk's own records: in place). Up to round 4 such a bin was moved as it was: 1e8 reads
+            // with 1 % low-complexity reads then sent 2e7 keys of ONE k-mer through one parking slot of the scatter and one cursor of the giant split
+            // (k_expand_scatter_pair 1.08 s, k_giant_scatter 0.55 s, k_deep_split 0.29 s per step: profiles/r05_skewed_input.txt). An ordinary bin is its own single chunk.
+            const uint32_t nch = n > (uint32_t)SLOTS ? (n + SLOTS - 1) / SLOTS : 1u;
+            uint32_t pos = 0;
+            for (uint32_t ch = 0; ch < nch; ch++) {
+                uint32_t cn = n;
+                if (nch > 1) {
+                    cn = min((uint32_t)SLOTS, n - ch * SLOTS);
 #pragma unroll
-            for (int r = 0; r < KM; r++) cnt[r] = 0;
-            uint32_t nout = 0; int kpl = 0;                                   // kpl 0: the bin is moved as it is
-            if (n >= 2 && n <= 64) { nout = dd_sort_bin<RW, 1>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 1; }
-            else if (n > 64 && n <= 128) { nout = dd_sort_bin<RW, 2>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 2; }
-            else if (KM >= 4 && n > 128 && n <= 256) { nout = dd_sort_bin<RW, (KM >= 4 ? 4 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 4; }
-            else if (KM >= 8 && n > 256 && n <= 512) { nout = dd_sort_bin<RW, (KM >= 8 ? 8 : KM)>(in, n, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 8; }
-            uint32_t x = nout;
+                    for (int r = 0; r < KM; r++) { const uint32_t i = r * 64 + lane; if (i < cn) in[r] = dd_load<RW>(part + (size_t)(s0 + ch * SLOTS + i) * RW); }
+                }
+                DRec<RW> rec[KM]; uint32_t cnt[KM];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-            uint32_t total = kpl ? (uint32_t)__builtin_amdgcn_readlane((int)x, 63) : n;
-            // my turn? (the bins of a partition are handed to the waves in order: the wave of bin - 1 is another wave of this workgroup)
-            while (s_next != bin) __builtin_amdgcn_s_sleep(1);
-            const uint32_t pos0 = s_pos;
-            if (!kpl && n > (uint32_t)SLOTS) {
-                // More than the wave's registers hold: one record copied 10^5 .. 10^7 times (the super-k-mers of poly-A / (AC)n reads, of a repeat family at hundreds of
-                // copies: every copy hashes into this bin). Round 5: the bin is deduplicated CHUNK by chunk of SLOTS records — each chunk sorted and merged like a bin of
-                // its own, its output placed behind the output of the chunk before (always left of the chunk's own records: in place). Up to round 4 such a bin was moved
-                // as it was: 1e8 reads with 1 % low-complexity reads then sent 2e7 keys of ONE k-mer through one parking slot of the scatter and one cursor of the
-                // giant split (k_expand_scatter_pair 1.08 s, k_giant_scatter 0.55 s, k_deep_split 0.29 s per step: profiles/r05_skewed_input.txt).
-                uint32_t pos = pos0;
-                for (uint32_t i0 = 0; i0 < n; i0 += SLOTS) {
-                    const uint32_t nc = min((uint32_t)SLOTS, n - i0);
-                    DRec<RW> cin[KM];
+                for (int r = 0; r < KM; r++) cnt[r] = 0;
+                uint32_t nout = 0; int kpl = 0;                                   // kpl 0: one record (or none), moved as it is
+                if (cn >= 2 && cn <= 64) { nout = dd_sort_bin<RW, 1>(in, cn, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 1; }
+                else if (cn > 64 && cn <= 128) { nout = dd_sort_bin<RW, 2>(in, cn, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 2; }
+                else if (KM >= 4 && cn > 128 && cn <= 256) { nout = dd_sort_bin<RW, (KM >= 4 ? 4 : KM)>(in, cn, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 4; }
+                else if (KM >= 8 && cn > 256 && cn <= 512) { nout = dd_sort_bin<RW, (KM >= 8 ? 8 : KM)>(in, cn, lane, s_win[wave], rec, cnt, ik, WCAP); kpl = 8; }
+                uint32_t x = nout;
 #pragma unroll
-                    for (int r = 0; r < KM; r++) { const uint32_t i = r * 64 + lane; if (i < nc) cin[r] = dd_load<RW>(part + (size_t)(s0 + i0 + i) * RW); }
-                    if (nc < 2) { if (lane == 0) dd_store<RW>(part + (size_t)pos * RW, cin[0]); pos += nc; continue; }
-                    DRec<RW> crec[KM]; uint32_t ccnt[KM];
-                    const uint32_t cn = dd_sort_bin<RW, KM>(cin, nc, lane, s_win[wave], crec, ccnt, ik, WCAP);
-                    uint32_t cx = cn;
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+                const uint32_t total = kpl ? (uint32_t)__builtin_amdgcn_readlane((int)x, 63) : cn;
+                if (ch == 0) {
+                    // my turn? (the bins of a partition are handed to the waves in order: the wave of bin - 1 is another wave of this workgroup)
+                    while (s_next != bin) __builtin_amdgcn_s_sleep(1);
+                    pos = s_pos;
+                }
+                const uint32_t pos0 = pos;
+                if (!kpl && cn) {
+                    // one record: moved left BEFORE the next bin may place its output (which may reach into this bin's old range)
+                    DRec<RW> q;
+                    if (lane < cn) q = dd_load<RW>(part + (size_t)(s0 + ch * SLOTS + lane) * RW);
+                    if (lane < cn) dd_store<RW>(part + (size_t)(pos0 + lane) * RW, q);
+                }
+                if (ch + 1 == nch) {                                              // the last chunk is in registers: the next bin may go
+                    __threadfence_block();
+                    if (lane == 0) { s_pos = pos0 + total; __threadfence_block(); s_next = bin + 1; }
+                }
+                if (kpl) {
+                    uint32_t wp = pos0 + x - nout;
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(cx, d, 64); if (lane >= d) cx += y; }
-                    uint32_t cp = pos + cx - cn;
-#pragma unroll
-                    for (int r = 0; r < KM; r++) if (ccnt[r]) {
-                        const uint32_t nbk = (uint32_t)(crec[r].w[0] >> 56);
-                        for (uint32_t c = ccnt[r]; c; ) {
+                    for (int r = 0; r < KM; r++) if (cnt[r]) {
+                        const uint32_t nbk = (uint32_t)(rec[r].w[0] >> 56);
+                        for (uint32_t c = cnt[r]; c; ) {
                             const uint32_t w = c < WCAP ? c : WCAP;
-                            DRec<RW> o = crec[r]; o.w[RW - 1] |= (uint64_t)(w - 1);
-                            dd_store<RW>(part + (size_t)cp * RW, o); cp++;
+                            DRec<RW> o = rec[r]; o.w[RW - 1] |= (uint64_t)(w - 1);
+                            dd_store<RW>(part + (size_t)wp * RW, o); wp++;
                             ok += nbk; c -= w;
                         }
                     }
-                    pos += (uint32_t)__builtin_amdgcn_readlane((int)cx, 63);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                 // (the next chunk reuses the wave's LDS window)
                 }
-                total = pos - pos0;
-            } else if (!kpl && n) {
-                // one record: moved left BEFORE the next bin may place its output (which may reach into this bin's old range)
-                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    DRec<RW> q;
-                    if (i0 + lane < n) q = dd_load<RW>(part + (size_t)(s0 + i0 + lane) * RW);
-                    if (i0 + lane < n) dd_store<RW>(part + (size_t)(pos0 + i0 + lane) * RW, q);
-                }
-            }
-            __threadfence_block();
-            if (lane == 0) { s_pos = pos0 + total; __threadfence_block(); s_next = bin + 1; }
-            if (kpl) {
-                uint32_t pos = pos0 + x - nout;
-#pragma unroll
-                for (int r = 0; r < KM; r++) if (cnt[r]) {
-                    const uint32_t nbk = (uint32_t)(rec[r].w[0] >> 56);
-                    for (uint32_t c = cnt[r]; c; ) {
-                        const uint32_t w = c < WCAP ? c : WCAP;
-                        DRec<RW> o = rec[r]; o.w[RW - 1] |= (uint64_t)(w - 1);
-                        dd_store<RW>(part + (size_t)pos * RW, o); pos++;
-                        ok += nbk; c -= w;
-                    }
-                }
+                pos = pos0 + total;
+                if (nch > 1) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // (the next chunk reuses the wave's LDS window and reads behind what was just written)
             }
         }
         __syncthreads();
