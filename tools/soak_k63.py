@@ -7,5 +7,5 @@ spec = importlib.util.spec_from_file_location("tgp", os.path.join(os.path.dirnam
 gkc = ge.load().gkc
 for it in range(8):
     for (k, n, parts) in [(63, 100_000_000, 4096), (47, 60_000_000, 2048), (33, 60_000_000, 2048)]:
-        m.test_size_independent_properties(gkc, k, n, parts)
+        m.test_size_independent_properties(gkc, k, n, parts, it % 2)          # odd rounds: the repeat-rich generator (GKC_SYNTH_SKEWED)
     print("round", it, "ok", flush=True)
