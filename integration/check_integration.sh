@@ -3,7 +3,7 @@
 #   integration/check_integration.sh [scratch dir] [--link [gatb build dir with lib/Release/libgatbcore.a]]
 # 1. runs the reference's cmake CONFIGURE step in the scratch dir (generates gatb/system/api/config.hpp and the HDF5 configuration headers;
 #    nothing is built, the reference tree is not written);
-# 2. applies the patch to scratch copies of the six files it touches (integration/make_patched_sources.py);
+# 2. applies the patch to scratch copies of the seven files it touches (integration/make_patched_sources.py);
 # 3. g++ -fsyntax-only of the reference's own template instantiation units that hold them — template/TemplateSpecialization1.cpp.in (ConfigurationAlgorithm),
 #    2 (SortingCountAlgorithm + PartitionsCommand), 3 (BloomAlgorithm, DebloomAlgorithm, DebloomMinimizerAlgorithm), 4 (MPHFAlgorithm) — for spans 32
 #    and 64 with -DGATB_WITH_DEVICE_COUNTING, plus explicit instantiations of PartitionsByDeviceCommand and of BloomDevice<LargeInt<1>>, <LargeInt<2>>;

@@ -96,15 +96,27 @@ public:
     /** Bag: buffered per thread stripe; a full stripe goes to the device as one block */
     void insert (const Item& item)
     {
-        Stripe& s = _stripes [std::hash<std::thread::id>() (std::this_thread::get_id()) % NB_STRIPES];
+        Stripe& s = _stripes [stripeOfThread()];
         std::lock_guard<std::mutex> guard (s.lock);
-        _hostReady.store (false, std::memory_order_release);
+        /* (read before written: a store per insert from the 256 threads of a Dispatcher keeps one cache line travelling between all of them — the cascading
+         *  step of the debloom, DebloomAlgorithm.cpp:520-548, took 3.8 s instead of the CPU classes' 1.2 s at 10^7 reads) */
+        if (_hostReady.load (std::memory_order_relaxed))  { _hostReady.store (false, std::memory_order_release); }
         s.items.push_back (item);
         if (s.items.size() >= (size_t) BLOCK_ITEMS)  { sendStripe (s); }
     }
     void flush ()
     {
-        for (size_t i = 0; i < (size_t) NB_STRIPES; i++)  { std::lock_guard<std::mutex> guard (_stripes[i].lock);  sendStripe (_stripes[i]); }
+        std::vector<Item> pending;       /* what the stripes still hold, as ONE block */
+        for (size_t i = 0; i < (size_t) NB_STRIPES; i++)
+        {
+            std::lock_guard<std::mutex> guard (_stripes[i].lock);
+            pending.insert (pending.end(), _stripes[i].items.begin(), _stripes[i].items.end());  _stripes[i].items.clear();
+        }
+        if (pending.empty())  { return; }
+        std::lock_guard<std::mutex> guard (_sync);
+        toDevice();
+        check (gkc_bloom_insert (_bloom, pending.data(), pending.size(), (uint32_t) sizeof(Item)));
+        _inserted += pending.size();  _hostStale = true;
     }
     /** a whole array of items (stride sizeof(Item)) at once */
     void insertBatch (const Item* items, size_t n)
@@ -149,8 +161,16 @@ public:
     unsigned long weight     ()        { return twin()->weight(); }
 
 private:
-    enum { NB_STRIPES = 64, BLOCK_ITEMS = 1 << 18 };
-    struct Stripe  { std::mutex lock;  std::vector<Item> items; };
+    enum { NB_STRIPES = 512, BLOCK_ITEMS = 1 << 16 };
+    struct Stripe  { std::mutex lock;  std::vector<Item> items;  char apart[64]; };      /* (no two stripes' lock and vector in one cache line) */
+    /* threads take stripes in the order they first insert (a Dispatcher starts new threads for every iterate: Command.cpp:128-175), so the threads of one
+     * iteration — up to -nb-cores of them — get stripes of their own */
+    static size_t stripeOfThread ()
+    {
+        static std::atomic<size_t> next (0);
+        thread_local size_t mine = next.fetch_add (1, std::memory_order_relaxed);
+        return mine % NB_STRIPES;
+    }
 
     void check (int rc)  { if (rc != GKC_OK) { throw system::Exception ("BloomDevice: error %d: %s", rc, gkc_last_error(_ctx)); } }
 

@@ -4,7 +4,7 @@ would apply (integration/gatb-core.device.patch).
 
     python integration/make_patched_sources.py <reference gatb-core dir> <scratch include dir> [--write-patch]
 
-Six files are touched (file:line cited per hunk below); every edit is anchored on text of the reference file that must be found exactly once, and everything
+Seven files are touched (file:line cited per hunk below); every edit is anchored on text of the reference file that must be found exactly once, and everything
 new is guarded by GATB_WITH_DEVICE_COUNTING, so the patched files still build the CPU path without the macro:
   kmer/impl/SortingCountAlgorithm.cpp       fillPartitions -> Stage A on the device, the partition command, the join, device time keys in getInfo()
   kmer/impl/ConfigurationAlgorithm.cpp      partitions / passes sized from the HBM of the device instead of host RAM and disk
@@ -12,6 +12,7 @@ new is guarded by GATB_WITH_DEVICE_COUNTING, so the patched files still build th
   kmer/impl/BloomAlgorithm.cpp              execute(): the solid k-mers are inserted where the counting step left them in HBM
   kmer/impl/MPHFAlgorithm.cpp               execute(): BooPHF built on the device, stored, loaded by the reference's own MapMPHF::load; populate() on the device
   kmer/impl/DebloomMinimizerAlgorithm.cpp   contains8 of a partition's solid k-mers as ONE batched device query instead of one call per k-mer
+  kmer/impl/RepartitionAlgorithm.cpp        the two serial sampling iterations (m-mer frequencies, super-k-mer statistics) counted on the device
 The scratch copies land under <scratch include dir>/gatb/..., which check_integration.sh puts in front of the reference's src/ on the include path."""
 import difflib
 import os
@@ -315,7 +316,34 @@ def patch_config_algo(src):
     return out
 
 
-FILES = [(REL, patch), (CONFIG_ALGO, patch_config_algo), (BLOOM_HPP, patch_bloom_hpp), (BLOOM_ALGO, patch_bloom_algo), (MPHF_ALGO, patch_mphf_algo), (DEBLOOM_ALGO, patch_debloom_algo)]
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# kmer/impl/RepartitionAlgorithm.cpp — the two serial sampling iterations (:348-353 MmersFrequency, :464-474 SampleRepart of a single bank)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+REPART_ALGO = "src/gatb/kmer/impl/RepartitionAlgorithm.cpp"
+RA_INCLUDE_ANCHOR = "#include <gatb/kmer/impl/RepartitionAlgorithm.hpp>"
+RA_INCLUDE = "#ifdef GATB_WITH_DEVICE_COUNTING\n#include <gatb_device/RepartitorDevice.hpp>   /* the sampling functors' work on the MI355X (libgkc_hip.so) */\n#endif\n"
+RA_FREQ_ANCHOR = "    serialDispatcher.iterate (it_all_reads,  MmersFrequency<span> (\n"
+RA_FREQ_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+    /* the m-mers of the sample are counted on the device (gkc_count_mmers); false = no device / outside its range: the functor below runs */
+    if (RepartitorDevice::countMmers (_bank, _config, nbseq_sample, m_mer_counts) == false)
+#endif
+"""
+RA_SAMPLE_ANCHOR = "\t\tserialDispatcher.iterate (it_all_reads, SampleRepart<span> (\n"
+RA_SAMPLE_DEVICE = """#ifdef GATB_WITH_DEVICE_COUNTING
+\t\t/* super-k-mers, k-mers and kx-mers per minimizer of the sample on the device (gkc_sample_exact, the reference's stop rule); false: the functor below runs */
+\t\tif (RepartitorDevice::sample (_bank, _config, _freq_order, nbseq_sample, sample_info) == false)
+#endif
+"""
+
+
+def patch_repart_algo(src):
+    out = insert_after_line(src, RA_INCLUDE_ANCHOR, RA_INCLUDE)
+    out = insert_before(out, RA_FREQ_ANCHOR, RA_FREQ_DEVICE)
+    out = insert_before(out, RA_SAMPLE_ANCHOR, RA_SAMPLE_DEVICE)
+    return out
+
+
+FILES = [(REL, patch), (CONFIG_ALGO, patch_config_algo), (BLOOM_HPP, patch_bloom_hpp), (BLOOM_ALGO, patch_bloom_algo), (MPHF_ALGO, patch_mphf_algo), (DEBLOOM_ALGO, patch_debloom_algo), (REPART_ALGO, patch_repart_algo)]
 PATCH_NAME = "gatb-core.device.patch"
 
 

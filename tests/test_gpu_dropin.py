@@ -310,6 +310,70 @@ def test_several_passes_release_the_earlier_ones(tmp_path):
     assert np.array_equal(dump_dataset(h5, "/bloom/bloom", "LE"), z["bloom"])
 
 
+@needs_artefacts
+@pytest.mark.parametrize("tag", ["k21_freq_4parts", "k21_default_parts", "k63_neighbor_mphf"])
+def test_repartitor_sampling_runs_on_the_device(tmp_path, tag):
+    """SURVEY 8(f)2 inside the reference: RepartitorAlgorithm's two serial iterations (RepartitionAlgorithm.cpp:348 MmersFrequency, :464 SampleRepart) are counted on the
+    device (integration/gatb_device/RepartitorDevice.hpp); the tables the reference's own code builds from them are the unpatched reference's, and with
+    GATB_DEVICE_NO_REPARTITOR=1 the functors run instead: the same tables."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
+    freq = "-minimizer-type" in CASES[tag][0]
+    tables = []
+    for how, env in (("device", {"GATB_DEVICE_VERBOSE": "1"}), ("functors", {"GATB_DEVICE_VERBOSE": "1", "GATB_DEVICE_NO_REPARTITOR": "1"})):
+        p, h5 = run_dbgh5(tag, str(tmp_path), env, out_name=how)
+        log = p.communicate(timeout=600)[0]
+        assert p.returncode == 0, log[-2000:]
+        assert ("gkc_sample_exact" in log) == (how == "device"), log[-3000:]
+        assert ("gkc_count_mmers" in log) == (how == "device" and freq), log[-3000:]
+        check_h5(h5, tag)
+        tables.append(dump_dataset(h5, "/minimizers/minimRepart", "LE"))
+        if freq:
+            f = dump_dataset(h5, "/minimizers/minimFrequency", "LE")
+            assert np.array_equal(f, z["minimFrequency"]), "minimFrequency differs from the unpatched reference's"
+    assert np.array_equal(tables[0], tables[1])
+
+
+REF_DBGH5 = os.path.join(ROOT, "integration", "_build", "ref", "dbgh5")
+
+
+@needs_artefacts
+@pytest.mark.skipif(not os.path.exists(REF_DBGH5), reason="integration/_build/ref/dbgh5 (the unpatched reference) absent")
+@pytest.mark.parametrize("freq", [False, True])
+def test_repartitor_stop_rules_against_the_unpatched_reference(tmp_path, freq):
+    """The sample sizes only bite on a bank larger than the fixtures: SampleRepart stops in the sequence where more than max(5 % of the sequences, 10^6) super-k-mers have been
+    seen (RepartitionAlgorithm.cpp:451, :205-212), MmersFrequency after 5 % of the sequences + 1 (:322, :113-117). 2.5e5 reads of 150 bp hold 2.7e6 super-k-mers: the
+    unpatched reference run HERE on the same file is the expectation for /minimizers/minimRepart and minimFrequency."""
+    rng = np.random.default_rng(20250930)
+    G, n, L = 2_000_000, 250_000, 150
+    genome = rng.integers(0, 4, G).astype(np.uint8)
+    start = rng.integers(0, G - L, n)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[genome[start[:, None] + np.arange(L)[None, :]]]
+    bases[rng.random((n, L)) < 0.002] = ord("N")                                  # (some sequences lose k-mers and super-k-mers to N)
+    rec = np.empty((n, L + 4), dtype=np.uint8); rec[:, 0] = ord(">"); rec[:, 1] = ord("r"); rec[:, 2] = 10; rec[:, 3:3 + L] = bases; rec[:, 3 + L] = 10
+    fa = os.path.join(str(tmp_path), "reads.fa"); rec.tofile(fa)
+    flags = ["-kmer-size", "31", "-abundance-min", "2", "-out-tmp", str(tmp_path), "-nb-cores", "8", "-max-memory", "200", "-verbose", "0"] + COUNT_ONLY
+    flags += ["-minimizer-type", "1", "-repartition-type", "1"] if freq else []
+    env = dict(os.environ); env["GATB_DEVICE_REFERENCE_CONFIG"] = "1"; env["GATB_DEVICE_VERBOSE"] = "1"
+    out = {}
+    for name, exe in (("ref", REF_DBGH5), ("dev", EXE)):
+        o = os.path.join(str(tmp_path), name)
+        r = subprocess.run([exe, "-in", fa, "-out", o] + flags, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        out[name] = (o + ".h5", r.stdout + r.stderr)
+    log = out["dev"][1]
+    assert "gkc_sample_exact" in log and ("gkc_count_mmers" in log) == freq, log[-3000:]
+    import re
+    sampled = int(re.search(r"(\d+) super-k-mers of the first (\d+) sequences sampled", log).group(1))
+    assert 1_000_000 < sampled < 1_000_000 + 64, sampled                               # stopped in the sequence that crossed the threshold, not at the end of the bank
+    a = dump_dataset(out["ref"][0], "/minimizers/minimRepart", "LE"); b = dump_dataset(out["dev"][0], "/minimizers/minimRepart", "LE")
+    assert len(a) > 2 * 4 ** 10 and int(a[:2].copy().view("<u2")[0]) > 1                  # (Repartitor::save: the number of partitions first — several: the table says something)
+    assert np.array_equal(a, b), "minimRepart differs from the unpatched reference's"
+    if freq:
+        assert np.array_equal(dump_dataset(out["ref"][0], "/minimizers/minimFrequency", "LE"), dump_dataset(out["dev"][0], "/minimizers/minimFrequency", "LE"))
+    for ds in ("/histogram/histogram",):
+        assert np.array_equal(dump_dataset(out["ref"][0], ds, "FILE"), dump_dataset(out["dev"][0], ds, "FILE"))
+
+
 UNITIGS = os.path.join(ROOT, "integration", "_build", "unitigs_check")            # GraphUnitigs linked WITH the patched units: counts on the device
 UNITIGS_REF = os.path.join(ROOT, "integration", "_build", "ref", "unitigs_check")  # GraphUnitigs of the unpatched library: the consumer of an .h5
 

@@ -111,7 +111,8 @@ def main():
                     print("#   same distinct / solid counts as the first run: %s" % (counts == ref_counts))
         if mode in ("pipeline", "all"):
             print("# dbgh5 with its DEFAULT flags (MPHF, neighbor Bloom, cascading debloom, branching nodes), same input, -max-memory 5000")
-            print("# %-86s %8s %8s %8s %8s %8s %10s %12s %14s %10s" % ("run", "wall s", "dsk s", "mphf s", "bloom s", "debloom", "branching", "solid", "bloom bits", "cfp nb"))
+            print("# (debloom = fill_debloom_file + finalize_debloom_file + cascading, the reference's own TimeInfo keys)")
+            print("# %-86s %8s %8s %8s %8s %8s %8s %8s %8s %10s %12s %14s %10s" % ("run", "wall s", "dsk s", "mphf s", "bloom s", "debloom", "fill", "finalize", "cascad.", "branching", "solid", "bloom bits", "cfp nb"))
             runs = [] if skip_ref else [("reference (unpatched dbgh5)", os.path.join(REF, "dbgh5"), {})]
             runs += [("patched: counting, MPHF, Bloom, debloom queries on the device (default)", DEV, {}),
                      ("patched: only the counting step on the device (GATB_DEVICE_NO_BLOOM=1 GATB_DEVICE_NO_MPHF=1)", DEV, {"GATB_DEVICE_NO_BLOOM": "1", "GATB_DEVICE_NO_MPHF": "1"})]
@@ -120,7 +121,8 @@ def main():
                 v = run(name, exe, env, [], "5000")
                 if v is None:
                     continue
-                print("  %-86s %8s %8s %8s %8s %8s %10s %12s %14s %10s" % (name, v["_wall"], g(v, "dsk/time"), g(v, "mphf/time"), g(v, "bloom/time"), g(v, "debloom/time"),
+                print("  %-86s %8s %8s %8s %8s %8s %8s %8s %8s %10s %12s %14s %10s" % (name, v["_wall"], g(v, "dsk/time"), g(v, "mphf/time"), g(v, "bloom/time"), g(v, "debloom/time"),
+                                                                     g(v, "debloom/time/fill_debloom_file"), g(v, "debloom/time/finalize_debloom_file"), g(v, "debloom/time/cascading"),
                                                                      g(v, "branching/time/build"), g(v, "dsk/stats/kmers/kmers_nb_solid"), g(v, "bloom/stats/bitsize"), g(v, "debloom/stats/cfp/nb")), flush=True)
                 # (the number of critical false positives is left out of the comparison: in the UNPATCHED reference it moves by one with the partition layout —
                 #  150000 reads, k=31: 291572 with 4 partitions, 291573 with 108 or 324 — and the device-sized Configuration is another layout)
