@@ -1030,7 +1030,8 @@ private:
         // the device and also counts the kx-mers computeDistrib balances on.
         const uint64_t nbSeqSample = std::max<uint64_t>((uint64_t)(nseq * 0.05), 1000000ULL);
         std::vector<uint64_t> nsk(nm, 0), nk(nm, 0), nkx(nm, 0); uint64_t used = 0;
-        check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, 1, (uint32_t)_config._nb_passes, freq.empty() ? GKC_MINIMIZER_LEXI : GKC_MINIMIZER_FREQ, dummy.data(), freq.empty() ? nullptr : freq.data()));
+        // (ONE pass here whatever the run's number: SampleRepart is a Sequence2SuperKmer of 1 pass, :225 — every super-k-mer counts; the passes enter in computeDistrib)
+        check(gkc_configure(_ctx, (uint32_t)_config._kmerSize, (uint32_t)m, 1, 1, freq.empty() ? GKC_MINIMIZER_LEXI : GKC_MINIMIZER_FREQ, dummy.data(), freq.empty() ? nullptr : freq.data()));
         check(gkc_sample_exact(_ctx, bases.data(), offs.data(), nseq, nbSeqSample, nsk.data(), nk.data(), nkx.data(), &used));
         if (_config._minimizerType == 1) rep->justGroup(nk, counts);
         else { rep->computeDistrib(nkx); if (_config._repartitionType == 1) rep->justGroupLexi(nk); }

@@ -80,7 +80,8 @@ int gkc_sample_minimizers(gkc_ctx* ctx, const char* bases, const uint64_t* offse
                           uint64_t* superkmers_per_minim, uint64_t* kmers_per_minim);
 int gkc_count_mmers(gkc_ctx* ctx, uint32_t m, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t* counts);
 /* The EXACT sample of RepartitorAlgorithm::computeRepartition (RepartitionAlgorithm.cpp:395-475): the reads are walked one by one like
- * Sequence2SuperKmer does (no tiles), the sample stops with the read in which the running number of super-k-mers of pass 0 first exceeds
+ * Sequence2SuperKmer does (no tiles), the sample stops with the read in which the running number of super-k-mers of pass 0 (of the context's
+ * nb_passes: the reference's SampleRepart is a ONE-pass Sequence2SuperKmer, :225, so its callers configure 1 pass for the sample) first exceeds
  * max_superkmers (SampleRepart::processSuperkmer :205-212 sets the cancel flag, checked between sequences), and per minimizer value the
  * super-k-mers, k-mers AND kx-mers are counted (:186-203, _kx = 4) — the last being what Repartitor::computeDistrib balances on
  * (PartiInfo.cpp:48-106). Arrays of 4^m u64 (any may be NULL), ACCUMULATED into; *reads_used = reads of the sample. */

@@ -5,8 +5,9 @@
  *                       (at most 5e7, :322) are counted by the MmersFrequency functor (:88-150); the ranking of the counts is the minimizer order of the run;
  *   computeRepartition  (:395-475): SampleRepart (:156-229) splits sequences into super-k-mers until more than max(5 % of the sequences, 1e6) of them have been
  *                       seen and counts super-k-mers, k-mers and kx-mers per minimizer value; justGroup / computeDistrib build the partition table from that.
- * At 10^8 reads of 150 bp that is 7e8 m-mers and 5e6 super-k-mers through scalar code on one core — seconds, beside a counting step of 3-5 s for the whole bank
- * (measured with the unpatched reference: 18 ns per m-mer, i.e. ~13 s of computeFrequencies at that size).
+ * At 10^8 reads of 150 bp that is 7e8 m-mers (4.9e6 sequences) and 4.9e6 super-k-mers (4.6e5 sequences) through scalar code on one core, beside a counting step of
+ * 3-4 s for the whole bank: profiles/r05_repartitor_1e8reads.txt — dbgh5's wall outside the DSK step 3.4 s in frequency mode with the reference's functors, 1.4 s
+ * with the device (0.49 + 0.23 s in the two calls below, most of it the bank iterator); 1.5 -> 0.9 s in the default (lexicographic) mode.
  *
  * Here the sequences of the sample are still read by the reference's own bank iterator (any bank: FASTA, FASTQ, gz, album), packed into flat blocks, and the
  * counting itself is the device's: gkc_count_mmers (the MmersFrequency functor) and gkc_sample_exact (SampleRepart, with the reference's stop rule: the cancel

@@ -2,7 +2,7 @@
 /dev/shm, as the reference's own dbginfo prints them from the .h5 (getInfo() of every algorithm: SortingCountAlgorithm.cpp:770-781, BloomAlgorithm.cpp:188-193,
 MPHFAlgorithm.cpp:268-275, DebloomAlgorithm), plus the process wall.
 
-    python tools/dropin_timing.py [n_reads=10000000] [abundance_min=2] [count|pipeline|all]        -> stdout (kept under profiles/)
+    python tools/dropin_timing.py [n_reads=10000000] [abundance_min=2] [count|pipeline|repart|all]        -> stdout (kept under profiles/)
 
   count      the DSK step alone (-bloom none -debloom none -branching-nodes none -no-mphf): the reference; the patched binary with the device-sized Configuration
              (default) at -max-memory 5000 and 200000; the patched binary with the REFERENCE's Configuration (GATB_DEVICE_REFERENCE_CONFIG=1: 2816 partitions at
@@ -109,6 +109,19 @@ def main():
                     ref_counts = counts
                 else:
                     print("#   same distinct / solid counts as the first run: %s" % (counts == ref_counts))
+        if mode in ("repart", "all"):
+            # RepartitorAlgorithm's serial sampling (RepartitionAlgorithm.cpp:348, :464) inside the patched dbgh5: functors of the reference vs the device (RepartitorDevice.hpp);
+            # -minimizer-type 1 -repartition-type 1 is what GraphUnitigs forces (GraphUnitigs.cpp:861-870): there computeFrequencies walks 5 % of the bank on one core
+            print("# the Repartitor's sampling inside the patched dbgh5 (count-only flags, -max-memory 5000): the reference's serial functors (GATB_DEVICE_NO_REPARTITOR=1) vs the device")
+            print("# %-86s %8s %8s %9s %10s %12s" % ("run", "wall s", "dsk s", "fill_part", "fill_solid", "solid"))
+            freq = ["-minimizer-type", "1", "-repartition-type", "1"]
+            for name, env, flags in (("lexicographic minimizers (default), sampling on the device", {}, []),
+                                     ("lexicographic minimizers (default), the reference's functors", {"GATB_DEVICE_NO_REPARTITOR": "1"}, []),
+                                     ("frequency minimizers (GraphUnitigs' mode), sampling on the device", {}, freq),
+                                     ("frequency minimizers (GraphUnitigs' mode), the reference's functors", {"GATB_DEVICE_NO_REPARTITOR": "1"}, freq)):
+                v = run(name, DEV, env, count_only + flags, "5000")
+                if v is not None:
+                    print("  %-86s %8s %8s %9s %10s %12s" % (name, v["_wall"], g(v, "dsk/time"), g(v, "dsk/time/fill_partitions"), g(v, "dsk/time/fill_solid_kmers"), g(v, "dsk/stats/kmers/kmers_nb_solid")), flush=True)
         if mode in ("pipeline", "all"):
             print("# dbgh5 with its DEFAULT flags (MPHF, neighbor Bloom, cascading debloom, branching nodes), same input, -max-memory 5000")
             print("# (debloom = fill_debloom_file + finalize_debloom_file + cascading, the reference's own TimeInfo keys)")
