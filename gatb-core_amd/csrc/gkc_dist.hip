@@ -489,7 +489,7 @@ int gkc_comm_create_rccl(gkc_ctx* c, const uint8_t id[GKC_COMM_ID_BYTES], int wo
     m->rccl = true;
     // several GPUs: the blocks RCCL sends from / receives into come from hipMalloc as in rounds 1-4 (whether it takes hipMemCreate-mapped ranges as user buffers
     // could not be checked on a one-GPU box; GKC_VMM_WITH_RCCL=1 to try). What the pool already handed out stays valid.
-    if (world > 1 && !(getenv("GKC_VMM_WITH_RCCL") && atoi(getenv("GKC_VMM_WITH_RCCL")) == 1)) { std::lock_guard<std::recursive_mutex> lk(c->pool.mu); c->pool.vmm_ok = false; }
+    if (world > 1 && !(getenv("GKC_VMM_WITH_RCCL") && atoi(getenv("GKC_VMM_WITH_RCCL")) == 1)) { std::lock_guard<std::recursive_mutex> lk(c->pool.mu); c->pool.vmm_ok = false; c->pool.trim(); }      // (parked mapped ranges go: none is handed out as an exchange buffer later)
     return GKC_OK;
 }
 int gkc_comm_create_transport(gkc_ctx* c, const gkc_transport* t, int world, int rank, gkc_comm** out)
@@ -504,7 +504,7 @@ int gkc_comm_enable_ipc(gkc_comm* m, int on)
     if (!m) return GKC_ERR_ARG;
     if (m->rccl) { m->ctx->set_error(GKC_ERR_ARG, "gkc_comm_enable_ipc: an RCCL communicator moves its messages itself"); return GKC_ERR_ARG; }
     m->ipc = on != 0;
-    if (m->ipc) { std::lock_guard<std::recursive_mutex> lk(m->ctx->pool.mu); m->ctx->pool.vmm_ok = false; }      // an IPC handle names a hipMalloc allocation
+    if (m->ipc) { std::lock_guard<std::recursive_mutex> lk(m->ctx->pool.mu); m->ctx->pool.vmm_ok = false; m->ctx->pool.trim(); }      // an IPC handle names a hipMalloc allocation
     return GKC_OK;
 }
 int gkc_comm_create_files(gkc_ctx* c, const char* directory, int world, int rank, gkc_comm** out)
