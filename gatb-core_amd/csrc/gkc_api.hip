@@ -308,6 +308,14 @@ int gkc_set_max_superkmer(gkc_ctx* c, uint32_t maxs)
     return GKC_OK;
 }
 
+int gkc_set_batch_keys(gkc_ctx* c, uint64_t max_keys)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (bg_active(c)) GKC_FAIL(c, GKC_ERR_ARG, "gkc_set_batch_keys while gkc_finish_pass_async is in flight");
+    c->batch_cap = (size_t)max_keys;
+    return GKC_OK;
+}
+
 int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
 {
     if (!c) return GKC_ERR_ARG;

@@ -88,14 +88,23 @@ struct DevPool {
         hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
         VmmBlock B; B.bytes = total;
         size_t off = 0;
+        static const size_t chunk_bytes = getenv("GKC_VMM_CHUNK_MB") ? (size_t)std::max(2, atoi(getenv("GKC_VMM_CHUNK_MB"))) << 20 : VMM_CHUNK;
+        static const bool dbg = getenv("GKC_POOL_DEBUG") != nullptr;
+        double t_create = 0, t_map = 0, t_access = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         while (off < total && e == hipSuccess) {
-            const size_t n = std::min(VMM_CHUNK / vmm_gran * vmm_gran, total - off);
+            const size_t n = std::min(std::max(chunk_bytes / vmm_gran, (size_t)1) * vmm_gran, total - off);
             hipMemGenericAllocationHandle_t h;
+            const auto t0 = now();
             e = hipMemCreate(&h, n, &prop, 0);
+            const auto t1 = now();
             if (e == hipSuccess) { e = hipMemMap((char*)base + off, n, 0, h, 0); if (e != hipSuccess) (void)hipMemRelease(h); }
+            t_create += ms(t0, t1); t_map += ms(t1, now());
             if (e == hipSuccess) { B.handles.push_back(h); B.sizes.push_back(n); off += n; }
         }
-        if (e == hipSuccess) { hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite; e = hipMemSetAccess(base, total, &acc, 1); }
+        if (e == hipSuccess) { const auto t0 = now(); hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite; e = hipMemSetAccess(base, total, &acc, 1); t_access = ms(t0, now()); }
+        if (dbg && t_create + t_map + t_access > 20.0) fprintf(stderr, "[gkc pool] %.2f GB in %zu chunks: hipMemCreate %.1f ms, hipMemMap %.1f ms, hipMemSetAccess %.1f ms\n", (double)total / 1e9, B.handles.size(), t_create, t_map, t_access);
         if (e != hipSuccess) {                                   // (out of memory, mostly: the caller trims the parked blocks and asks again)
             (void)hipGetLastError();
             size_t o = 0; for (size_t i = 0; i < B.handles.size(); i++) { (void)hipMemUnmap((char*)base + o, B.sizes[i]); (void)hipMemRelease(B.handles[i]); o += B.sizes[i]; }
@@ -152,6 +161,11 @@ struct DevPool {
         const double ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         malloc_ms += ms_;
         if (ms_ > 20.0 && getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] %.2f GB took %.1f ms (%s)\n", (double)want / 1e9, ms_, vmm.count(p) ? "mapped chunks" : "hipMalloc");
+        if (getenv("GKC_POOL_TRACE") && want >= ((size_t)256 << 20)) {
+            size_t live_b = 0; for (auto& kv : live) live_b += kv.second;
+            size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
+            fprintf(stderr, "[gkc pool trace] +%.2f GB in %.1f ms; before it: live %.1f GB, parked %.1f GB, device free %.1f of %.1f GB\n", (double)want / 1e9, ms_, (double)live_b / 1e9, (double)cached_bytes / 1e9, (double)fr / 1e9, (double)tot / 1e9);
+        }
         *err = e;
         if (e != hipSuccess) return nullptr;
         live[p] = want;
@@ -264,6 +278,7 @@ struct gkc_ctx {
     DevBuf d_scan_matrix;      // [grid][P] per-workgroup partition bases (u64) + counts (u32) (LDS-counter scan)
     DevBuf d_desc, d_desc_tile; // record descriptors of the count pass, per-tile (offset,count)
     size_t key_budget = 0;     // max keys per Stage-B batch (0 = auto)
+    size_t batch_cap = 0;      // gkc_set_batch_keys: upper bound of the planned batch size (0 = the library's own: few, large batches)
 
     void set_error(int code, const char* fmt, ...) {
         char buf[1024]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);

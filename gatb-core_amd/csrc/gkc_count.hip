@@ -2667,7 +2667,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     // With a host sink (streamed results) the batches are three times smaller: the first records start over PCIe sooner and the copy that is left
     // when the last batch has been counted is shorter (1e8 reads, abundance-min 2: 431 -> ms per step with everything landed; profiles/r02_*)
     const size_t cap_default = c->key_words == 1 ? (size_t)3200000000ULL : (size_t)1600000000ULL;
-    const size_t cap = cap_env ? cap_env : (c->sink ? cap_default / 3 : cap_default);   // the same with one lane or two
+    const size_t cap = cap_env ? cap_env : c->batch_cap ? std::max<size_t>(c->batch_cap, (size_t)1 << 24) : (c->sink ? cap_default / 3 : cap_default);   // the same with one lane or two
     uint64_t done_keys = 0, done_solid = 0;                                  // this pass: finished batches (keys, resident records) (guarded by plan_mu)
     // budget for a given solid-per-key ratio d. Deterministic in (free memory rounded to GB, total keys, d rounded up to 0.05): every
     // pass of a context plans the same sizes, so from the second pass on all blocks are parked already.

@@ -16,7 +16,7 @@ _LIB = None
 
 SYMBOLS = [
     "gkc_create", "gkc_destroy", "gkc_last_error", "gkc_version", "gkc_configure", "gkc_set_solidity",
-    "gkc_set_max_superkmer", "gkc_begin_pass", "gkc_push_reads", "gkc_push_reads_device", "gkc_finish_pass",
+    "gkc_set_max_superkmer", "gkc_set_batch_keys", "gkc_begin_pass", "gkc_push_reads", "gkc_push_reads_device", "gkc_finish_pass",
     "gkc_partition_info", "gkc_partition_counts", "gkc_partition_counts_range", "gkc_partition_counts_device", "gkc_histogram", "gkc_get_stats",
     "gkc_get_timing", "gkc_partition_superkmers", "gkc_segment_count", "gkc_segment_export", "gkc_segment_import",
     "gkc_segments_clear", "gkc_bloom_create", "gkc_bloom_destroy", "gkc_bloom_nbytes", "gkc_bloom_bitsize",
@@ -90,6 +90,7 @@ def lib():
         "gkc_configure": (C.c_int, [vp, u32, u32, u32, u32, C.c_int, vp, vp]),
         "gkc_set_solidity": (C.c_int, [vp, i32, i32, u32]),
         "gkc_set_max_superkmer": (C.c_int, [vp, u32]),
+        "gkc_set_batch_keys": (C.c_int, [vp, u64]),
         "gkc_begin_pass": (C.c_int, [vp, u32]),
         "gkc_push_reads": (C.c_int, [vp, vp, vp, u64]),
         "gkc_push_reads_device": (C.c_int, [vp, vp, vp, u64, u64]),
@@ -301,6 +302,10 @@ class Counter:
 
     def set_max_superkmer(self, maxs):
         self._chk(self.L.gkc_set_max_superkmer(self.h, maxs))
+
+    def set_batch_keys(self, max_keys):
+        """upper bound on the k-mers of one Stage-B batch (0: the library's plan)"""
+        self._chk(self.L.gkc_set_batch_keys(self.h, max_keys))
 
     def begin_pass(self, p=0):
         self._chk(self.L.gkc_begin_pass(self.h, p))

@@ -67,6 +67,15 @@ int gkc_set_solidity(gkc_ctx* ctx, int32_t abundance_min, int32_t abundance_max,
 /* Super-k-mer length cap (Sequence2SuperKmer.hpp:147). 0 = reference default 28 (k<=31) / 60 (k<=63). */
 int gkc_set_max_superkmer(gkc_ctx* ctx, uint32_t maxs);
 
+/* Upper bound on the k-mers of one Stage-B batch (0 = the library's plan). Stage B counts a pass in batches of whole partitions; their size sets the working set
+ * in HBM (about 22 bytes per k-mer of a batch, two batches in flight) and how often the chip drains between batches. The library's own plan is made for a host
+ * that counts pass after pass in one process: few, large batches (3.2e9 k-mers with 8-byte keys: 10^8 reads = 4 batches, 130 GB of working set, every block reused
+ * by the next pass). A host that counts ONE pass per process — dbgh5 — asks for less: 2^30 k-mers per batch cost 8 % of Stage B (157 vs 145 ms at 10^8 reads) and
+ * take 46 GB, and a machine whose memory is handed out slowly the first time (28 ms per GB beyond ~120 GB on a freshly booted MI355X box: profiles/
+ * r05_cold_pass.txt) does not charge the difference to the one pass there is. The reference's counterpart is the memory the partitions of a pass are sized for
+ * (-max-memory, ConfigurationAlgorithm.cpp:398-425). Results do not depend on it. */
+int gkc_set_batch_keys(gkc_ctx* ctx, uint64_t max_keys);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Repartitor sampling — device side of RepartitorAlgorithm (kmer/impl/RepartitionAlgorithm.cpp:287-492). The tables
  * themselves (computeDistrib / justGroup / justGroupLexi, kmer/impl/PartiInfo.cpp:48-218, and the frequency ranking,

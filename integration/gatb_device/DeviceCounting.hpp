@@ -84,6 +84,13 @@ public:
         const u_int64_t nbMinims = (u_int64_t)1 << (2 * config._minim_size);
         std::vector<uint16_t> table (nbMinims);
         for (u_int64_t m = 0; m < nbMinims; m++)  { table[m] = (uint16_t) repartitor (m); }
+        /* one pass per process is what a dbgh5 run is: batches of 2^30 k-mers instead of the library's 3.2e9 (a host that counts pass after pass keeps those) —
+         * a third of Stage B's working set for 8 % of its time; on a freshly booted box, where HBM beyond ~120 GB costs 28 ms per GB the first time it is handed out,
+         * that is 2 s of the one pass there is (profiles/r05_cold_pass.txt). GATB_DEVICE_BATCH_KEYS=<n> sets another bound, 0 the library's plan. */
+        {
+            const char* keys = getenv ("GATB_DEVICE_BATCH_KEYS");
+            check (gkc_set_batch_keys (_ctx, keys != 0 ? (uint64_t) strtoull (keys, 0, 10) : ((uint64_t)1 << 30)));
+        }
         if (plan.on)  { check (gkc_set_solidity (_ctx, plan.abundanceMin, plan.abundanceMax, plan.histoMax)); }
         else          { check (gkc_set_solidity (_ctx, 1, 2147483647, 10000)); }      /* the histogram and the filter are the chain's job */
         check (gkc_configure (_ctx, (uint32_t) config._kmerSize, (uint32_t) config._minim_size, (uint32_t) config._nb_partitions, (uint32_t) config._nb_passes,
