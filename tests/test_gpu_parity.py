@@ -451,6 +451,31 @@ def test_size_independent_properties(gkc, k, n, parts, profile):
     c.device_free(db); c.device_free(do)
 
 
+@pytest.mark.parametrize("k,n,parts,profile,batch_keys", [(31, 100_000_000, 4096, 0, 1 << 30), (31, 40_000_000, 1024, 1, 1 << 26), (63, 30_000_000, 2048, 0, 1 << 24)])
+def test_batch_keys_do_not_change_the_count(gkc, k, n, parts, profile, batch_keys):
+    """gkc_set_batch_keys (what the drop-in asks for: 2^30 k-mers per Stage-B batch, a third of the library's working set; down to 2^24 here: dozens of batches per lane):
+    the records are the count of the input whatever the batches were — multiset checksum against the independent kernel, and every sampled partition byte for byte what
+    the library's own plan produced."""
+    c = gkc.Counter(0)
+    L, m = 150, 10
+    c.configure(k, m, parts, simple_repart(m, parts))
+    db, do = c.synth_reads_device(5, n, L, n * 5, 10000, profile=profile)
+    cs, nv = c.kmer_checksum_device(db, do, n, n * L)
+    sample = list(range(0, parts, max(1, parts // 16)))
+    c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+    assert c.result_checksum() == (cs, nv)
+    ref = [c.partition_records(0, p).copy() for p in sample]
+    hist = c.histogram().copy()
+    c.set_batch_keys(batch_keys)
+    c.begin_pass(0); c.push_reads_device(db, do, n, n * L); c.finish_pass()
+    assert c.result_checksum() == (cs, nv)
+    for p, r in zip(sample, ref):
+        assert np.array_equal(c.partition_records(0, p), r), "partition %d differs with batches of %d k-mers" % (p, batch_keys)
+    assert np.array_equal(c.histogram(), hist)
+    c.set_batch_keys(0)
+    c.device_free(db); c.device_free(do)
+
+
 def test_share_of_8_path_at_full_size(gkc):
     """BASELINE configs[2]'s per-GPU share exactly as bench.py's `share_of_8` block runs it (that path had no correctness check anywhere): k=31,
     1.25e8 reads in FOUR pushes, 32768 partitions (two-level Stage A: 4096 groups of 8), every push followed by gkc_exchange through a one-rank RCCL communicator
