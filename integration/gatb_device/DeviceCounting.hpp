@@ -31,6 +31,7 @@
 #include <vector>
 #include <mutex>
 #include <condition_variable>
+#include <functional>
 #include <deque>
 #include <list>
 #include <atomic>
@@ -370,7 +371,7 @@ public:
     void finishPass (size_t pass)
     {
         _finishWall = wallNow();
-        if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  _stageBPending = true;  return; }
+        if (_comm == 0)  { check (gkc_finish_pass_async (_ctx));  _stageBPending = true;  startPreparer (pass);  return; }
         check (gkc_finish_pass (_ctx));
         check (gkc_gather_results (_ctx, _comm, 0));
     }
@@ -381,6 +382,7 @@ public:
         /* (fillSolidKmers_aux runs once per processor of the run — two with -abundance-min auto, SortingCountAlgorithm.cpp:1388-1393 — over the same device results:
          *  Stage B is joined by the first) */
         if (_comm == 0  &&  _stageBPending)  { _stageBPending = false;  check (gkc_finish_pass_wait (_ctx)); }
+        joinPreparer();
         if (hasRing())  { drainWriter(); }                                /* every Count[] of the pass is in the file */
         if (pass + 1 == nbPasses)  { freeRing(); }
         if (pass + 1 == nbPasses  &&  nbPasses == 1  &&  _plan.on  &&  (_comm == 0  ||  _rank == 0))
@@ -479,10 +481,41 @@ public:
         _ring = 0;  _ringFree.clear();  _paths.clear();
     }
 
+    /** The datasets of a pass made AHEAD of the partition commands, by one thread. Every command used to replace its partition's dataset itself
+     *  (SolidSinkDirect::prepare: H5Ldelete + H5Dcreate2 + H5Dget_offset under the storage's lock): 26 us alone, but with the 256 commands of a group
+     *  arriving at the lock together ~0.4-0.6 ms each — at 3884 partitions more than the 1.5 s the writer needs for the records, and the writer starved
+     *  (fill_solid_kmers 2.3-2.5 s against 1.84 s with 2816 partitions and the same bytes: profiles/r05_dropin_timing_1e8reads.txt). Now one thread follows Stage B
+     *  partition by partition (gkc_wait_partition), makes the dataset, publishes {address, path}; a command only waits for its entry.
+     *  `fn` comes from PartitionsByDeviceCommand<span>::bulkPlan (it knows the Count type and the Partition). GATB_DEVICE_NO_PREPARER=1: the commands prepare. */
+    typedef std::function<bool (size_t part, size_t pass, uint64_t nbItems, uint64_t& address, std::string& path)> PrepareFn;
+    void setPreparer (const PrepareFn& fn)  { joinPreparer();  _prepareFn = fn; }
+    void startPreparer (size_t pass)
+    {
+        joinPreparer();
+        if (!_plan.on  ||  !hasRing()  ||  !_prepareFn  ||  getenv ("GATB_DEVICE_NO_PREPARER") != 0)  { return; }
+        { std::lock_guard<std::mutex> guard (_prepLock);  _prepared.assign (_nbPartitions, Prepared());  _prepError.clear();  _prepActive = true; }
+        _preparer = std::thread ([this, pass] { preparerLoop (pass); });
+    }
+    void joinPreparer ()
+    {
+        if (_preparer.joinable())  { _preparer.join(); }
+        std::lock_guard<std::mutex> guard (_prepLock);  _prepActive = false;
+    }
+    bool preparerActive ()  { std::lock_guard<std::mutex> guard (_prepLock);  return _prepActive; }
+    /** the entry of a partition: true = its dataset exists at its final size, the records go to `address` of `path`; false = not a direct-sink collection */
+    bool waitPrepared (size_t part, uint64_t& address, std::string& path)
+    {
+        std::unique_lock<std::mutex> lk (_prepLock);
+        _prepCv.wait (lk, [this, part] { return !_prepError.empty()  ||  _prepared[part].state != 0; });
+        if (_prepared[part].state == 0)  { throw system::Exception ("%s", _prepError.c_str()); }
+        address = _prepared[part].address;  path = _prepared[part].path;
+        return _prepared[part].state == 1;
+    }
+
     /** called by every partition command: seconds it waited for Stage B / spent handing its records over */
     void addCommandTimes (double waitS, double handOverS)  { std::lock_guard<std::mutex> guard (_timesLock);  _waitS += waitS;  _handOverS += handOverS; }
 
-    ~DeviceSession ()  { freeRing();  for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); } }      /* (the context is the process's: DeviceContext) */
+    ~DeviceSession ()  { if (_preparer.joinable()) { _preparer.join(); }  freeRing();  for (int i = 0; i < 2; i++) { if (_text[i]) { free (_text[i]); } }  if (_comm) { gkc_comm_destroy (_comm); } }      /* (the context is the process's: DeviceContext) */
 
 private:
     DeviceSession () : _ctx(0), _comm(0), _ranks(1), _rank(0), _nbExchanges(1), _exchangesDone(0), _readsPerExchange(1), _pushedReads(0), _nbPartitions(0) {}
@@ -539,6 +572,30 @@ private:
         }
         if (fd >= 0)  { ::close (fd); }
     }
+    struct Prepared  { int state;  uint64_t address;  std::string path;  Prepared () : state(0), address(0) {} };      /* state 0: not yet, 1: direct, 2: the collection's own insert */
+    void preparerLoop (size_t pass)
+    {
+        std::string error;
+        try
+        {
+            for (size_t p = 0; p < _nbPartitions; p++)
+            {
+                const void* landed = 0;  uint64_t nbSolid = 0;
+                check (gkc_wait_partition (_ctx, (uint32_t) pass, (uint32_t) p, &landed, &nbSolid));
+                Prepared e;  e.state = 2;
+                if (landed == 0  &&  nbSolid > 0  &&  _prepareFn (p, pass, nbSolid, e.address, e.path))  { e.state = 1; }
+                { std::lock_guard<std::mutex> guard (_prepLock);  _prepared[p] = e; }
+                _prepCv.notify_all();
+            }
+        }
+        catch (system::Exception& e)  { error = e.getMessage(); }
+        catch (std::exception& e)     { error = e.what(); }
+        if (!error.empty())  { { std::lock_guard<std::mutex> guard (_prepLock);  _prepError = "device sink (dataset preparation): " + error; }  _prepCv.notify_all(); }
+    }
+    std::mutex _prepLock;  std::condition_variable _prepCv;
+    std::vector<Prepared> _prepared;  std::string _prepError;  bool _prepActive = false;
+    PrepareFn  _prepareFn;
+    std::thread _preparer;
     std::mutex _ringLock;  std::condition_variable _ringCv, _jobCv, _idleCv;
     void*     _ring = 0;
     std::vector<void*> _ringFree;
@@ -645,6 +702,15 @@ public:
         if (histo == 0  ||  solid == 0  ||  dump == 0  ||  histo->getHistogram() == 0)  { return plan; }
         plan.on = true;
         if (dump->getSolidCounts() != 0)  { SolidSinkDirect<Count>::closeHandles (*dump->getSolidCounts()); }      /* (what the direct sink needs of the partition before the commands run) */
+        {
+            tools::storage::impl::Partition<Count>* solids = dump->getSolidCounts();
+            const size_t nbPartitions = config._nb_partitions;  const size_t recBytes = config._kmerSize <= 31 ? 16 : 32;
+            if (solids != 0  &&  sizeof(Count) == recBytes)
+                DeviceSession::singleton().setPreparer ([solids, nbPartitions] (size_t part, size_t pass, uint64_t n, uint64_t& address, std::string& path)
+                    { return SolidSinkDirect<Count>::prepare ((*solids) [part + pass * nbPartitions], (size_t) n, address, path); });
+            else
+                DeviceSession::singleton().setPreparer (DeviceSession::PrepareFn());
+        }
         plan.abundanceMin = (int32_t) config._abundance[0].getBegin();
         plan.abundanceMax = (int32_t) config._abundance[0].getEnd();
         plan.histoMax     = (uint32_t) histo->getHistogram()->getLength();
@@ -712,7 +778,10 @@ public:
         if (bulk  &&  landed == 0  &&  nbSolid > 0  &&  sizeof(Count) == recBytes  &&  dev.hasRing())
         {
             uint64_t address = 0;  std::string path;
-            if (SolidSinkDirect<Count>::prepare ((*dump->getSolidCounts()) [actualPartId], (size_t) nbSolid, address, path))
+            /* (the dataset: made ahead by the session's preparer thread, else here) */
+            const bool direct = dev.preparerActive() ? dev.waitPrepared (this->_parti_num, address, path)
+                                                     : SolidSinkDirect<Count>::prepare ((*dump->getSolidCounts()) [actualPartId], (size_t) nbSolid, address, path);
+            if (direct)
             {
                 const uint64_t per = (uint64_t) DeviceSession::SLOT_BYTES / recBytes;
                 for (uint64_t first = 0; first < nbSolid; first += per)
