@@ -176,10 +176,11 @@ def test_bank_statistics_of_the_text_path(tmp_path):
 
 
 @needs_artefacts
-def test_a_bank_of_two_files_goes_to_the_device_as_text(tmp_path):
+@pytest.mark.parametrize("tag", ["k21_default_parts", "k21_freq_4parts"])
+def test_a_bank_of_two_files_goes_to_the_device_as_text(tmp_path, tag):
     """-in a.fa,b.fa is a BankComposite of two BankFasta (Bank::open): DeviceSession::plainTextFiles walks it and both files are parsed on the device, one after
-    the other; the datasets are those of the one-file run (the reads are the same, cut at a record start)"""
-    tag = "k21_default_parts"
+    the other; the datasets are those of the one-file run (the reads are the same, cut at a record start). The Repartitor of a composite bank: the m-mer frequencies
+    (frequency order) are counted on the device over the composite's iterator, the per-bank SampleRepart loop (RepartitionAlgorithm.cpp:405-438) stays the reference's."""
     z, k, m, nbpart, table, parts = load(os.path.join(ROOT, "tests", "golden", "reference_run", tag + ".npz"))
     text = bytes(z["fasta"])
     cut = text.index(b"\n>", len(text) // 2) + 1
@@ -192,6 +193,11 @@ def test_a_bank_of_two_files_goes_to_the_device_as_text(tmp_path):
     r = subprocess.run(cmd, env=dict(os.environ, GATB_DEVICE_VERBOSE="1", GATB_DEVICE_REFERENCE_CONFIG="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     check_h5(out + ".h5", tag)
+    log = r.stdout + r.stderr
+    assert "gkc_sample_exact" not in log, log[-2000:]
+    assert ("gkc_count_mmers" in log) == (tag == "k21_freq_4parts"), log[-2000:]
+    if tag == "k21_freq_4parts":
+        assert np.array_equal(dump_dataset(out + ".h5", "/minimizers/minimFrequency", "LE"), z["minimFrequency"])
 
 
 def h5_attr(h5, path):
