@@ -346,6 +346,29 @@ def host_landed_leg(c, gkc, step, sync, distinct, n_steps=5, n_steps_amin2=5, ex
     return out
 
 
+def bind_to_gpu_numa_node(torch, local):
+    """Several ranks on one host: this process (and with it the page-locked sink it allocates and the library's unpack threads, which follow the sink's node) goes to the
+    NUMA node its GPU hangs on — 8 ranks left where the launcher put them tend to land on one socket and share ITS memory controllers for 8 x 100 GB per step.
+    Returns a note for the line, or None when the topology cannot be read (nothing is changed then)."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return "rank bound to NUMA node %d of GPU %s (%d cores)" % (node, bdf, len(cpus))
+    except Exception:      # noqa
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +411,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
+    numa_note = bind_to_gpu_numa_node(torch, local) if (world > 1 or os.environ.get("GKC_BENCH_NUMA_BIND") == "1") and os.environ.get("GKC_BENCH_NO_NUMA_BIND") is None else None
     red_dev = "cuda" if (not use_dist or dist.get_backend() == "nccl") else "cpu"      # where the few scalars of the line are all-reduced
     gkc = ge.load().gkc
     if not os.path.exists(gkc.SO):
@@ -709,6 +733,8 @@ def main():
                                "transport": ("RCCL grouped ncclSend/ncclRecv inside libgkc_hip.so (gkc_exchange), %d pushes per pass" % n_push) if kind == "rccl" and red_dev == "cuda" else
                                ("%s%s; %d pushes per pass" % ("DRY RUN (GKC_BENCH_BACKEND=%s, the ranks share %d device(s)): " % (dist.get_backend(), torch.cuda.device_count()) if red_dev != "cuda" else "", kind, n_push)),
                                "per_rank": exch}
+            if numa_note:
+                out["exchange"]["host_placement"] = numa_note + " (rank 0; every rank does the same for its own GPU)"
         if landed is not None:
             out["value_host_landed"] = value                   # (name kept from round 4: now the same number as `value`)
             all_verified.append(landed["sink_ok"])
