@@ -157,6 +157,9 @@ __device__ __forceinline__ void for_each_kmer32(const uint64_t (&R)[4], uint32_t
 // complement). Those are decided by the TOP 64 bits of the two (the first 32 nt of the k-mer / the reverse complement of its last 32):
 // when the top words tie, both give the same sub-bucket. So the walk keeps two 64-bit words only: one funnel shift for the forward
 // top word, a rolling reverse complement of the last 32 nt. calls f(sub-bucket) for every k-mer of the record (32 <= k <= 63).
+#ifndef GKC_SUB32_WORDS
+#define GKC_SUB32_WORDS 1
+#endif
 template <class F>
 __device__ __forceinline__ void for_each_sub32(const uint64_t (&R)[4], uint32_t k, uint32_t bits, F f)
 {
@@ -168,6 +171,35 @@ __device__ __forceinline__ void for_each_sub32(const uint64_t (&R)[4], uint32_t 
     const u128 rv0 = revcomp128(((u128)fh << 64) | fl, k);
     const uint64_t rh = (uint64_t)(rv0 >> 64), rl = (uint64_t)rv0;
     uint64_t rtop = down == 64 ? rl : (rh << down) | (rl >> (64 - down));
+#if GKC_SUB32_WORDS
+    // The same walk on 32-bit words (round 5): the sub-bucket is at most 14 bits, so the top THIRTY-TWO bits of the two strands decide it just as well (a tie there leaves the
+    // top 14 bits equal either way), and the loop counter is the same in every lane: with the record's string as eight 32-bit words W[] and a copy T[] of it moved up by 2k bits
+    // once per record (nucleotide i + k of the string = nucleotide i of T), k-mer i reads fixed words at fixed shifts once the 16 steps of a word are unrolled —
+    // one v_alignbit for the forward top word, one v_bfe for the nucleotide that enters, a shift-or for the rolling reverse complement, v_min, a shift:
+    // ~8 VALU per k-mer against ~30 of the 64-bit form below (five 64-bit shifts, two 4-way word selects, a 64-bit compare).
+    const uint32_t W[9] = { (uint32_t)(S0 >> 32), (uint32_t)S0, (uint32_t)(S1 >> 32), (uint32_t)S1, (uint32_t)(S2 >> 32), (uint32_t)S2, (uint32_t)(S3 >> 32), (uint32_t)S3, 0u };
+    const uint32_t kw = (2 * k) >> 5, kb = (2 * k) & 31;                      // k in [32, 63]: kw = 2 or 3 (wave-uniform)
+    uint32_t T[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t hi = kw == 2 ? W[j + 2] : W[j + 3], lo = kw == 2 ? W[j + 3] : W[j + 4];
+        T[j] = kb ? __builtin_amdgcn_alignbit(hi, lo, 32 - kb) : hi;
+    }
+    uint32_t r32 = (uint32_t)(rtop >> 32);
+    const uint32_t sh32 = 32 - bits;
+    for (uint32_t a = 0; a < 4; a++) {                                        // (a: wave-uniform; the words of this round picked once)
+        const uint32_t w0 = a == 0 ? W[0] : (a == 1 ? W[1] : (a == 2 ? W[2] : W[3])), w1 = a == 0 ? W[1] : (a == 1 ? W[2] : (a == 2 ? W[3] : W[4]));
+        const uint32_t ta = a == 0 ? T[0] : (a == 1 ? T[1] : (a == 2 ? T[2] : T[3]));
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (16 * a + q >= nbk) return;
+            const uint32_t f32 = q ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * q) : w0;
+            const uint32_t m32 = f32 < r32 ? f32 : r32;
+            f(bits ? m32 >> sh32 : 0u);
+            r32 = (r32 >> 2) | ((((ta >> (30 - 2 * q)) & 3u) ^ 2u) << 30);    // nucleotide i + k enters the next k-mer at the right
+        }
+    }
+#else
     const uint32_t idx_sh = 64 - bits;
     for (uint32_t i = 0; i < nbk; i++) {
         const uint32_t s = 2 * i, t = s & 63;
@@ -180,6 +212,7 @@ __device__ __forceinline__ void for_each_sub32(const uint64_t (&R)[4], uint32_t 
         const uint64_t W = w == 0 ? S0 : (w == 1 ? S1 : (w == 2 ? S2 : S3));
         rtop = (rtop >> 2) | ((((W >> sh) & 3ull) ^ 2ull) << 62);
     }
+#endif
 }
 // record width -> fastest k-mer walk (the generic per-nucleotide for_each_kmer stays as the reference restatement for other widths)
 template <int KW, int RW, class F>
