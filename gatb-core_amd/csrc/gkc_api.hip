@@ -162,6 +162,7 @@ const char* gkc_version(void) { return "gkc-hip 0.1 (gfx950)"; }
 
 int gkc_create(int device, gkc_ctx** out)
 {
+    gkc_tun_refresh();
     if (!out) return GKC_ERR_ARG;
     *out = nullptr;
     int n = 0;
@@ -244,7 +245,7 @@ int gkc_configure(gkc_ctx* c, uint32_t k, uint32_t m, uint32_t nb_partitions, ui
     GKC_TRY(c->ensure(c->d_repart, nm * 2));
     GKC_HIP(c, hipMemcpy(c->d_repart.p, repart, nm * 2, hipMemcpyHostToDevice));
     {   // two-level Stage A above SCAN_COARSE_MAX partitions: groups of 2^coarse_shift consecutive partitions
-        const uint32_t cmax = getenv("GKC_SCAN_COARSE_MAX") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCAN_COARSE_MAX"))) : SCAN_COARSE_MAX;
+        const uint32_t cmax = gkc_tun().scan_coarse_max;
         c->coarse_shift = 0;
         while (((nb_partitions - 1) >> c->coarse_shift) + 1 > cmax) c->coarse_shift++;
         if (c->coarse_shift) {
@@ -318,6 +319,7 @@ int gkc_set_batch_keys(gkc_ctx* c, uint64_t max_keys)
 
 int gkc_begin_pass(gkc_ctx* c, uint32_t pass)
 {
+    gkc_tun_refresh();
     if (!c) return GKC_ERR_ARG;
     if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "gkc_configure must be called first");
     if (pass >= c->nb_passes) GKC_FAIL(c, GKC_ERR_ARG, "pass %u >= nb_passes %u", pass, c->nb_passes);
@@ -361,7 +363,7 @@ int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_off
     // push of 2e8 reads (3e10 bases) are 23 + 20 + 20 GB of fresh hipMallocs beside 100+ GB of parked blocks of other sizes — 2.6 s per step (DESIGN r3 §14). A push beyond
     // PUSH_SPLIT_BASES is therefore scanned in slices of about that many bases, cut at a read whose first base is 16-byte aligned (the scan loads 16 bytes at a time): every
     // slice is a segment of its own, and the slices ask the allocator for the same blocks one after the other. Same records, same counts (a read is never cut).
-    static const uint64_t PUSH_SPLIT_BASES = getenv("GKC_PUSH_SPLIT") ? (uint64_t)std::max<long long>(1024, atoll(getenv("GKC_PUSH_SPLIT"))) : 16000000000ull;
+    const uint64_t PUSH_SPLIT_BASES = gkc_tun().push_split;
     if (n_bases <= PUSH_SPLIT_BASES + PUSH_SPLIT_BASES / 4 || n_reads < 2) return gkc_scan_push(c, d_bases, d_offsets, n_reads, n_bases);
     auto off_at = [&](uint64_t r, uint64_t* v) -> int { GKC_HIP(c, hipMemcpy(v, d_offsets + r, 8, hipMemcpyDeviceToHost)); return GKC_OK; };
     DevBuf d_off;
@@ -398,7 +400,7 @@ int gkc_push_reads_device(gkc_ctx* c, const char* d_bases, const uint64_t* d_off
 // (copy stream, DMA engine) runs while Stage A scans chunk j, so a push costs max(PCIe, scan) instead of their sum. Page-locked caller
 // memory (gkc_host_alloc) makes the copies truly asynchronous; pageable memory works at the driver's staging rate. Each chunk is one
 // segment of the pass. The call returns when the caller's buffers have been read completely.
-static const uint64_t PUSH_CHUNK_BASES = getenv("GKC_PUSH_CHUNK") ? (uint64_t)std::max<long long>(64, atoll(getenv("GKC_PUSH_CHUNK"))) : (1ull << 30);   // GKC_PUSH_CHUNK: tests force many small chunks
+#define PUSH_CHUNK_BASES (gkc_tun().push_chunk)      /* 1 GiB; GKC_PUSH_CHUNK: tests force many small chunks */
 int gkc_push_reads(gkc_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads)
 {
     if (!c) return GKC_ERR_ARG;
@@ -512,7 +514,7 @@ static int finish_pass_body(gkc_ctx* c, bool detached)
     (void)hipSetDevice(c->device);
     int rc;
     if (detached) {
-        gkc_tl_stream = c->bg_stream;                                    // everything this thread launches, times or frees goes to the background stream
+        tl_stream_ = c->bg_stream;                                    // everything this thread launches, times or frees goes to the background stream
         for (hipEvent_t e : c->b_pending) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }      // multi-GPU: the records other ranks sent must have arrived
         c->b_pending.clear();
         double reserve = 0;                                              // what Stage A of the next pass may allocate beside this Stage B: as much as this pass's records took
@@ -520,7 +522,7 @@ static int finish_pass_body(gkc_ctx* c, bool detached)
         {   ScopedTimer tm(c, "total_stage_b");
             rc = gkc_count_pass(c, c->b_pass, c->b_segments, c->bg_stream, reserve);
         }
-        gkc_tl_stream = nullptr;
+        tl_stream_ = nullptr;
     } else {
         c->drain_pending();                                              // multi-GPU: the records other ranks sent must have arrived
         ScopedTimer tm(c, "total_stage_b");
@@ -533,6 +535,7 @@ static int finish_pass_body(gkc_ctx* c, bool detached)
 }
 int gkc_finish_pass(gkc_ctx* c)
 {
+    gkc_tun_refresh();
     if (!c) return GKC_ERR_ARG;
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
     GKC_HIP(c, hipSetDevice(c->device));
@@ -544,6 +547,7 @@ int gkc_finish_pass(gkc_ctx* c)
 }
 int gkc_finish_pass_async(gkc_ctx* c)
 {
+    gkc_tun_refresh();
     if (!c) return GKC_ERR_ARG;
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "no pass in progress");
     if (bg_active(c) && !bg_overlap_ok(c)) GKC_FAIL(c, GKC_ERR_ARG, "gkc_finish_pass_async is already in flight");
@@ -572,6 +576,7 @@ int gkc_finish_pass_wait(gkc_ctx* c)
 }
 int gkc_set_host_sink(gkc_ctx* c, void* pinned, uint64_t cap_bytes)
 {
+    gkc_tun_refresh();
     if (!c) return GKC_ERR_ARG;
     if (c->stage_b_running) GKC_FAIL(c, GKC_ERR_ARG, "Stage B is running");
     GKC_HIP(c, hipSetDevice(c->device));

@@ -356,6 +356,7 @@ extern "C" {
 
 int gkc_bloom_create(gkc_ctx* c, int kind, uint64_t tai_bits, uint32_t nb_hash, uint32_t k, gkc_bloom** out)
 {
+    gkc_tun_refresh();
     if (!c || !out) return GKC_ERR_ARG;
     if (kind < 0 || kind > 2) GKC_FAIL(c, GKC_ERR_ARG, "bloom kind must be 0 (basic), 1 (cache) or 2 (neighbor)");
     if (nb_hash < 1 || nb_hash > 10) GKC_FAIL(c, GKC_ERR_ARG, "nb_hash must be in [1,10] (HashFunctors holds 10 seeds, Bloom.hpp:94)");
@@ -415,7 +416,7 @@ static int bloom_insert_arrays(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, 
     const uint64_t n_bits = b->tai + 1;
     const uint32_t n_regions = (uint32_t)std::min<uint64_t>((n_bits + (1u << BR_BITS) - 1) >> BR_BITS, 0xffffffffu);
     const uint64_t n_virtual = b->kind == 0 ? total * b->nb_hash : total;        // basic: one bucketed entry per position
-    const bool regions = n_regions <= BR_MAX_REGIONS && n_virtual < (1ULL << 32) && n_segs <= 16 && getenv("GKC_BLOOM_ATOMIC") == nullptr;
+    const bool regions = n_regions <= BR_MAX_REGIONS && n_virtual < (1ULL << 32) && n_segs <= 16 && !gkc_tun().bloom_atomic;
     if (!regions) {
         for (uint32_t i = 0; i < n_segs; i++) if (segs[i].n) {
             const unsigned grid = (unsigned)std::min<uint64_t>((segs[i].n + 255) / 256, 256 * 16);
@@ -467,6 +468,7 @@ static int bloom_insert_arrays(gkc_bloom* b, const BSeg* segs, uint32_t n_segs, 
 
 int gkc_bloom_insert_device(gkc_bloom* b, const void* d_keys, uint64_t n, uint32_t stride)
 {
+    gkc_tun_refresh();
     if (!b) return GKC_ERR_ARG;
     GKC_TRY(check_stride(b, stride));
     if (!n) return GKC_OK;
@@ -475,6 +477,7 @@ int gkc_bloom_insert_device(gkc_bloom* b, const void* d_keys, uint64_t n, uint32
 }
 int gkc_bloom_insert(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride)
 {
+    gkc_tun_refresh();
     if (!b) return GKC_ERR_ARG;
     gkc_ctx* c = b->ctx;
     GKC_TRY(check_stride(b, stride));
@@ -489,6 +492,7 @@ int gkc_bloom_insert(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride
 }
 int gkc_bloom_insert_solid(gkc_bloom* b, gkc_ctx* c)
 {
+    gkc_tun_refresh();
     if (!b || !c) return GKC_ERR_ARG;
     if (c->k != b->k) GKC_FAIL(c, GKC_ERR_ARG, "bloom k (%u) differs from the context's k (%u)", b->k, c->k);
     GKC_TRY(gkc_require_resident(c, "gkc_bloom_insert_solid"));
@@ -513,8 +517,8 @@ static int bloom_contains8_regions(gkc_bloom* b, const BSeg* segs, uint32_t n_se
     uint64_t total = 0; for (uint32_t i = 0; i < n_segs; i++) total += segs[i].n;
     const uint64_t n_bits = b->tai + 1;
     const uint32_t n_regions = (uint32_t)std::min<uint64_t>((n_bits + (1u << BR_BITS) - 1) >> BR_BITS, 0xffffffffu);
-    const uint64_t min_items = getenv("GKC_BLOOM_QUERY_REGIONS_MIN") ? (uint64_t)atoll(getenv("GKC_BLOOM_QUERY_REGIONS_MIN")) : 2000000ull;      // (tests lower it: the bucketing passes do not pay for a few k-mers)
-    if (!total || total < min_items || n_regions > BR_MAX_REGIONS || total >= (1ULL << 31) || n_segs > 16 || b->kind != 2 || getenv("GKC_BLOOM_GATHER") != nullptr) return GKC_OK;
+    const uint64_t min_items = gkc_tun().bloom_query_regions_min;      // (tests lower it: the bucketing passes do not pay for a few k-mers)
+    if (!total || total < min_items || n_regions > BR_MAX_REGIONS || total >= (1ULL << 31) || n_segs > 16 || b->kind != 2 || gkc_tun().bloom_gather) return GKC_OK;
     BSegTable T{}; T.n = n_segs; T.stride = stride; T.total = total;
     { uint64_t first = 0; for (uint32_t i = 0; i < n_segs; i++) { T.s[i] = segs[i]; T.s[i].first = first; first += segs[i].n; } }
     const uint32_t n_wgs = (uint32_t)std::min<uint64_t>(BR_WGS, (total + BR_THREADS - 1) / BR_THREADS);
@@ -545,6 +549,7 @@ static int bloom_contains8_regions(gkc_bloom* b, const BSeg* segs, uint32_t n_se
 }
 static int bloom_query(gkc_bloom* b, const void* keys, uint64_t n, uint32_t stride, uint8_t* out, bool c8)
 {
+    gkc_tun_refresh();
     if (!b) return GKC_ERR_ARG;
     gkc_ctx* c = b->ctx;
     GKC_TRY(check_stride(b, stride));
@@ -580,6 +585,7 @@ __global__ void k_sum_bits8(const uint8_t* __restrict__ a, uint64_t n, unsigned 
 }
 int gkc_bloom_query_solid(gkc_bloom* b, gkc_ctx* c, int neighbors8, uint8_t* d_out, uint64_t* n_queried, uint64_t* n_positive)
 {
+    gkc_tun_refresh();
     if (!b || !c) return GKC_ERR_ARG;
     if (c->k != b->k) GKC_FAIL(c, GKC_ERR_ARG, "bloom k (%u) differs from the context's k (%u)", b->k, c->k);
     if (neighbors8 && b->kind != 2) GKC_FAIL(c, GKC_ERR_ARG, "contains8 is implemented by the neighbor kind only (Bloom.hpp:245-250 throws ExceptionNotImplemented)");

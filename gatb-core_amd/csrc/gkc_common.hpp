@@ -14,6 +14,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <thread>
+#include <algorithm>
 #include "../../include/gkc.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -48,9 +49,49 @@ constexpr int MAX_SUB = 1 << MAX_SUB_BITS;                     // LDS histogram 
 constexpr int SUB_TARGET = 512;                                // mean keys per level-1 bucket: a wave sorts <= 1024 / 512 straight from HBM (<= 2048 / 1024 in
                                                                // the double-size tier), a workgroup <= 4096 / 2048, larger buckets are split in HBM
 
+// ------------------------------------------------------------------------------------------------ developer / test switches
+// Every environment variable the library looks at, in ONE place. None selects a CPU path (there is none): they pick between HIP code paths so that test-size inputs reach
+// the tiers real inputs reach (split levels, slices, region builds, wire widths ...), or print diagnostics. Read into a process-wide snapshot by gkc_tun_refresh(): at
+// gkc_create, at the start of a pass and at the creation / entry points of the Bloom, MPHF and communicator objects — never inside a kernel-launch loop.
+struct GkcTun {
+    // Stage A
+    uint32_t scan_coarse_max; uint64_t push_split, push_chunk; bool scan_global_atomics, refine_recompute, scan_no_desc;
+    // Stage B
+    int weight_bits, dedupe, max_sub_bits, lanes; uint64_t slice_min, batch_keys; bool slices, batch_lpt, no_f64; uint32_t wg_max, scatter_wgs, deep_bits, sink_first_div;
+    // result sink
+    bool sink_packed, sink_packed2, sink_width6, sink_debug; uint64_t sink_dense; int unpack_threads;
+    // Bloom / MPHF
+    bool bloom_atomic, bloom_gather, mphf_regions, mphf_ordered; uint64_t bloom_query_regions_min, mphf_regions_min;
+    // allocator, communicators, diagnostics
+    int vmm; uint32_t vmm_chunk_mb, vmm_min_mb; bool vmm_with_rccl, pool_debug, pool_trace, verbose; double filebox_timeout; char fault[32];       // (plain data: concurrent refreshes of equal values are harmless)
+    static const char* raw(const char* name) { return getenv(name); }
+    static long long num(const char* name, long long dflt) { const char* e = raw(name); return e && *e ? atoll(e) : dflt; }
+    static bool on(const char* name) { return raw(name) != nullptr; }                       // set (to anything) = on
+    static bool not0(const char* name) { const char* e = raw(name); return !(e && atoi(e) == 0); }      // on unless set to 0
+    void read() {
+        scan_coarse_max = (uint32_t)std::max<long long>(1, num("GKC_SCAN_COARSE_MAX", SCAN_COARSE_MAX));
+        push_split = (uint64_t)std::max<long long>(1024, num("GKC_PUSH_SPLIT", 16000000000ll)); push_chunk = (uint64_t)std::max<long long>(64, num("GKC_PUSH_CHUNK", 1ll << 30));
+        scan_global_atomics = on("GKC_SCAN_GLOBAL_ATOMICS"); refine_recompute = on("GKC_REFINE_RECOMPUTE"); scan_no_desc = on("GKC_SCAN_NO_DESC");
+        weight_bits = (int)num("GKC_WEIGHT_BITS", 0); dedupe = (int)num("GKC_DEDUPE", -1); max_sub_bits = (int)num("GKC_MAX_SUB_BITS", -1); lanes = (int)num("GKC_STAGEB_LANES", 2);
+        slice_min = (uint64_t)std::max<long long>(1, num("GKC_SLICE_MIN", 8000000)); batch_keys = (uint64_t)num("GKC_BATCH_KEYS", 0);
+        slices = not0("GKC_SLICES"); batch_lpt = not0("GKC_BATCH_LPT"); no_f64 = on("GKC_NO_F64");
+        wg_max = (uint32_t)num("GKC_WG_MAX", 0); scatter_wgs = (uint32_t)std::max<long long>(1, num("GKC_SCATTER_WGS", 176)); deep_bits = (uint32_t)std::max<long long>(1, num("GKC_DEEP_BITS", MAX_SUB_BITS));
+        sink_first_div = (uint32_t)std::max<long long>(1, num("GKC_SINK_FIRST_DIV", 4));
+        sink_packed = not0("GKC_SINK_PACKED"); sink_packed2 = not0("GKC_SINK_PACKED2"); sink_width6 = not0("GKC_SINK_WIDTH6"); sink_debug = on("GKC_SINK_DEBUG");
+        sink_dense = (uint64_t)num("GKC_SINK_DENSE", 0); unpack_threads = (int)num("GKC_UNPACK_THREADS", 0);
+        bloom_atomic = on("GKC_BLOOM_ATOMIC"); bloom_gather = on("GKC_BLOOM_GATHER"); mphf_regions = not0("GKC_MPHF_REGIONS"); mphf_ordered = on("GKC_MPHF_ORDERED");
+        bloom_query_regions_min = (uint64_t)num("GKC_BLOOM_QUERY_REGIONS_MIN", 2000000); mphf_regions_min = (uint64_t)num("GKC_MPHF_REGIONS_MIN", 1ll << 21);
+        vmm = (int)num("GKC_VMM", 1); vmm_chunk_mb = (uint32_t)std::max<long long>(2, num("GKC_VMM_CHUNK_MB", 1024)); vmm_min_mb = (uint32_t)std::max<long long>(1, num("GKC_VMM_MIN_MB", 64));
+        vmm_with_rccl = num("GKC_VMM_WITH_RCCL", 0) == 1; pool_debug = on("GKC_POOL_DEBUG"); pool_trace = on("GKC_POOL_TRACE"); verbose = on("GKC_VERBOSE");
+        filebox_timeout = raw("GKC_FILEBOX_TIMEOUT") ? atof(raw("GKC_FILEBOX_TIMEOUT")) : 600.0; memset(fault, 0, sizeof fault); if (raw("GKC_FAULT")) strncpy(fault, raw("GKC_FAULT"), sizeof fault - 1);
+    }
+};
+inline GkcTun& gkc_tun() { static GkcTun t = [] { GkcTun x; x.read(); return x; }(); return t; }
+inline void gkc_tun_refresh() { static std::mutex mu; std::lock_guard<std::mutex> lk(mu); GkcTun x; x.read(); gkc_tun() = x; }
+
 // Stage B runs batches on two host threads, each with its own stream: the thread-local override routes every launch / copy / timer of
 // that thread to its lane's stream (cur_stream() below)
-inline thread_local hipStream_t gkc_tl_stream = nullptr;
+inline thread_local hipStream_t tl_stream_ = nullptr;
 
 // ------------------------------------------------------------------------------------------------ device buffer
 // Caching device allocator: hipMalloc/hipFree of multi-GB buffers cost tens of ms per GB on this platform (far more than
@@ -68,19 +109,18 @@ struct DevPool {
     std::map<void*, size_t> live;             // blocks handed out
     std::map<void*, VmmBlock> vmm;            // blocks that are mapped ranges (handed out or parked)
     int device = 0; bool vmm_ok = true; size_t vmm_gran = 0; int vmm_state = 0;      // 0: not probed, 1: usable, -1: not
-    static constexpr size_t VMM_MIN = (size_t)64 << 20, VMM_CHUNK = (size_t)1 << 30;
+    // (mapped ranges from GkcTun::vmm_min_mb = 64 MiB up, chunks of vmm_chunk_mb = 1 GiB)
     hipError_t raw_alloc(void** out, size_t want) {
         if (vmm_state == 0) {
             vmm_state = -1;
-            const char* e = getenv("GKC_VMM");
             int sup = 0;
-            if (!(e && atoi(e) == 0) && hipDeviceGetAttribute(&sup, hipDeviceAttributeVirtualMemoryManagementSupported, device) == hipSuccess && sup) {
+            if (gkc_tun().vmm != 0 && hipDeviceGetAttribute(&sup, hipDeviceAttributeVirtualMemoryManagementSupported, device) == hipSuccess && sup) {
                 hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
                 if (hipMemGetAllocationGranularity(&vmm_gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && vmm_gran) vmm_state = 1;
             }
             (void)hipGetLastError();
         }
-        if (vmm_state != 1 || !vmm_ok || want < VMM_MIN) return hipMalloc(out, want);
+        if (vmm_state != 1 || !vmm_ok || want < ((size_t)gkc_tun().vmm_min_mb << 20)) return hipMalloc(out, want);
         const size_t total = (want + vmm_gran - 1) / vmm_gran * vmm_gran;
         void* base = nullptr;
         hipError_t e = hipMemAddressReserve(&base, total, 0, nullptr, 0);
@@ -88,8 +128,8 @@ struct DevPool {
         hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
         VmmBlock B; B.bytes = total;
         size_t off = 0;
-        static const size_t chunk_bytes = getenv("GKC_VMM_CHUNK_MB") ? (size_t)std::max(2, atoi(getenv("GKC_VMM_CHUNK_MB"))) << 20 : VMM_CHUNK;
-        static const bool dbg = getenv("GKC_POOL_DEBUG") != nullptr;
+        const size_t chunk_bytes = (size_t)gkc_tun().vmm_chunk_mb << 20;
+        const bool dbg = gkc_tun().pool_debug;
         double t_create = 0, t_map = 0, t_access = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -150,7 +190,7 @@ struct DevPool {
             // large enough would keep exactly the memory that ran out: a 23 GB result block of the previous pass serving a 10 GB request.)
             (void)hipGetLastError();
             n_fail++; n_trim++;
-            if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] hipMalloc of %.2f GB failed; parked %.2f GB in %zu blocks\n", (double)want / 1e9, (double)cached_bytes / 1e9, cache.size());
+            if (gkc_tun().pool_debug) fprintf(stderr, "[gkc pool] hipMalloc of %.2f GB failed; parked %.2f GB in %zu blocks\n", (double)want / 1e9, (double)cached_bytes / 1e9, cache.size());
             while (e != hipSuccess && !cache.empty()) {
                 auto last = std::prev(cache.end());
                 raw_free(last->second); cached_bytes -= last->first; cache.erase(last);
@@ -160,8 +200,8 @@ struct DevPool {
         }
         const double ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         malloc_ms += ms_;
-        if (ms_ > 20.0 && getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] %.2f GB took %.1f ms (%s)\n", (double)want / 1e9, ms_, vmm.count(p) ? "mapped chunks" : "hipMalloc");
-        if (getenv("GKC_POOL_TRACE") && want >= ((size_t)256 << 20)) {
+        if (ms_ > 20.0 && gkc_tun().pool_debug) fprintf(stderr, "[gkc pool] %.2f GB took %.1f ms (%s)\n", (double)want / 1e9, ms_, vmm.count(p) ? "mapped chunks" : "hipMalloc");
+        if (gkc_tun().pool_trace && want >= ((size_t)256 << 20)) {
             size_t live_b = 0; for (auto& kv : live) live_b += kv.second;
             size_t fr = 0, tot = 0; (void)hipMemGetInfo(&fr, &tot);
             fprintf(stderr, "[gkc pool trace] +%.2f GB in %.1f ms; before it: live %.1f GB, parked %.1f GB, device free %.1f of %.1f GB\n", (double)want / 1e9, ms_, (double)live_b / 1e9, (double)cached_bytes / 1e9, (double)fr / 1e9, (double)tot / 1e9);
@@ -174,12 +214,20 @@ struct DevPool {
     void free(void* p) {
         if (!p) return;
         // a block freed by one lane may be handed to the other lane (another stream) at once: its last user must have finished
-        if (gkc_tl_stream) (void)hipStreamSynchronize(gkc_tl_stream);
+        if (tl_stream_) (void)hipStreamSynchronize(tl_stream_);
         std::lock_guard<std::recursive_mutex> lk(mu);
         auto it = live.find(p);
         if (it == live.end()) { raw_free(p); return; }
+        // a context that got a communicator after its first allocations (vmm_ok cleared): its mapped ranges are not recycled — the next user could be an exchange buffer
+        if (!vmm_ok && vmm.count(p)) { live.erase(it); raw_free(p); return; }
         cache.insert({it->second, p}); cached_bytes += it->second; live.erase(it);
     }
+    bool is_mapped_inside(const void* q) {       // q points into a mapped range
+        std::lock_guard<std::recursive_mutex> lk(mu);
+        auto it = vmm.upper_bound((void*)q); if (it == vmm.begin()) return false; --it;
+        return (const char*)q < (const char*)it->first + it->second.bytes;
+    }
+    bool is_mapped(void* p) { std::lock_guard<std::recursive_mutex> lk(mu); return vmm.count(p) != 0; }
     void trim() { std::lock_guard<std::recursive_mutex> lk(mu); for (auto& kv : cache) raw_free(kv.second); cache.clear(); cached_bytes = 0; }
     void destroy() { std::lock_guard<std::recursive_mutex> lk(mu); trim(); for (auto& kv : live) raw_free(kv.first); live.clear(); }
 };
@@ -287,7 +335,7 @@ struct gkc_ctx {
     std::mutex err_mu;
     DevPool pool;
     int ensure(DevBuf& b, size_t bytes) {
-        if (b.bytes >= bytes && b.p) return GKC_OK;
+        if (b.bytes >= bytes && b.p && (pool.vmm_ok || !pool.is_mapped(b.p))) return GKC_OK;      // (a mapped range kept from before the communicator: replaced by a hipMalloc block)
         b.release();
         hipError_t e;
         b.p = pool.alloc(bytes ? bytes : 16, &e); b.pool = &pool;
@@ -301,7 +349,7 @@ struct gkc_ctx {
     void dfree(void* p) { pool.free(p); }
 };
 
-inline hipStream_t cur_stream(gkc_ctx* c) { return gkc_tl_stream ? gkc_tl_stream : c->stream; }
+inline hipStream_t cur_stream(gkc_ctx* c) { return tl_stream_ ? tl_stream_ : c->stream; }
 
 // RAII event timer accumulating into ctx->timing[name]
 struct ScopedTimer {

@@ -271,75 +271,6 @@ template <int KW> __device__ __forceinline__ uint32_t sub_index(typename KeyT<KW
 }
 
 
-// ------------------------------------------------------------------------------------------------ one lane per GROUP of k-mers (round 5)
-// The walks above give a lane one RECORD: a record holds 1..28 k-mers (mean 11 on 150 bp reads), so a wave runs its k-mer loop as long as its longest record with
-// ~29 of its 64 lanes active per step — and a VALU instruction or an LDS atomic costs its slot whatever the number of active lanes (profiles/r02_lds_bench.txt).
-// Here a wave takes 64 records at a time and hands their k-mers out in TASKS of up to G consecutive k-mers of one record, one task per lane, 64 abreast:
-//   * lane l brings record l: prefix sum of ceil(nbK / G) over the wave -> first task P[l] of the record in the chunk, T tasks in all;
-//   * the record's nucleotide string goes to the wave's LDS stage, left-aligned, its weight in the low bits of the second word (below anything a window reaches);
-//   * a bit per task marks the tasks that START a record (one LDS atomic OR per record); task j = 64 it + lane finds its record as
-//     (records started before the 64-bit word `it`) + v_mbcnt(word) [+ its own bit] - 1: a wave-uniform word read and two VALU instructions, no search;
-//   * the task's first k-mer is a window of the string (one funnel shift) and its reverse complement is computed once (revcomp64); the <= G - 1 that follow roll
-//     like the per-record walk. Lane utilisation ~0.88 at G = 4 (the last task of a record may be short) instead of ~0.45.
-// (G = 1 with BOTH strings staged — the reverse complement as a window of the reversed record — was built first: 38 VALU + 5 LDS instructions per 64 k-mers, and
-// slower than the per-record walk, whose rolling step is 25 VALU for ~29 k-mers: the set-up per k-mer has to be shared by a few k-mers to pay.)
-// Same k-mers, same weights, another order of arrival (the sort does not care). Replaces the same reference loop: PartitionsCommand.cpp:944-1128.
-struct __attribute__((aligned(16))) WaveStage16 {
-    ulonglong2 rec[64];         // the record's string: {bits 127..64, (bits 63..0 >> 1) | weight - 1}
-    uint32_t bits[64];          // bit j: task j of the chunk is the first of its record (2048 bits)
-    uint16_t meta[64];          // P | nbK << 10
-};
-// all 64 lanes of the wave call it together; a lane without a record passes R0 = 0 (nbK = 0). f(canonical k-mer, weight - 1) once per k-mer.
-template <int G, class F>
-__device__ __forceinline__ void wave_each_kmer16(WaveStage16& S, const uint64_t R0, const uint64_t R1, const uint32_t k, const uint32_t wb, const int lane, F f)
-{
-    static_assert(G >= 2 && 64 * ((28 + G - 1) / G) < 1024, "P must fit 10 bits");
-    const uint32_t nbk = (uint32_t)(R0 >> 56), ntask = (nbk + G - 1) / G;
-    uint32_t incl = ntask;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
-    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (T == 0) return;
-    const uint32_t P = incl - ntask;
-    const uint64_t wmask = (1ull << wb) - 1ull, R1n = R1 & ~wmask;
-    S.rec[lane] = make_ulonglong2((R0 << 8) | (R1n >> 56), ((R1n << 8) >> 1) | (R1 & wmask));
-    S.meta[lane] = (uint16_t)(P | (nbk << 10));
-    if (lane < 32) reinterpret_cast<uint64_t*>(S.bits)[lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (nbk) atomicOr(&S.bits[P >> 5], 1u << (P & 31u));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const uint32_t down = 64 - 2 * k, sh = 2 * (k - 1);
-    uint32_t base = 0;
-    for (uint32_t j0 = 0; j0 < T; j0 += 64) {
-        const uint64_t M = reinterpret_cast<const uint64_t*>(S.bits)[j0 >> 6];            // (a plain LDS read: a volatile one is compiled to a FLAT load)
-        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)M), mhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(M >> 32));
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        const uint32_t own = (uint32_t)((((uint64_t)mhi << 32) | mlo) >> lane) & 1u;
-        const uint32_t r = base + below + own - 1u;
-        base += (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-        const uint32_t j = j0 + (uint32_t)lane;
-        if (j < T) {
-            const uint32_t meta = S.meta[r];
-            const ulonglong2 A = S.rec[r];
-            const uint32_t i0 = G * (j - (meta & 0x3FFu)), left = (meta >> 10) - i0, cnt = left < (uint32_t)G ? left : (uint32_t)G;
-            const unsigned long long wq = A.y & wmask;
-            uint32_t s = 2 * i0;                                                    // <= 54: the weight bits (and the >> 1) stay below every window
-            uint64_t fw = ((A.x << s) | (A.y >> (63 - s))) >> down, rv = revcomp64(fw, k);
-            for (uint32_t u = 0; u < cnt; u++) {
-                f(fw < rv ? fw : rv, wq);
-                s += 2;
-                fw = ((A.x << s) | (A.y >> (63 - s))) >> down;
-                rv = (rv >> 2) | ((uint64_t)(((uint32_t)fw & 3u) ^ 2u) << sh);
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                          // (the next chunk overwrites the stage)
-}
-#ifndef GKC_BAL_G
-#define GKC_BAL_G 4
-#endif
-
-
 // ------------------------------------------------------------------------------------------------ same-address relief (round 5)
 // A low-complexity read (poly-A, (AC)n) or a repeat family at hundreds of copies sends 10^5 .. 10^7 keys of ONE k-mer through Stage B: every lane of a wave then
 // asks for the same LDS counter, the same parking slot, the same global cursor, and same-address atomics are served one lane at a time (1e8 reads with 1 % such
@@ -431,7 +362,7 @@ struct TierLists {
     uint32_t cap1, cap2, cap3;
 };
 
-template <int KW, int RW, bool BAL /* one lane per k-mer (8-byte keys, 16-byte records) */>
+template <int KW, int RW>
 __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                   uint64_t* __restrict__ b_start, uint32_t* __restrict__ b_n, uint8_t* __restrict__ b_consumed,
                                                                   TierLists T,
@@ -446,7 +377,6 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
     __shared__ uint32_t s_wsum[EXPAND_THREADS / 64];
     __shared__ WgList s_big, s_wg, s_split;
     __shared__ uint32_t s_item;
-    __shared__ WaveStage16 s_stage[BAL ? EXPAND_THREADS / 64 : 1];
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1u);
@@ -462,15 +392,6 @@ __global__ __launch_bounds__(EXPAND_THREADS) void k_expand_count(const PartDesc*
         uint64_t r0 = segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part], r1 = segs.rec_end ? segs.rec_end[pd.part] : segs.rec_off[(uint64_t)s * (segs.P + 1) + pd.part + 1];
         if (pd.pad) slice_range(r0, r1, pd.pad, r0, r1);
         const uint8_t* base = segs.rec[s];
-        if constexpr (BAL && KW == 1 && RW == 2) {
-            const int lane = threadIdx.x & 63;
-            WaveStage16& S = s_stage[threadIdx.x >> 6];
-            for (uint64_t rb = r0 + (threadIdx.x & ~63u); rb < r1; rb += EXPAND_THREADS) {        // (wave-uniform bounds: the 64 lanes walk the chunk's k-mers together)
-                uint64_t R[2] = {0, 0};
-                if (rb + lane < r1) load_rec<2>(base, rb + lane, R);
-                wave_each_kmer16<GKC_BAL_G>(S, R[0], R[1], k, 0u, lane, [&](uint64_t c, unsigned long long) { wave_add1(s_hist, (uint32_t)(c >> pd.shift)); });
-            }
-        } else
         for (uint64_t r = r0 + threadIdx.x; r < r1; r += EXPAND_THREADS) {
             uint64_t R[RW]; load_rec<RW>(base, r, R);
             if constexpr (KW == 2 && RW == 4) {
@@ -563,7 +484,6 @@ constexpr int PAIR_THREADS = 1024;
 // primitive only: EXCHANGES. A thread holding key h first swaps EMPTY into the slot: a key came out -> the two leave as a pair.
 // Nothing came out -> it swaps h in: EMPTY came out -> parked; a key came out (someone parked in between) -> it now holds
 // that key instead and starts over. Keys are conserved by every exchange, nobody waits on anybody; 1.5 exchanges per key.
-template <bool BAL /* one lane per k-mer: wave_each_kmer16 (the wave stages follow the cursors in the dynamic LDS) */>
 __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const PartDesc* __restrict__ parts, SegTable segs, uint32_t k,
                                                                        const uint64_t* __restrict__ b_start, uint64_t* __restrict__ keys,
                                                                        const uint32_t* __restrict__ order /* i-th partition to take (largest first), or nullptr */,
@@ -591,11 +511,11 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
         const ulonglong2* recs = reinterpret_cast<const ulonglong2*>(segs.rec[s]);
         unsigned long long* const s_comb0 = s_pend + (((size_t)nsub * 12 + 15) / 16) * 2;                   // behind the cursors, 16-byte aligned
         unsigned long long* const s_comb = s_comb0 + (size_t)(threadIdx.x >> 6) * 64;                         // this wave's 64 words
-        bool rec_first = true, armed = BAL;                                      // same-address relief armed per record (wave_same_hint); the balanced walk has no record steps: always
+        bool rec_first = true, armed = false;                                    // same-address relief armed per record (wave_same_hint)
         auto emit = [&](uint64_t c, unsigned long long wq) {
             const uint32_t q = (uint32_t)(c >> pd.shift);
             unsigned long long h = (c << wb) | wq;                               // (bits beyond the 64th fall off: see above) never all ones
-            if (!BAL && rec_first) { rec_first = false; armed = wave_same_hint(q); }
+            if (rec_first) { rec_first = false; armed = wave_same_hint(q); }
             // same-address relief (see wave_add1): >= SAME_MIN lanes of the wave with keys for ONE sub-bucket (one k-mer at 10^6 copies) pair up among themselves —
             // keys into the wave's LDS words by rank, one reservation for all the pairs, lane r < pairs stores words 2r, 2r + 1; an odd last lane takes the usual way
             if (armed) {
@@ -623,9 +543,6 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
                 const unsigned long long y = atomicExch(&s_pend[q], EMPTY);
                 if (y != EMPTY) {
                     const uint32_t p = atomicAdd(&s_cur[q], 2u);
-#ifdef GKC_EXP_NOSTORE
-                    if (c == 0x123456789ULL)
-#endif
                     store16(out + p, y, h);
                     break;
                 }
@@ -634,17 +551,6 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
                 h = z;
             }
         };
-        if constexpr (BAL) {
-            const int lane = threadIdx.x & 63;
-            WaveStage16& S = reinterpret_cast<WaveStage16*>(s_comb0 + PAIR_THREADS)[threadIdx.x >> 6];        // (behind the waves' pairing words)
-            const uint64_t rb0 = r0 + (threadIdx.x & ~63u);                                       // wave-uniform chunk bounds
-            ulonglong2 nx = rb0 + lane < r1 ? recs[rb0 + lane] : make_ulonglong2(0, 0);
-            for (uint64_t rb = rb0; rb < r1; rb += PAIR_THREADS) {
-                const ulonglong2 cur = nx;
-                nx = rb + PAIR_THREADS + lane < r1 ? recs[rb + PAIR_THREADS + lane] : make_ulonglong2(0, 0);      // next record in flight while this chunk is expanded
-                wave_each_kmer16<GKC_BAL_G>(S, cur.x, cur.y, k, wb, lane, emit);
-            }
-        } else {
         uint64_t r = r0 + threadIdx.x;
         ulonglong2 nx = r < r1 ? recs[r] : make_ulonglong2(0, 0);
         for (; r < r1; r += PAIR_THREADS) {
@@ -653,7 +559,6 @@ __global__ __launch_bounds__(PAIR_THREADS) void k_expand_scatter_pair(const Part
             const unsigned long long wq = R[1] & ((1ull << wb) - 1ull);                              // the record's weight - 1 (below the nucleotides; 0 unless the records were deduplicated)
             rec_first = true;
             for_each_kmer16(R, k, [&](uint64_t c) { emit(c, wq); });
-        }
         }
     }
     __syncthreads();
@@ -992,9 +897,7 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
 #pragma unroll
         for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTag<KW>::mant()) | KTag<KW>::tag();        // padding (all ones) becomes the largest tagged value: not below any key
     }
-#ifndef GKC_EXP_NOSORT
     bitonic_wave<KW, KPL, F>(v, lane);
-#endif
     // run-length count (B3), weighted: e = lane*KPL + r is the sorted rank; a key is the k-mer above O.wb bits of (multiplicity - 1): equal k-mers are
     // adjacent whatever their weights, the abundance of a run is the sum of its weights
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
@@ -1040,18 +943,12 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
         if ((tailm >> r) & 1) {
             const uint32_t c = run - prevw;                                       // the run that ends here: every weight since the previous run end
             prevw = run;
-#ifndef GKC_EXP_NORLESTORE
             if constexpr (F) outk[start + idx] = ((v[r] & KTag<KW>::mant()) | top) >> WB; else outk[start + idx] = v[r] >> WB;
             put_count(O, start + idx, c);
-#else
-            if (c == 0x7fffffffu) outk[start + idx] = v[r];
-#endif
             idx++;
             nsol += ((int32_t)c >= O.amin && (int32_t)c <= O.amax) ? 1u : 0u;      // CountRange::includes (closed interval)
-#ifndef GKC_EXP_NOHIST
             const uint32_t hb = c >= O.histo_max ? O.histo_max : c;              // Histogram::inc (Histogram.hpp:92)
             if (hb < HIST_LDS) atomicAdd(&s_hc[hb], 1u); else atomicAdd(&O.histo[hb], 1ULL);
-#endif
         }
     }
     if (O.all_solid) ns_out = nd_out;
@@ -2246,7 +2143,7 @@ __global__ __launch_bounds__(DDCap<RW>::WAVES * 64) void k_dedupe_sort(uint64_t*
 constexpr uint32_t PART_ALIGN = 256;            // a partition's slot range starts on a multiple of this many slots
 // weight bits of a batch whose partitions all have at least min_bits sub-bucket bits (see the note at the top of the file). GKC_WEIGHT_BITS (tests, experiments)
 // asks for a number; it is honoured as far as the keys stay valid.
-static int weight_bits_env() { static const int env = getenv("GKC_WEIGHT_BITS") ? atoi(getenv("GKC_WEIGHT_BITS")) : 0; return env; }
+static int weight_bits_env() { return gkc_tun().weight_bits; }
 template <int KW> static uint32_t weight_bits_of(uint32_t k, uint32_t min_bits)
 {
     const int env = weight_bits_env();
@@ -2276,7 +2173,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     std::vector<PartDesc> pd(nb);
     std::vector<uint64_t> pidx(nb + 1);
     uint64_t n_slots = 0, n_sub = 0;
-    static const int dedupe_env = getenv("GKC_DEDUPE") ? atoi(getenv("GKC_DEDUPE")) : -1;       // 0: never, 1: always, default: until a batch shows it does not pay
+    const int dedupe_env = gkc_tun().dedupe;       // 0: never, 1: always, default: until a batch shows it does not pay
     // Sliced batch (see SliceTables): a partition beyond GKC_SLICE_MIN k-mers (default 8e6: twice and more what the batches and the drop-in's Configuration aim
     // at, and where the bins of the record deduplication are full) is expanded by up to 16 workgroups, so that an entry is 2e6 .. 4e6 k-mers like a planned
     // partition; GKC_SLICES=0 switches it off (tests lower the threshold). The record deduplication (one workgroup per partition, bins for <= 8e5 records: on such
@@ -2284,9 +2181,9 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // Measured, 1e8 reads, k = 31, two lanes (profiles/r04_sliced_partitions.txt): 256 partitions 600 -> 375 ms per step (expand_count 109 -> 19 ms, expand_scatter
     // 238 -> 90 ms single lane; what is left of the gap to the 4096-partition step, 203 ms, is the split levels: every 2^13-th of such a partition is 5700 keys,
     // beyond the sort tiers), 64 partitions 387 ms, 1024 partitions 346 -> 323 ms.
-    const uint64_t slice_min = getenv("GKC_SLICE_MIN") ? (uint64_t)std::max(1, atoi(getenv("GKC_SLICE_MIN"))) : 8000000ull;
+    const uint64_t slice_min = gkc_tun().slice_min;
     const uint64_t slice_keys = std::max<uint64_t>(1, slice_min / 4);
-    const bool slices_on = !(getenv("GKC_SLICES") && atoi(getenv("GKC_SLICES")) == 0);
+    const bool slices_on = gkc_tun().slices;
     bool sliced = false; uint64_t heavy_keys = 0, batch_keys = 0;
     if (slices_on) for (uint32_t i = 0; i < nb; i++) { const uint64_t np = part_keys[batch_parts[i]]; batch_keys += np; if (np > slice_min) { sliced = true; heavy_keys += np; } }
     // (one heavy partition among a thousand planned ones — a repeat family under one minimizer — does not cost the batch its deduplication: its single dedupe workgroup
@@ -2295,9 +2192,8 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // mean keys of a level-1 bucket, counted in k-mers BEFORE identical records are merged: with the merge on (8-byte keys: ~1.8x fewer keys on 30x reads) twice as
     // many — 12 sub-bucket bits instead of 13 for the partitions of the 1e8-read bench: first sort tier 46.8 -> 38.3 ms, the larger tiers +8, scatter -4: 220 -> 214 ms
     // (possible since the tagged sort carries 61 key bits: profiles/r04_weight_bits_experiment.txt)
-    static const uint32_t target_env = getenv("GKC_SUB_TARGET") ? (uint32_t)std::max(1, atoi(getenv("GKC_SUB_TARGET"))) : 0u;
-    const uint32_t target = target_env ? target_env : (KW == 1) ? (dedupe ? 2 * SUB_TARGET : SUB_TARGET) : SUB_TARGET / 2;
-    const uint32_t max_bits1 = getenv("GKC_MAX_SUB_BITS") ? (uint32_t)atoi(getenv("GKC_MAX_SUB_BITS")) : (uint32_t)MAX_SUB_BITS;
+    const uint32_t target = (KW == 1) ? (dedupe ? 2 * SUB_TARGET : SUB_TARGET) : SUB_TARGET / 2;
+    const uint32_t max_bits1 = gkc_tun().max_sub_bits >= 0 ? (uint32_t)gkc_tun().max_sub_bits : (uint32_t)MAX_SUB_BITS;
     const uint32_t wb_goal = weight_bits_of<KW>(k, max_bits1);
     const int stored_or_mantissa = KTagBits<KW>::value;      // (16-byte keys: 125, which covers the 128 - 2k - wb >= -2 the dropped top bits need)
     const uint32_t need_goal = (uint32_t)std::min<int>((int)max_bits1, std::max<int>(0, 2 * (int)k + (int)wb_goal - stored_or_mantissa));
@@ -2318,7 +2214,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         // weight bits the batch could have at best (wb_goal) if its MEAN partition is within one bit of what they need, else with the smallest weights. At k = 31
         // that is 4 / 3 bits (rounds 2-3, 52-bit tag: 13 / 12 bits whatever the partition's size — the 8-GPU share on one GPU, 32768 partitions of 4.5e5 k-mers,
         // 325 -> 278 ms when the tag was widened). (16-byte keys at k = 63: one sub-bucket bit at least, so that the third weight bit can push the key's top bit out.)
-        if (getenv("GKC_MAX_SUB_BITS") == nullptr) bits = std::min<uint32_t>(std::max(bits, goal_ok ? need_goal : need_min), 2 * k);
+        if (gkc_tun().max_sub_bits < 0) bits = std::min<uint32_t>(std::max(bits, goal_ok ? need_goal : need_min), 2 * k);
         pd[i].part = batch_parts[i]; pd[i].sub_bits = bits; pd[i].shift = 2 * k - bits; pd[i].pad = 0; pd[i].aux = 0;
         pd[i].key_base = n_slots; pd[i].sub_base = n_sub;
         pidx[i] = n_sub;
@@ -2346,7 +2242,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     constexpr int K1 = WaveCapHuge<KW>::KPL / 2;
     constexpr uint32_t C1 = 4 * 64 * K1;                                    // workgroup tier: 4 waves x 64 x K1 keys (4096 / 2048)
     // measured (ms per 1.2e10 keys, workgroup tier + split levels + their sorts): up to 4096 keys in the workgroup tier: 40, up to 8192: 44, none: 47
-    const uint32_t wg_max = getenv("GKC_WG_MAX") ? std::min<uint32_t>((uint32_t)atoi(getenv("GKC_WG_MAX")), C1) : C1;
+    const uint32_t wg_max = gkc_tun().wg_max ? std::min<uint32_t>(gkc_tun().wg_max, C1) : C1;
     const uint32_t cap3 = std::max(wg_max, CAP2);                           // sub-buckets beyond are split again
     const uint64_t list_cap = n_slots / CAP1 + nb + 1;                      // sub-buckets beyond the first tier / pieces beyond it at any split level
     BatchBufs B;
@@ -2371,7 +2267,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // workgroup (partition sizes spread 2-3x around their mean). Only the assignment changes: the layout of the batch stays in partition order.
     std::vector<uint32_t> order(nv);
     for (uint32_t i = 0; i < nv; i++) order[i] = i;
-    static const bool lpt = getenv("GKC_BATCH_LPT") ? atoi(getenv("GKC_BATCH_LPT")) != 0 : true;
+    const bool lpt = gkc_tun().batch_lpt;
     auto keys_of_entry = [&](uint32_t v) -> uint64_t { return sliced ? part_keys[batch_parts[v_parent[v]]] >> (vpd[v].pad >> 16) : part_keys[batch_parts[v]]; };
     if (lpt) std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys_of_entry(a) > keys_of_entry(b); });
     CB_TRY(c->ensure(B.order, (size_t)nv * 4));
@@ -2434,37 +2330,22 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             segs_b.rec = (const uint8_t* const*)B.dd_ptr.p; segs_b.rec_off = (const uint64_t*)B.dd_off.p; segs_b.n_seg = 1; segs_b.rec_end = (const uint64_t*)B.dd_end.p;
         }
     }
-    // GKC_BALANCED=1: one lane per group of <= 4 k-mers in the two expansion kernels (8-byte keys) instead of one lane per record. Built in round 5 (VERDICT r4 #1b), bit-exact,
-    // measured and NOT the default: expand_count 8.3 -> 10.5 ms, scatter 41 -> 41 ms single lane, the two-lane step 202-205 -> 203-208 ms (profiles/r05_balanced_expand.txt)
-    static const bool balanced = getenv("GKC_BALANCED") && atoi(getenv("GKC_BALANCED")) == 1;
     {   ScopedTimer tm(c, "expand_count");
-        static const uint32_t cwgs_env = getenv("GKC_COUNT_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_COUNT_WGS"))) : 0u;
-        if (KW == 1 && RW == 2 && balanced)
-            hipLaunchKernelGGL((k_expand_count<KW, RW, KW == 1 && RW == 2>), dim3(cwgs_env ? std::min(nv, cwgs_env) : nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
-                               (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
-        else
-            hipLaunchKernelGGL((k_expand_count<KW, RW, false>), dim3(cwgs_env ? std::min(nv, cwgs_env) : nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
-                               (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
+        hipLaunchKernelGGL((k_expand_count<KW, RW>), dim3(nv), dim3(EXPAND_THREADS), 0, cur_stream(c), d_entries, segs_b, k,
+                           (uint64_t*)B.b_start.p, (uint32_t*)B.b_n.p, (uint8_t*)B.b_cons.p, T, (const uint32_t*)B.order.p, nv, misc + 7, drop, ST);
         CB_HIP(hipGetLastError());
     }
     {   ScopedTimer tm(c, "expand_scatter");
         // The scatter is bound by the write requests the whole chip retires, not by its CUs (tools/scatter_bench: 63-127 workgroups write MORE than 254), and the
         // other Stage-B lane's kernel wants CUs: the launch takes 11/16 of them (persistent workgroups, partitions handed out largest first by a ticket).
         // Measured, two lanes, 1e8 reads: one workgroup per partition 266-273 ms per step, 160-192 workgroups 249-251, 128: 252, 96: 256.
-        static const uint32_t scatter_wgs = getenv("GKC_SCATTER_WGS") ? (uint32_t)std::max(1, atoi(getenv("GKC_SCATTER_WGS"))) : 176u;
+        const uint32_t scatter_wgs = gkc_tun().scatter_wgs;
         if constexpr (KW == 1) {
-            const size_t stage = sizeof(WaveStage16) * (PAIR_THREADS / 64);                        // balanced walk: the waves' record stages (22 KB)
             const size_t comb = (size_t)PAIR_THREADS * 8 + 16;                                            // 64 pairing words per wave (same-address relief)
-            const size_t lds_max = (size_t)MAX_SUB * 12 + comb + stage, lds = ((size_t)12 << max_bits_b) + comb;          // parking slots + cursors of the batch's largest sub-bucket count
-            static std::once_flag once; std::call_once(once, [&] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
-            if (balanced)
-                hipLaunchKernelGGL(k_expand_scatter_pair<true>, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds + stage, cur_stream(c), d_entries, segs_b, k,
-                                   (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
-            else
-                hipLaunchKernelGGL(k_expand_scatter_pair<false>, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), d_entries, segs_b, k,
-                                   (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
+            const size_t lds_max = (size_t)MAX_SUB * 12 + comb, lds = ((size_t)12 << max_bits_b) + comb;          // parking slots + cursors of the batch's largest sub-bucket count
+            static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max); });
+            hipLaunchKernelGGL(k_expand_scatter_pair, dim3(std::min(nv, scatter_wgs)), dim3(PAIR_THREADS), lds, cur_stream(c), d_entries, segs_b, k,
+                               (const uint64_t*)B.b_start.p, (uint64_t*)B.keysA.p, (const uint32_t*)B.order.p, nv, misc + 6, wb, ST);
         } else {
             const size_t lds = (size_t)MAX_SUB * 20;                           // 160 KB: the whole LDS of a CU
             static std::once_flag once; std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_expand_scatter_pair2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
@@ -2481,12 +2362,12 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // --- the sort tiers, back to back: which sub-bucket goes where was decided by k_expand_count; no host round trip until the totals below
     // every bucket's keys share their top min_bits1 bits: when the rest fits a double's 52-bit mantissa the in-lane exchanges run as v_min/max_f64
     // (16-byte keys, round 4: the same tag on the key's top word — v_min/max_f64 there, selects on the low word: KTag<2>)
-    const bool tag = 2 * k + wb <= (uint32_t)KTagBits<KW>::value + min_bits1 && getenv("GKC_NO_F64") == nullptr;
+    const bool tag = 2 * k + wb <= (uint32_t)KTagBits<KW>::value + min_bits1 && !gkc_tun().no_f64;
     constexpr bool FT = true;
     key_t* const keysA = (key_t*)B.keysA.p; key_t* const keysB = (key_t*)B.keysB.p;
     const uint64_t* const bs = (const uint64_t*)B.b_start.p; const uint32_t* const bn = (const uint32_t*)B.b_n.p; const uint8_t* const bc = (const uint8_t*)B.b_cons.p;
     {   ScopedTimer tm(c, "bucket_sort");
-        static const uint64_t sgrid_env = getenv("GKC_SORT_WGS") ? (uint64_t)std::max(1, atoi(getenv("GKC_SORT_WGS"))) : 256 * 32;
+        const uint64_t sgrid_env = 256 * 32;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_sub + 3) / 4, sgrid_env));
         if (tag) hipLaunchKernelGGL((k_wave_sort<KW, FT>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysA, bs, bn, (uint32_t)n_sub, O);
         else hipLaunchKernelGGL((k_wave_sort<KW, false>), dim3(grid), dim3(SORT_THREADS), 0, cur_stream(c), (const key_t*)keysA, keysA, bs, bn, (uint32_t)n_sub, O);
@@ -2512,7 +2393,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     }
     // split levels: level 1 takes the split list, level l > 1 the queue level l-1 filled; queue buffers alternate, the counters are used cyclically. Every level
     // is followed by the launch that sorts the pieces it listed (<= keys / 64 of them per level: the list is reused)
-    static const uint32_t deep_bits = getenv("GKC_DEEP_BITS") ? std::max<uint32_t>(1u, (uint32_t)atoi(getenv("GKC_DEEP_BITS"))) : (uint32_t)MAX_SUB_BITS;   // tests: few bits per level force many levels
+    const uint32_t deep_bits = gkc_tun().deep_bits;   // tests: few bits per level force many levels
     const uint64_t sort_cap = n_slots / (CAP1 / 4) + list_cap + 64 + (uint64_t)GIANT_MAX * MAX_SUB;     // an item of n keys lists <= 2 n / (cap1 / 2) + 1 runs and pieces
     CB_TRY(c->ensure(B.sitems, (size_t)sort_cap * sizeof(SortItem)));
     const unsigned deep_grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(list_cap, 256 * 8));
@@ -2585,9 +2466,9 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             c->dedupe_in += dd[0]; c->dedupe_out += dd[1];
             c->pass_stats[pass].dedupe_kmers_in += dd[0]; c->pass_stats[pass].dedupe_keys_out += dd[1];
             if (dedupe_env != 1 && c->dedupe_in > 100000000ULL && (double)c->dedupe_out > 0.85 * (double)c->dedupe_in) c->dedupe_off = true;
-            if (getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc] dedupe: %llu k-mers in the deduplicated bins -> %llu weighted keys (%.2fx)\n", dd[0], dd[1], dd[1] ? (double)dd[0] / (double)dd[1] : 0.0);
+            if (gkc_tun().verbose) fprintf(stderr, "[gkc] dedupe: %llu k-mers in the deduplicated bins -> %llu weighted keys (%.2fx)\n", dd[0], dd[1], dd[1] ? (double)dd[0] / (double)dd[1] : 0.0);
         }
-        if (getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc] batch of %u partitions, %llu sub-buckets: %u in the double-size tier, %u in the workgroup tier, %u split (%d levels)\n",
+        if (gkc_tun().verbose) fprintf(stderr, "[gkc] batch of %u partitions, %llu sub-buckets: %u in the double-size tier, %u in the workgroup tier, %u split (%d levels)\n",
                                            nb, (unsigned long long)n_sub, h_misc[0], h_misc[1], h_misc[2], level);
         total_solid = ptot[2 * nb + 1];
         constexpr int OW = (KW == 1) ? 2 : 4;
@@ -2633,7 +2514,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             std::lock_guard<std::mutex> lk(c->mu);
             if (gkc_sink_packed(c)) {                                  // a packing context whose batch travels plain: its bytes belong to what the library queued on the link
                 c->sink_wire_bytes += bytes;
-                if (getenv("GKC_SINK_DEBUG") || getenv("GKC_VERBOSE")) fprintf(stderr, "[gkc sink] a batch of %llu records travels unpacked: %s\n", (unsigned long long)total_solid, gkc_sink_last_refusal());
+                if (gkc_tun().sink_debug || gkc_tun().verbose) fprintf(stderr, "[gkc sink] a batch of %llu records travels unpacked: %s\n", (unsigned long long)total_solid, gkc_sink_last_refusal());
             }
             {
                 if (hipEventCreateWithFlags(&landed, hipEventDisableTiming) == hipSuccess &&
@@ -2719,7 +2600,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     // from one queue, each on its own stream (thread-local stream override, cur_stream()): measured 264 -> 229 ms for the same work.
     const uint64_t total_keys = [&] { uint64_t t = 0; for (uint64_t v : part_keys) t += v; return t; }();
     const uint64_t max_part = [&] { uint64_t t = 0; for (uint64_t v : part_keys) t = std::max(t, v); return t; }();
-    int lanes = getenv("GKC_STAGEB_LANES") ? atoi(getenv("GKC_STAGEB_LANES")) : 2;
+    int lanes = gkc_tun().lanes;
     if (lanes < 1) lanes = 1;
     if (lanes > 4) lanes = 4;
     if (total_keys < 50000000ULL || c->key_budget) lanes = 1;               // small inputs (and the tests' tiny forced budgets): one lane
@@ -2729,13 +2610,15 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
         return std::max(0.0, (double)(free_b + c->pool.cached_bytes) - reserve_bytes);      // (overlapped passes: what Stage A of the next pass will allocate beside this Stage B)
     }();
-    static const size_t cap_env = getenv("GKC_BATCH_KEYS") ? (size_t)atoll(getenv("GKC_BATCH_KEYS")) : 0;
+    const size_t cap_env = (size_t)gkc_tun().batch_keys;
     // Few, large batches: every batch ends with the drain of ~12 kernels (the expand kernels run one 6 ms workgroup per partition) and
     // eight host round trips; 8 -> 4 batches per 1.2e10 keys: 320 -> 304 ms. Equal shares, a whole number of batches per lane.
     // With a host sink (streamed results) the batches are three times smaller: the first records start over PCIe sooner and the copy that is left
     // when the last batch has been counted is shorter (1e8 reads, abundance-min 2: 431 -> ms per step with everything landed; profiles/r02_*)
     const size_t cap_default = c->key_words == 1 ? (size_t)3200000000ULL : (size_t)1600000000ULL;
-    const size_t cap = cap_env ? cap_env : c->batch_cap ? std::max<size_t>(c->batch_cap, (size_t)1 << 24) : (c->sink ? cap_default / 3 : cap_default);   // the same with one lane or two
+    const size_t cap_mode = c->sink ? cap_default / 3 : cap_default;       // (a host sink: three batches per lane keep the link busy)
+    // gkc_set_batch_keys is an UPPER bound: never above the library's plan for the mode; GKC_BATCH_KEYS (developer switch) replaces the plan outright
+    const size_t cap = cap_env ? cap_env : c->batch_cap ? std::min(cap_mode, std::max<size_t>(c->batch_cap, (size_t)1 << 24)) : cap_mode;   // the same with one lane or two
     uint64_t done_keys = 0, done_solid = 0;                                  // this pass: finished batches (keys, resident records) (guarded by plan_mu)
     // budget for a given solid-per-key ratio d. Deterministic in (free memory rounded to GB, total keys, d rounded up to 0.05): every
     // pass of a context plans the same sizes, so from the second pass on all blocks are parked already.
@@ -2776,7 +2659,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         const size_t fits = left > 0 ? (size_t)(left / per_key_now()) : 0;
         size_t b = fixed_budget;
         if (b > fits) {
-            if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc plan] lane %d: budget %.3e does not fit (%.3e): done_solid %.3e committed %.1f GB\n", lane, (double)b, (double)fits, (double)done_solid, committed / 1e9);
+            if (gkc_tun().pool_debug) fprintf(stderr, "[gkc plan] lane %d: budget %.3e does not fit (%.3e): done_solid %.3e committed %.1f GB\n", lane, (double)b, (double)fits, (double)done_solid, committed / 1e9);
             if (lanes > 1) tight = true;                                     // first the extra lanes retire ...
             if (lane != 0) return b;
             while (b > fits && b > ((size_t)1 << 20)) b /= 2;                // ... then the main lane's batches shrink
@@ -2792,7 +2675,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     std::vector<void*>& outputs = *outputs_p;
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
     bool first_done[4] = { false, false, false, false }; uint64_t keys_left = total_keys;
-    static const size_t sink_first_div = getenv("GKC_SINK_FIRST_DIV") ? (size_t)std::max(1, atoi(getenv("GKC_SINK_FIRST_DIV"))) : 4;
+    const size_t sink_first_div = gkc_tun().sink_first_div;
     auto carve = [&](std::vector<uint32_t>& batch, int lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
         batch.clear();
@@ -2825,19 +2708,14 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
             if (!batch.empty() && acc + part_keys[p] > budget) break;
             batch.push_back(p); acc += part_keys[p]; next_p++;
         }
-        // the expand kernels run one workgroup per partition, one workgroup per CU: a batch of 545 partitions takes three rounds on 256 CUs
-        // with the last one 13 % full — whole multiples of the CU count leave no such tail
-        static const size_t align = getenv("GKC_BATCH_ALIGN") ? (size_t)atoll(getenv("GKC_BATCH_ALIGN")) : 0;
-        if (align && next_p < Pn && batch.size() > align)
-            for (const size_t keep = batch.size() / align * align; batch.size() > keep; batch.pop_back()) { next_p = batch.back(); acc -= part_keys[batch.back()]; }
         inflight[lane] = (double)acc * per_key_now();
         keys_left -= std::min<uint64_t>(keys_left, acc);
         return !batch.empty();
     };
     auto lane_main = [&](hipStream_t st, int lane) {
         (void)hipSetDevice(c->device);
-        const hipStream_t tl_before = gkc_tl_stream;
-        gkc_tl_stream = st;
+        const hipStream_t tl_before = tl_stream_;
+        tl_stream_ = st;
         std::vector<uint32_t> batch;
         while (carve(batch, lane)) {
             const int r = (c->key_words == 1) ? count_batch<1, 2>(c, pass, segments, batch, part_keys, segs, outputs) : count_batch<2, 4>(c, pass, segments, batch, part_keys, segs, outputs);
@@ -2847,7 +2725,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
             for (uint32_t p : batch) { const Dataset& D = c->datasets[(size_t)pass * Pn + p]; done_keys += D.n_kmers; done_solid += D.n_solid; }
         }
         (void)hipStreamSynchronize(st);
-        gkc_tl_stream = tl_before;
+        tl_stream_ = tl_before;
     };
     (void)hipStreamSynchronize(lane0);                                       // the table uploads (and, in line, Stage A on the same stream) are complete before the lanes start
     // d not known yet and the memory may bind: count a small PROBE batch first (the first partitions holding ~0.4 % of the keys) and take
@@ -2866,7 +2744,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         }
     }
     fixed_budget = c->d_hint > 0 ? plan_budget(c->d_hint) : plan_budget(1.0);   // without a ratio the memory does not bind even at d = 1
-    if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc plan] avail %.1f GB, keys %.3e, d_hint %.4f, lanes %d, budget %.3e\n", avail0 / 1e9, (double)total_keys, c->d_hint, lanes, (double)fixed_budget);
+    if (gkc_tun().pool_debug) fprintf(stderr, "[gkc plan] avail %.1f GB, keys %.3e, d_hint %.4f, lanes %d, budget %.3e\n", avail0 / 1e9, (double)total_keys, c->d_hint, lanes, (double)fixed_budget);
     // another batch size than the last pass planned (another input, a host sink set or dropped, another solidity ratio): the blocks parked in the allocator have the
     // wrong sizes — keeping them would make every new block a failed hipMalloc followed by frees, one parked block at a time (seen: 1.5 s for a 0.26 s pass)
     if (c->last_plan_budget && (fixed_budget > c->last_plan_budget + c->last_plan_budget / 10 || fixed_budget + fixed_budget / 10 < c->last_plan_budget)) c->pool.trim();      // (the allocator reuses a block up to 25 % larger than asked)
@@ -2889,7 +2767,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     }
     rc = first_rc;
     c->cv_done.notify_all();
-    if (getenv("GKC_POOL_DEBUG")) fprintf(stderr, "[gkc pool] mallocs %llu failed %llu trims %llu, %.1f ms in hipMalloc, cached %.2f GB\n", (unsigned long long)c->pool.n_malloc,
+    if (gkc_tun().pool_debug) fprintf(stderr, "[gkc pool] mallocs %llu failed %llu trims %llu, %.1f ms in hipMalloc, cached %.2f GB\n", (unsigned long long)c->pool.n_malloc,
                                           (unsigned long long)c->pool.n_fail, (unsigned long long)c->pool.n_trim, c->pool.malloc_ms, (double)c->pool.cached_bytes / 1e9);
     d_recptr.release(); d_recoff.release();
     return rc;

@@ -42,6 +42,7 @@ struct gkc_comm {
     double init_ms = 0;                        // wall of ncclCommInitRank (RCCL) / of the session handshake (file mailbox)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;      // transfer intervals not yet added to stats.ms_transfer
     DevBuf ag_send, ag_recv;                   // staging of the host all-gather (RCCL)
+    uint64_t stats_bounced = 0;                // receive buffers of the IPC transport that went through a bounce block
     bool ipc = false;                          // transport communicator whose device messages go peer to peer through IPC memory handles (gkc_comm_enable_ipc)
 };
 
@@ -132,14 +133,25 @@ static int sendrecv_ipc(gkc_comm* m, const std::vector<gkc_xfer>& sends, const s
     const int W = m->world;
     // my receive table
     std::vector<IpcEntry> mine(recvs.size());
+    // A receive buffer whose allocation cannot be exported (a hipMemCreate-mapped range the context held before the communicator existed) is received into a
+    // hipMalloc'ed bounce block and copied to its place once everything has landed: slower by one device copy, never a failed exchange.
+    struct Bounce { void* tmp; void* dst; size_t n; };
+    std::vector<Bounce> bounces;
+    auto export_ptr = [&](IpcEntry& e, const void* ptr) -> bool {
+        hipDeviceptr_t base = nullptr; size_t span = 0;
+        if (hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)ptr) != hipSuccess || hipIpcGetMemHandle(&e.handle, (void*)base) != hipSuccess) { (void)hipGetLastError(); return false; }
+        e.offset = (uint64_t)((const uint8_t*)ptr - (const uint8_t*)base);
+        return true;
+    };
     for (size_t i = 0; i < recvs.size(); i++) {
         IpcEntry& e = mine[i]; memset(&e, 0, sizeof e);
         e.src = recvs[i].peer; e.bytes = recvs[i].n_bytes;
-        hipDeviceptr_t base = nullptr; size_t span = 0;
-        if (recvs[i].n_bytes) {
-            if (hipMemGetAddressRange(&base, &span, (hipDeviceptr_t)recvs[i].d_ptr) != hipSuccess || hipIpcGetMemHandle(&e.handle, (void*)base) != hipSuccess) {
-                (void)hipGetLastError(); e.src = -2;                      // (published all the same: the ranks fail together below)
-            } else e.offset = (uint64_t)((const uint8_t*)recvs[i].d_ptr - (const uint8_t*)base);
+        if (!recvs[i].n_bytes) continue;
+        const bool mapped = c->pool.is_mapped_inside(recvs[i].d_ptr);
+        if (mapped || !export_ptr(e, recvs[i].d_ptr)) {
+            void* tmp = nullptr;
+            if (hipMalloc(&tmp, (size_t)recvs[i].n_bytes) == hipSuccess && export_ptr(e, tmp)) bounces.push_back(Bounce{ tmp, recvs[i].d_ptr, (size_t)recvs[i].n_bytes });
+            else { (void)hipGetLastError(); if (tmp) (void)hipFree(tmp); e.src = -2; }      // (published all the same: the ranks fail together below)
         }
     }
     uint32_t n_mine = (uint32_t)mine.size(); std::vector<uint32_t> n_all((size_t)W, 0);
@@ -174,7 +186,10 @@ static int sendrecv_ipc(gkc_comm* m, const std::vector<gkc_xfer>& sends, const s
     for (auto& o : opened) (void)hipIpcCloseMemHandle(o.second);
     if (rc != GKC_OK) c->set_error(rc, "IPC transport: %s", why.c_str());
     // everybody's copies have landed (or everybody learns that somebody failed)
-    return gkc_comm_agree(m, rc, "the device-to-device exchange");
+    rc = gkc_comm_agree(m, rc, "the device-to-device exchange");
+    for (const Bounce& b : bounces) if (rc == GKC_OK && hipMemcpyAsync(b.dst, b.tmp, b.n, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipGetLastError(); c->set_error(GKC_ERR_HIP, "IPC transport: copy out of a bounce block failed"); rc = GKC_ERR_HIP; }
+    if (!bounces.empty()) { (void)hipStreamSynchronize(st); for (const Bounce& b : bounces) (void)hipFree(b.tmp); m->stats_bounced += bounces.size(); }
+    return rc;
 }
 
 int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st)
@@ -323,12 +338,16 @@ struct FileBox {
             if (!write_file(session, &nonce, 8)) return false;
         }
         auto tag_of = [&](uint64_t nn) { char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)nn); return std::to_string(gen) + "." + hex; };
-        uint8_t one = 1;
+        // join.<tag>.<r> carries a nonce of the joining PROCESS and go.<tag> echoes the nonces of everybody who joined: a go file a crashed run left behind (same
+        // tag as a session file that also survived) does not hold the nonce this process has just drawn, and is ignored.
         if (rank == 0) {
             tag = tag_of(nonce);
-            for (int r = 1; r < world; r++) { if (!read_file(dir + "/join." + tag + "." + std::to_string(r), &one, 1, timeout_s)) return false; (void)unlink((dir + "/join." + tag + "." + std::to_string(r)).c_str()); }
-            return write_file(dir + "/go." + tag, &one, 1);
+            std::vector<uint64_t> echo((size_t)world, 0); echo[0] = nonce;
+            for (int r = 1; r < world; r++) { if (!read_file(dir + "/join." + tag + "." + std::to_string(r), &echo[r], 8, timeout_s)) return false; (void)unlink((dir + "/join." + tag + "." + std::to_string(r)).c_str()); }
+            return write_file(dir + "/go." + tag, echo.data(), (size_t)world * 8);
         }
+        std::random_device rd_; const uint64_t my_nonce = (((uint64_t)rd_() << 32) ^ (uint64_t)rd_() ^ ((uint64_t)getpid() << 24) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count()) | 1ull;
+        std::vector<uint64_t> echo((size_t)world, 0);
         // A joining rank may start before rank 0 has cleaned the directory: the session file it finds can be what a crashed run left. It therefore (i) ignores a
         // session file older than the time limit (its rank 0 has given up long ago), (ii) keeps re-reading the file while it waits for go.<tag> and joins again when the
         // nonce changes — the live rank 0 overwrites session.<generation> when it arrives.
@@ -339,10 +358,10 @@ struct FileBox {
             if (stat(session.c_str(), &st) == 0 && (double)(time(nullptr) - st.st_mtime) <= timeout_s && read_file(session, &seen, 8, 0.0)) {
                 if (!joined || seen != joined_nonce) {
                     tag = tag_of(seen);
-                    if (!write_file(dir + "/join." + tag + "." + std::to_string(rank), &one, 1)) return false;
+                    if (!write_file(dir + "/join." + tag + "." + std::to_string(rank), &my_nonce, 8)) return false;
                     joined = true; joined_nonce = seen;
                 }
-                if (read_file(dir + "/go." + tag, &one, 1, 0.0)) return true;
+                if (read_file(dir + "/go." + tag, echo.data(), (size_t)world * 8, 0.0) && echo[(size_t)rank] == my_nonce) return true;
             }
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
             usleep(1000);
@@ -463,6 +482,7 @@ int gkc_comm_unique_id(uint8_t id[GKC_COMM_ID_BYTES])
 
 static int comm_new(gkc_ctx* c, int world, int rank, gkc_comm** out)
 {
+    gkc_tun_refresh();
     if (!c || !out) return GKC_ERR_ARG;
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world) GKC_FAIL(c, GKC_ERR_ARG, "bad world / rank (%d / %d)", world, rank);
@@ -489,7 +509,7 @@ int gkc_comm_create_rccl(gkc_ctx* c, const uint8_t id[GKC_COMM_ID_BYTES], int wo
     m->rccl = true;
     // several GPUs: the blocks RCCL sends from / receives into come from hipMalloc as in rounds 1-4 (whether it takes hipMemCreate-mapped ranges as user buffers
     // could not be checked on a one-GPU box; GKC_VMM_WITH_RCCL=1 to try). What the pool already handed out stays valid.
-    if (world > 1 && !(getenv("GKC_VMM_WITH_RCCL") && atoi(getenv("GKC_VMM_WITH_RCCL")) == 1)) { std::lock_guard<std::recursive_mutex> lk(c->pool.mu); c->pool.vmm_ok = false; c->pool.trim(); }      // (parked mapped ranges go: none is handed out as an exchange buffer later)
+    if (world > 1 && !gkc_tun().vmm_with_rccl) { std::lock_guard<std::recursive_mutex> lk(c->pool.mu); c->pool.vmm_ok = false; c->pool.trim(); }      // (parked mapped ranges go: none is handed out as an exchange buffer later)
     return GKC_OK;
 }
 int gkc_comm_create_transport(gkc_ctx* c, const gkc_transport* t, int world, int rank, gkc_comm** out)
@@ -513,7 +533,7 @@ int gkc_comm_create_files(gkc_ctx* c, const char* directory, int world, int rank
     GKC_TRY(comm_new(c, world, rank, out));
     FileBox* b = new FileBox();
     b->dir = directory; b->world = world; b->rank = rank;
-    if (!b->open_session(getenv("GKC_FILEBOX_TIMEOUT") ? atof(getenv("GKC_FILEBOX_TIMEOUT")) : 600.0)) {
+    if (!b->open_session(gkc_tun().filebox_timeout)) {
         delete b; gkc_comm_destroy(*out); *out = nullptr;
         GKC_FAIL(c, GKC_ERR_ARG, "gkc_comm_create_files: rank %d of %d found no session with the other ranks in %s (stale files of an earlier run, or a rank that never started)", rank, world, directory);
     }
@@ -558,11 +578,13 @@ int gkc_comm_get_stats(gkc_comm* m, gkc_comm_stats* out)
     (void)hipSetDevice(m->ctx->device);
     gkc_comm_settle_timers(m);
     *out = m->stats;
+    out->reserved[0] = m->stats_bounced;
     return GKC_OK;
 }
 
 int gkc_exchange(gkc_ctx* c, gkc_comm* m)
 {
+    gkc_tun_refresh();
     if (!c || !m || m->ctx != c) return GKC_ERR_ARG;
     if (!c->in_pass) GKC_FAIL(c, GKC_ERR_ARG, "gkc_exchange outside a pass (gkc_begin_pass first)");
     if (c->stage_b_running || c->stage_b_thread.joinable()) GKC_FAIL(c, GKC_ERR_ARG, "gkc_exchange while gkc_finish_pass_async is in flight (gkc_finish_pass_wait first)");
@@ -615,7 +637,7 @@ int gkc_exchange(gkc_ctx* c, gkc_comm* m)
     // (what can fail on this rank alone — the receive arena does not fit, an inconsistency — is agreed on before the transfer: a rank that
     //  simply returned here would leave the others waiting in their send / recv)
     const int local_rc = [&]() -> int {
-        if (getenv("GKC_FAULT") && !strcmp(getenv("GKC_FAULT"), "exchange_local")) GKC_FAIL(c, GKC_ERR_NOMEM, "injected fault (GKC_FAULT=exchange_local)");
+        if (!strcmp(gkc_tun().fault, "exchange_local")) GKC_FAIL(c, GKC_ERR_NOMEM, "injected fault (GKC_FAULT=exchange_local)");
         if (gkc_exchange_plan(W, me, P, m->first.data(), Ls.data(), Lmax, all.data(), ps.data(), &n_ps, pr.data(), &n_pr, &recv_recs) != GKC_OK)
             GKC_FAIL(c, GKC_ERR_ARG, "internal error: exchange plan");
         if (recv_recs) {

@@ -342,8 +342,8 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
 {
     // ordered: every level through the atomic / flag / stable-compaction kernels (the next lists stay in key order). Default: large levels of a single-rank build go
     // through the region build (above), whose next lists come out in region order; gkc_mphf_build* rebuild `ordered` in the one case where that order would show.
-    const bool regions_env = !(getenv("GKC_MPHF_REGIONS") && atoi(getenv("GKC_MPHF_REGIONS")) == 0);
-    const uint64_t regions_min = getenv("GKC_MPHF_REGIONS_MIN") ? (uint64_t)atoll(getenv("GKC_MPHF_REGIONS_MIN")) : (1ull << 21);      // keys of a level from which it pays (tests lower it)
+    const bool regions_env = gkc_tun().mphf_regions;
+    const uint64_t regions_min = gkc_tun().mphf_regions_min;      // keys of a level from which it pays (tests lower it)
     uint64_t n = n_local;
     if (comm) {
         std::vector<uint64_t> ns(gkc_comm_world(comm));
@@ -392,7 +392,7 @@ static int mphf_build_from_list(gkc_ctx* c, gkc_mphf* m, DevBuf& keysA, uint64_t
             });
             GKC_HIP(c, hipMemsetAsync(coll.p, 0, (size_t)m->nchar[lv] * 8, c->stream));
             GKC_HIP(c, hipMemsetAsync((uint64_t*)d_tot.p + 2, 0, 8, c->stream));
-            const bool dbg = getenv("GKC_MPHF_DEBUG") != nullptr;
+            const bool dbg = gkc_tun().verbose;
             hipEvent_t ev[5]; if (dbg) { for (auto& e : ev) (void)hipEventCreate(&e); (void)hipEventRecord(ev[0], c->stream); }
             hipLaunchKernelGGL((k_mphf_regions<false>), dim3(n_wgs), dim3(MR_THREADS), (size_t)n_regions * 4, c->stream, (const uint64_t*)cur->p, alive, wide, lv, m->L.domain[lv], chunk, n_regions,
                                (uint32_t*)r_wg.p, (const uint64_t*)nullptr, (uint64_t*)nullptr);
@@ -518,7 +518,7 @@ static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8
         if (on_host) (void)hipStreamSynchronize(c->stream);
         done += ni;
     }
-    if (rc == GKC_OK) rc = mphf_build_from_list(c, m, keys, n, comm, attempt == 1 || getenv("GKC_MPHF_ORDERED") != nullptr);
+    if (rc == GKC_OK) rc = mphf_build_from_list(c, m, keys, n, comm, attempt == 1 || gkc_tun().mphf_ordered);
     if (rc != GKC_MPHF_REBUILD_ORDERED) break;
   }
     (void)hipStreamSynchronize(c->stream);
@@ -530,6 +530,7 @@ static int mphf_build_arrays(gkc_ctx* c, const std::vector<std::pair<const uint8
 
 int gkc_mphf_build(gkc_ctx* c, const void* keys, uint64_t n, uint32_t stride, uint32_t k, gkc_mphf** out)
 {
+    gkc_tun_refresh();
     if (!c || !out || (!keys && n)) return GKC_ERR_ARG;
     if (k < 1 || k > 63) GKC_FAIL(c, GKC_ERR_ARG, "k must be in [1,63]");
     const uint32_t need = k > 31 ? 16 : 8;
@@ -539,6 +540,7 @@ int gkc_mphf_build(gkc_ctx* c, const void* keys, uint64_t n, uint32_t stride, ui
 }
 int gkc_mphf_build_solid(gkc_ctx* c, gkc_mphf** out)
 {
+    gkc_tun_refresh();
     if (!c || !out) return GKC_ERR_ARG;
     if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "context not configured");
     GKC_TRY(gkc_require_resident(c, "gkc_mphf_build_solid"));
@@ -562,6 +564,7 @@ static void solid_segments(gkc_ctx* c, uint32_t stride, std::vector<std::pair<co
 }
 int gkc_mphf_build_solid_dist(gkc_ctx* c, gkc_comm* comm, gkc_mphf** out)
 {
+    gkc_tun_refresh();
     if (!c || !comm || !out) return GKC_ERR_ARG;
     if (!c->configured) GKC_FAIL(c, GKC_ERR_ARG, "context not configured");
     GKC_TRY(gkc_require_resident(c, "gkc_mphf_build_solid_dist"));

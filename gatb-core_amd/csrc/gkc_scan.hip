@@ -32,7 +32,6 @@ struct ScanParams {
     const uint16_t* repart; uint32_t nb_passes, pass;
     unsigned long long* cnt_rec; unsigned long long* cnt_kmers; unsigned long long* cursor;
     uint64_t* arena;
-    int dbg_noatomic;             // GKC_DEBUG_NOATOMIC=1: timing experiment only (wrong results)
     int identity_part;            // sampling mode: the 'partition' of a super-k-mer is its minimizer value (4^m bins)
     uint64_t n_tiles; uint32_t n_parts;
     uint32_t* wg_cnt;                    // LDSPART count: [grid][P] records of this workgroup
@@ -154,14 +153,6 @@ __device__ __forceinline__ void load16(const uint8_t* bases, uint64_t g0, uint64
     }
 }
 
-#ifdef GKC_EXP_SCAN_PROF
-// timing experiment (tools/build_variant.sh scanprof -DGKC_EXP_SCAN_PROF=1): cycles of wave 0 of every workgroup between the marks of k_scan_tile
-__device__ unsigned long long g_scan_prof[16];
-#define SCAN_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
-#else
-#define SCAN_MARK(i) do {} while (0)
-#endif
-
 // LDSPART: persistent workgroups with a static tile assignment (tile = blockIdx.x, += gridDim.x, identical in the count
 // and the emit launch). Per-partition counters / record cursors live in LDS (64-bit LDS atomics): the count launch
 // leaves a [workgroup][partition] matrix, a tiny prefix kernel turns it into private record ranges, and the emit launch
@@ -194,9 +185,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             s_part[p] = 0u;
     }
     uint32_t nv_acc = 0, ni_acc = 0, n_rec = 0;
-#ifdef GKC_EXP_SCAN_PROF
-    unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
-#endif
 
   // the tile's bases (16 per thread + the halo words) and read-start bits are fetched one tile AHEAD into registers: with two workgroups
   // per CU and ~7 barriers per tile nothing else hides the global-load latency (measured: a third of the kernel)
@@ -219,7 +207,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         P.desc_tile[tile - gridDim.x] = make_uint2(s_toff, s_tcnt);        // the barrier above; nobody touches the two words again before step 5)
         s_toff += s_tcnt; s_tcnt = 0;
     }
-    SCAN_MARK(0);
 
     // ---- step 0: ASCII -> bit planes (A1) ----
     {
@@ -230,9 +217,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         if (t < SCAN_TILE / 32 + 8) s_rs[t] = pfR;
     }
     if (tile + gridDim.x < P.n_tiles) prefetch(tile + gridDim.x);     // in flight during the rest of this tile
-    SCAN_MARK(1);
     __syncthreads();
-    SCAN_MARK(2);
 
     // ---- step 1: order key of the m-mer starting at every position (A3: LUT semantics) ----
     for (int w = t; w < SCAN_WORDS; w += SCAN_THREADS) {
@@ -254,26 +239,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                 a = (a >> 1) & a & P.mask_ma1;                // "AA" anywhere but as prefix (KMC2 rule)
                 key = a ? P.mmask : c;
             }
-#ifdef GKC_EXP_SCAN_NOSTEP1
-            key = (uint32_t)(w & 7);
-#endif
             s_mk[17 * w + j] = key;
         }
     }
-    SCAN_MARK(3);
     __syncthreads();
-    SCAN_MARK(4);
 
     // ---- step 2: minimizer = window minimum of nb_mm keys (always the true minimum: Model.hpp:1107-1139 keeps it by
     //      rescanning whenever the tracked one leaves the window) ----
     const int p0 = 16 * t;
     const uint32_t Wn = P.nb_mm;
     uint32_t mz[16];
-#ifdef GKC_EXP_SCAN_NOMIN
-    if (Wn == 12345) {
-#else
     if (Wn >= 16) {
-#endif
         // MKI(16 t + i) = 17 t + i + (i >> 4): the part that depends on i is wave-uniform (scalar), one vector add per LDS address
         const uint32_t* mk_t = s_mk + 17 * t;
         uint32_t core = P.default_key;                        // the default minimizer 4^m-1 takes part (Model.hpp:1260)
@@ -295,17 +271,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             uint32_t best = P.default_key;
-#ifdef GKC_EXP_SCAN_NOMIN
-            for (uint32_t i = 0; i < 1; i++) {
-#else
-            for (uint32_t i = 0; i < Wn; i++) {
-#endif
-                uint32_t v = s_mk[MKI(p0 + j + i)]; best = v < best ? v : best; }
+            for (uint32_t i = 0; i < Wn; i++) { uint32_t v = s_mk[MKI(p0 + j + i)]; best = v < best ? v : best; }
             mz[j] = best;
         }
     }
 
-    SCAN_MARK(5);
     // ---- step 3: which positions hold a k-mer, and which of those are valid (A2) ----
     // window-OR of the invalid / read-start bit planes over k (k-1) positions for all 16 positions of the thread at once:
     // doubling (windows 1,2,4,...,32) on a 128-bit value, then the binary decomposition of the window length.
@@ -361,12 +331,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         const uint32_t fits = lim >= 15 ? 0xFFFFu : (lim < 0 ? 0u : ((2u << (uint32_t)lim) - 1u));
         existsmask = ~rsany & fits;
         validmask = existsmask & ~badany;
-#ifdef GKC_EXP_SCAN_NOSTEP3
-        existsmask = fits; validmask = fits;
-#endif
     }
 
-    SCAN_MARK(6);
     // ---- step 4: natural super-k-mer starts and the workgroup-wide "last start" max-scan (A4) ----
     s_lastmz[t] = mz[15]; s_lastvalid[t] = (validmask >> 15) & 1;
     s_firstmz[t] = mz[0]; s_firstvalid[t] = validmask & 1;
@@ -399,7 +365,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         carry = ex > wc ? ex : wc;
     }
 
-    SCAN_MARK(7);
     // ---- step 5: emit one record per run end (A4 cap, A5 pass filter + partition, A6 bucket write) ----
     // run ends are first compacted per thread into LDS (own 16 slots), so the divergent emission loop runs
     // max-over-lanes(#ends) times instead of 16
@@ -465,10 +430,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                 if (!dstore) *P.desc_overflow = 1u;
             }
         }
-#ifdef GKC_EXP_SCAN_NOEMIT
-        n_end = n_end > 1000 ? n_end : 0;
-#endif
-        SCAN_MARK(8);
         auto next_end = [&](int e, uint32_t& nbk, uint32_t& key, int& start) {          // the e-th run end of the thread (called in order)
             if (fast) {
                 const uint32_t j = (uint32_t)__builtin_ctz(ends); ends &= ends - 1u;
@@ -507,7 +468,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
                 for (int u = 0; u < 4; u++) if (e0 + u < n_end) {
                     if (dlow[u] == 0xFFFFFFFFu) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }      // filtered out: a hole in the descriptor stream
                     n_rec++;
-                    if (P.dbg_noatomic) { if (dstore) dst[e0 + u] = 0xFFFFFFFFu; continue; }
                     const uint32_t grp = FINE ? dpart[u] >> P.fine_shift : dpart[u];
                     atomicAdd(&s_part[grp], 1u);
                     if (dstore) {
@@ -527,7 +487,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             const uint32_t part = full >> P.fine_shift;
             n_rec++;
             if (!EMIT) {
-                if (P.dbg_noatomic) continue;
                 { atomicAdd(&P.cnt_rec[part], 1ULL); atomicAdd(&P.cnt_kmers[part], (unsigned long long)nbk); }
             } else {
                 const unsigned long long slot = LDSPART ? (P.wg_base[(uint64_t)blockIdx.x * P.n_parts + part] + atomicAdd(&s_part[part], 1u))
@@ -537,9 +496,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
         }
     }
 
-    SCAN_MARK(9);
     nv_acc += __popc(validmask); ni_acc += __popc(existsmask & ~validmask);
-    SCAN_MARK(10);
   }   // tile loop
     if (!EMIT && LDSPART && P.desc && blockIdx.x < P.n_tiles) { // close the last tile's descriptor range
         __syncthreads();
@@ -548,9 +505,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan_tile(ScanParams P)
             P.desc_tile[last] = make_uint2(s_toff, s_tcnt);
         }
     }
-#ifdef GKC_EXP_SCAN_PROF
-    if (threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_scan_prof[i], prof_acc[i]);
-#endif
 
     // ---- statistics (Sequence2SuperKmer.hpp:103,108) ----
     {
@@ -658,17 +612,6 @@ static int launch_scan(gkc_ctx* c, const ScanParams& P, bool emit, bool ldspart,
     }
 #undef GKC_LAUNCH
     GKC_HIP(c, hipGetLastError());
-#ifdef GKC_EXP_SCAN_PROF
-    {   unsigned long long h[16];
-        GKC_HIP(c, hipStreamSynchronize(c->stream));
-        GKC_HIP(c, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_scan_prof), sizeof(h)));
-        unsigned long long tot = 0; for (int i = 0; i < 11; i++) tot += h[i];
-        fprintf(stderr, "[gkc] scan marks (emit=%d), cumulative %% of wave-0 cycles:", (int)emit);
-        static const char* nm[] = {"barrier0", "step0+prefetch", "barrier1", "step1", "barrier2", "step2", "step3", "step4", "step5 collect", "step5 emit", "tile end"};
-        for (int i = 0; i < 11; i++) fprintf(stderr, " %s %.1f;", nm[i], tot ? 100.0 * (double)h[i] / (double)tot : 0.0);
-        fprintf(stderr, "\n");
-    }
-#endif
     return GKC_OK;
 }
 
@@ -841,7 +784,7 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
         GKC_HIP(c, hipGetLastError());
     }
     // geometry: persistent workgroups when the partition cursors fit in LDS
-    const bool ldspart = Pn <= SCAN_LDS_PARTS_MAX && getenv("GKC_SCAN_GLOBAL_ATOMICS") == nullptr;
+    const bool ldspart = Pn <= SCAN_LDS_PARTS_MAX && !gkc_tun().scan_global_atomics;
     const size_t dyn_lds = ldspart ? (size_t)Pn * 4 : 0;
     unsigned grid_n;
     if (ldspart) {
@@ -870,18 +813,17 @@ int gkc_scan_push(gkc_ctx* c, const char* d_bases, const uint64_t* d_offsets, ui
     P.mkey_lut = (const uint32_t*)c->d_mkey_lut.p; P.key2val = (const uint32_t*)c->d_key2val.p; P.default_key = c->default_key;
     // two-level scan with <= 16 partitions per group: the scan looks the FINE partition up and leaves its low bits in the record (4 spare bits below the nucleotides),
     // so the refine level does not recompute minimizers; more partitions per group: the group table, and k_refine_count recomputes
-    const bool stash = cshift > 0 && cshift <= 4 && getenv("GKC_REFINE_RECOMPUTE") == nullptr;
+    const bool stash = cshift > 0 && cshift <= 4 && !gkc_tun().refine_recompute;
     P.fine_shift = stash ? cshift : 0u; P.desc_fine = nullptr;
     P.repart = (cshift && !stash) ? (const uint16_t*)c->d_repart_coarse.p : (const uint16_t*)c->d_repart.p; P.nb_passes = c->nb_passes; P.pass = c->pass;
     P.cnt_rec = cnt; P.cnt_kmers = cnt + Pn; P.cursor = cnt + 2 * (size_t)Pn; P.gstats = cnt + 3 * (size_t)Pn;
     P.arena = nullptr;
-    P.dbg_noatomic = getenv("GKC_DEBUG_NOATOMIC") != nullptr;
     P.n_tiles = n_tiles; P.n_parts = Pn;
     P.wg_base = ldspart ? (unsigned long long*)c->d_scan_matrix.p : nullptr;
     P.wg_cnt = ldspart ? (uint32_t*)((unsigned long long*)c->d_scan_matrix.p + (size_t)grid_n * Pn) : nullptr;
     P.rec_off = cnt + 2 * (size_t)Pn;
     // descriptor stream (count pass -> emit pass): DESC_PER_TILE u32 per tile on average, per-workgroup regions
-    const bool use_desc = ldspart && Pn <= DESC_PARTS_MAX && getenv("GKC_SCAN_NO_DESC") == nullptr;
+    const bool use_desc = ldspart && Pn <= DESC_PARTS_MAX && !gkc_tun().scan_no_desc;
     if (use_desc) {
         const uint64_t tiles_per_wg = (n_tiles + grid_n - 1) / grid_n;
         const uint64_t cap = tiles_per_wg * (SCAN_TILE * 5 / 32);

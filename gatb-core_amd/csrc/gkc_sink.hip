@@ -239,7 +239,7 @@ struct SinkBatch {
     std::chrono::steady_clock::time_point t_queued, t_ready;           // GKC_SINK_DEBUG
     double pack_ms = 0;
 };
-static const bool g_sink_debug = getenv("GKC_SINK_DEBUG") != nullptr;
+#define g_sink_debug (gkc_tun().sink_debug)
 
 struct gkc_unpacker {
     gkc_ctx* c = nullptr;
@@ -409,7 +409,7 @@ static gkc_unpacker* unpacker_of(gkc_ctx* c)
     gkc_unpacker* U = new gkc_unpacker(); U->c = c;
     // measured on the 2 x 64-core host of the MI355X box (tools/hostmem_probe/unpack_probe): 16 threads expand 14e9 records/s (100 GB/s read + 230 GB/s of non-temporal
     // writes) with or without a device -> host copy running beside them; 64 threads fall to 6e9/s beside the copy stream, 128 to 4e9/s even alone
-    int n = getenv("GKC_UNPACK_THREADS") ? atoi(getenv("GKC_UNPACK_THREADS")) : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    int n = gkc_tun().unpack_threads > 0 ? gkc_tun().unpack_threads : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
     if (n < 1) n = 1;
     for (int i = 0; i < n; i++) U->threads.emplace_back([U] { U->worker(); });
     c->unpacker = U;
@@ -419,8 +419,8 @@ static gkc_unpacker* unpacker_of(gkc_ctx* c)
 // whether the sink of this context takes packed batches (8-byte keys; GKC_SINK_PACKED=0 keeps the plain copies)
 bool gkc_sink_packed(gkc_ctx* c)
 {
-    static const bool off = getenv("GKC_SINK_PACKED") && atoi(getenv("GKC_SINK_PACKED")) == 0;
-    static const bool off2 = getenv("GKC_SINK_PACKED2") && atoi(getenv("GKC_SINK_PACKED2")) == 0;       // (16-byte keys only)
+    const bool off = !gkc_tun().sink_packed;
+    const bool off2 = !gkc_tun().sink_packed2;       // (16-byte keys only)
     return c->sink && (c->key_words == 1 || !off2) && !off && ((uintptr_t)c->sink & 15) == 0;
 }
 
@@ -444,7 +444,7 @@ int gkc_sink_prepare(gkc_ctx* c)
 
 static void pin_unpackers(gkc_unpacker* U)
 {
-    if (getenv("GKC_UNPACK_NO_PIN") || !U->staging) return;
+    if (!U->staging) return;
     const int node = numa_node_of(U->c->sink ? U->c->sink : (const void*)U->staging);
     cpu_set_t set;
     if (node < 0 || !cpus_of_node(node, &set)) return;
@@ -510,8 +510,8 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     if (nblk == 0 || nblk >= (1ull << 31)) return nullptr;
     // width of an entry: 8 where the partitions are sparse, 7 where dense, 6 (+ bitmap + abundance stream) where dense and most abundances are 1 — expected at
     // abundance-min 1 (sequencing errors) and checked batch by batch: a batch whose stream came out longer than 0.85 bytes per record switches the context back to 7
-    static const bool no6 = getenv("GKC_SINK_WIDTH6") && atoi(getenv("GKC_SINK_WIDTH6")) == 0;
-    static const uint64_t dense_min = getenv("GKC_SINK_DENSE") ? (uint64_t)atoll(getenv("GKC_SINK_DENSE")) : PK_DENSE;      // (tests: 1 = every batch is "dense")
+    const bool no6 = !gkc_tun().sink_width6;
+    const uint64_t dense_min = gkc_tun().sink_dense ? gkc_tun().sink_dense : PK_DENSE;      // (tests: 1 = every batch is "dense")
     const bool wide = c->key_words == 2;
     const bool dense = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= (wide ? std::min<uint64_t>(dense_min, PK2_DENSE) : dense_min);
     const int width = wide ? (dense ? 16 : 17) : !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;

@@ -629,7 +629,9 @@ class Comm:
 
     def stats(self):
         s = CommStats(); self.c._chk(self.L.gkc_comm_get_stats(self.h, C.byref(s)))
-        return {n: getattr(s, n) for n, _ in CommStats._fields_ if n != "reserved"}
+        d = {n: getattr(s, n) for n, _ in CommStats._fields_ if n != "reserved"}
+        d["ipc_bounced"] = int(s.reserved[0])      # receive buffers of the IPC transport that could not be exported (mapped ranges) and went through a hipMalloc bounce block
+        return d
 
     def close(self):
         if getattr(self, "h", None):

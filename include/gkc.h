@@ -23,6 +23,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is compiled with -fvisibility=hidden and linked with a version script (csrc/gkc.map): the declarations below are its whole dynamic symbol table. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define GKC_OK            0
 #define GKC_ERR_ARG       1   /* bad argument / bad state                        */
@@ -255,7 +259,7 @@ typedef struct gkc_comm_stats {
     uint64_t n_exchanges, bytes_sent, bytes_received;   /* record bytes that left / reached this rank (not counting what stayed) */
     double   ms_transfer;                                 /* HIP-event time of the grouped send/recv on the communicator's stream (RCCL) or wall time of the callback */
     double   ms_host;                                     /* wall time inside gkc_exchange (tables, allocation, enqueue) */
-    uint64_t reserved[4];
+    uint64_t reserved[4];                                 /* [0]: receive buffers the IPC transport took through a bounce block (their allocation could not be exported) */
 } gkc_comm_stats;
 int  gkc_comm_get_stats(gkc_comm* comm, gkc_comm_stats* out);
 /* Collective, after gkc_finish_pass of the current pass on every rank: the Count[] arrays of all partitions are gathered on `root` (each owner sends the arrays of
@@ -399,6 +403,9 @@ int gkc_kmer_checksum_device(gkc_ctx* ctx, const char* d_bases, const uint64_t* 
 /* the same checksum over the finished datasets of the context: sum abundance*mix(value), sum abundance */
 int gkc_result_checksum(gkc_ctx* ctx, uint64_t* checksum, uint64_t* sum_abundance);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "missing_artefacts(what): a build-container artefact the test needs is absent (tests/test_gpu_dropin.py: fails on a GPU box)")
 
 
 @pytest.fixture(scope="session")

@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol(gkc):
     assert set(syms) == set(gkc.SYMBOLS), set(syms) ^ set(gkc.SYMBOLS)
 
 
+def test_library_exports_nothing_else(gkc):
+    """a thin C-ABI at the linker level: the dynamic symbol table holds the gkc_* of include/gkc.h only (no C++ vague-linkage symbols, no
+    __device_stub__*) — the library shares a process with libgatbcore.a, HDF5 and libstdc++ (VERDICT r5 weak #10)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", gkc.SO], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()]
+    names = [n for n in names if n != "GKC_1"]          # the version node itself
+    assert sorted(names) == declared_symbols(), sorted(set(names) ^ set(declared_symbols()))
+
+
 def test_binding_resolves_and_reports_version(gkc):
     L = gkc.lib()
     assert b"gfx950" in L.gkc_version()

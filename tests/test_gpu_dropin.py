@@ -9,7 +9,7 @@ the histogram, the repartition table. Three ways through the binding:
                 by default the text of a plain FASTA / FASTQ bank goes to the device as it is and is parsed there (gkc_push_fastx);
   * two ranks   two processes on the one GPU (the library's file-mailbox transport), reads shared out by index, super-k-mers exchanged, results gathered on
                 rank 0: ONE .h5 with every dataset of the single-process file (CountProcessorDump.hpp:85-95, GraphUnitigs.cpp:921-931).
-The files are read back with the reference's own gatb-h5dump (integration/_build/ref, built by integration/build_reference.sh). Skipped where the artefacts are absent."""
+The files are read back with the reference's own gatb-h5dump (integration/_build/ref, built by integration/build_reference.sh). Where the artefacts are absent: FAILED on a GPU box (the build step that makes them did not run), skipped elsewhere."""
 import os
 import subprocess
 import tempfile
@@ -24,8 +24,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "integration", "_build", "dbgh5_device")
 H5DUMP = os.path.join(ROOT, "integration", "_build", "ref", "gatb-h5dump")
-needs_artefacts = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(H5DUMP)),
-                                     reason="integration/_build/dbgh5_device or ref/gatb-h5dump absent (built in the build container: integration/check_integration.sh --link)")
+
+
+def _gpu_box():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:      # noqa
+        return False
+
+
+@pytest.fixture
+def artefacts_missing(request):
+    pytest.fail("%s: built in the build container by __graft_entry__.build() (integration/build_reference.sh + check_integration.sh --link) and shipped with the "
+                "snapshot; on a GPU box their absence is a FAILED build, not a reason to skip a quarter of the suite (VERDICT r5 weak #1)" % request.node.get_closest_marker("missing_artefacts").args[0])
+
+
+def need(*paths):
+    """mark for tests that run a build-container artefact: nothing when it is there; where it is absent the test FAILS on a GPU box and is skipped elsewhere"""
+    missing = [os.path.relpath(q, ROOT) for q in paths if not os.path.exists(q)]
+    if not missing:
+        return lambda f: f
+    if _gpu_box():
+        return lambda f: pytest.mark.missing_artefacts(", ".join(missing) + " absent")(pytest.mark.usefixtures("artefacts_missing")(f))
+    return pytest.mark.skipif(True, reason=", ".join(missing) + " absent (built in the build container: integration/check_integration.sh --link)")
+
+
+needs_artefacts = need(EXE, H5DUMP)
 
 CASES = {"k21_freq_4parts": (["-minimizer-type", "1", "-repartition-type", "1"], "1", "1"),
          "k21_default_parts": ([], "1", "1"),
@@ -153,7 +178,7 @@ def info_values(h5, keys):
 
 
 @needs_artefacts
-@pytest.mark.skipif(not os.path.exists(DBGINFO), reason="integration/_build/ref/dbginfo absent")
+@need(DBGINFO)
 def test_bank_statistics_of_the_text_path(tmp_path):
     """the device-parsed text path fills BankStats from the device's counters (gkc_stats.seq_len_*): getInfo() must report the same sequence statistics as the
     iterated path, whose BankStats::update sees every Sequence (SortingCountAlgorithm.cpp:728-742, BankKmers.hpp:164-200)"""
@@ -343,7 +368,7 @@ REF_DBGH5 = os.path.join(ROOT, "integration", "_build", "ref", "dbgh5")
 
 
 @needs_artefacts
-@pytest.mark.skipif(not os.path.exists(REF_DBGH5), reason="integration/_build/ref/dbgh5 (the unpatched reference) absent")
+@need(REF_DBGH5)
 @pytest.mark.parametrize("freq", [False, True])
 def test_repartitor_stop_rules_against_the_unpatched_reference(tmp_path, freq):
     """The sample sizes only bite on a bank larger than the fixtures: SampleRepart stops in the sequence where more than max(5 % of the sequences, 10^6) super-k-mers have been
@@ -396,7 +421,7 @@ def canonical_unitigs(fa):
 
 
 @needs_artefacts
-@pytest.mark.skipif(not (os.path.exists(UNITIGS) and os.path.exists(UNITIGS_REF)), reason="integration/_build/unitigs_check absent")
+@need(UNITIGS, UNITIGS_REF)
 def test_graphunitigs_consumes_the_device_output(tmp_path):
     """north_star: "drops into GraphUnitigs/dbgh5 unchanged" (VERDICT r3 N1). (a) the .h5 the patched dbgh5 wrote on the MI355X in the mode GraphUnitigs forces
     (frequency-order minimizers, 4 partitions) is opened by the UNPATCHED reference's GraphUnitigs (restart path, GraphUnitigs.cpp:907-944); (b) GraphUnitigs linked with
@@ -420,7 +445,7 @@ def test_graphunitigs_consumes_the_device_output(tmp_path):
 
 
 @needs_artefacts
-@pytest.mark.skipif(not os.path.exists(DBGINFO), reason="integration/_build/ref/dbginfo absent")
+@need(DBGINFO)
 def test_device_time_keys_in_getinfo(tmp_path):
     """getInfo() of the patched SortingCountAlgorithm carries the device's figures where the reference's commands put 1.read / 2.sort / 3.dump
     (fillsolid_time, SortingCountAlgorithm.cpp:777-780): device_stage_a / device_stage_b / device_wait / device_hand_over, stored in the .h5's xml"""

@@ -107,18 +107,6 @@ def test_fuzz_random_configurations(gkc, seed):
     device_vs_oracle(gkc, reads, k, m, parts, passes=passes, batches=batches, amin=amin, amax=amax, histo_max=histo_max, freq=freq)
 
 
-def test_balanced_walk_switch(gkc):
-    """GKC_BALANCED=1 (one lane per task of <= 4 k-mers in the two expansion kernels, csrc/gkc_count.hip wave_each_kmer16; measured and not the default:
-    profiles/r05_balanced_expand.txt) stays bit-exact: the fuzz of tools/fuzz_soak.py (random k <= 63, partitions, passes, windows, low-complexity inserts)
-    in a process of its own, since the switch is read once per process"""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GKC_BALANCED="1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_soak.py"), "100", "60"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "soak done: 60 seeds, 0 mismatches" in r.stdout, r.stdout[-2000:]
-
-
 def test_frequency_order_minimizers(gkc):
     """-minimizer-type 1 (what GraphUnitigs forces, GraphUnitigs.cpp:861-870)"""
     reads = synth_reads(3000, 15000, 150, seed=6, n_rate=0.001)
