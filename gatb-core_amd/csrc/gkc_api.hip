@@ -591,6 +591,14 @@ int gkc_set_host_sink(gkc_ctx* c, void* pinned, uint64_t cap_bytes)
     c->sink = pinned; c->sink_cap = pinned ? cap_bytes : 0; c->sink_used = 0; c->sink_overflow = false; c->sink_no6 = false;
     return gkc_sink_prepare(c);                                          // 8-byte keys: the page-locked staging buffer of the packed transfer (7/16 of the sink)
 }
+int gkc_set_sink_mode(gkc_ctx* c, int mode)
+{
+    if (!c) return GKC_ERR_ARG;
+    if (mode != GKC_SINK_PACKED && mode != GKC_SINK_RAW) GKC_FAIL(c, GKC_ERR_ARG, "gkc_set_sink_mode: unknown mode %d", mode);
+    if (c->stage_b_running) GKC_FAIL(c, GKC_ERR_ARG, "Stage B is running");
+    c->sink_raw = mode == GKC_SINK_RAW;
+    return c->sink ? gkc_set_host_sink(c, c->sink, c->sink_cap) : GKC_OK;      // (a sink already set: its staging buffer is made / kept for the new mode)
+}
 int gkc_wait_partition(gkc_ctx* c, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid)
 {
     if (!c) return GKC_ERR_ARG;

@@ -421,7 +421,7 @@ bool gkc_sink_packed(gkc_ctx* c)
 {
     const bool off = !gkc_tun().sink_packed;
     const bool off2 = !gkc_tun().sink_packed2;       // (16-byte keys only)
-    return c->sink && (c->key_words == 1 || !off2) && !off && ((uintptr_t)c->sink & 15) == 0;
+    return c->sink && !c->sink_raw && (c->key_words == 1 || !off2) && !off && ((uintptr_t)c->sink & 15) == 0;
 }
 
 // the staging buffer holds the packed stream of ONE pass (like the sink holds one pass of records): 7/16 of the sink + the block slack of every partition

@@ -28,7 +28,7 @@ SYMBOLS = [
     "gkc_host_to_device", "gkc_comm_unique_id", "gkc_comm_create_rccl", "gkc_comm_create_transport", "gkc_comm_create_files", "gkc_comm_enable_ipc", "gkc_gather_results", "gkc_comm_loopback", "gkc_comm_selftest", "gkc_comm_peer_bytes", "gkc_comm_destroy", "gkc_comm_set_owners",
     "gkc_comm_get_owners", "gkc_balanced_owner_ranges", "gkc_exchange", "gkc_comm_get_stats", "gkc_bloom_allreduce_or",
     "gkc_mphf_build_solid_dist", "gkc_mphf_abundance_map_dist", "gkc_exchange_plan",
-    "gkc_sample_exact", "gkc_set_host_sink", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
+    "gkc_sample_exact", "gkc_set_host_sink", "gkc_set_sink_mode", "gkc_finish_pass_async", "gkc_wait_partition", "gkc_finish_pass_wait",
 ]
 
 
@@ -159,6 +159,7 @@ def lib():
         "gkc_mphf_abundance_map_dist": (C.c_int, [vp, vp, vp, vp, u64, P(u64)]),
         "gkc_sample_exact": (C.c_int, [vp, vp, vp, u64, u64, vp, vp, vp, P(u64)]),
         "gkc_set_host_sink": (C.c_int, [vp, vp, u64]),
+        "gkc_set_sink_mode": (C.c_int, [vp, C.c_int]),
         "gkc_finish_pass_async": (C.c_int, [vp]),
         "gkc_wait_partition": (C.c_int, [vp, u32, u32, P(vp), P(u64)]),
         "gkc_finish_pass_wait": (C.c_int, [vp]),
@@ -324,6 +325,10 @@ class Counter:
         """stream every Stage-B batch's records into ``host_buffer`` (a HostBuffer: page-locked) while Stage B runs; None switches it off"""
         self._sink = host_buffer
         self._chk(self.L.gkc_set_host_sink(self.h, None if host_buffer is None else host_buffer._p, 0 if host_buffer is None else host_buffer.nbytes))
+
+    def set_sink_mode(self, mode):
+        """"packed" (default: 0.4x of the bytes on the link, expanded by host threads) | "raw" (plain Count[] by DMA, no host core touches a byte)"""
+        self._chk(self.L.gkc_set_sink_mode(self.h, {"packed": 0, "raw": 1}[mode]))
 
     def finish_pass_async(self):
         self._chk(self.L.gkc_finish_pass_async(self.h))

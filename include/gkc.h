@@ -135,6 +135,15 @@ int gkc_finish_pass(gkc_ctx* ctx);
  *                           context has not begun another pass meanwhile, the pass is in progress again — as after a failed gkc_finish_pass — and
  *                           gkc_finish_pass / gkc_finish_pass_async may be called again (the retry of gkc_count_pass). */
 int gkc_set_host_sink(gkc_ctx* ctx, void* pinned_host, uint64_t cap_bytes);     /* NULL: no sink */
+/* How the batches cross the link, chosen before gkc_set_host_sink (default GKC_SINK_PACKED):
+ *   GKC_SINK_PACKED  as described above: 0.4x of the bytes on the link, and per record 6.3 B read + 16 B of non-temporal stores by CPU threads of this host;
+ *   GKC_SINK_RAW     the Count[] of every batch lands at its place in the sink by ONE DMA copy: 16 / 32 B per record on the link, NO host core touches a byte.
+ * One rank per host: packed (the link is the bound). Several ranks sharing ONE host's DRAM (8 GPUs of a node, each with its own PCIe link): the expansion threads of all
+ * ranks meet at the host's memory controllers (104 B of host traffic per record packed against 16 raw) — the launcher measures one step each way and keeps the faster
+ * (bench.py does; DESIGN.md section 5 has the numbers). Both modes leave byte for byte the same sink. */
+#define GKC_SINK_PACKED 0
+#define GKC_SINK_RAW    1
+int gkc_set_sink_mode(gkc_ctx* ctx, int mode);
 int gkc_finish_pass_async(gkc_ctx* ctx);
 int gkc_wait_partition(gkc_ctx* ctx, uint32_t pass, uint32_t part, const void** host_records, uint64_t* n_solid);
 int gkc_finish_pass_wait(gkc_ctx* ctx);

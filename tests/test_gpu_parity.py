@@ -877,6 +877,39 @@ def test_packed_sink_16_byte_keys(gkc, monkeypatch, k, amin, dense):
     c.set_host_sink(None)
 
 
+@pytest.mark.parametrize("k,amin", [(31, 1), (31, 2), (63, 1)])
+def test_raw_sink_mode_lands_the_same_bytes(gkc, k, amin):
+    """gkc_set_sink_mode(GKC_SINK_RAW): every batch's Count[] lands in the sink by one DMA copy (no packing on the device, no expansion threads on the host) — the mode
+    several ranks sharing one host's DRAM fall back to. The sink must hold byte for byte what the packed mode leaves there and what the oracle
+    counts; the mode is switched on a live context (packed -> raw -> packed), the wire-byte statistic follows (0 in raw mode)."""
+    reads = synth_reads(6000, 30000, 150, seed=90 + k, n_rate=0.001)
+    reads += [reads[0]] * 300
+    bases, offs = gko.pack_reads(reads)
+    m, parts = 8, 6
+    rep = simple_repart(m, parts)
+    c = gkc.Counter(0); c.configure(k, m, parts, rep); c.set_solidity(amin, 2147483647, 10000)
+    sink = gkc.HostBuffer(512 << 20)
+    c.set_host_sink(sink)
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, abundance_min=amin)
+    landed = {}
+    for mode in ("packed", "raw", "packed"):
+        c.set_sink_mode(mode)
+        c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
+        got = []
+        for p in range(parts):
+            view, n = c.wait_partition(0, p)
+            exp = ref.part_records(p)
+            assert n * c.rec_bytes == len(exp)
+            if n:
+                assert view is not None and np.array_equal(view, exp), (mode, p)
+            got.append(bytes(view) if n else b"")
+        wire = c.stats()["sink_wire_bytes"]
+        assert (wire == 0) == (mode == "raw"), (mode, wire)
+        landed.setdefault(mode, got)
+        assert got == landed["packed"]
+    c.set_host_sink(None)
+
+
 @pytest.mark.parametrize("switch", ["GKC_SINK_DENSE=1", "GKC_SINK_DENSE=1,GKC_SINK_WIDTH6=0", "GKC_SINK_DENSE=1,GKC_UNPACK_THREADS=1"])
 def test_packed_sink_entry_widths(switch):
     """The three entry widths of the packed transfer on the same inputs (GKC_SINK_DENSE=1 declares every batch dense): 6-byte deltas + abundance bitmap + abundance
