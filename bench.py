@@ -522,6 +522,23 @@ def main():
     if value_mode == "host":
         pcie_gbs = pcie_probe(c, sink)
         c.set_host_sink(sink)
+        # Several ranks share ONE host: packed batches cost the link 0.4x but the host 104 B of DRAM traffic per record (6.3 B DMA-written, read again by the expansion
+        # threads, 16 B of non-temporal stores) against 16 B raw — N ranks' expansion threads meet at the same memory controllers (tools/hostmem_probe/unpack_ranks_probe:
+        # DESIGN.md section 5). So with N > 1 (or GKC_BENCH_SINK_MODE=trial) every rank runs one untimed step each way, all ranks at once, and the job keeps the mode whose
+        # slowest rank was faster; GKC_BENCH_SINK_MODE=packed|raw pins it. One rank: packed (the link is the bound), no trial.
+        sink_mode = os.environ.get("GKC_BENCH_SINK_MODE", "trial" if world > 1 else "packed")
+        sink_trial = None
+        if sink_mode == "trial":
+            sink_trial = {}
+            for md in ("packed", "raw"):
+                c.set_sink_mode(md)
+                step(); sync()                                   # (the batch plan of the mode; staging buffers)
+                t0_ = time.perf_counter(); step(); sync(); d_ = time.perf_counter() - t0_
+                if world > 1:
+                    t = torch.tensor([d_], device=red_dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); d_ = float(t.item())
+                sink_trial[md + "_ms"] = d_ * 1e3
+            sink_mode = "raw" if sink_trial["raw_ms"] < sink_trial["packed_ms"] else "packed"
+        c.set_sink_mode(sink_mode)
         dt_host, per_host, ktime_host = timed_region(max(1, args.warmup), args.steps)        # (the batch plan changes with a sink: at least one untimed step)
         st_h = c.stats()
         wire = st_h["sink_wire_bytes"] if st_h.get("sink_wire_bytes", 0) > 0 else st_h["kmers_nb_solid"] * c.rec_bytes
@@ -530,7 +547,8 @@ def main():
                   "solid_records": st_h["kmers_nb_solid"], "bytes_landed": st_h["kmers_nb_solid"] * c.rec_bytes, "bytes_over_the_link": wire,
                   "packed_on_the_wire": st_h.get("sink_wire_bytes", 0) > 0, "pcie_d2h_GBps": pcie_gbs,
                   "link_GBps_over_the_step": wire / (dt_host / args.steps) / 1e9, "frac_of_pcie": wire / (dt_host / args.steps) / 1e9 / pcie_gbs,
-                  "sink_GB": sink.nbytes / 1e9, "sink_alloc_s": sink.alloc_s, "sink_overflow": "sink" in err_}
+                  "sink_GB": sink.nbytes / 1e9, "sink_alloc_s": sink.alloc_s, "sink_overflow": "sink" in err_,
+                  "sink_mode": sink_mode, "sink_mode_trial": sink_trial}
         # outside the clock: what landed is what the device holds (first / middle / last partition this rank owns)
         try:
             same = True
@@ -549,7 +567,7 @@ def main():
         landed["verified"] = landed["sink_ok"]
         if world > 1:
             t = torch.tensor([1 if landed["sink_ok"] else 0], device=red_dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); landed["sink_ok"] = bool(int(t.item()))
-        c.set_host_sink(None)
+        c.set_host_sink(None); c.set_sink_mode("packed")
         dt, per_dev, ktime = timed_region(1, args.steps)             # the same K steps with the records left in HBM
         dt_value, ktime_value = dt_host, ktime_host
     else:

@@ -34,11 +34,18 @@ constexpr uint64_t pk_slot(int W) { return (uint64_t)PK_BLOCK * (uint64_t)W; }  
 constexpr uint64_t pk_esc(int W) { return (1ull << (8 * (W - 1))) - 1ull; }
 constexpr uint64_t PK_KEY_EXC = 1ull << 63;
 constexpr uint64_t PK_DENSE = 300000;                                   // records per partition from which 6-byte deltas are used
-// PK6 (width 6): a block slot = PK_BLOCK 6-byte deltas (escape 2^48 - 1 as in width 7) + a bitmap of PK_BLOCK bits (abundance != 1); the abundance bytes of the
-// flagged records, in record order, sit in the batch's abundance stream from the block's offset on (u32 per block in the header, written by the block's workgroup
-// after ONE reservation on the stream's cursor: the order of the blocks in the stream is whatever it came out as)
-constexpr uint64_t PK6_ENTRIES = (uint64_t)PK_BLOCK * 6, PK6_SLOT = PK6_ENTRIES + PK_BLOCK / 8;                 // 49152 + 1024 bytes: a multiple of 16
-constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PK6_SLOT : pk_slot(width); }
+// PKV (reported as width 6; round 6, it replaces the fixed 6-byte deltas of rounds 3-5): every block of PK_BLOCK records carries its deltas at the block's OWN bit width
+// W = bits of its largest delta (canonical k-mers thin out towards the top of the key space, density 2 (1 - x): the gaps of a partition of 8.9e5 records average 2^42 and
+// range from 2^41 at the bottom to 2^50 in its last blocks, so one width for all either wastes bits at the bottom or escapes at the top: 48 bits + 0.03 % escapes before,
+// 45.6 bits on average and NO key escapes now = 5.7 instead of 6.0 bytes per record), bit-packed: 8 records = W bytes. A block's payload = its entries (chunks of
+// PKV_CHUNK records, each chunk 256 W bytes) + a bitmap of PK_BLOCK bits (abundance != 1), at an offset of the batch's payload stream the block's workgroup reserves
+// (u32 in 16-byte units + u8 width per block in the header); the abundance bytes of the flagged records, in record order, sit in the batch's abundance stream from the
+// block's offset on (u32 per block in the header) — both reserved by ONE atomic each: the order of the blocks in the streams is whatever it came out as.
+// W > 56 (a host extraction reads 8 bytes at any bit offset: 7 + W <= 63) is sent as W = 64.
+constexpr uint32_t PKV_CHUNK = 2048;                                                                            // records per pack iteration: 256 threads x 8 records
+constexpr uint64_t PKV_BITMAP = PK_BLOCK / 8, PKV_BLOCK_MAX = (uint64_t)PK_BLOCK * 8 + PKV_BITMAP;              // worst case of a block's payload (W = 64)
+__host__ __device__ constexpr uint64_t pkv_entries_bytes(uint32_t n, uint32_t W) { return (uint64_t)((n + PKV_CHUNK - 1) / PKV_CHUNK) * (PKV_CHUNK / 8) * W; }
+constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PKV_BLOCK_MAX : pk_slot(width); }
 // 16-byte keys (k >= 32; round 4, second session): the same scheme on 32-byte Count records {u128 value; i32 abundance; 12 bytes of padding} (Abundance.hpp:68-129 with
 // LargeInt<2>): per block the first key (16 bytes), per record [key delta : 15 or 16 bytes][abundance : 1 byte] = widths 16 / 17 instead of 32. A partition of 5.6e5 records in a
 // 126-bit key space has deltas of ~2^107 — but canonical k-mers thin out towards the top of the key space (density 2 (1 - x)), and with 14-byte deltas 0.1-0.4 % of them escaped
@@ -100,15 +107,17 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __re
 }
 
 __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint32_t* __restrict__ cb_off,
-                                                             uint8_t* __restrict__ payload, uint8_t* __restrict__ cb_stream, unsigned long long* __restrict__ cb_cursor,
+                                                             uint32_t* __restrict__ pay_off16, uint8_t* __restrict__ wbits,
+                                                             uint8_t* __restrict__ payload, unsigned long long* __restrict__ pay_cursor /* bytes */,
+                                                             uint8_t* __restrict__ cb_stream, unsigned long long* __restrict__ cb_cursor,
                                                              uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
 {
-    constexpr uint64_t PK_ESC = pk_esc(7);
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 6];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 64];                  // one chunk's entries: 256 x W bytes
+    __shared__ uint64_t s_key[PKV_CHUNK + 1];                                                 // the chunk's keys, [0] = the key before the chunk
     __shared__ __attribute__((aligned(16))) unsigned long long s_bits[PK_BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint8_t s_cb[PK_BLOCK];
     __shared__ uint32_t s_p, s_wcnt[PK_THREADS / 64];
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_pay, s_max[PK_THREADS / 64];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) {                                               // partition of block slot g: the largest p with blk_first[p] <= g
         uint32_t lo = 0, hi = P.nb;
@@ -121,20 +130,17 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
     const uint64_t s1 = P.ptot[2 * (p + 1) + 1], r0 = P.ptot[2 * p + 1] + (uint64_t)j * PK_BLOCK;
     const uint32_t n = (uint32_t)min((uint64_t)PK_BLOCK, s1 - r0);
     if (t == 0) bases[g] = recs[2 * r0];
-    uint8_t* dstp = payload + (uint64_t)g * PK6_SLOT;
-    uint32_t run = 0;                                           // flagged records of the chunks before this one (the same in every thread)
+    // ---- pass 1 (coalesced): the block's largest delta -> its width; the abundance side (bitmap, stream bytes, escapes of abundances >= 255) as before
+    uint64_t dmax = 0;
+    uint32_t run = 0;                                           // flagged records of the rounds before this one (the same in every thread)
     for (uint32_t i0 = 0; i0 < n; i0 += PK_THREADS) {
         const uint32_t i = i0 + t;
-        uint64_t d = 0; uint32_t ab8 = 1;
+        uint32_t ab8 = 1;
         if (i < n) {
             const ulonglong2 me = *reinterpret_cast<const ulonglong2*>(recs + 2 * (r0 + i));
             const uint64_t prev = i ? recs[2 * (r0 + i - 1)] : me.x;
-            d = me.x - prev;
-            if (d >= PK_ESC) {
-                const unsigned long long e = atomicAdd(n_exc, 1ull);
-                if (e < exc_cap) { exc[2 * e] = PK_KEY_EXC | (r0 + i); exc[2 * e + 1] = me.x; }
-                d = PK_ESC;
-            }
+            const uint64_t d = me.x - prev;
+            dmax = d > dmax ? d : dmax;
             const uint32_t ab = (uint32_t)me.y;
             ab8 = ab;
             if (ab >= 255u) {
@@ -146,21 +152,57 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
         const bool flag = ab8 != 1u;
         const unsigned long long bal = __ballot(flag);
         if (lane == 0) { s_bits[(i0 >> 6) + wave] = bal; s_wcnt[wave] = (uint32_t)__popcll(bal); }
-        uint8_t* o = s_out + 6 * t;
-#pragma unroll
-        for (int b = 0; b < 6; b++) o[b] = (uint8_t)(d >> (8 * b));
         __syncthreads();
         uint32_t before = run, total = 0;
 #pragma unroll
         for (int w = 0; w < PK_THREADS / 64; w++) { if (w < (int)wave) before += s_wcnt[w]; total += s_wcnt[w]; }
         if (flag) s_cb[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)ab8;
         run += total;
-        if (t < PK_THREADS * 6 / 16) reinterpret_cast<uint4*>(dstp + (uint64_t)i0 * 6)[t] = reinterpret_cast<const uint4*>(s_out)[t];      // 1536 bytes = 96 x 16
         __syncthreads();
     }
-    if (t < PK_BLOCK / 8 / 16) reinterpret_cast<uint4*>(dstp + PK6_ENTRIES)[t] = reinterpret_cast<const uint4*>(s_bits)[t];               // the bitmap: 1024 bytes = 64 x 16
-    if (t == 0) { s_base = run ? atomicAdd(cb_cursor, (unsigned long long)run) : 0ull; cb_off[g] = (uint32_t)s_base; }                   // (the stream is shorter than 2^32 bytes: one byte per record at most)
+#pragma unroll
+    for (int d_ = 32; d_ >= 1; d_ >>= 1) { const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)dmax, d_, 64); dmax = y > dmax ? y : dmax; }
+    if (lane == 0) s_max[wave] = dmax;
     __syncthreads();
+    if (t == 0) {
+        uint64_t m = 0;
+        for (int w = 0; w < PK_THREADS / 64; w++) m = s_max[w] > m ? s_max[w] : m;
+        uint32_t W = m ? 64u - (uint32_t)__clzll((long long)m) : 1u;
+        if (W > 56u) W = 64u;
+        const uint64_t bytes = pkv_entries_bytes(n, W) + PKV_BITMAP;                        // a multiple of 16
+        s_pay = atomicAdd(pay_cursor, (unsigned long long)bytes);
+        pay_off16[g] = (uint32_t)(s_pay >> 4); wbits[g] = (uint8_t)W;
+        s_base = run ? atomicAdd(cb_cursor, (unsigned long long)run) : 0ull; cb_off[g] = (uint32_t)s_base;      // (the stream is shorter than 2^32 bytes: one byte per record at most)
+        s_p = W;
+    }
+    __syncthreads();
+    const uint32_t W = s_p;
+    uint8_t* dstp = payload + s_pay;
+    // ---- pass 2 (the block's records again: L2): chunks of 2048 keys through LDS, every thread packs 8 consecutive deltas into W bytes, the chunk leaves as 16-byte words
+    for (uint32_t c0 = 0; c0 < n; c0 += PKV_CHUNK) {
+        for (uint32_t i = t; i < PKV_CHUNK; i += PK_THREADS) s_key[1 + i] = c0 + i < n ? recs[2 * (r0 + c0 + i)] : 0ull;
+        if (t == 0) s_key[0] = c0 ? recs[2 * (r0 + c0 - 1)] : recs[2 * r0];
+        __syncthreads();
+        {
+            unsigned __int128 acc = 0; uint32_t nbits = 0;
+            uint8_t* o = s_out + (size_t)t * W;
+            uint64_t prev = s_key[8 * t];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t i = c0 + 8 * t + q;
+                const uint64_t key = s_key[1 + 8 * t + q];
+                const uint64_t d = i < n ? key - prev : 0ull;                               // (beyond the block's records: zero bits)
+                prev = key;
+                acc |= (unsigned __int128)d << nbits; nbits += W;
+                while (nbits >= 8) { *o++ = (uint8_t)acc; acc >>= 8; nbits -= 8; }
+            }
+        }
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(dstp + (uint64_t)(c0 / PKV_CHUNK) * (PKV_CHUNK / 8) * W);
+        for (uint32_t w = t; w < 16u * W; w += PK_THREADS) dst[w] = reinterpret_cast<const uint4*>(s_out)[w];      // 256 W bytes = 16 W words of 16 bytes
+        __syncthreads();
+    }
+    if (t < PKV_BITMAP / 16) reinterpret_cast<uint4*>(dstp + pkv_entries_bytes(n, W))[t] = reinterpret_cast<const uint4*>(s_bits)[t];      // the bitmap: 1024 bytes = 64 x 16
     uint8_t* cb = cb_stream + s_base;
     for (uint32_t i = t; i < run; i += PK_THREADS) cb[i] = s_cb[i];
 }
@@ -229,6 +271,7 @@ struct SinkBatch {
     const uint8_t* stage = nullptr;              // [bases: 8 x nblk, padded to 64][payload: nblk x PK_SLOT][exceptions: 16 x n_exc]
     uint64_t nblk = 0, n_exc = 0, pay_off = 0, exc_off = 0; int width = 7;
     uint64_t cboff_off = 0, cb_off = 0, n_cb = 0;        // width 6: the blocks' offsets into the abundance stream (u32 each), the stream, its length
+    uint64_t pay16_off = 0, wbits_off = 0, pay_bytes = 0; // width 6: the blocks' payload offsets (u32, 16-byte units) and bit widths (u8) in the header; bytes of the payload stream
     std::vector<uint64_t> blk_rec0; std::vector<uint32_t> blk_n;       // per block: first record (index in the batch), records
     uint8_t* dest = nullptr;                     // the batch's records in the caller's sink
     void* d_packed = nullptr;                    // device buffer, given back once copied
@@ -270,22 +313,23 @@ struct gkc_unpacker {
             _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));      // {u64 value; i32 abundance; 4 bytes of padding = 0}
         }
     }
-    static void unpack_block_6(const SinkBatch& B, uint64_t g)
+    static void unpack_block_6(const SinkBatch& B, uint64_t g)                       // PKV: the block's own delta width, no key escapes
     {
-        constexpr uint64_t PK_ESC = pk_esc(7);
-        const uint8_t* pay = B.stage + B.pay_off + g * PK6_SLOT;
-        const uint64_t* bits = reinterpret_cast<const uint64_t*>(pay + PK6_ENTRIES);
-        const uint8_t* cb = B.stage + B.cb_off + reinterpret_cast<const uint32_t*>(B.stage + B.cboff_off)[g];
         const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
+        const uint32_t W = B.stage[B.wbits_off + g];
+        const uint8_t* pay = B.stage + B.pay_off + ((uint64_t)reinterpret_cast<const uint32_t*>(B.stage + B.pay16_off)[g] << 4);
+        const uint64_t* bits = reinterpret_cast<const uint64_t*>(pay + pkv_entries_bytes(n, W));
+        const uint8_t* cb = B.stage + B.cb_off + reinterpret_cast<const uint32_t*>(B.stage + B.cboff_off)[g];
         uint64_t key = reinterpret_cast<const uint64_t*>(B.stage)[g];
         __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 16);
+        const uint64_t mask = W >= 64 ? ~0ull : (1ull << W) - 1ull;
+        uint64_t bit = 0;
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             uint64_t m = bits[i0 >> 6];
             const uint32_t e = std::min<uint32_t>(n, i0 + 64);
-            for (uint32_t i = i0; i < e; i++, m >>= 1) {
-                uint64_t w; memcpy(&w, pay + 6 * (size_t)i, 8);      // (two bytes beyond the entry: the next entry or the bitmap)
-                const uint64_t d = w & PK_ESC;
-                if (i) key = d == PK_ESC ? lookup(B.exc, PK_KEY_EXC | (r0 + i)) : key + d;
+            for (uint32_t i = i0; i < e; i++, m >>= 1, bit += W) {
+                uint64_t w; memcpy(&w, pay + (bit >> 3), 8);         // (W <= 56: the W bits from bit offset (bit & 7) on lie inside these 8 bytes; W = 64: byte-aligned; up to 7 bytes beyond
+                key += (w >> (bit & 7)) & mask;                      //  the entries: the bitmap / the next block / the padding behind the stream) the first delta of a block is 0
                 const uint32_t f = (uint32_t)(m & 1ull);                 // 16 % of the records, at random: no branch on it (the byte under the cursor is read either way;
                 uint32_t ab = 1u + f * ((uint32_t)*cb - 1u); cb += f;    // the stream is followed by padding)
                 if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
@@ -361,7 +405,7 @@ struct gkc_unpacker {
                         const auto t00 = all.empty() ? B->t_queued : all.front()->t_queued;
                         fprintf(stderr, "[gkc sink] +%.1f ms: batch of %llu blocks (%.2f GB packed, %llu exceptions): pack %.1f ms, queued -> copied %.1f ms (the copy itself %.1f ms), unpack %.1f ms\n",
                                 std::chrono::duration<double, std::milli>(B->t_queued - t00).count(), (unsigned long long)B->nblk,
-                                (double)(B->nblk * pk_slot_of(B->width) + B->n_cb) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
+                                (double)((B->width == 6 ? B->pay_bytes : B->nblk * pk_slot_of(B->width)) + B->n_cb) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
                                 std::chrono::duration<double, std::milli>(now - B->t_ready).count());
                     }
                     { std::lock_guard<std::mutex> lk(mu); B->done.store(true); }
@@ -516,8 +560,9 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     const bool dense = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= (wide ? std::min<uint64_t>(dense_min, PK2_DENSE) : dense_min);
     const int width = wide ? (dense ? 16 : 17) : !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;
     const uint64_t n_rec = solid_prefix[nb];
-    const uint64_t bases_bytes = (nblk * (wide ? 16 : 8) + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0, hdr_bytes = bases_bytes + cboff_bytes;
-    const uint64_t pay_bytes = nblk * pk_slot_of(width), cb_cap = width == 6 ? (n_rec + 63) / 64 * 64 : 0;
+    const uint64_t bases_bytes = (nblk * (wide ? 16 : 8) + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0;
+    const uint64_t wbits_bytes = width == 6 ? (nblk + 63) / 64 * 64 : 0, hdr_bytes = bases_bytes + 2 * cboff_bytes + wbits_bytes;      // width 6: [bases | abundance-stream offsets | payload offsets | widths]
+    const uint64_t pay_bytes = nblk * pk_slot_of(width) + 64, cb_cap = width == 6 ? (n_rec + 63) / 64 * 64 : 0;                           // (width 6: the worst case — every block at 64 bits; what is copied is what was used)
     const uint32_t exc_cap = 1u << 20;
     g_sink_why = "no device memory for the packed copy";
     DevBuf d_first; if (c->ensure(d_first, (size_t)(nb + 1) * 4) != GKC_OK) return nullptr;
@@ -526,14 +571,14 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     hipStream_t st = cur_stream(c);
     const auto t_pack0 = std::chrono::steady_clock::now();
     uint8_t* const d_pay = d_packed + hdr_bytes; uint8_t* const d_cb = d_pay + pay_bytes; uint8_t* const d_exc = d_cb + cb_cap;
-    unsigned long long* d_nexc = reinterpret_cast<unsigned long long*>(d_exc + (uint64_t)exc_cap * 16);        // [0] exceptions [1] bytes of the abundance stream
-    unsigned long long h_cnt[2] = {0, 0};
+    unsigned long long* d_nexc = reinterpret_cast<unsigned long long*>(d_exc + (uint64_t)exc_cap * 16);        // [0] exceptions [1] bytes of the abundance stream [2] bytes of the payload stream (width 6)
+    unsigned long long h_cnt[3] = {0, 0, 0};
     bool ok = hipMemcpyAsync(d_first.p, blk_first.data(), (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess
-           && hipMemsetAsync(d_nexc, 0, 16, st) == hipSuccess;
+           && hipMemsetAsync(d_nexc, 0, 24, st) == hipSuccess;
     if (ok) {
         PackPlan P{ (const uint32_t*)d_first.p, d_ptot, nb };
         if (width == 6) hipLaunchKernelGGL(k_pack_counts6, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, (uint32_t*)(d_packed + bases_bytes),
-                                           d_pay, d_cb, d_nexc + 1, (uint64_t*)d_exc, d_nexc, exc_cap);
+                                           (uint32_t*)(d_packed + bases_bytes + cboff_bytes), d_packed + bases_bytes + 2 * cboff_bytes, d_pay, d_nexc + 2, d_cb, d_nexc + 1, (uint64_t*)d_exc, d_nexc, exc_cap);
         else if (width == 16) hipLaunchKernelGGL((k_pack_counts2<16>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
                                                  (uint64_t*)d_exc, d_nexc, exc_cap);
         else if (width == 17) hipLaunchKernelGGL((k_pack_counts2<17>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
@@ -542,23 +587,25 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
                                                 (uint64_t*)d_exc, d_nexc, exc_cap);
         else hipLaunchKernelGGL((k_pack_counts<8>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
                                 (uint64_t*)d_exc, d_nexc, exc_cap);
-        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h_cnt, d_nexc, 16, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h_cnt, d_nexc, 24, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     }
     d_first.release();
     const unsigned long long h_nexc = h_cnt[0], h_ncb = h_cnt[1];
+    const uint64_t pay_used = width == 6 ? ((uint64_t)h_cnt[2] + 63) / 64 * 64 : pay_bytes;               // bytes of the payload that travel (and are staged)
     g_sink_why = !ok ? "pack launch failed" : "too many exceptions";
-    if (!ok || h_nexc > exc_cap || h_ncb > cb_cap) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
+    if (!ok || h_nexc > exc_cap || h_ncb > cb_cap || (width == 6 && h_cnt[2] > pay_bytes - 64)) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
     if (width == 6 && (double)h_ncb > 0.85 * (double)n_rec) c->sink_no6 = true;      // (this batch still travels as it was packed: 7.1 bytes per record at worst)
     SinkBatch* B = new SinkBatch();
     const uint64_t cb_stage = (h_ncb + 63) / 64 * 64;
-    const uint64_t need = hdr_bytes + pay_bytes + cb_stage + h_nexc * 16 + 64;
+    const uint64_t need = hdr_bytes + pay_used + cb_stage + h_nexc * 16 + 64;
     {   std::lock_guard<std::mutex> lk(c->mu);
         if (U->staging_used + need > U->staging_cap) { g_sink_why = "staging buffer full"; delete B; c->dfree(d_packed); return nullptr; }
         B->stage = U->staging + U->staging_used; U->staging_used += (need + 63) / 64 * 64;
-        c->sink_wire_bytes += hdr_bytes + pay_bytes + h_ncb + h_nexc * 16;
+        c->sink_wire_bytes += hdr_bytes + pay_used + h_ncb + h_nexc * 16;
     }
-    B->nblk = nblk; B->n_exc = h_nexc; B->width = width; B->pay_off = hdr_bytes; B->cboff_off = bases_bytes; B->cb_off = hdr_bytes + pay_bytes; B->n_cb = h_ncb;
-    B->exc_off = hdr_bytes + pay_bytes + cb_stage; B->dest = h_dest; B->d_packed = d_packed;
+    B->nblk = nblk; B->n_exc = h_nexc; B->width = width; B->pay_off = hdr_bytes; B->cboff_off = bases_bytes; B->cb_off = hdr_bytes + pay_used; B->n_cb = h_ncb;
+    B->pay16_off = bases_bytes + cboff_bytes; B->wbits_off = bases_bytes + 2 * cboff_bytes; B->pay_bytes = pay_used;
+    B->exc_off = hdr_bytes + pay_used + cb_stage; B->dest = h_dest; B->d_packed = d_packed;
     B->blk_rec0.resize(nblk); B->blk_n.resize(nblk);
     for (uint32_t i = 0; i < nb; i++) {
         const uint64_t s0 = solid_prefix[i], s1 = solid_prefix[i + 1];
@@ -566,7 +613,7 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     }
     if (g_sink_debug && hipEventCreate(&B->copy_start) == hipSuccess) (void)hipEventRecord(B->copy_start, c->copy_stream);
     bool queued = hipEventCreateWithFlags(&B->copied, g_sink_debug ? hipEventDefault : hipEventDisableTiming) == hipSuccess
-               && hipMemcpyAsync((void*)B->stage, d_packed, (size_t)(hdr_bytes + pay_bytes), hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess
+               && hipMemcpyAsync((void*)B->stage, d_packed, (size_t)(hdr_bytes + pay_used), hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess
                && (h_ncb == 0 || hipMemcpyAsync((void*)(B->stage + B->cb_off), d_cb, (size_t)h_ncb, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
                && (h_nexc == 0 || hipMemcpyAsync((void*)(B->stage + B->exc_off), d_exc, (size_t)h_nexc * 16, hipMemcpyDeviceToHost, c->copy_stream) == hipSuccess)
                && hipEventRecord(B->copied, c->copy_stream) == hipSuccess;

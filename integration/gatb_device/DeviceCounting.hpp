@@ -81,7 +81,7 @@ public:
         device::DeviceContext::singleton().setResident (device::DeviceContext::Resident());      /* a new count: what an earlier one left in HBM is going away */
         _plan = plan;  _nbPartitions = config._nb_partitions;  _kmerSize = config._kmerSize;
         _waitS = _handOverS = 0;
-        if (plan.on)  { prepareRing (config._nbCores); }                  /* (page-locked once, before anything runs on the device) */
+        if (plan.on  &&  _prepareFn)  { prepareRing (config._nbCores); }     /* (page-locked once, before anything runs on the device; only where the direct sink can take the records: bulkPlan set a preparer) */
         const u_int64_t nbMinims = (u_int64_t)1 << (2 * config._minim_size);
         std::vector<uint16_t> table (nbMinims);
         for (u_int64_t m = 0; m < nbMinims; m++)  { table[m] = (uint16_t) repartitor (m); }
@@ -248,12 +248,13 @@ public:
         {
             const int fd = ::open (files[fi].c_str(), O_RDONLY);
             if (fd < 0)  { throw system::Exception ("device counting: cannot open %s", files[fi].c_str()); }
-            struct stat sb;  if (fstat (fd, &sb) != 0)  { ::close (fd);  throw system::Exception ("device counting: cannot stat %s", files[fi].c_str()); }
+            struct Handles  { int fd;  gzFile zf;  ~Handles ()  { if (zf != 0) { gzclose (zf); }  if (fd >= 0) { ::close (fd); } } }  handles = { fd, 0 };      /* closed on every way out, exceptions included */
+            struct stat sb;  if (fstat (fd, &sb) != 0)  { throw system::Exception ("device counting: cannot stat %s", files[fi].c_str()); }
             const uint64_t fileSize = (uint64_t) sb.st_size;
             uint64_t off = 0, size = fileSize;
             if (_ranks > 1  &&  fileSize > 0)
             {
-                char first = 0;  if (pread (fd, &first, 1, 0) != 1)  { ::close (fd);  throw system::Exception ("device counting: read error in %s", files[fi].c_str()); }
+                char first = 0;  if (pread (fd, &first, 1, 0) != 1)  { throw system::Exception ("device counting: read error in %s", files[fi].c_str()); }
                 const bool fastq = first == '@';
                 off  = recordStart (fd, fileSize / (uint64_t)_ranks * (uint64_t)_rank, fileSize, fastq);
                 size = _rank + 1 == _ranks ? fileSize : recordStart (fd, fileSize / (uint64_t)_ranks * (uint64_t)(_rank + 1), fileSize, fastq);
@@ -280,7 +281,8 @@ public:
             if (gz)
             {
                 zf = gzopen (files[fi].c_str(), "rb");
-                if (zf == 0)  { ::close (fd);  throw system::Exception ("device counting: cannot open %s through zlib", files[fi].c_str()); }
+                if (zf == 0)  { throw system::Exception ("device counting: cannot open %s through zlib", files[fi].c_str()); }
+                handles.zf = zf;
                 gzbuffer (zf, 1 << 20);
                 if (getenv ("GATB_DEVICE_VERBOSE") != 0)  { fprintf (stderr, "[device counting] %s: gzipped text, inflated on a host thread into the device parser\n", files[fi].c_str()); }
                 size = ~(uint64_t)0;  off = 0;
@@ -324,7 +326,7 @@ public:
                 if (gz  &&  next > 0)  { next = nextGot.load();  gzEnd = next < (uint64_t)CHUNK; }      /* (next == 0: the text ended exactly at the chunk: what is left goes out as the final piece below) */
                 const uint64_t left = final ? 0 : have - consumed;
                 if (rc == GKC_ERR_FORMAT  ||  (rc == GKC_OK  &&  left > (uint64_t)PAD))  { ok = false;  break; }      /* (or a record larger than the room: a genome, not reads) */
-                if (rc != GKC_OK)  { ::close (fd);  check (rc); }
+                if (rc != GKC_OK)  { check (rc); }
                 /* reads of THIS pass so far (gkc_stats.nb_sequences is pass 0's only: on later passes it would add the whole bank at the first chunk and
                  * nothing afterwards — progress, and with several ranks the pacing of the exchanges, need the pass's own count) */
                 gkc_stats st;  check (gkc_get_stats (_ctx, &st));
@@ -344,7 +346,7 @@ public:
                     {
                         uint64_t c2 = 0;
                         const int rc2 = gkc_push_fastx (_ctx, ptr + consumed, left, 1, &c2);
-                        if (rc2 == GKC_ERR_FORMAT)  { ok = false; }  else if (rc2 != GKC_OK)  { if (zf) { gzclose (zf); }  ::close (fd);  check (rc2); }
+                        if (rc2 == GKC_ERR_FORMAT)  { ok = false; }  else if (rc2 != GKC_OK)  { check (rc2); }
                     }
                     break;
                 }
@@ -352,8 +354,6 @@ public:
                 if (left > 0)  { memcpy (nptr, ptr + consumed, left); }
                 ptr = nptr;  have = left + next;  if (!gz) { off += next; }  cur ^= 1;
             }
-            if (zf)  { gzclose (zf); }
-            ::close (fd);
             if (readError)  { throw system::Exception ("device counting: read error in %s", files[fi].c_str()); }
             if (!ok)
             {
@@ -566,6 +566,7 @@ private:
                 _writerBusyS += wallNow() - w0;  _writerBytes += j.bytes;
             }
             catch (system::Exception& e)  { error = e.getMessage(); }
+            catch (std::exception& e)     { error = e.what(); }           /* (the commands wait in takeSlot / drainWriter: the writer must outlive whatever it meets) */
             giveSlot (j.slot);
             { std::lock_guard<std::mutex> guard (_ringLock);  if (!error.empty()  &&  _writerError.empty()) { _writerError = error; }  _jobsPending--; }
             _idleCv.notify_all();

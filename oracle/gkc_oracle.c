@@ -499,6 +499,7 @@ typedef struct {
     const char* seq; unsigned k; uint32_t pass, nb_passes; const uint16_t* repart; bytebuf* log;
     uint64_t* part_bytes; uint64_t* part_nk; uint64_t* part_nsk;
     uint64_t nsk; uint64_t bytes;
+    const uint8_t* keep;      /* gko_dsk_run_parts: only super-k-mers of the partitions p with keep[p] != 0 are kept (NULL: all) */
 } fill_ctx;
 
 static void fill_cb(void* c, uint64_t mn, uint64_t first, unsigned nbk)   /* FillPartitions::processSuperkmer (:1081-1097) */
@@ -506,6 +507,7 @@ static void fill_cb(void* c, uint64_t mn, uint64_t first, unsigned nbk)   /* Fil
     fill_ctx* f = (fill_ctx*)c;
     if ((mn % f->nb_passes) != f->pass) return;
     uint32_t p = f->repart[mn];
+    if (f->keep && !f->keep[p]) return;                        /* (test infrastructure: a sampled-partition count of a full-size input) */
     uint8_t rec[2 + 1 + 64 + 80];
     rec[0] = (uint8_t)(p & 255); rec[1] = (uint8_t)(p >> 8);
     size_t len = gko_superkmer_encode(f->seq + first, f->k, nbk, rec + 2);
@@ -541,6 +543,7 @@ typedef struct {
     uint8_t* arena; uint64_t* part_off;   /* [nb_partitions+1] byte offsets of the partitions inside arena: this share's "partition files" */
     uint64_t* part_nk; uint64_t* part_nsk;
     uint64_t stats[8];
+    const uint8_t* keep;
 } fill_job;
 
 static void fill_range(fill_job* J)
@@ -549,7 +552,7 @@ static void fill_range(fill_job* J)
     bytebuf log = { NULL, 0, 0, 0, 0 };
     uint64_t* pb = (uint64_t*)calloc(P, sizeof(uint64_t));
     J->part_nk = (uint64_t*)calloc(P, sizeof(uint64_t)); J->part_nsk = (uint64_t*)calloc(P, sizeof(uint64_t));
-    fill_ctx fc = { NULL, J->k, J->pass, J->nb_passes, J->repart, &log, pb, J->part_nk, J->part_nsk, 0, 0 };
+    fill_ctx fc = { NULL, J->k, J->pass, J->nb_passes, J->repart, &log, pb, J->part_nk, J->part_nsk, 0, 0, J->keep };
     for (uint64_t r = J->r0; r < J->r1; r++) {
         const char* seq = J->bases + J->offsets[r]; uint64_t len = J->offsets[r + 1] - J->offsets[r];
         fc.seq = seq;
@@ -646,10 +649,15 @@ static void* mt_main(void* arg)
     return NULL;
 }
 
-gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_reads,
-                        unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
-                        const uint16_t* repart, const uint32_t* freq_order,
-                        int32_t amin, int32_t amax, uint32_t histo_max, int maxs, uint32_t n_threads)
+/* The same run restricted to the partitions p with keep[p] != 0 (keep == NULL: every partition): the super-k-mers of the other partitions are dropped where
+ * FillPartitions::processSuperkmer would append them (SortingCountAlgorithm.cpp:1081-1097), so a FULL-SIZE input can be counted exactly for a few sampled partitions in
+ * the time of its fillPartitions step (the shape of TestDSK.cpp:254-305: the solid k-mers of a run compared with an independent count). The kept partitions' datasets,
+ * n_kmers and n_sk are those of the unrestricted run; valid / invalid k-mers and sequences are still those of the whole input, distinct / solid / histogram / super-k-mer
+ * totals cover the kept partitions only. */
+gko_dsk* gko_dsk_run_parts(const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                           unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
+                           const uint16_t* repart, const uint32_t* freq_order,
+                           int32_t amin, int32_t amax, uint32_t histo_max, int maxs, uint32_t n_threads, const uint8_t* keep)
 {
     if (n_threads < 1) n_threads = 1;
     gko_dsk* R = (gko_dsk*)calloc(1, sizeof(gko_dsk));
@@ -671,7 +679,7 @@ gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_r
             fill_job* J = &fills[i];
             J->bases = bases; J->offsets = offsets; J->r0 = n_reads * i / n_fill; J->r1 = n_reads * (i + 1) / n_fill;
             J->k = k; J->m = m; J->nb_partitions = nb_partitions; J->nb_passes = nb_passes; J->pass = pass; J->repart = repart;
-            J->freq_order = freq_order; J->lut = lut; J->maxs = maxs;
+            J->freq_order = freq_order; J->lut = lut; J->maxs = maxs; J->keep = keep;
         }
         uint32_t next = 0;
         for (uint32_t t = 0; t < n_threads; t++) { W[t].phase = 1; W[t].fills = fills; W[t].n_fill = n_fill; W[t].next_fill = &next; }
@@ -696,6 +704,14 @@ gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_r
     }
     free(W); free(th); free(lut);
     return R;
+}
+
+gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                        unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
+                        const uint16_t* repart, const uint32_t* freq_order,
+                        int32_t amin, int32_t amax, uint32_t histo_max, int maxs, uint32_t n_threads)
+{
+    return gko_dsk_run_parts(bases, offsets, n_reads, k, m, nb_partitions, nb_passes, repart, freq_order, amin, amax, histo_max, maxs, n_threads, NULL);
 }
 
 gko_dsk* gko_dsk_run(const char* bases, const uint64_t* offsets, uint64_t n_reads,

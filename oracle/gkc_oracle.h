@@ -86,6 +86,11 @@ gko_dsk* gko_dsk_run_mt(const char* bases, const uint64_t* offsets, uint64_t n_r
                         unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
                         const uint16_t* repart, const uint32_t* freq_order,
                         int32_t abundance_min, int32_t abundance_max, uint32_t histo_max, int maxs, uint32_t n_threads);
+/* restricted to the partitions with keep[p] != 0 (NULL: all): exact count of a few sampled partitions of a full-size input (see gkc_oracle.c) */
+gko_dsk* gko_dsk_run_parts(const char* bases, const uint64_t* offsets, uint64_t n_reads,
+                           unsigned k, unsigned m, uint32_t nb_partitions, uint32_t nb_passes,
+                           const uint16_t* repart, const uint32_t* freq_order,
+                           int32_t amin, int32_t amax, uint32_t histo_max, int maxs, uint32_t n_threads, const uint8_t* keep);
 void     gko_dsk_free(gko_dsk*);
 uint64_t gko_dsk_part_size(const gko_dsk*, uint32_t dataset);
 /* copies dataset as (lo, hi, abundance) arrays */

@@ -62,6 +62,9 @@ def lib():
     L.gko_dsk_run_mt.restype = vp
     L.gko_dsk_run_mt.argtypes = [vp, u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_uint32, C.c_uint32, u16p, vp,
                                  C.c_int32, C.c_int32, C.c_uint32, C.c_int, C.c_uint32]
+    L.gko_dsk_run_parts.restype = vp
+    L.gko_dsk_run_parts.argtypes = [vp, u64p, C.c_uint64, C.c_uint, C.c_uint, C.c_uint32, C.c_uint32, u16p, vp,
+                                    C.c_int32, C.c_int32, C.c_uint32, C.c_int, C.c_uint32, vp]
     L.gko_dsk_free.restype = None; L.gko_dsk_free.argtypes = [vp]
     L.gko_dsk_part_size.restype = C.c_uint64; L.gko_dsk_part_size.argtypes = [vp, C.c_uint32]
     L.gko_dsk_part_copy.restype = None; L.gko_dsk_part_copy.argtypes = [vp, C.c_uint32, u64p, u64p, i32p]
@@ -199,7 +202,7 @@ class Dsk:
     """Result of the oracle's SortingCountAlgorithm restatement."""
 
     def __init__(self, bases, offsets, k, m, nb_partitions, repart, nb_passes=1, freq_order=None,
-                 abundance_min=1, abundance_max=2147483647, histo_max=10000, maxs=0, threads=1):
+                 abundance_min=1, abundance_max=2147483647, histo_max=10000, maxs=0, threads=1, only_parts=None):
         L = lib()
         self.k = k; self.nb_partitions = nb_partitions; self.nb_passes = nb_passes; self.histo_max = histo_max
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -207,8 +210,12 @@ class Dsk:
         repart = np.ascontiguousarray(repart, dtype=np.uint16)
         assert repart.size == 4 ** m
         # threads > 1: the same run parallelised like the reference (reads shared out for fillPartitions, partitions for fillSolidKmers)
-        self._h = L.gko_dsk_run_mt(_ptr(bases), offsets, len(offsets) - 1, k, m, nb_partitions, nb_passes, repart,
-                                   _ptr(freq_order), abundance_min, abundance_max, histo_max, maxs, threads)
+        # only_parts: count nothing but these partitions (gko_dsk_run_parts): an exact count of sampled partitions of a full-size input
+        keep = None
+        if only_parts is not None:
+            keep = np.zeros(nb_partitions, np.uint8); keep[np.asarray(list(only_parts), dtype=np.int64)] = 1
+        self._h = L.gko_dsk_run_parts(_ptr(bases), offsets, len(offsets) - 1, k, m, nb_partitions, nb_passes, repart,
+                                      _ptr(freq_order), abundance_min, abundance_max, histo_max, maxs, threads, _ptr(keep))
         s = np.zeros(8, np.uint64); L.gko_dsk_stats(self._h, s)
         self.stats = dict(kmers_nb_valid=int(s[0]), kmers_nb_invalid=int(s[1]), kmers_nb_distinct=int(s[2]),
                           kmers_nb_solid=int(s[3]), nb_superkmers=int(s[4]), nb_sequences=int(s[5]),

@@ -311,3 +311,22 @@ def test_parallel_oracle_equals_sequential_oracle():
         assert a.stats == b.stats and np.array_equal(a.histogram(), b.histogram())
         for d in range(parts * passes):
             assert np.array_equal(a.part_records(d), b.part_records(d))
+
+
+def test_partition_restricted_oracle_equals_the_full_run():
+    """gko_dsk_run_parts (the exact count of a few sampled partitions of a full-size input, tests/test_gpu_parity.py): on the kept partitions every dataset, k-mer and
+    super-k-mer count is that of the unrestricted run; the other partitions are empty; the whole-input statistics stay"""
+    for k, m, parts, passes, threads in ((31, 8, 12, 1, 1), (63, 9, 7, 2, 3), (21, 6, 5, 1, 2)):
+        reads = synth_reads(800, 6000, 150, seed=70 + k, n_rate=0.002, ragged=True)
+        bases, offs = gko.pack_reads(reads)
+        rep = simple_repart(m, parts)
+        full = gko.Dsk(bases, offs, k, m, parts, rep, nb_passes=passes)
+        keep = [0, parts // 2, parts - 1]
+        some = gko.Dsk(bases, offs, k, m, parts, rep, nb_passes=passes, threads=threads, only_parts=keep)
+        for d in range(parts * passes):
+            if d % parts in keep:
+                assert np.array_equal(some.part_records(d), full.part_records(d)) and some.part_stats(d) == full.part_stats(d)
+            else:
+                assert len(some.part_records(d)) == 0 and some.part_stats(d) == (0, 0)
+        assert some.stats["kmers_nb_valid"] == full.stats["kmers_nb_valid"] and some.stats["nb_sequences"] == full.stats["nb_sequences"]
+        assert 0 < some.stats["kmers_nb_distinct"] < full.stats["kmers_nb_distinct"]
