@@ -195,7 +195,9 @@ static int sendrecv_ipc(gkc_comm* m, const std::vector<gkc_xfer>& sends, const s
 int gkc_comm_sendrecv(gkc_comm* m, const std::vector<gkc_xfer>& sends, const std::vector<gkc_xfer>& recvs, hipStream_t st)
 {
     gkc_ctx* c = m->ctx;
-    if (sends.empty() && recvs.empty()) return GKC_OK;
+    // (a rank with nothing to send or receive — it owns no partition and pushed nothing since the last exchange — still takes part in the IPC transport's
+    // all-gathers: leaving here would shift every later collective of the communicator by one on this rank; found by the 4- and 8-rank tests of round 6)
+    if (sends.empty() && recvs.empty() && !(m->ipc && !m->rccl && m->world > 1)) return GKC_OK;
     // split long messages the same way on both sides
     std::vector<gkc_xfer> s2, r2;
     auto split = [](const std::vector<gkc_xfer>& in, std::vector<gkc_xfer>& out) {

@@ -454,6 +454,15 @@ static gkc_unpacker* unpacker_of(gkc_ctx* c)
     // measured on the 2 x 64-core host of the MI355X box (tools/hostmem_probe/unpack_probe): 16 threads expand 14e9 records/s (100 GB/s read + 230 GB/s of non-temporal
     // writes) with or without a device -> host copy running beside them; 64 threads fall to 6e9/s beside the copy stream, 128 to 4e9/s even alone
     int n = gkc_tun().unpack_threads > 0 ? gkc_tun().unpack_threads : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    // Several ranks of one job share the host (a communicator of W ranks on this context = W processes, taken to be spread evenly over the host's NUMA nodes): 24 threads
+    // per NODE is what the memory controllers take — 8 ranks x 24 threads expand 4.7e9 records/s in all where ONE rank's 24 reach 1.3e10 (round 6,
+    // tools/hostmem_probe/unpack_ranks_probe on the 2 x 64-core host: profiles/r06_host_unpack_ceiling.txt) — so every rank takes its share of them.
+    if (gkc_tun().unpack_threads <= 0 && c->comm_world > 1) {
+        int nodes = 0; cpu_set_t tmp; while (nodes < 64 && cpus_of_node(nodes, &tmp)) nodes++;
+        if (nodes < 1) nodes = 1;
+        const int per_node = (c->comm_world + nodes - 1) / nodes;
+        n = std::max(3, n / std::max(1, per_node));
+    }
     if (n < 1) n = 1;
     for (int i = 0; i < n; i++) U->threads.emplace_back([U] { U->worker(); });
     c->unpacker = U;

@@ -129,10 +129,14 @@ def test_ranks_on_one_gpu_end_to_end(world, k, parts, amin, try_rccl, ipc, owner
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
     pinned = _pinned_owners(parts, world) if owners == "pinned" else None
+    import time
+    t0 = time.time()
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, k, parts, amin, q, try_rccl, ipc, pinned, premap)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    t1 = time.time()
     [p.join(timeout=120) for p in procs]
+    print("TIMING world %d: ranks' results after %.1f s, processes gone after %.1f s more" % (world, t1 - t0, time.time() - t1))
     assert all(p.exitcode == 0 for p in procs)
     # ---- expected: the oracle over ALL reads, and a single-context run for the Bloom / MPHF bytes
     gkc = ge.load().gkc

@@ -61,13 +61,13 @@ static void* numa_alloc(size_t bytes) { void* p = mmap(nullptr, bytes, PROT_READ
 int main(int argc, char** argv)
 {
     const uint64_t n_rec = (uint64_t)(argc > 1 ? atof(argv[1]) : 2.5e8) / BLK * BLK;
-    const int T = argc > 2 ? atoi(argv[2]) : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    const int T0 = argc > 2 ? atoi(argv[2]) : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
     const int rounds = argc > 3 ? atoi(argv[3]) : 4;
     int n_nodes = 0; { cpu_set_t s; while (cpus_of_node(n_nodes, &s)) n_nodes++; }
     if (n_nodes == 0) n_nodes = 1;
-    printf("host: %u hardware threads, %d NUMA node(s); %d unpack threads per rank (the library's default), %.2e records per rank and round, %d rounds\n",
-           std::thread::hardware_concurrency(), n_nodes, T, (double)n_rec, rounds);
-    printf("%-6s %-28s %14s %14s %12s %12s | %18s\n", "ranks", "rank -> NUMA node", "records/s", "per rank", "GB/s read", "GB/s written", "NT stores only GB/s");
+    printf("host: %u hardware threads, %d NUMA node(s); up to %d unpack threads per rank (the library's default for one rank), %.2e records per rank and round, %d rounds\n",
+           std::thread::hardware_concurrency(), n_nodes, T0, (double)n_rec, rounds);
+    printf("%-6s %-12s %-8s %14s %14s %12s %12s | %18s\n", "ranks", "rank->node", "thr/rank", "records/s", "per rank", "GB/s read", "GB/s written", "NT stores only GB/s");
     for (int spread = 0; spread < 2; spread++)
     for (int R : {1, 2, 4, 8}) {
         if (spread && (R == 8 || n_nodes == 1)) continue;
@@ -94,6 +94,8 @@ int main(int argc, char** argv)
             });
             for (auto& t : init) t.join();
         }
+        for (int T : {T0, T0 / 2, T0 / 4, T0 / 8}) {
+        if (T < 1 || (T != T0 && R == 1)) continue;
         double rate = 0, rd = 0, wr = 0, nt = 0;
         for (int what = 0; what < 2; what++) {      // 0: the unpack, 1: non-temporal stores only
             for (Rank& K : ranks) K.next.store(0);
@@ -117,8 +119,9 @@ int main(int argc, char** argv)
             const double dt = now() - t0, recs = (double)n_rec * rounds * R;
             if (what == 0) { rate = recs / dt; rd = recs * 6.3 / dt / 1e9; wr = recs * 16 / dt / 1e9; } else nt = recs * 16 / dt / 1e9;
         }
-        printf("%-6d %-28s %14.3e %14.3e %12.1f %12.1f | %18.1f\n", R, map, rate, rate / R, rd, wr, nt);
+        printf("%-6d %-12s %-8d %14.3e %14.3e %12.1f %12.1f | %18.1f\n", R, map, T, rate, rate / R, rd, wr, nt);
         fflush(stdout);
+        }
         for (Rank& K : ranks) { munmap(K.stage, K.nblk * SLOT + 64); munmap(K.cb, n_rec / 4 + 4096); munmap(K.sink, n_rec * 16); }
     }
     return 0;

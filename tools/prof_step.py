@@ -9,10 +9,18 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 parts = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
 profile = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # 1 = GKC_SYNTH_SKEWED
+freq_mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0         # 1 = minimizers in frequency order (table from the first 10^6 reads, as bench.py's freq_order block)
 c = gkc.Counter(0)
 rep = bench.repart_for_bench(10, parts)
-c.configure(k, 10, parts, rep)
 db, do = c.synth_reads_device(2, n, 150, n * 5, 10000, profile=profile)
+freq = None
+if freq_mode:
+    m = 10; n_s = min(n, 1_000_000)
+    hb = c.device_to_host(db, n_s * 150); ho = np.arange(n_s + 1, dtype=np.uint64) * np.uint64(150)
+    cnts = c.count_mmers(m, hb, ho)
+    idx = np.nonzero(cnts)[0]; order_ = idx[np.lexsort((idx, cnts[idx]))]
+    freq = np.full(4 ** m, 4 ** m, dtype=np.uint32); freq[order_] = np.arange(len(order_), dtype=np.uint32); freq[-1] = 4 ** m - 1
+c.configure(k, 10, parts, rep, freq_order=freq)
 names = ["scan_count", "scan_emit", "scan_refine", "dedupe_bin", "dedupe_sort", "expand_count", "expand_scatter", "bucket_sort", "bucket_sort_big", "bucket_sort_wg", "bucket_sort_deep", "split_levels", "compact",
          "total_stage_a", "total_stage_b"]
 for it in range(3):
