@@ -641,8 +641,8 @@ def main():
             workload = ("BASELINE configs[2] at %d GPU(s): k=%d, %d synthetic 150 bp reads per GPU (%d in all), minimizer-partition exchange (gkc_exchange: RCCL send/recv over xGMI), "
                         "m=%d, %d partitions" % (world, k, n_reads, n_reads * world, m, parts))
         traffic = None
-        kname = {"scan_count": "k_scan_tile<false, 2, true, false>", "scan_emit": "k_emit_desc<2>", "expand_count": "k_expand_count<1, 2, false>",
-                 "expand_scatter": "k_expand_scatter_pair<false>", "bucket_sort": "k_wave_sort<1, true>", "compact": "k_gather_counts<1>", "dedupe_bin": "k_dedupe_bin<2>", "dedupe_sort": "k_dedupe_sort<2>"}
+        kname = {"scan_count": "k_scan_tile<false, 2, true, false>", "scan_emit": "k_emit_desc<2>", "expand_count": "k_expand_count<1, 2>",
+                 "expand_scatter": "k_expand_scatter_pair", "bucket_sort": "k_wave_sort<1, true>", "compact": "k_gather_counts<1>", "dedupe_bin": "k_dedupe_bin<2>", "dedupe_sort": "k_dedupe_sort<2>"}
         try:   # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py), only if they were taken on this exact workload
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == workload and kname.get(dom) in pt["kernels"]:

@@ -454,14 +454,14 @@ static gkc_unpacker* unpacker_of(gkc_ctx* c)
     // measured on the 2 x 64-core host of the MI355X box (tools/hostmem_probe/unpack_probe): 16 threads expand 14e9 records/s (100 GB/s read + 230 GB/s of non-temporal
     // writes) with or without a device -> host copy running beside them; 64 threads fall to 6e9/s beside the copy stream, 128 to 4e9/s even alone
     int n = gkc_tun().unpack_threads > 0 ? gkc_tun().unpack_threads : (int)std::min<unsigned>(24u, std::max(2u, std::thread::hardware_concurrency() / 2));
-    // Several ranks of one job share the host (a communicator of W ranks on this context = W processes, taken to be spread evenly over the host's NUMA nodes): 24 threads
-    // per NODE is what the memory controllers take — 8 ranks x 24 threads expand 4.7e9 records/s in all where ONE rank's 24 reach 1.3e10 (round 6,
-    // tools/hostmem_probe/unpack_ranks_probe on the 2 x 64-core host: profiles/r06_host_unpack_ceiling.txt) — so every rank takes its share of them.
+    // Several ranks of one job share the host (a communicator of W ranks on this context = W processes, taken to be spread evenly over the host's NUMA nodes): the host
+    // expands 1.2-1.4e10 records/s in all however many ranks ask, and FEWER threads reach it — 8 ranks x 24 threads get 5.2e9 records/s, 8 x 3 threads 1.33e10 (round 6,
+    // tools/hostmem_probe/unpack_ranks_probe on the 2 x 64-core host: profiles/r06_host_unpack_ceiling.txt) — so every rank takes its share of 12 threads per node.
     if (gkc_tun().unpack_threads <= 0 && c->comm_world > 1) {
         int nodes = 0; cpu_set_t tmp; while (nodes < 64 && cpus_of_node(nodes, &tmp)) nodes++;
         if (nodes < 1) nodes = 1;
         const int per_node = (c->comm_world + nodes - 1) / nodes;
-        n = std::max(3, n / std::max(1, per_node));
+        n = std::max(2, std::min(n, 12) / std::max(1, per_node));             // 12 per node: 2 ranks on 2 nodes 1.11e10 records/s with 12 or 24 each; 8 ranks: 3 each 1.33e10, 6: 1.01e10, 24: 5.2e9
     }
     if (n < 1) n = 1;
     for (int i = 0; i < n; i++) U->threads.emplace_back([U] { U->worker(); });
@@ -561,8 +561,8 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     blk_first[nb] = (uint32_t)nblk;
     g_sink_why = "no records / too many blocks";
     if (nblk == 0 || nblk >= (1ull << 31)) return nullptr;
-    // width of an entry: 8 where the partitions are sparse, 7 where dense, 6 (+ bitmap + abundance stream) where dense and most abundances are 1 — expected at
-    // abundance-min 1 (sequencing errors) and checked batch by batch: a batch whose stream came out longer than 0.85 bytes per record switches the context back to 7
+    // width of an entry: 8 where the partitions are sparse, 7 where dense, "6" = per-block delta widths + bitmap + abundance stream (PKV) where dense at abundance-min 1
+    // (most abundances are 1: sequencing errors), checked batch by batch: a batch that came out above 7 bytes per record switches the context back to 7
     const bool no6 = !gkc_tun().sink_width6;
     const uint64_t dense_min = gkc_tun().sink_dense ? gkc_tun().sink_dense : PK_DENSE;      // (tests: 1 = every batch is "dense")
     const bool wide = c->key_words == 2;
@@ -603,7 +603,9 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     const uint64_t pay_used = width == 6 ? ((uint64_t)h_cnt[2] + 63) / 64 * 64 : pay_bytes;               // bytes of the payload that travel (and are staged)
     g_sink_why = !ok ? "pack launch failed" : "too many exceptions";
     if (!ok || h_nexc > exc_cap || h_ncb > cb_cap || (width == 6 && h_cnt[2] > pay_bytes - 64)) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
-    if (width == 6 && (double)h_ncb > 0.85 * (double)n_rec) c->sink_no6 = true;      // (this batch still travels as it was packed: 7.1 bytes per record at worst)
+    // (a batch whose per-block widths + abundance stream came out above the 7 bytes per record of the fixed entries — wide gaps AND few abundances of 1 — switches the
+    //  context to those; this batch still travels as it was packed)
+    if (width == 6 && (double)(h_cnt[2] + h_ncb) > 7.0 * (double)n_rec) c->sink_no6 = true;
     SinkBatch* B = new SinkBatch();
     const uint64_t cb_stage = (h_ncb + 63) / 64 * 64;
     const uint64_t need = hdr_bytes + pay_used + cb_stage + h_nexc * 16 + 64;

@@ -204,6 +204,24 @@ def test_oversize_buckets_low_complexity(gkc):
     assert c.stats()["oversize_buckets"] > 0
 
 
+@pytest.mark.parametrize("k", [63, 47, 33])
+def test_top_word_sort_of_16_byte_keys_with_ties(gkc, k):
+    """16-byte keys are sorted by their tagged TOP word only (csrc/gkc_count.hip ce_inlane<2, true, TOP>: one compare per exchange instead of three) and a sub-bucket is
+    sorted again with the full order when two different k-mers tied there. Here they do: reads that share their first 100+ bases and differ in the last few
+    nucleotides give k-mers with 74+ leading bits in common — several neighbours per top word, in shuffled arrival order, at every sort tier (copies from 1 to 600)."""
+    rng = np.random.default_rng(k)
+    stem = "".join("ACGT"[i] for i in rng.integers(0, 4, 150))
+    reads = []
+    for stem_ in (stem, "A" * 150, "ACGGT" * 30):
+        for i in range(400):
+            tail = "".join("ACGT"[j] for j in rng.integers(0, 4, 12))
+            reads += [(stem_[:138] + tail).encode()] * int(1 + (i % 7 == 0) * rng.integers(1, 600))
+    order = rng.permutation(len(reads)); reads = [reads[i] for i in order]
+    reads += synth_reads(2000, 12000, 150, seed=k, n_rate=0.001)
+    device_vs_oracle(gkc, reads, k, 10, 3)
+    device_vs_oracle(gkc, reads, k, 8, 1, amin=2, amax=500)
+
+
 @pytest.mark.parametrize("k,m,parts,n_reads,skew,smin", [(31, 10, 1, 100_000, False, 1), (31, 9, 3, 160_000, False, 1_000_000), (63, 10, 2, 150_000, False, 1), (21, 8, 2, 120_000, False, 3_000_000),
                                                          (31, 10, 5, 110_000, True, 2_000_000), (41, 10, 4, 130_000, True, 1), (63, 11, 3, 90_000, True, 1_500_000),
                                                          (31, 10, 5, 110_000, 0.4, 3_000_000), (30, 9, 6, 120_000, 0.35, 2_500_000)])

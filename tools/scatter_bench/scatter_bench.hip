@@ -42,6 +42,21 @@ __global__ __launch_bounds__(1024) void k_scatter(uint8_t* __restrict__ out, uin
     }
 }
 
+// Round 6 ("fold k_dedupe_bin into Stage A's emit"): what a DIRECT emission of records to (partition, hash bin) slots costs. The fan-out — 4096
+// partitions x 2048 bins = 2^23 open buckets — is far beyond any workgroup's LDS, so the cursors live in global memory: every record is one returning global
+// atomic on a random cursor + one 16-byte store behind it. NCUR_TOTAL cursors over the whole buffer, every workgroup scatters over all of them.
+__global__ __launch_bounds__(1024) void k_scatter_global(uint8_t* __restrict__ out, uint32_t* __restrict__ cur, uint64_t bucket_bytes, uint32_t ncur_total, uint32_t iters)
+{
+    uint64_t h = mix64(((uint64_t)blockIdx.x << 32) | threadIdx.x);
+    for (uint32_t it = 0; it < iters; it++) {
+        h = mix64(h);
+        const uint32_t q = (uint32_t)((h >> 24) % ncur_total);
+        const uint32_t pos = atomicAdd(&cur[q], 16u);
+        if (pos + 16 > bucket_bytes) continue;
+        *reinterpret_cast<ulonglong2*>(out + (uint64_t)q * bucket_bytes + pos) = make_ulonglong2(h, ~h);
+    }
+}
+
 // coalesced streaming write of the same bytes: the practical ceiling on this box
 __global__ void k_stream(ulonglong2* __restrict__ out, uint64_t n16)
 {
@@ -86,6 +101,26 @@ int main(int argc, char** argv)
     printf("   (GB/s of useful bytes, fill 0.7)\n");
 #define ROW(W) do { printf("%8d", W); for (uint32_t n : ncurs) printf(" %8.0f", run<W>(buf, regions, region_bytes, n, 0.7)); printf("\n"); fflush(stdout); } while (0)
     ROW(8); ROW(16); ROW(32); ROW(64); ROW(128); ROW(256);
+    {   // direct scatter with global cursors (16-byte records), fan-out 2^12 .. 2^23 over the whole buffer
+        const uint64_t total = (uint64_t)regions * region_bytes;
+        printf("16-byte records through GLOBAL cursors (one returning atomic + one store per record), GB/s of useful bytes / records per s:\n");
+        for (uint32_t lg : {12u, 16u, 18u, 20u, 23u}) {
+            const uint32_t nc = 1u << lg; const uint64_t bucket = total / nc / 16 * 16;
+            uint32_t* cur; CK(hipMalloc(&cur, (size_t)nc * 4));
+            const uint64_t stores = (uint64_t)((double)total * 0.7 / 16); const uint32_t wgs = 256 * 4, iters = (uint32_t)(stores / ((uint64_t)wgs * 1024));
+            hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+            float ms = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                CK(hipMemset(cur, 0, (size_t)nc * 4)); CK(hipDeviceSynchronize());
+                CK(hipEventRecord(a));
+                hipLaunchKernelGGL(k_scatter_global, dim3(wgs), dim3(1024), 0, 0, buf, cur, bucket, nc, iters);
+                CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+            }
+            const double recs = (double)wgs * 1024.0 * iters;
+            printf("  2^%-2u cursors: %7.0f GB/s  %.2e records/s  (%.1f ms for 1.07e9 records)\n", lg, recs * 16 / (ms * 1e-3) / 1e9, recs / (ms * 1e-3), 1.07e9 / (recs / (ms * 1e-3)) * 1e3);
+            CK(hipFree(cur));
+        }
+    }
     CK(hipFree(buf));
     return 0;
 }
