@@ -944,10 +944,10 @@ def test_raw_sink_mode_lands_the_same_bytes(gkc, k, amin):
 
 @pytest.mark.parametrize("switch", ["GKC_SINK_DENSE=1", "GKC_SINK_DENSE=1,GKC_SINK_WIDTH6=0", "GKC_SINK_DENSE=1,GKC_UNPACK_THREADS=1"])
 def test_packed_sink_entry_widths(switch):
-    """The three entry widths of the packed transfer on the same inputs (GKC_SINK_DENSE=1 declares every batch dense): 6-byte deltas + abundance bitmap + abundance
-    stream (abundance-min 1, the default there), 7-byte entries (GKC_SINK_WIDTH6=0, and abundance-min 2), with delta escapes (k=31: few records per partition, gaps
+    """The three entry widths of the packed transfer on the same inputs (GKC_SINK_DENSE=1 declares every batch dense): per-block delta widths + abundance bitmap +
+    abundance stream (PKV, reported as width 6; abundance-min 1, the default there), 7-byte entries (GKC_SINK_WIDTH6=0, and abundance-min 2), with delta escapes (k=31: few records per partition, gaps
     beyond 2^48), abundance escapes (a read copied 700 times), partitions of several blocks (k=15) and an empty one; an error-free input (nearly every abundance
-    > 1) makes the first batch switch the context from 6 to 7 for the following ones. What lands in the sink == gkc_partition_counts == the oracle; the bytes
+    > 1) keeps the block widths as long as they stay below 7 bytes per record. What lands in the sink == gkc_partition_counts == the oracle; the bytes
     the library says it queued (gkc_stats.reserved[1]) are what the widths promise where the partitions fill their blocks."""
     import json, os, subprocess, sys
     code = r"""
@@ -993,7 +993,9 @@ print(json.dumps(res))
     assert all(0 < b < 9 for n_, v in res.items() if n_.startswith("k15") for b in v["bytes_per_record"]), res      # (partitions of a few records still travel as whole block slots)
     if "WIDTH6=0" not in switch:
         assert res["k15"]["bytes_per_record"][0] < 7.0, res                                 # 6-byte entries where most abundances are 1 ...
-        assert res["k15_clean"]["bytes_per_record"][1] < res["k15_clean"]["bytes_per_record"][0], res      # ... and back to 7-byte entries where they are not
+        # ... and they stay where the block widths + the abundance stream are below the 7 bytes of the fixed entries (k = 15: narrow deltas) even though nearly
+        # every abundance is > 1 (rounds 3-5, fixed 6-byte deltas: such a batch switched the context to 7-byte entries)
+        assert res["k15_clean"]["bytes_per_record"][1] <= res["k15_clean"]["bytes_per_record"][0] * 1.001 < 7.0, res
 
 
 def test_push_reads_in_overlapped_chunks(gkc):
