@@ -768,10 +768,7 @@ template <int KW> __device__ __forceinline__ bool key_differs(typename KeyT<KW>:
 template <int KW> struct KTag;
 template <> struct KTag<1> { static __device__ __forceinline__ uint64_t mant() { return KTAG64_MANT; }  static __device__ __forceinline__ uint64_t tag() { return KTAG64; } };
 template <> struct KTag<2> { static __device__ __forceinline__ u128 mant() { return ((u128)KTAG64_MANT << 64) | (u128)~0ULL; }  static __device__ __forceinline__ u128 tag() { return (u128)KTAG64 << 64; } };
-// TOP (16-byte keys, tagged; round 6): the order is decided by the TOP word alone — one compare instead of three; the low word travels with it. Keys that tie on
-// their 61 tagged top bits (beyond the >= 13 bits the sub-bucket shares: 74 bits of the k-mer) are copies of one k-mer, or — low-complexity input — neighbours the
-// caller detects after the sort and sorts again with the full order (wave_sort_bucket). Ties never swap, on either side of a pair: no key is lost.
-template <int KW, bool F, bool TOP = false> __device__ __forceinline__ void ce_inlane(typename KeyT<KW>::type& a, typename KeyT<KW>::type& b)
+template <int KW, bool F> __device__ __forceinline__ void ce_inlane(typename KeyT<KW>::type& a, typename KeyT<KW>::type& b)
 {
     if constexpr (F && KW == 1) {
         const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
@@ -781,7 +778,7 @@ template <int KW, bool F, bool TOP = false> __device__ __forceinline__ void ce_i
         a = (uint64_t)__double_as_longlong(lo); b = (uint64_t)__double_as_longlong(hi);
     } else if constexpr (F && KW == 2) {
         const uint64_t ah = (uint64_t)(a >> 64), al = (uint64_t)a, bh = (uint64_t)(b >> 64), bl = (uint64_t)b;
-        const bool sw = TOP ? (bh < ah) : ((bh < ah) | ((bh == ah) & (bl < al)));
+        const bool sw = (bh < ah) | ((bh == ah) & (bl < al));
         const double x = __longlong_as_double((long long)ah), y = __longlong_as_double((long long)bh);
         double mn, mx;
         asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(x), "v"(y));
@@ -793,13 +790,13 @@ template <int KW, bool F, bool TOP = false> __device__ __forceinline__ void ce_i
 
 // bitonic network over N = 64*KPL keys (blocked index e = lane*KPL + r), all comparators ascending, as compile-time recursion so
 // that every lane mask is a template constant
-template <int KW, int KPL, int S, bool F = false, bool TOP = false> struct HalfClean {                    // e <-> e ^ S, then S/2, ..., 1
+template <int KW, int KPL, int S, bool F = false> struct HalfClean {                    // e <-> e ^ S, then S/2, ..., 1
     static __device__ __forceinline__ void run(typename KeyT<KW>::type (&v)[KPL], const int lane) {
         typedef typename KeyT<KW>::type key_t;
         if constexpr (S >= 1) {
             if constexpr (S < KPL) {
 #pragma unroll
-                for (int r = 0; r < KPL; r++) if ((r & S) == 0) ce_inlane<KW, F, TOP>(v[r], v[r | S]);
+                for (int r = 0; r < KPL; r++) if ((r & S) == 0) ce_inlane<KW, F>(v[r], v[r | S]);
             } else {
                 constexpr int LS = S / KPL;
                 const bool low = (lane & LS) == 0;
@@ -820,35 +817,27 @@ template <int KW, int KPL, int S, bool F = false, bool TOP = false> struct HalfC
                             for (int u = 0; u < C; u++) { double d; asm volatile("v_max_f64 %0, %1, %2" : "=v"(d) : "v"(__longlong_as_double((long long)v[r0 + u])), "v"(y[u])); v[r0 + u] = (uint64_t)__double_as_longlong(d); }
                         }
                     }
-                } else if constexpr (TOP && KW == 2) {
-#pragma unroll
-                for (int r = 0; r < KPL; r++) {                  // strict on both sides: the lower lane takes the partner's key if its top word is smaller, the upper one if it is larger
-                    const key_t y = Shfl<KW>::template x<LS>(v[r]);
-                    const uint64_t yh = (uint64_t)(y >> 64), vh = (uint64_t)(v[r] >> 64);
-                    const bool take = low ? (yh < vh) : (vh < yh);
-                    v[r] = take ? y : v[r];
-                }
                 } else {
 #pragma unroll
                 for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LS>(v[r]); const bool ylt = key_lt<KW>(y, v[r]); v[r] = (ylt == low) ? y : v[r]; }
                 }
             }
-            HalfClean<KW, KPL, S / 2, F, TOP>::run(v, lane);
+            HalfClean<KW, KPL, S / 2, F>::run(v, lane);
         }
     }
 };
-template <int KW, int KPL, int SIZE, bool F = false, bool TOP = false> struct BitonicMerge {              // sorted runs of SIZE/2 -> sorted runs of SIZE
+template <int KW, int KPL, int SIZE, bool F = false> struct BitonicMerge {              // sorted runs of SIZE/2 -> sorted runs of SIZE
     static __device__ __forceinline__ void run(typename KeyT<KW>::type (&v)[KPL], const int lane) {
         typedef typename KeyT<KW>::type key_t;
         if constexpr (SIZE >= 2) {
-            BitonicMerge<KW, KPL, SIZE / 2, F, TOP>::run(v, lane);
+            BitonicMerge<KW, KPL, SIZE / 2, F>::run(v, lane);
             // mirror step: e <-> e ^ (SIZE-1)
             if constexpr (SIZE <= KPL) {
 #pragma unroll
-                for (int r = 0; r < KPL; r++) { const int pr = r ^ (SIZE - 1); if (pr > r) ce_inlane<KW, F, TOP>(v[r], v[pr]); }
+                for (int r = 0; r < KPL; r++) { const int pr = r ^ (SIZE - 1); if (pr > r) ce_inlane<KW, F>(v[r], v[pr]); }
             } else {
-                constexpr int LMASK = SIZE / KPL - 1, TOPLANE = (SIZE / KPL) >> 1;
-                const bool low = (lane & TOPLANE) == 0;
+                constexpr int LMASK = SIZE / KPL - 1, TOP = (SIZE / KPL) >> 1;
+                const bool low = (lane & TOP) == 0;
                 if constexpr (F && KW == 1 && GKC_CROSS_MINMAX) {
                     // partner of (lane, r) is (lane ^ LMASK, KPL-1-r): registers r and KPL-1-r are exchanged together, so nothing is overwritten early
                     constexpr int H = KPL >= 2 ? KPL / 2 : 1, C = H < 2 ? H : 2;
@@ -877,21 +866,17 @@ template <int KW, int KPL, int SIZE, bool F = false, bool TOP = false> struct Bi
                 } else {
                 key_t w[KPL];
 #pragma unroll
-                for (int r = 0; r < KPL; r++) {
-                    const key_t y = Shfl<KW>::template x<LMASK>(v[KPL - 1 - r]);
-                    if constexpr (TOP && KW == 2) { const uint64_t yh = (uint64_t)(y >> 64), vh = (uint64_t)(v[r] >> 64); w[r] = (low ? (yh < vh) : (vh < yh)) ? y : v[r]; }
-                    else { const bool ylt = key_lt<KW>(y, v[r]); w[r] = (ylt == low) ? y : v[r]; }
-                }
+                for (int r = 0; r < KPL; r++) { const key_t y = Shfl<KW>::template x<LMASK>(v[KPL - 1 - r]); const bool ylt = key_lt<KW>(y, v[r]); w[r] = (ylt == low) ? y : v[r]; }
 #pragma unroll
                 for (int r = 0; r < KPL; r++) v[r] = w[r];
                 }
             }
-            HalfClean<KW, KPL, SIZE / 4, F, TOP>::run(v, lane);
+            HalfClean<KW, KPL, SIZE / 4, F>::run(v, lane);
         }
     }
 };
-template <int KW, int KPL, bool F = false, bool TOP = false>
-__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane) { BitonicMerge<KW, KPL, 64 * KPL, F, TOP>::run(v, lane); }
+template <int KW, int KPL, bool F = false>
+__device__ __forceinline__ void bitonic_wave(typename KeyT<KW>::type (&v)[KPL], const int lane) { BitonicMerge<KW, KPL, 64 * KPL, F>::run(v, lane); }
 
 // sort + run-length count one bucket of n <= 64*KPL keys held by one wave; writes distinct keys / abundances at
 // outk[start + j], O.cnt[start + j] (j-th distinct key) — ascending; slots start+nd .. start+n-1 keep abundance 0.
@@ -912,30 +897,12 @@ __device__ __forceinline__ void wave_sort_bucket(const typename KeyT<KW>::type* 
 #pragma unroll
         for (int r = 0; r < KPL; r++) v[r] = (v[r] & KTag<KW>::mant()) | KTag<KW>::tag();        // padding (all ones) becomes the largest tagged value: not below any key
     }
-    constexpr bool TOP = F && KW == 2;                          // 16-byte tagged keys: sorted by their top word, checked, sorted again with the full order if two k-mers tied there
-    bitonic_wave<KW, KPL, F, TOP>(v, lane);
-    const uint32_t WB = O.wb, WMASK = (1u << WB) - 1u;
-    if constexpr (TOP) {
-        // among keys with one top word the order is whatever the network left: fine for copies of ONE k-mer (their weights are summed), wrong as soon as two k-mers
-        // share the word and are not in order — (AAAA..AC, AAAA..AG from low-complexity reads; never on random sequence: 74 leading bits in common)
-        const key_t pl = Shfl<KW>::up(v[KPL - 1]);
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < KPL; r++) {
-            const key_t a = r ? v[r - 1] : pl, b = v[r];
-            const bool same_top = (uint64_t)(a >> 64) == (uint64_t)(b >> 64), down_low = ((uint64_t)a >> WB) > ((uint64_t)b >> WB);
-            bad |= same_top && down_low && (r || lane);
-        }
-        if (__any(bad)) {
-#pragma unroll
-            for (int r = 0; r < KPL; r++) { const uint32_t i = r * 64 + lane; v[r] = i < n ? src[i] : KeyT<KW>::max(); v[r] = (v[r] & KTag<KW>::mant()) | KTag<KW>::tag(); }
-            bitonic_wave<KW, KPL, F, false>(v, lane);
-        }
-    }
+    bitonic_wave<KW, KPL, F>(v, lane);
     // run-length count (B3), weighted: e = lane*KPL + r is the sorted rank; a key is the k-mer above O.wb bits of (multiplicity - 1): equal k-mers are
     // adjacent whatever their weights, the abundance of a run is the sum of its weights
     const key_t prev_last = Shfl<KW>::up(v[KPL - 1]);
     const key_t next_first = Shfl<KW>::down(v[0]);
+    const uint32_t WB = O.wb, WMASK = (1u << WB) - 1u;
     auto differs = [WMASK](key_t a, key_t b) -> uint32_t { return key_differs<KW>(a, b, WMASK) ? 1u : 0u; };
     // whole-lane bit masks (bit r = rank lane*KPL + r): one compare per key, the tail logic on the masks
     uint32_t neq = lane == 0 ? 1u : differs(v[0], prev_last);                      // k-mer differs from the one before it (rank 0: always)

@@ -205,10 +205,11 @@ def test_oversize_buckets_low_complexity(gkc):
 
 
 @pytest.mark.parametrize("k", [63, 47, 33])
-def test_top_word_sort_of_16_byte_keys_with_ties(gkc, k):
-    """16-byte keys are sorted by their tagged TOP word only (csrc/gkc_count.hip ce_inlane<2, true, TOP>: one compare per exchange instead of three) and a sub-bucket is
-    sorted again with the full order when two different k-mers tied there. Here they do: reads that share their first 100+ bases and differ in the last few
-    nucleotides give k-mers with 74+ leading bits in common — several neighbours per top word, in shuffled arrival order, at every sort tier (copies from 1 to 600)."""
+def test_16_byte_keys_that_share_their_top_word(gkc, k):
+    """16-byte keys whose TOP 64-bit words are equal and whose low words differ (reads that share their first 100+ bases and differ in the last few nucleotides: what
+    every sequencing error in the second half of a k-mer produces): several neighbours per top word, in shuffled arrival order, at every sort tier (copies from 1 to
+    600). Round 6 tried ordering such keys by the top word alone (one compare per exchange instead of three, re-sort on ties): bit-exact and SLOWER on reads with
+    errors — every sub-bucket holds such neighbours, so every sub-bucket sorted twice (k = 63: 282 -> 390 ms of Stage B); the test stays."""
     rng = np.random.default_rng(k)
     stem = "".join("ACGT"[i] for i in rng.integers(0, 4, 150))
     reads = []

@@ -8,7 +8,7 @@ OUT=gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 LEAN="--no-k63 --no-two-pass --no-share-of-8 --no-cpu-baseline --no-bloom-mphf --no-freq-order --no-skewed"
 # ---- 1
-for R in 1000000 12500000; do
+for R in 1000000 5000000; do
   GKC_BENCH_BACKEND=gloo timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 3 --warmup 1 --reads $R \
       > $OUT/r06_bench_8ranks_dryrun_${R}.json 2> $OUT/r06_bench_8ranks_dryrun_${R}.err
   tail -c 300 $OUT/r06_bench_8ranks_dryrun_${R}.json; echo; grep -E "communicator|sink" $OUT/r06_bench_8ranks_dryrun_${R}.err | head -5
