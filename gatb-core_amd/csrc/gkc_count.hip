@@ -2674,7 +2674,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
     std::vector<void*>* outputs_p; { std::lock_guard<std::mutex> lk(c->mu); outputs_p = &c->pass_outputs[pass]; }      // (std::map nodes stay where they are)
     std::vector<void*>& outputs = *outputs_p;
     std::mutex plan_mu; uint32_t next_p = 0; int first_rc = GKC_OK;
-    bool first_done[4] = { false, false, false, false }; uint64_t keys_left = total_keys;
+    uint32_t lane_batches[4] = { 0, 0, 0, 0 }; uint64_t keys_left = total_keys;
     const size_t sink_first_div = gkc_tun().sink_first_div;
     auto carve = [&](std::vector<uint32_t>& batch, int lane) -> bool {   // next batch of consecutive partitions; false when nothing is left
         std::lock_guard<std::mutex> lk(plan_mu);
@@ -2687,13 +2687,17 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
         // streamed results: the link idles until the first batch has been counted and packed — the first batch of every lane is a quarter of the others (same
         // working buffers: they are sized for the budget), the copies start ~25 ms sooner
         // — and the last one as well: what is left when the last copy has landed is the expansion of the last batch on the host
+        // Round 6: a RAMP instead of one small batch — 1/4, 1/2 of the budget, then whole ones. Stage B makes packed records ~2.6x faster than the link takes
+        // them, so a batch twice the one before is ready before the link has drained; with one quarter batch per lane followed by whole ones (round 5) the link
+        // sat idle between the end of the two small copies and the arrival of the first whole batches (GKC_SINK_DEBUG timeline: 13 ms at 5e7 reads).
         else if (c->sink && sink_first_div > 1 && !c->key_budget) {
-            const size_t small = std::max<size_t>(budget / sink_first_div, (size_t)1 << 20), tail = small * (size_t)lanes;      // keys kept back for the small last batches
-            if (!first_done[lane]) budget = small;
+            const size_t small = std::max<size_t>(budget / 4, (size_t)1 << 20), tail = small * (size_t)lanes;      // keys kept back for the small last batches
+            const size_t ramp = sink_first_div >> std::min<uint32_t>(lane_batches[lane], 31u);                     // 4, 2, 1 (GKC_SINK_FIRST_DIV: the first divisor; measured 1/4: 483.8 ms per step, 1/8: 490.4, 1/16: 491.8; no ramp: 498.3)
+            if (ramp > 1) budget = std::max<size_t>(budget / ramp, (size_t)1 << 20);
             else if (keys_left <= tail + small / 2) budget = small;
             else if (keys_left < budget + tail) budget = std::max<size_t>(small, (size_t)(keys_left - tail));
         }
-        first_done[lane] = true;
+        lane_batches[lane]++;
         uint64_t acc = 0;
         while (next_p < Pn) {
             const uint32_t p = next_p;
