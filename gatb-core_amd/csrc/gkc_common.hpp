@@ -59,7 +59,7 @@ struct GkcTun {
     // Stage B
     int weight_bits, dedupe, max_sub_bits, lanes; uint64_t slice_min, batch_keys; bool slices, batch_lpt, no_f64; uint32_t wg_max, scatter_wgs, deep_bits, sink_first_div;
     // result sink
-    bool sink_packed, sink_packed2, sink_width6, sink_debug; uint64_t sink_dense; int unpack_threads;
+    bool sink_packed, sink_packed2, sink_width6, sink_debug; int sink_adaptive; uint64_t sink_dense; int unpack_threads;
     // Bloom / MPHF
     bool bloom_atomic, bloom_gather, mphf_regions, mphf_ordered; uint64_t bloom_query_regions_min, mphf_regions_min;
     // allocator, communicators, diagnostics
@@ -77,7 +77,7 @@ struct GkcTun {
         slices = not0("GKC_SLICES"); batch_lpt = not0("GKC_BATCH_LPT"); no_f64 = on("GKC_NO_F64");
         wg_max = (uint32_t)num("GKC_WG_MAX", 0); scatter_wgs = (uint32_t)std::max<long long>(1, num("GKC_SCATTER_WGS", 176)); deep_bits = (uint32_t)std::max<long long>(1, num("GKC_DEEP_BITS", MAX_SUB_BITS));
         sink_first_div = (uint32_t)std::max<long long>(1, num("GKC_SINK_FIRST_DIV", 4));
-        sink_packed = not0("GKC_SINK_PACKED"); sink_packed2 = not0("GKC_SINK_PACKED2"); sink_width6 = not0("GKC_SINK_WIDTH6"); sink_debug = on("GKC_SINK_DEBUG");
+        sink_packed = not0("GKC_SINK_PACKED"); sink_packed2 = not0("GKC_SINK_PACKED2"); sink_width6 = not0("GKC_SINK_WIDTH6"); sink_debug = on("GKC_SINK_DEBUG"); sink_adaptive = (int)num("GKC_SINK_ADAPTIVE", 1);      /* 0: never raw on its own, 1: when the host is behind, 2 (tests): every other batch */
         sink_dense = (uint64_t)num("GKC_SINK_DENSE", 0); unpack_threads = (int)num("GKC_UNPACK_THREADS", 0);
         bloom_atomic = on("GKC_BLOOM_ATOMIC"); bloom_gather = on("GKC_BLOOM_GATHER"); mphf_regions = not0("GKC_MPHF_REGIONS"); mphf_ordered = on("GKC_MPHF_ORDERED");
         bloom_query_regions_min = (uint64_t)num("GKC_BLOOM_QUERY_REGIONS_MIN", 2000000); mphf_regions_min = (uint64_t)num("GKC_MPHF_REGIONS_MIN", 1ll << 21);
@@ -378,6 +378,7 @@ int gkc_export_superkmers(gkc_ctx* c, uint32_t part, uint8_t* out, uint64_t cap,
 int gkc_require_resident(gkc_ctx* c, const char* who);
 // packed result batches (gkc_sink.hip)
 bool  gkc_sink_packed(gkc_ctx* c);
+bool  gkc_sink_host_behind(gkc_ctx* c, uint64_t n_records);   // several ranks on one host: landed, unexpanded records beyond 1.5 batches -> this batch travels raw
 int   gkc_sink_prepare(gkc_ctx* c);
 void  gkc_sink_reset(gkc_ctx* c);
 void  gkc_sink_drain(gkc_ctx* c);

@@ -2503,7 +2503,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
             if (c->sink_used + bytes > c->sink_cap) c->sink_overflow = true;          // the records stay on the device (gkc_partition_counts still serves them)
             else { h_base = (const uint8_t*)c->sink + c->sink_used; c->sink_used += bytes; room = true; }
         }
-        if (room && gkc_sink_packed(c)) {
+        if (room && gkc_sink_packed(c) && !gkc_sink_host_behind(c, total_solid)) {
             std::vector<uint64_t> solid_prefix(nb + 1);
             for (uint32_t i = 0; i <= nb; i++) solid_prefix[i] = ptot[2 * i + 1];
             sink_batch = gkc_sink_send_packed(c, out, (const uint64_t*)B.ptot.p, solid_prefix, (uint8_t*)h_base);      // (synchronizes the lane's stream)

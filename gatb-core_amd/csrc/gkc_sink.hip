@@ -292,6 +292,7 @@ struct gkc_unpacker {
     std::vector<SinkBatch*> all;                 // every batch of the pass (owned)
     bool stop = false;
     uint8_t* staging = nullptr; uint64_t staging_cap = 0, staging_used = 0;
+    std::atomic<uint64_t> n_decisions{0}, n_adaptive_raw{0};     // batches of this context that travelled raw because the host was behind (gkc_sink_host_behind)
 
     static uint64_t lookup(const std::vector<std::pair<uint64_t, uint64_t>>& exc, uint64_t tag)
     {
@@ -544,10 +545,33 @@ void gkc_sink_wait_batch(gkc_ctx* c, const void* batch)
     U->cv_done.wait(lk, [&] { return B->done.load(); });
 }
 
+// Round 6 — several ranks on one host: is the HOST behind? Records whose copy has landed in the staging buffer and that no thread has expanded yet, against what this
+// batch holds. One rank alone expands a batch in 2/3 of the time its copy takes (the link is the bound: at most the batch in hand is pending); 2-8 ranks sharing the
+// host's memory controllers get 1.0-1.4e10 records/s between them (profiles/r06_host_unpack_ceiling.txt) and their staging buffers fill with landed, unexpanded
+// batches. A batch queued then travels RAW instead (16 B per record on this rank's own link, no host work) — the link is busy 2.6x longer with it and the expansion
+// threads catch up: every rank balances its link against its share of the host by itself, batch by batch. The sink ends up byte for byte the same either way.
+static thread_local const char* g_sink_why = "";                   // why the last batch of this thread did not travel packed (GKC_SINK_DEBUG)
+bool gkc_sink_host_behind(gkc_ctx* c, uint64_t n_records)
+{
+    gkc_unpacker* U = c->unpacker;
+    if (!U || !gkc_tun().sink_adaptive) return false;
+    uint64_t pending = 0;
+    {   std::lock_guard<std::mutex> lk(U->mu);
+        for (SinkBatch* B : U->all) {
+            if (B->done.load()) continue;
+            if (B->ready || hipEventQuery(B->copied) == hipSuccess) pending += B->nblk - std::min<uint64_t>(B->finished.load(), B->nblk);
+        }
+    }
+    (void)hipGetLastError();                                        // (hipErrorNotReady of the queries)
+    const bool behind = gkc_tun().sink_adaptive == 2 ? (U->n_decisions++ & 1) != 0                       // (tests: packed and raw batches alternate in one pass)
+                                                     : pending * PK_BLOCK > std::max<uint64_t>(n_records + n_records / 2, (uint64_t)1 << 22);
+    if (behind) { g_sink_why = "the host is behind with the expansion (landed, unexpanded records beyond 1.5 batches): this batch travels raw"; U->n_adaptive_raw++; }
+    return behind;
+}
+
 // One Stage-B batch: d_out = its Count[] (total records, partition i = [solid_prefix[i], solid_prefix[i+1])), d_ptot = the (distinct, solid) prefixes on the device,
 // h_dest = where the records belong in the sink. Runs on the calling lane's stream up to the point where the copy can be queued; returns the batch handle
 // (nullptr: not packed — no staging room, too many exceptions — the caller sends the plain records).
-static thread_local const char* g_sink_why = "";                   // why the last gkc_sink_send_packed of this thread returned nullptr (GKC_SINK_DEBUG)
 const char* gkc_sink_last_refusal() { return g_sink_why; }
 void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot, const std::vector<uint64_t>& solid_prefix, uint8_t* h_dest)
 {

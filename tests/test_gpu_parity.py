@@ -943,6 +943,34 @@ def test_raw_sink_mode_lands_the_same_bytes(gkc, k, amin):
     c.set_host_sink(None)
 
 
+@pytest.mark.parametrize("k", [31, 63])
+def test_sink_mixes_packed_and_raw_batches(gkc, monkeypatch, k):
+    """Several ranks on one host: a rank whose share of the host's expansion threads is behind sends its next batch RAW (gkc_sink_host_behind: landed, unexpanded records
+    beyond 1.5 batches) — packed and raw batches then alternate inside one pass, on one copy stream, into one sink. GKC_SINK_ADAPTIVE=2 makes every other batch raw:
+    ~10 batches of 2^24 k-mers; the sink must hold the oracle's records, and the bytes on the link lie between all-packed and all-raw."""
+    monkeypatch.setenv("GKC_SINK_ADAPTIVE", "2")
+    n = 700_000
+    reads = synth_reads(n, n * 5, 150, seed=17 + k, n_rate=0.0005)
+    bases, offs = gko.pack_reads(reads)
+    m, parts = 10, 96
+    rep = simple_repart(m, parts)
+    c = gkc.Counter(0); c.configure(k, m, parts, rep)
+    c.set_batch_keys(1 << 24)
+    sink = gkc.HostBuffer(4 << 30)
+    c.set_host_sink(sink)
+    ref = gko.Dsk(bases, offs, k, m, parts, rep, threads=os.cpu_count() or 1)
+    c.begin_pass(0); c.push_reads(bases, offs); c.finish_pass()
+    nrec = 0
+    for p in range(parts):
+        view, cnt = c.wait_partition(0, p)
+        exp = ref.part_records(p)
+        assert cnt * c.rec_bytes == len(exp) and (cnt == 0 or np.array_equal(view, exp)), p
+        nrec += cnt
+    wire = c.stats()["sink_wire_bytes"]
+    assert 0.45 * nrec * c.rec_bytes < wire < 0.95 * nrec * c.rec_bytes, (wire, nrec)       # about half of the records packed (0.4x), half raw
+    c.set_host_sink(None)
+
+
 @pytest.mark.parametrize("switch", ["GKC_SINK_DENSE=1", "GKC_SINK_DENSE=1,GKC_SINK_WIDTH6=0", "GKC_SINK_DENSE=1,GKC_UNPACK_THREADS=1"])
 def test_packed_sink_entry_widths(switch):
     """The three entry widths of the packed transfer on the same inputs (GKC_SINK_DENSE=1 declares every batch dense): per-block delta widths + abundance bitmap +
