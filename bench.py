@@ -75,9 +75,11 @@ def cpu_baseline(c, k, m, parts, rep, n_reads=10_000_000):
             "single_thread": single}
 
 
-def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct, keys_moved=None):
+def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct, keys_moved=None, dom_from=None):
     """algorithmic bytes of every timed kernel group (SURVEY §8d per-unit figures x the units of one step) -> the dominant one's roofline entry.
-    ktime: {name: (ms, launches)} over `steps` steps; keys / distinct: this rank's share."""
+    ktime: {name: (ms, launches)} over `steps` steps; keys / distinct: this rank's share. dom_from: the timers the dominant kernel is CHOSEN from (the device-resident
+    steps: there an event interval is kernel work; in the host-landed region the intervals of the groups that talk to the host — "compact" fetches its prefix
+    tables — also hold the waits of their small copies behind the bulk transfers); its time is then taken from `ktime`."""
     rec_bytes = 16 if k <= 31 else 32; key_bytes = 8 if k <= 31 else 16
     alg = {
         "scan_count": n_bases * 1.0,
@@ -90,7 +92,8 @@ def kernel_roofline(ktime, steps, n_bases, st, k, keys, distinct, keys_moved=Non
     if "dedupe_bin" in ktime and ktime["dedupe_bin"][0] > 0:
         alg["dedupe_bin"] = st["nb_superkmers"] * rec_bytes * 3.0            # records read twice (bin count, bin scatter), written once
         alg["dedupe_sort"] = st["nb_superkmers"] * rec_bytes * 2.0           # ... read once and rewritten (at most once) by the sort
-    dom = max(alg, key=lambda n_: ktime[n_][0])
+    pick = dom_from if dom_from is not None else ktime
+    dom = max(alg, key=lambda n_: pick[n_][0])
     dom_ms = ktime[dom][0] / max(1, steps)
     achieved = alg[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     launches = max(1, ktime[dom][1] // max(1, steps))
@@ -635,7 +638,7 @@ def main():
         # dominant kernel = the one with the largest accumulated time; its algorithmic bytes per launch are stated in DESIGN.md §Kernels
         keys_per_rank = valid / world
         key_bytes = 8 if k <= 31 else 16
-        alg, dom, dom_ms, achieved, launches_per_step = kernel_roofline(ktime, args.steps, n_bases, st, k, keys_per_rank, distinct / world)
+        alg, dom, dom_ms, achieved, launches_per_step = kernel_roofline(ktime, args.steps, n_bases, st, k, keys_per_rank, distinct / world, dom_from=ktime_dev)
         workload = ("k=%d, %d synthetic 150 bp reads per GPU, single-pass count (no Bloom), m=%d, %d partitions" % (k, n_reads, m, parts))
         if world > 1:
             workload = ("BASELINE configs[2] at %d GPU(s): k=%d, %d synthetic 150 bp reads per GPU (%d in all), minimizer-partition exchange (gkc_exchange: RCCL send/recv over xGMI), "

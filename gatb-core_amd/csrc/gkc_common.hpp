@@ -353,8 +353,8 @@ inline hipStream_t cur_stream(gkc_ctx* c) { return tl_stream_ ? tl_stream_ : c->
 
 // RAII event timer accumulating into ctx->timing[name]
 struct ScopedTimer {
-    gkc_ctx* c; const char* name; hipEvent_t a, b; bool on;
-    ScopedTimer(gkc_ctx* c_, const char* n) : c(c_), name(n), on(true) {
+    gkc_ctx* c; const char* name; hipEvent_t a, b; bool on; uint64_t counts;
+    ScopedTimer(gkc_ctx* c_, const char* n, uint64_t counts_ = 1 /* launches this interval stands for (0: a further piece of an interval already counted) */) : c(c_), name(n), on(true), counts(counts_) {
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(a, cur_stream(c));
     }
@@ -362,7 +362,7 @@ struct ScopedTimer {
         if (!on) return;
         (void)hipEventRecord(b, cur_stream(c)); (void)hipEventSynchronize(b);
         float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
-        { std::lock_guard<std::mutex> lk(c->mu); Timing& t = c->timing[name]; t.ms += ms; t.launches += 1; }
+        { std::lock_guard<std::mutex> lk(c->mu); Timing& t = c->timing[name]; t.ms += ms; t.launches += counts; }
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     }
 };

@@ -2437,19 +2437,22 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
     // --- dump: prefix over the per-bucket counts -> Count records
     uint64_t total_solid = 0;
     std::vector<uint64_t> ptot((size_t)(nb + 1) * 2);
-    {   ScopedTimer tm(c, "compact");
+    {   // "compact" times the KERNELS of the dump (two intervals: the prefix kernels, the gather kernels); the fetch of the prefix tables, the wait for it and the
+        // allocation of the output block between them are host time — inside one interval they made the group look 2-3x its size wherever the host was busy (round 6)
         const uint32_t n_chunks = (uint32_t)((n_sub + SCAN2_CHUNK - 1) / SCAN2_CHUNK);
         if (n_chunks > (uint32_t)SCAN2_CHUNK) { B.release(); GKC_FAIL(c, GKC_ERR_ARG, "batch too large for the sub-bucket scan"); }
         CB_TRY(c->ensure(B.chunk, (size_t)std::max<uint32_t>(n_chunks, 1) * 16));
         uint64_t* ca = (uint64_t*)B.chunk.p; uint64_t* cb = ca + std::max<uint32_t>(n_chunks, 1);
         uint32_t h_misc[64];
         int level = DEEP_FIXED;
-        for (;;) {
+        for (uint64_t first = 1;; first = 0) {
+            {   ScopedTimer tm(c, "compact", first);
             if (n_chunks) hipLaunchKernelGGL(k_scan2_chunks, dim3(n_chunks), dim3(1024), 0, cur_stream(c), (const uint32_t*)O.nd, (const uint32_t*)O.ns, n_sub, (uint64_t*)B.off_d.p, (uint64_t*)B.off_s.p, ca, cb);
             hipLaunchKernelGGL(k_scan2_totals, dim3(1), dim3(1024), 0, cur_stream(c), ca, cb, n_chunks, (uint64_t*)B.off_d.p, (uint64_t*)B.off_s.p, n_sub);
             if (n_chunks) hipLaunchKernelGGL(k_scan2_add, dim3(n_chunks), dim3(1024), 0, cur_stream(c), (uint64_t*)B.off_d.p, (uint64_t*)B.off_s.p, n_sub, (const uint64_t*)ca, (const uint64_t*)cb);
             hipLaunchKernelGGL(k_gather_u64, dim3((nb + 1 + 255) / 256), dim3(256), 0, cur_stream(c), (const uint64_t*)B.off_d.p, (const uint64_t*)B.off_s.p,
                                (const uint64_t*)B.pidx.p, nb + 1, (uint64_t*)B.ptot.p);
+            }
             CB_HIP(hipGetLastError());
             CB_HIP(hipMemcpyAsync(ptot.data(), B.ptot.p, (size_t)(nb + 1) * 16, hipMemcpyDeviceToHost, cur_stream(c)));
             CB_HIP(hipMemcpyAsync(h_misc, B.misc.p, sizeof(h_misc), hipMemcpyDeviceToHost, cur_stream(c)));
@@ -2476,6 +2479,7 @@ static int count_batch(gkc_ctx* c, const uint32_t pass, const std::vector<Segmen
         if (!out) { B.release(); return GKC_ERR_NOMEM; }
         { std::lock_guard<std::mutex> lk(c->mu); outputs.push_back(out); }
         if (n_sub) {
+            ScopedTimer tm(c, "compact", 0);
             const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_sub + 255) / 256, 256 * 16));
             hipLaunchKernelGGL((k_gather_counts<KW>), dim3(grid), dim3(GATHER_THREADS), 0, cur_stream(c), (const key_t*)keysA, (const uint8_t*)B.cnt8.p, (const uint32_t*)B.cnt.p,
                                bs, bn, (const uint32_t*)O.nd, (const uint64_t*)B.off_s.p, (uint32_t)n_sub, cap3, c->amin, c->amax, O.all_solid, (uint64_t*)out, bc, 2 * k - drop);
