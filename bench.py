@@ -414,7 +414,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
-    numa_note = bind_to_gpu_numa_node(torch, local) if (world > 1 or os.environ.get("GKC_BENCH_NUMA_BIND") == "1") and os.environ.get("GKC_BENCH_NO_NUMA_BIND") is None else None
+    # The process (and with it the page-locked sink it allocates, and the library's expansion threads, which follow the sink's node) goes to the NUMA node its GPU hangs on:
+    # a sink on the other socket costs the headline 8 % on the 2-socket host of these boxes (465 vs 502 ms per step, same wire bytes, round 6). One rank: the original
+    # affinity comes back before the CPU baseline runs (it uses every core of the host).
+    affinity0 = os.sched_getaffinity(0)
+    numa_note = bind_to_gpu_numa_node(torch, local) if os.environ.get("GKC_BENCH_NO_NUMA_BIND") is None else None
     red_dev = "cuda" if (not use_dist or dist.get_backend() == "nccl") else "cpu"      # where the few scalars of the line are all-reduced
     gkc = ge.load().gkc
     if not os.path.exists(gkc.SO):
@@ -552,6 +556,8 @@ def main():
                   "link_GBps_over_the_step": wire / (dt_host / args.steps) / 1e9, "frac_of_pcie": wire / (dt_host / args.steps) / 1e9 / pcie_gbs,
                   "sink_GB": sink.nbytes / 1e9, "sink_alloc_s": sink.alloc_s, "sink_overflow": "sink" in err_,
                   "sink_mode": sink_mode, "sink_mode_trial": sink_trial}
+        if numa_note:
+            landed["host_placement"] = numa_note
         # outside the clock: what landed is what the device holds (first / middle / last partition this rank owns)
         try:
             same = True
@@ -1022,6 +1028,7 @@ def main():
             c8.close()
         if not args.no_cpu_baseline and world == 1:
             cb = c if c is not None else gkc.Counter(local)
+            os.sched_setaffinity(0, affinity0)                    # (every core of the host for the CPU baseline)
             ref_b = cpu_baseline_reference(cb, k)
             cp = int(min(parts, 4096))
             port_b = cpu_baseline(cb, k, m, cp, repart_for_bench(m, cp))

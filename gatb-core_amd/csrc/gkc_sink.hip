@@ -18,6 +18,7 @@
 #include "gkc_common.hpp"
 #include "gkc_device.hpp"
 #include <algorithm>
+#include <utility>
 #include <atomic>
 #include <deque>
 #include <immintrin.h>
@@ -34,17 +35,17 @@ constexpr uint64_t pk_slot(int W) { return (uint64_t)PK_BLOCK * (uint64_t)W; }  
 constexpr uint64_t pk_esc(int W) { return (1ull << (8 * (W - 1))) - 1ull; }
 constexpr uint64_t PK_KEY_EXC = 1ull << 63;
 constexpr uint64_t PK_DENSE = 300000;                                   // records per partition from which 6-byte deltas are used
-// PKV (reported as width 6; round 6, it replaces the fixed 6-byte deltas of rounds 3-5): every block of PK_BLOCK records carries its deltas at the block's OWN bit width
-// W = bits of its largest delta (canonical k-mers thin out towards the top of the key space, density 2 (1 - x): the gaps of a partition of 8.9e5 records average 2^42 and
-// range from 2^41 at the bottom to 2^50 in its last blocks, so one width for all either wastes bits at the bottom or escapes at the top: 48 bits + 0.03 % escapes before,
-// 45.6 bits on average and NO key escapes now = 5.7 instead of 6.0 bytes per record), bit-packed: 8 records = W bytes. A block's payload = its entries (chunks of
-// PKV_CHUNK records, each chunk 256 W bytes) + a bitmap of PK_BLOCK bits (abundance != 1), at an offset of the batch's payload stream the block's workgroup reserves
-// (u32 in 16-byte units + u8 width per block in the header); the abundance bytes of the flagged records, in record order, sit in the batch's abundance stream from the
-// block's offset on (u32 per block in the header) — both reserved by ONE atomic each: the order of the blocks in the streams is whatever it came out as.
-// W > 56 (a host extraction reads 8 bytes at any bit offset: 7 + W <= 63) is sent as W = 64.
-constexpr uint32_t PKV_CHUNK = 2048;                                                                            // records per pack iteration: 256 threads x 8 records
+// PKV (reported as width 6; round 6, it replaces the fixed 6-byte deltas of rounds 3-5): the deltas travel bit-packed at the width of the largest delta of their
+// SUB-BLOCK of PKV_SUB = 128 records (64 sub-blocks per block of PK_BLOCK records, one width byte each in the header). Canonical k-mers thin out towards the top of
+// the key space (density 2 (1 - x)): the gaps of a partition of 8.9e5 records average 2^42 and range from 2^41 at the bottom to 2^50 in its last blocks, so one width
+// for all either wastes bits at the bottom or escapes at the top (48 bits + 0.03 % escapes before); the largest of 128 exponential gaps is 2.3 bits above their mean
+// (of 8192: 3.2 + what the clusters of k-mers that start with their minimizer add): ~44.6 bits on average and NO key escapes. 128 W bits = 16 W bytes: every
+// sub-block starts on a byte, a thread packs 8 records into W bytes. A block's payload = its sub-blocks back to back + a bitmap of PK_BLOCK bits (abundance != 1), at
+// an offset of the batch's payload stream the block's workgroup reserves (u32 in 16-byte units in the header); the abundance bytes of the flagged records, in record
+// order, sit in the batch's abundance stream from the block's offset on (u32 per block in the header) — both reserved by ONE atomic each: the order of the blocks in
+// the streams is whatever it came out as. W > 56 (a host extraction reads 8 bytes at any bit offset: 7 + W <= 63) is sent as W = 64.
+constexpr uint32_t PKV_CHUNK = 2048, PKV_SUB = 128, PKV_NSUB = PK_BLOCK / PKV_SUB;                              // records per pack iteration (256 threads x 8); per width; widths per block
 constexpr uint64_t PKV_BITMAP = PK_BLOCK / 8, PKV_BLOCK_MAX = (uint64_t)PK_BLOCK * 8 + PKV_BITMAP;              // worst case of a block's payload (W = 64)
-__host__ __device__ constexpr uint64_t pkv_entries_bytes(uint32_t n, uint32_t W) { return (uint64_t)((n + PKV_CHUNK - 1) / PKV_CHUNK) * (PKV_CHUNK / 8) * W; }
 constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PKV_BLOCK_MAX : pk_slot(width); }
 // 16-byte keys (k >= 32; round 4, second session): the same scheme on 32-byte Count records {u128 value; i32 abundance; 12 bytes of padding} (Abundance.hpp:68-129 with
 // LargeInt<2>): per block the first key (16 bytes), per record [key delta : 15 or 16 bytes][abundance : 1 byte] = widths 16 / 17 instead of 32. A partition of 5.6e5 records in a
@@ -107,17 +108,19 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts(const uint64_t* __re
 }
 
 __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint32_t* __restrict__ cb_off,
-                                                             uint32_t* __restrict__ pay_off16, uint8_t* __restrict__ wbits,
+                                                             uint32_t* __restrict__ pay_off16, uint8_t* __restrict__ wbits /* [nblk][PKV_NSUB] */,
                                                              uint8_t* __restrict__ payload, unsigned long long* __restrict__ pay_cursor /* bytes */,
                                                              uint8_t* __restrict__ cb_stream, unsigned long long* __restrict__ cb_cursor,
                                                              uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 64];                  // one chunk's entries: 256 x W bytes
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 64];                  // one chunk's entries: 16 sub-blocks of 16 W bytes
     __shared__ uint64_t s_key[PKV_CHUNK + 1];                                                 // the chunk's keys, [0] = the key before the chunk
     __shared__ __attribute__((aligned(16))) unsigned long long s_bits[PK_BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint8_t s_cb[PK_BLOCK];
+    __shared__ unsigned long long s_wmax[PKV_NSUB];                                           // largest delta of every sub-block
+    __shared__ uint32_t s_w[PKV_NSUB], s_off[PKV_NSUB + 1];                                   // its width, the byte offset of its entries in the block's payload
     __shared__ uint32_t s_p, s_wcnt[PK_THREADS / 64];
-    __shared__ unsigned long long s_base, s_pay, s_max[PK_THREADS / 64];
+    __shared__ unsigned long long s_base, s_pay;
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) {                                               // partition of block slot g: the largest p with blk_first[p] <= g
         uint32_t lo = 0, hi = P.nb;
@@ -125,22 +128,21 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
         s_p = lo;
     }
     for (uint32_t i = t; i < PK_BLOCK / 64; i += PK_THREADS) s_bits[i] = 0ull;
+    if (t < PKV_NSUB) s_wmax[t] = 0ull;
     __syncthreads();
     const uint32_t p = s_p, j = g - P.blk_first[p];
     const uint64_t s1 = P.ptot[2 * (p + 1) + 1], r0 = P.ptot[2 * p + 1] + (uint64_t)j * PK_BLOCK;
     const uint32_t n = (uint32_t)min((uint64_t)PK_BLOCK, s1 - r0);
     if (t == 0) bases[g] = recs[2 * r0];
-    // ---- pass 1 (coalesced): the block's largest delta -> its width; the abundance side (bitmap, stream bytes, escapes of abundances >= 255) as before
-    uint64_t dmax = 0;
+    // ---- pass 1 (coalesced): the largest delta of every sub-block -> its width; the abundance side (bitmap, stream bytes, escapes of abundances >= 255) as before
     uint32_t run = 0;                                           // flagged records of the rounds before this one (the same in every thread)
     for (uint32_t i0 = 0; i0 < n; i0 += PK_THREADS) {
         const uint32_t i = i0 + t;
-        uint32_t ab8 = 1;
+        uint32_t ab8 = 1; uint64_t d = 0;
         if (i < n) {
             const ulonglong2 me = *reinterpret_cast<const ulonglong2*>(recs + 2 * (r0 + i));
             const uint64_t prev = i ? recs[2 * (r0 + i - 1)] : me.x;
-            const uint64_t d = me.x - prev;
-            dmax = d > dmax ? d : dmax;
+            d = me.x - prev;
             const uint32_t ab = (uint32_t)me.y;
             ab8 = ab;
             if (ab >= 255u) {
@@ -149,6 +151,9 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
                 ab8 = 255u;
             }
         }
+#pragma unroll
+        for (int d_ = 32; d_ >= 1; d_ >>= 1) { const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)d, d_, 64); d = y > d ? y : d; }      // (a wave's 64 records lie in one sub-block)
+        if (lane == 0 && d) atomicMax(&s_wmax[(i0 >> 7) + (wave >> 1)], (unsigned long long)d);
         const bool flag = ab8 != 1u;
         const unsigned long long bal = __ballot(flag);
         if (lane == 0) { s_bits[(i0 >> 6) + wave] = bal; s_wcnt[wave] = (uint32_t)__popcll(bal); }
@@ -160,49 +165,55 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
         run += total;
         __syncthreads();
     }
-#pragma unroll
-    for (int d_ = 32; d_ >= 1; d_ >>= 1) { const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)dmax, d_, 64); dmax = y > dmax ? y : dmax; }
-    if (lane == 0) s_max[wave] = dmax;
-    __syncthreads();
-    if (t == 0) {
-        uint64_t m = 0;
-        for (int w = 0; w < PK_THREADS / 64; w++) m = s_max[w] > m ? s_max[w] : m;
-        uint32_t W = m ? 64u - (uint32_t)__clzll((long long)m) : 1u;
+    if (t < PKV_NSUB) {                                         // (wave 0) widths, and the exclusive prefix of the sub-blocks' 16 W bytes
+        const uint64_t m = s_wmax[t];
+        uint32_t W = m ? 64u - (uint32_t)__clzll((long long)m) : 0u;
         if (W > 56u) W = 64u;
-        const uint64_t bytes = pkv_entries_bytes(n, W) + PKV_BITMAP;                        // a multiple of 16
-        s_pay = atomicAdd(pay_cursor, (unsigned long long)bytes);
-        pay_off16[g] = (uint32_t)(s_pay >> 4); wbits[g] = (uint8_t)W;
-        s_base = run ? atomicAdd(cb_cursor, (unsigned long long)run) : 0ull; cb_off[g] = (uint32_t)s_base;      // (the stream is shorter than 2^32 bytes: one byte per record at most)
-        s_p = W;
+        if (t * PKV_SUB >= n) W = 0u;
+        uint32_t x = 16u * W;
+#pragma unroll
+        for (int d_ = 1; d_ < 64; d_ <<= 1) { const uint32_t y = __shfl_up(x, d_, 64); if ((int)lane >= d_) x += y; }
+        s_w[t] = W; s_off[t] = x - 16u * W;
+        if (t == PKV_NSUB - 1) s_off[PKV_NSUB] = x;
+        wbits[(uint64_t)g * PKV_NSUB + t] = (uint8_t)W;
     }
     __syncthreads();
-    const uint32_t W = s_p;
+    if (t == 0) {
+        const uint64_t bytes = (uint64_t)s_off[PKV_NSUB] + PKV_BITMAP;                        // a multiple of 16
+        s_pay = atomicAdd(pay_cursor, (unsigned long long)bytes);
+        pay_off16[g] = (uint32_t)(s_pay >> 4);
+        s_base = run ? atomicAdd(cb_cursor, (unsigned long long)run) : 0ull; cb_off[g] = (uint32_t)s_base;      // (the stream is shorter than 2^32 bytes: one byte per record at most)
+    }
+    __syncthreads();
     uint8_t* dstp = payload + s_pay;
-    // ---- pass 2 (the block's records again: L2): chunks of 2048 keys through LDS, every thread packs 8 consecutive deltas into W bytes, the chunk leaves as 16-byte words
+    // ---- pass 2 (the block's records again: L2): chunks of 2048 keys through LDS, every thread packs 8 consecutive deltas into the W bytes of its sub-block's width,
+    //      the chunk (16 sub-blocks back to back) leaves as 16-byte words
     for (uint32_t c0 = 0; c0 < n; c0 += PKV_CHUNK) {
         for (uint32_t i = t; i < PKV_CHUNK; i += PK_THREADS) s_key[1 + i] = c0 + i < n ? recs[2 * (r0 + c0 + i)] : 0ull;
         if (t == 0) s_key[0] = c0 ? recs[2 * (r0 + c0 - 1)] : recs[2 * r0];
         __syncthreads();
+        const uint32_t sub0 = c0 / PKV_SUB, sub = sub0 + (t >> 4), W = s_w[sub], cbase = s_off[sub0];
         {
             unsigned __int128 acc = 0; uint32_t nbits = 0;
-            uint8_t* o = s_out + (size_t)t * W;
+            uint8_t* o = s_out + (s_off[sub] - cbase) + (size_t)(t & 15u) * W;
             uint64_t prev = s_key[8 * t];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const uint32_t i = c0 + 8 * t + q;
                 const uint64_t key = s_key[1 + 8 * t + q];
-                const uint64_t d = i < n ? key - prev : 0ull;                               // (beyond the block's records: zero bits)
+                const uint64_t d = i < n ? key - prev : 0ull;                               // (beyond the block's records: zero bits; W = 0: nothing is written)
                 prev = key;
                 acc |= (unsigned __int128)d << nbits; nbits += W;
                 while (nbits >= 8) { *o++ = (uint8_t)acc; acc >>= 8; nbits -= 8; }
             }
         }
         __syncthreads();
-        uint4* dst = reinterpret_cast<uint4*>(dstp + (uint64_t)(c0 / PKV_CHUNK) * (PKV_CHUNK / 8) * W);
-        for (uint32_t w = t; w < 16u * W; w += PK_THREADS) dst[w] = reinterpret_cast<const uint4*>(s_out)[w];      // 256 W bytes = 16 W words of 16 bytes
+        const uint32_t cwords = (s_off[sub0 + PKV_CHUNK / PKV_SUB] - cbase) >> 4;             // (sub0 + 16 <= 64)
+        uint4* dst = reinterpret_cast<uint4*>(dstp + cbase);
+        for (uint32_t w = t; w < cwords; w += PK_THREADS) dst[w] = reinterpret_cast<const uint4*>(s_out)[w];
         __syncthreads();
     }
-    if (t < PKV_BITMAP / 16) reinterpret_cast<uint4*>(dstp + pkv_entries_bytes(n, W))[t] = reinterpret_cast<const uint4*>(s_bits)[t];      // the bitmap: 1024 bytes = 64 x 16
+    if (t < PKV_BITMAP / 16) reinterpret_cast<uint4*>(dstp + s_off[PKV_NSUB])[t] = reinterpret_cast<const uint4*>(s_bits)[t];      // the bitmap: 1024 bytes = 64 x 16
     uint8_t* cb = cb_stream + s_base;
     for (uint32_t i = t; i < run; i += PK_THREADS) cb[i] = s_cb[i];
 }
@@ -314,28 +325,44 @@ struct gkc_unpacker {
             _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));      // {u64 value; i32 abundance; 4 bytes of padding = 0}
         }
     }
-    static void unpack_block_6(const SinkBatch& B, uint64_t g)                       // PKV: the block's own delta width, no key escapes
+    // One sub-block of PKV (<= 128 records at width W), W a template constant: 8 records = W bytes, so inside a group every byte offset and shift is a constant
+    // (the generic loop with a running bit position expanded 1.0e10 records/s on 24 threads — level with the link; this one keeps the margin of the fixed 6-byte format)
+    template <int W> static void pkv_sub(const SinkBatch& B, const uint8_t* pay, const uint32_t cnt, const uint64_t rec0, uint64_t& key, const uint64_t* bits /* the sub-block's 2 words */,
+                                         const uint8_t*& cb, __m128i* out)
     {
+        constexpr uint64_t mask = W >= 64 ? ~0ull : ((1ull << (W & 63)) - 1ull);
+        auto one = [&](const uint32_t i, const uint64_t w, const uint32_t sh, const uint32_t f) {
+            key += (w >> sh) & mask;
+            uint32_t ab = 1u + f * ((uint32_t)*cb - 1u); cb += f;            // 16 % of the records, at random: no branch on it (the byte under the cursor is read either way; padding follows the stream)
+            if (ab == 255u) ab = (uint32_t)lookup(B.exc, rec0 + i);
+            _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));
+        };
+        uint32_t i = 0;
+        for (; i + 8 <= cnt; i += 8) {
+            const uint8_t* q = pay + (size_t)(i >> 3) * W;
+            const uint32_t m = (uint32_t)(bits[i >> 6] >> (i & 63)) & 255u;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { uint64_t w; memcpy(&w, q + ((j * W) >> 3), 8); one(i + j, w, (uint32_t)((j * W) & 7), (m >> j) & 1u); }      // (up to 7 bytes beyond the group: the next one / the bitmap / padding)
+        }
+        for (uint64_t bit = (uint64_t)i * W; i < cnt; i++, bit += W) { uint64_t w; memcpy(&w, pay + (bit >> 3), 8); one(i, w, (uint32_t)(bit & 7), (uint32_t)(bits[i >> 6] >> (i & 63)) & 1u); }
+    }
+    typedef void (*pkv_fn)(const SinkBatch&, const uint8_t*, uint32_t, uint64_t, uint64_t&, const uint64_t*, const uint8_t*&, __m128i*);
+    template <size_t... I> static const pkv_fn* pkv_table(std::index_sequence<I...>) { static const pkv_fn t[] = { &pkv_sub<(int)I>... }; return t; }
+    static void unpack_block_6(const SinkBatch& B, uint64_t g)                       // PKV: one delta width per sub-block of 128 records, no key escapes
+    {
+        static const pkv_fn* const table = pkv_table(std::make_index_sequence<65>());
         const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
-        const uint32_t W = B.stage[B.wbits_off + g];
+        const uint8_t* wb = B.stage + B.wbits_off + g * PKV_NSUB;
         const uint8_t* pay = B.stage + B.pay_off + ((uint64_t)reinterpret_cast<const uint32_t*>(B.stage + B.pay16_off)[g] << 4);
-        const uint64_t* bits = reinterpret_cast<const uint64_t*>(pay + pkv_entries_bytes(n, W));
+        uint32_t total = 0; for (uint32_t s = 0; s < PKV_NSUB; s++) total += 16u * wb[s];
+        const uint64_t* bits = reinterpret_cast<const uint64_t*>(pay + total);
         const uint8_t* cb = B.stage + B.cb_off + reinterpret_cast<const uint32_t*>(B.stage + B.cboff_off)[g];
-        uint64_t key = reinterpret_cast<const uint64_t*>(B.stage)[g];
+        uint64_t key = reinterpret_cast<const uint64_t*>(B.stage)[g];           // (a block's first delta is 0)
         __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 16);
-        const uint64_t mask = W >= 64 ? ~0ull : (1ull << W) - 1ull;
-        uint64_t bit = 0;
-        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-            uint64_t m = bits[i0 >> 6];
-            const uint32_t e = std::min<uint32_t>(n, i0 + 64);
-            for (uint32_t i = i0; i < e; i++, m >>= 1, bit += W) {
-                uint64_t w; memcpy(&w, pay + (bit >> 3), 8);         // (W <= 56: the W bits from bit offset (bit & 7) on lie inside these 8 bytes; W = 64: byte-aligned; up to 7 bytes beyond
-                key += (w >> (bit & 7)) & mask;                      //  the entries: the bitmap / the next block / the padding behind the stream) the first delta of a block is 0
-                const uint32_t f = (uint32_t)(m & 1ull);                 // 16 % of the records, at random: no branch on it (the byte under the cursor is read either way;
-                uint32_t ab = 1u + f * ((uint32_t)*cb - 1u); cb += f;    // the stream is followed by padding)
-                if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
-                _mm_stream_si128(out + i, _mm_set_epi64x((long long)(uint64_t)ab, (long long)key));
-            }
+        for (uint32_t s0 = 0; s0 < n; s0 += PKV_SUB) {
+            const uint32_t W = std::min<uint32_t>(wb[s0 / PKV_SUB], 64u);
+            table[W](B, pay, std::min<uint32_t>(PKV_SUB, n - s0), r0 + s0, key, bits + (s0 >> 6), cb, out + s0);
+            pay += 16u * W;
         }
     }
     template <int W> static void unpack_block_2(const SinkBatch& B, uint64_t g)         // 16-byte keys: 32-byte records {value low, value high, abundance, 0}
@@ -594,7 +621,7 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     const int width = wide ? (dense ? 16 : 17) : !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;
     const uint64_t n_rec = solid_prefix[nb];
     const uint64_t bases_bytes = (nblk * (wide ? 16 : 8) + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0;
-    const uint64_t wbits_bytes = width == 6 ? (nblk + 63) / 64 * 64 : 0, hdr_bytes = bases_bytes + 2 * cboff_bytes + wbits_bytes;      // width 6: [bases | abundance-stream offsets | payload offsets | widths]
+    const uint64_t wbits_bytes = width == 6 ? nblk * PKV_NSUB : 0, hdr_bytes = bases_bytes + 2 * cboff_bytes + wbits_bytes;      // width 6: [bases | abundance-stream offsets | payload offsets | widths]
     const uint64_t pay_bytes = nblk * pk_slot_of(width) + 64, cb_cap = width == 6 ? (n_rec + 63) / 64 * 64 : 0;                           // (width 6: the worst case — every block at 64 bits; what is copied is what was used)
     const uint32_t exc_cap = 1u << 20;
     g_sink_why = "no device memory for the packed copy";
