@@ -46,7 +46,11 @@ constexpr uint64_t PK_DENSE = 300000;                                   // recor
 // the streams is whatever it came out as. W > 56 (a host extraction reads 8 bytes at any bit offset: 7 + W <= 63) is sent as W = 64.
 constexpr uint32_t PKV_CHUNK = 2048, PKV_SUB = 128, PKV_NSUB = PK_BLOCK / PKV_SUB;                              // records per pack iteration (256 threads x 8); per width; widths per block
 constexpr uint64_t PKV_BITMAP = PK_BLOCK / 8, PKV_BLOCK_MAX = (uint64_t)PK_BLOCK * 8 + PKV_BITMAP;              // worst case of a block's payload (W = 64)
-constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PKV_BLOCK_MAX : pk_slot(width); }
+// PKV for 16-byte keys (reported as width 14; round 6): the same layout with 128-bit deltas — a sub-block's width W is 0..128 bits, a record's W bits are the low
+// min(W, 64) bits of its delta followed by the W - 64 high ones; bases are 16 bytes per block. k = 63, 5.6e5 records per partition: gaps of 2^107 on average, 13.7 bytes
+// per record where the fixed entries carry 15 or 16 (+ escapes).
+constexpr uint64_t PKV2_BLOCK_MAX = (uint64_t)PK_BLOCK * 16 + PKV_BITMAP;
+constexpr uint64_t pk_slot_of(int width) { return width == 6 ? PKV_BLOCK_MAX : width == 14 ? PKV2_BLOCK_MAX : pk_slot(width); }
 // 16-byte keys (k >= 32; round 4, second session): the same scheme on 32-byte Count records {u128 value; i32 abundance; 12 bytes of padding} (Abundance.hpp:68-129 with
 // LargeInt<2>): per block the first key (16 bytes), per record [key delta : 15 or 16 bytes][abundance : 1 byte] = widths 16 / 17 instead of 32. A partition of 5.6e5 records in a
 // 126-bit key space has deltas of ~2^107 — but canonical k-mers thin out towards the top of the key space (density 2 (1 - x)), and with 14-byte deltas 0.1-0.4 % of them escaped
@@ -218,6 +222,122 @@ __global__ __launch_bounds__(PK_THREADS) void k_pack_counts6(const uint64_t* __r
     for (uint32_t i = t; i < run; i += PK_THREADS) cb[i] = s_cb[i];
 }
 
+// PKV, 16-byte keys (see PKV2_BLOCK_MAX above): recs = 4 words per record (value low, value high, abundance, 0); bases = 2 words per block
+__global__ __launch_bounds__(PK_THREADS) void k_pack_pkv2(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint32_t* __restrict__ cb_off,
+                                                          uint32_t* __restrict__ pay_off16, uint8_t* __restrict__ wbits /* [nblk][PKV_NSUB] */,
+                                                          uint8_t* __restrict__ payload, unsigned long long* __restrict__ pay_cursor /* bytes */,
+                                                          uint8_t* __restrict__ cb_stream, unsigned long long* __restrict__ cb_cursor,
+                                                          uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc, uint32_t exc_cap)
+{
+    typedef unsigned __int128 u128;
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PK_THREADS * 128];                 // one chunk's entries: 16 sub-blocks of 16 W bytes, W <= 128
+    __shared__ uint64_t s_klo[PKV_CHUNK + 1], s_khi[PKV_CHUNK + 1];                           // the chunk's keys, [0] = the key before the chunk
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bits[PK_BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cb[PK_BLOCK];
+    __shared__ uint32_t s_w[PKV_NSUB], s_off[PKV_NSUB + 1];                                   // a sub-block's width (bits of its largest delta), the byte offset of its entries
+    __shared__ uint32_t s_p, s_wcnt[PK_THREADS / 64];
+    __shared__ unsigned long long s_base, s_pay;
+    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) {
+        uint32_t lo = 0, hi = P.nb;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P.blk_first[mid] <= g) lo = mid; else hi = mid; }
+        s_p = lo;
+    }
+    for (uint32_t i = t; i < PK_BLOCK / 64; i += PK_THREADS) s_bits[i] = 0ull;
+    if (t < PKV_NSUB) s_w[t] = 0u;
+    __syncthreads();
+    const uint32_t p = s_p, j = g - P.blk_first[p];
+    const uint64_t s1 = P.ptot[2 * (p + 1) + 1], r0 = P.ptot[2 * p + 1] + (uint64_t)j * PK_BLOCK;
+    const uint32_t n = (uint32_t)min((uint64_t)PK_BLOCK, s1 - r0);
+    if (t == 0) { bases[2 * (uint64_t)g] = recs[4 * r0]; bases[2 * (uint64_t)g + 1] = recs[4 * r0 + 1]; }
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += PK_THREADS) {
+        const uint32_t i = i0 + t;
+        uint32_t ab8 = 1, wd = 0;
+        if (i < n) {
+            const ulonglong2 me = *reinterpret_cast<const ulonglong2*>(recs + 4 * (r0 + i));
+            ulonglong2 pv = me;
+            if (i) pv = *reinterpret_cast<const ulonglong2*>(recs + 4 * (r0 + i - 1));
+            const u128 d = (((u128)me.y << 64) | me.x) - (((u128)pv.y << 64) | pv.x);
+            const uint64_t dh = (uint64_t)(d >> 64), dl = (uint64_t)d;
+            wd = dh ? 128u - (uint32_t)__clzll((long long)dh) : dl ? 64u - (uint32_t)__clzll((long long)dl) : 0u;
+            const uint32_t ab = (uint32_t)recs[4 * (r0 + i) + 2];
+            ab8 = ab;
+            if (ab >= 255u) {
+                const unsigned long long e = atomicAdd(n_exc, 1ull);
+                if (e < exc_cap) { exc[2 * e] = r0 + i; exc[2 * e + 1] = ab; }
+                ab8 = 255u;
+            }
+        }
+#pragma unroll
+        for (int d_ = 32; d_ >= 1; d_ >>= 1) { const uint32_t y = __shfl_xor(wd, d_, 64); wd = y > wd ? y : wd; }      // (a wave's 64 records lie in one sub-block)
+        if (lane == 0 && wd) atomicMax(&s_w[(i0 >> 7) + (wave >> 1)], wd);
+        const bool flag = ab8 != 1u;
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) { s_bits[(i0 >> 6) + wave] = bal; s_wcnt[wave] = (uint32_t)__popcll(bal); }
+        __syncthreads();
+        uint32_t before = run, total = 0;
+#pragma unroll
+        for (int w = 0; w < PK_THREADS / 64; w++) { if (w < (int)wave) before += s_wcnt[w]; total += s_wcnt[w]; }
+        if (flag) s_cb[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = (uint8_t)ab8;
+        run += total;
+        __syncthreads();
+    }
+    if (t < PKV_NSUB) {
+        uint32_t W = s_w[t];
+        if (t * PKV_SUB >= n) W = 0u;
+        uint32_t x = 16u * W;
+#pragma unroll
+        for (int d_ = 1; d_ < 64; d_ <<= 1) { const uint32_t y = __shfl_up(x, d_, 64); if ((int)lane >= d_) x += y; }
+        s_w[t] = W; s_off[t] = x - 16u * W;
+        if (t == PKV_NSUB - 1) s_off[PKV_NSUB] = x;
+        wbits[(uint64_t)g * PKV_NSUB + t] = (uint8_t)W;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint64_t bytes = (uint64_t)s_off[PKV_NSUB] + PKV_BITMAP;
+        s_pay = atomicAdd(pay_cursor, (unsigned long long)bytes);
+        pay_off16[g] = (uint32_t)(s_pay >> 4);
+        s_base = run ? atomicAdd(cb_cursor, (unsigned long long)run) : 0ull; cb_off[g] = (uint32_t)s_base;
+    }
+    __syncthreads();
+    uint8_t* dstp = payload + s_pay;
+    for (uint32_t c0 = 0; c0 < n; c0 += PKV_CHUNK) {
+        for (uint32_t i = t; i < PKV_CHUNK; i += PK_THREADS) {
+            ulonglong2 q = make_ulonglong2(0, 0);
+            if (c0 + i < n) q = *reinterpret_cast<const ulonglong2*>(recs + 4 * (r0 + c0 + i));
+            s_klo[1 + i] = q.x; s_khi[1 + i] = q.y;
+        }
+        if (t == 0) { const uint64_t rp = c0 ? r0 + c0 - 1 : r0; s_klo[0] = recs[4 * rp]; s_khi[0] = recs[4 * rp + 1]; }
+        __syncthreads();
+        const uint32_t sub0 = c0 / PKV_SUB, sub = sub0 + (t >> 4), W = s_w[sub], cbase = s_off[sub0];
+        {
+            const uint32_t wl = W < 64u ? W : 64u, wh = W - wl;
+            u128 acc = 0; uint32_t nbits = 0;
+            uint8_t* o = s_out + (s_off[sub] - cbase) + (size_t)(t & 15u) * W;
+            u128 prev = ((u128)s_khi[8 * t] << 64) | s_klo[8 * t];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint32_t i = c0 + 8 * t + q;
+                const u128 key = ((u128)s_khi[1 + 8 * t + q] << 64) | s_klo[1 + 8 * t + q];
+                const u128 d = i < n ? key - prev : (u128)0;
+                prev = key;
+                acc |= (u128)(uint64_t)d << nbits; nbits += wl;                             // (the delta's low 64 bits hold nothing above wl bits unless W > 64, and then wl = 64)
+                while (nbits >= 8) { *o++ = (uint8_t)acc; acc >>= 8; nbits -= 8; }
+                if (wh) { acc |= (u128)(uint64_t)(d >> 64) << nbits; nbits += wh; while (nbits >= 8) { *o++ = (uint8_t)acc; acc >>= 8; nbits -= 8; } }
+            }
+        }
+        __syncthreads();
+        const uint32_t cwords = (s_off[sub0 + PKV_CHUNK / PKV_SUB] - cbase) >> 4;
+        uint4* dst = reinterpret_cast<uint4*>(dstp + cbase);
+        for (uint32_t w = t; w < cwords; w += PK_THREADS) dst[w] = reinterpret_cast<const uint4*>(s_out)[w];
+        __syncthreads();
+    }
+    if (t < PKV_BITMAP / 16) reinterpret_cast<uint4*>(dstp + s_off[PKV_NSUB])[t] = reinterpret_cast<const uint4*>(s_bits)[t];
+    uint8_t* cb = cb_stream + s_base;
+    for (uint32_t i = t; i < run; i += PK_THREADS) cb[i] = s_cb[i];
+}
+
 // 16-byte keys: recs = 4 words per record (value low, value high, abundance, 0); bases = 2 words per block; W = 16 (15-byte deltas) or 17 (16-byte deltas)
 template <int W>
 __global__ __launch_bounds__(PK_THREADS) void k_pack_counts2(const uint64_t* __restrict__ recs, PackPlan P, uint64_t* __restrict__ bases, uint8_t* __restrict__ payload,
@@ -365,6 +485,38 @@ struct gkc_unpacker {
             pay += 16u * W;
         }
     }
+    static void unpack_block_pkv2(const SinkBatch& B, uint64_t g)                     // PKV, 16-byte keys: 32-byte records {value low, value high, abundance, 0}
+    {
+        typedef unsigned __int128 u128;
+        const uint64_t r0 = B.blk_rec0[g]; const uint32_t n = B.blk_n[g];
+        const uint8_t* wb = B.stage + B.wbits_off + g * PKV_NSUB;
+        const uint8_t* pay = B.stage + B.pay_off + ((uint64_t)reinterpret_cast<const uint32_t*>(B.stage + B.pay16_off)[g] << 4);
+        uint32_t total = 0; for (uint32_t s = 0; s < PKV_NSUB; s++) total += 16u * wb[s];
+        const uint64_t* bits = reinterpret_cast<const uint64_t*>(pay + total);
+        const uint8_t* cb = B.stage + B.cb_off + reinterpret_cast<const uint32_t*>(B.stage + B.cboff_off)[g];
+        const uint64_t* b2 = reinterpret_cast<const uint64_t*>(B.stage) + 2 * g;
+        u128 key = ((u128)b2[1] << 64) | b2[0];                                  // (a block's first delta is 0)
+        __m128i* out = reinterpret_cast<__m128i*>(B.dest + r0 * 32);
+        for (uint32_t s0 = 0; s0 < n; s0 += PKV_SUB) {
+            const uint32_t W = wb[s0 / PKV_SUB], wl = W < 64u ? W : 64u, wh = W - wl;
+            const uint64_t ml = wl >= 64 ? ~0ull : (1ull << wl) - 1ull, mh = wh >= 64 ? ~0ull : (1ull << wh) - 1ull;
+            uint64_t bit = 0;
+            const uint32_t e = std::min<uint32_t>(n, s0 + PKV_SUB);
+            for (uint32_t i = s0; i < e; i++) {
+                u128 x; memcpy(&x, pay + (bit >> 3), 16);                        // (16 bytes from any byte: 7 + 64 bits lie inside; up to 15 bytes beyond the entries: bitmap / padding)
+                const uint64_t lo = (uint64_t)(x >> (bit & 7)) & ml; bit += wl;
+                uint64_t hi = 0;
+                if (wh) { memcpy(&x, pay + (bit >> 3), 16); hi = (uint64_t)(x >> (bit & 7)) & mh; bit += wh; }
+                key += ((u128)hi << 64) | lo;
+                const uint32_t f = (uint32_t)(bits[i >> 6] >> (i & 63)) & 1u;
+                uint32_t ab = 1u + f * ((uint32_t)*cb - 1u); cb += f;
+                if (ab == 255u) ab = (uint32_t)lookup(B.exc, r0 + i);
+                _mm_stream_si128(out + 2 * (size_t)i, _mm_set_epi64x((long long)(uint64_t)(key >> 64), (long long)(uint64_t)key));
+                _mm_stream_si128(out + 2 * (size_t)i + 1, _mm_set_epi64x(0ll, (long long)(uint64_t)ab));
+            }
+            pay += 16u * W;
+        }
+    }
     template <int W> static void unpack_block_2(const SinkBatch& B, uint64_t g)         // 16-byte keys: 32-byte records {value low, value high, abundance, 0}
     {
         typedef unsigned __int128 u128;
@@ -388,7 +540,7 @@ struct gkc_unpacker {
     }
     static void unpack_block(const SinkBatch& B, uint64_t g)
     {
-        if (B.width == 6) unpack_block_6(B, g); else if (B.width == 7) unpack_block_w<7>(B, g); else if (B.width == 8) unpack_block_w<8>(B, g);
+        if (B.width == 6) unpack_block_6(B, g); else if (B.width == 14) unpack_block_pkv2(B, g); else if (B.width == 7) unpack_block_w<7>(B, g); else if (B.width == 8) unpack_block_w<8>(B, g);
         else if (B.width == 16) unpack_block_2<16>(B, g); else unpack_block_2<17>(B, g);
     }
     void worker()
@@ -433,7 +585,7 @@ struct gkc_unpacker {
                         const auto t00 = all.empty() ? B->t_queued : all.front()->t_queued;
                         fprintf(stderr, "[gkc sink] +%.1f ms: batch of %llu blocks (%.2f GB packed, %llu exceptions): pack %.1f ms, queued -> copied %.1f ms (the copy itself %.1f ms), unpack %.1f ms\n",
                                 std::chrono::duration<double, std::milli>(B->t_queued - t00).count(), (unsigned long long)B->nblk,
-                                (double)((B->width == 6 ? B->pay_bytes : B->nblk * pk_slot_of(B->width)) + B->n_cb) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
+                                (double)((B->width == 6 || B->width == 14 ? B->pay_bytes : B->nblk * pk_slot_of(B->width)) + B->n_cb) / 1e9, (unsigned long long)B->n_exc, B->pack_ms, std::chrono::duration<double, std::milli>(B->t_ready - B->t_queued).count(), copy_ms,
                                 std::chrono::duration<double, std::milli>(now - B->t_ready).count());
                     }
                     { std::lock_guard<std::mutex> lk(mu); B->done.store(true); }
@@ -618,11 +770,13 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     const uint64_t dense_min = gkc_tun().sink_dense ? gkc_tun().sink_dense : PK_DENSE;      // (tests: 1 = every batch is "dense")
     const bool wide = c->key_words == 2;
     const bool dense = solid_prefix[nb] / std::max<uint32_t>(nb, 1) >= (wide ? std::min<uint64_t>(dense_min, PK2_DENSE) : dense_min);
-    const int width = wide ? (dense ? 16 : 17) : !dense ? 8 : (c->amin <= 1 && !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32)) ? 6 : 7;
+    const bool pkv_ok = !no6 && !c->sink_no6 && solid_prefix[nb] < (1ull << 32);
+    const int width = wide ? (pkv_ok ? 14 : dense ? 16 : 17) : !dense ? 8 : (c->amin <= 1 && pkv_ok) ? 6 : 7;
+    const bool pkv = width == 6 || width == 14;
     const uint64_t n_rec = solid_prefix[nb];
-    const uint64_t bases_bytes = (nblk * (wide ? 16 : 8) + 63) / 64 * 64, cboff_bytes = width == 6 ? (nblk * 4 + 63) / 64 * 64 : 0;
-    const uint64_t wbits_bytes = width == 6 ? nblk * PKV_NSUB : 0, hdr_bytes = bases_bytes + 2 * cboff_bytes + wbits_bytes;      // width 6: [bases | abundance-stream offsets | payload offsets | widths]
-    const uint64_t pay_bytes = nblk * pk_slot_of(width) + 64, cb_cap = width == 6 ? (n_rec + 63) / 64 * 64 : 0;                           // (width 6: the worst case — every block at 64 bits; what is copied is what was used)
+    const uint64_t bases_bytes = (nblk * (wide ? 16 : 8) + 63) / 64 * 64, cboff_bytes = pkv ? (nblk * 4 + 63) / 64 * 64 : 0;
+    const uint64_t wbits_bytes = pkv ? nblk * PKV_NSUB : 0, hdr_bytes = bases_bytes + 2 * cboff_bytes + wbits_bytes;      // width 6: [bases | abundance-stream offsets | payload offsets | widths]
+    const uint64_t pay_bytes = nblk * pk_slot_of(width) + 64, cb_cap = pkv ? (n_rec + 63) / 64 * 64 : 0;                           // (width 6: the worst case — every block at 64 bits; what is copied is what was used)
     const uint32_t exc_cap = 1u << 20;
     g_sink_why = "no device memory for the packed copy";
     DevBuf d_first; if (c->ensure(d_first, (size_t)(nb + 1) * 4) != GKC_OK) return nullptr;
@@ -639,6 +793,8 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
         PackPlan P{ (const uint32_t*)d_first.p, d_ptot, nb };
         if (width == 6) hipLaunchKernelGGL(k_pack_counts6, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, (uint32_t*)(d_packed + bases_bytes),
                                            (uint32_t*)(d_packed + bases_bytes + cboff_bytes), d_packed + bases_bytes + 2 * cboff_bytes, d_pay, d_nexc + 2, d_cb, d_nexc + 1, (uint64_t*)d_exc, d_nexc, exc_cap);
+        else if (width == 14) hipLaunchKernelGGL(k_pack_pkv2, dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, (uint32_t*)(d_packed + bases_bytes),
+                                                 (uint32_t*)(d_packed + bases_bytes + cboff_bytes), d_packed + bases_bytes + 2 * cboff_bytes, d_pay, d_nexc + 2, d_cb, d_nexc + 1, (uint64_t*)d_exc, d_nexc, exc_cap);
         else if (width == 16) hipLaunchKernelGGL((k_pack_counts2<16>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
                                                  (uint64_t*)d_exc, d_nexc, exc_cap);
         else if (width == 17) hipLaunchKernelGGL((k_pack_counts2<17>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, st, (const uint64_t*)d_out, P, (uint64_t*)d_packed, d_pay,
@@ -651,12 +807,12 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
     }
     d_first.release();
     const unsigned long long h_nexc = h_cnt[0], h_ncb = h_cnt[1];
-    const uint64_t pay_used = width == 6 ? ((uint64_t)h_cnt[2] + 63) / 64 * 64 : pay_bytes;               // bytes of the payload that travel (and are staged)
+    const uint64_t pay_used = pkv ? ((uint64_t)h_cnt[2] + 63) / 64 * 64 : pay_bytes;               // bytes of the payload that travel (and are staged)
     g_sink_why = !ok ? "pack launch failed" : "too many exceptions";
-    if (!ok || h_nexc > exc_cap || h_ncb > cb_cap || (width == 6 && h_cnt[2] > pay_bytes - 64)) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
+    if (!ok || h_nexc > exc_cap || h_ncb > cb_cap || (pkv && h_cnt[2] > pay_bytes - 64)) { (void)hipGetLastError(); c->dfree(d_packed); return nullptr; }
     // (a batch whose per-block widths + abundance stream came out above the 7 bytes per record of the fixed entries — wide gaps AND few abundances of 1 — switches the
     //  context to those; this batch still travels as it was packed)
-    if (width == 6 && (double)(h_cnt[2] + h_ncb) > 7.0 * (double)n_rec) c->sink_no6 = true;
+    if (pkv && (double)(h_cnt[2] + h_ncb) > (wide ? 16.0 : 7.0) * (double)n_rec) c->sink_no6 = true;
     SinkBatch* B = new SinkBatch();
     const uint64_t cb_stage = (h_ncb + 63) / 64 * 64;
     const uint64_t need = hdr_bytes + pay_used + cb_stage + h_nexc * 16 + 64;

@@ -865,8 +865,8 @@ def test_packed_sink_escapes_and_block_boundaries(gkc, k, amin):
     c.set_host_sink(None)
 
 
-@pytest.mark.parametrize("k,amin,dense", [(63, 1, 0), (63, 1, 1), (41, 2, 1), (33, 1, 1), (47, 1, 0)])
-def test_packed_sink_16_byte_keys(gkc, monkeypatch, k, amin, dense):
+@pytest.mark.parametrize("k,amin,dense,fixed", [(63, 1, 0, 0), (63, 1, 1, 0), (41, 2, 1, 0), (33, 1, 1, 0), (47, 1, 0, 0), (63, 1, 0, 1), (63, 1, 1, 1), (41, 2, 1, 1), (33, 1, 1, 1)])
+def test_packed_sink_16_byte_keys(gkc, monkeypatch, k, amin, dense, fixed):
     """k >= 32: the 32-byte Count records {u128 value; i32 abundance; padding} cross PCIe packed as well (csrc/gkc_sink.hip, k_pack_counts2: per block of 8192 records a
     16-byte base key, then [15- or 16-byte key delta][1-byte abundance] = 16 / 17 bytes instead of 32) and are expanded in the sink by the library's threads: what
     gkc_wait_partition hands out must be byte for byte gkc_partition_counts, and that the oracle's records. `dense` (GKC_SINK_DENSE=1) takes the 15-byte deltas on
@@ -874,6 +874,8 @@ def test_packed_sink_16_byte_keys(gkc, monkeypatch, k, amin, dense):
     the abundance byte); k=33 at 20000 reads in 2 partitions gives partitions of several blocks; an empty partition; two passes over the same staging buffer."""
     if dense:
         monkeypatch.setenv("GKC_SINK_DENSE", "1")
+    if fixed:
+        monkeypatch.setenv("GKC_SINK_WIDTH6", "0")          # rounds 4-5: fixed 15- / 16-byte deltas with escapes; default since round 6: a delta width per sub-block of 128 records (PKV, no key escapes)
     big = k == 33
     reads = synth_reads(20000 if big else 3000, 400000 if big else 20000, 150, seed=62 + k, n_rate=0.001)
     reads += [reads[0]] * 700 + [b"A" * 150] * 300 + [b"ACGT" * 40] * 260
