@@ -4,6 +4,8 @@
 //     per block of PK_BLOCK records: the first key (8 bytes), then per record 6 bytes of key DELTA + 1 byte of abundance            = 7 bytes instead of 16
 //     — and at abundance-min 1, where most records are the singletons of sequencing errors (84 % of the 30x input), the abundance byte travels only for the
 //     records whose abundance is NOT 1: 6 bytes of delta + 1 bit in the block's bitmap + a byte in the batch's abundance stream for those = 6.3 bytes (PK6)
+//     — and since round 6 the deltas of that format are bit-packed at the width of the largest delta of their sub-block of 128 records, one width byte per sub-block,
+//     8- and 16-byte keys alike (PKV below): 5.8 bytes per record at k = 31, 14.5 of 32 at k = 63 (10^8 reads), no key escapes
 // and library threads on the host expand it into the exact in-memory layout of Kmer<span>::Count ({u64 value; i32 abundance; pad}, Abundance.hpp:68-129) at its
 // place in the caller's sink: what gkc_wait_partition hands out is byte for byte what the unpacked copy would have been (tests: the sink against
 // gkc_partition_counts). Rare values leave through an exception list (record index, value): a delta of 2^48-1 or more (the delta field then holds the escape

@@ -124,8 +124,9 @@ int gkc_finish_pass(gkc_ctx* ctx);
  * in for is CountProcessorDump -> BagCache -> CollectionHDF5Patch (CountProcessorDump.hpp:148-152, CollectionHDF5Patch.hpp:262-308), fed per
  * partition by the dump threads. The sink must be page-locked (gkc_host_alloc) and holds ONE pass (gkc_begin_pass rewinds it); what does
  * not fit stays on the device and gkc_finish_pass reports GKC_ERR_CAPACITY in gkc_last_error while still returning 0 records lost.
- * On the link the batches travel PACKED (base key per block of 8192 records + key deltas + abundance bytes: 6.3 - 8 of the 16 bytes of a record at k <= 31,
- * 16 - 17 of the 32 at k <= 63) and are expanded into the exact Count[] layout inside the sink by threads of the library; what gkc_wait_partition hands out
+ * On the link the batches travel PACKED (base key per block of 8192 records + key deltas bit-packed at the width of their sub-block of 128 records + a bitmap and a
+ * stream of the abundances that are not 1: 5.8 of the 16 bytes of a record at k = 31, 14.5 of the 32 at k = 63, 10^8 reads; 7 - 8 / 16 - 17 with fixed-width entries
+ * where the partitions are sparse) and are expanded into the exact Count[] layout inside the sink by threads of the library; what gkc_wait_partition hands out
  * is byte for byte what gkc_partition_counts gives.
  *   gkc_finish_pass_async : Stage B on a worker thread of the library; returns at once.
  *   gkc_wait_partition    : blocks until dataset (pass, part) is counted and, with a sink, has landed; *host_records points into the sink
