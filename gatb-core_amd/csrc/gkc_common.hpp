@@ -299,6 +299,7 @@ struct gkc_ctx {
     gkc_stats& stats_now() { return pass_stats[pass]; }
     // streamed results (gkc_set_host_sink): every Stage-B batch is copied to page-locked host memory on a copy stream as soon as it is compacted
     void* sink = nullptr; uint64_t sink_cap = 0, sink_used = 0; bool sink_overflow = false; bool sink_raw = false;      // sink_raw: gkc_set_sink_mode(GKC_SINK_RAW)
+    std::chrono::steady_clock::time_point t_stage_b0;   // when the current gkc_count_pass began (GKC_SINK_DEBUG: how long the link waited for the first batch)
     uint64_t sink_wire_bytes = 0;         // bytes the packed batches of the pass took on the link (gkc_stats.reserved[1])
     std::atomic<bool> sink_no6{false};                // the packed transfer found too few abundances of 1 for its 6-byte entries to pay (gkc_sink.hip)
     hipStream_t copy_stream = nullptr;

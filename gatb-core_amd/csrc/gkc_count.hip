@@ -2552,6 +2552,7 @@ int gkc_count_pass(gkc_ctx* c, const uint32_t pass, const std::vector<Segment>& 
 {
     const uint32_t Pn = c->nb_partitions;
     const uint32_t n_seg = (uint32_t)segments.size();
+    c->t_stage_b0 = std::chrono::steady_clock::now();
     {   // a pass counted again (a retry after GKC_ERR_NOMEM, or gkc_finish_pass called twice) starts from a clean slate: what the
         // batches of the failed attempt added to the histogram, to the counters and to the result list must not be counted twice
         std::lock_guard<std::mutex> lk(c->mu);

@@ -839,6 +839,7 @@ void* gkc_sink_send_packed(gkc_ctx* c, const void* d_out, const uint64_t* d_ptot
                && hipEventRecord(B->copied, c->copy_stream) == hipSuccess;
     if (!queued) { g_sink_why = "copy could not be queued"; (void)hipGetLastError(); (void)hipStreamSynchronize(c->copy_stream); if (B->copied) (void)hipEventDestroy(B->copied); delete B; c->dfree(d_packed); return nullptr; }
     B->t_queued = std::chrono::steady_clock::now(); B->pack_ms = std::chrono::duration<double, std::milli>(B->t_queued - t_pack0).count();
+    if (g_sink_debug) { std::lock_guard<std::mutex> lk(U->mu); if (U->all.empty()) fprintf(stderr, "[gkc sink] first batch queued %.1f ms after Stage B began\n", std::chrono::duration<double, std::milli>(B->t_queued - c->t_stage_b0).count()); }
     { std::lock_guard<std::mutex> lk(U->mu); U->all.push_back(B); U->queue.push_back(B); }
     U->cv.notify_all();
     return B;
