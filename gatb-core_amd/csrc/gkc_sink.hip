@@ -425,7 +425,7 @@ struct gkc_unpacker {
     std::vector<SinkBatch*> all;                 // every batch of the pass (owned)
     bool stop = false;
     uint8_t* staging = nullptr; uint64_t staging_cap = 0, staging_used = 0;
-    std::atomic<uint64_t> n_decisions{0}, n_adaptive_raw{0};     // batches of this context that travelled raw because the host was behind (gkc_sink_host_behind)
+    std::atomic<uint64_t> n_decisions{0}, n_adaptive_raw{0}, max_batch_records{0};     // batches of this context that travelled raw because the host was behind (gkc_sink_host_behind)
 
     static uint64_t lookup(const std::vector<std::pair<uint64_t, uint64_t>>& exc, uint64_t tag)
     {
@@ -697,7 +697,7 @@ void gkc_sink_reset(gkc_ctx* c)
         U->queue.clear();
     }
     for (SinkBatch* B : U->all) { if (B->copied) (void)hipEventDestroy(B->copied); if (B->copy_start) (void)hipEventDestroy(B->copy_start); if (B->d_packed) c->dfree(B->d_packed); delete B; }
-    U->all.clear(); U->staging_used = 0; c->sink_wire_bytes = 0;
+    U->all.clear(); U->staging_used = 0; c->sink_wire_bytes = 0; U->max_batch_records = 0;
 }
 void gkc_sink_drain(gkc_ctx* c)
 {
@@ -744,8 +744,11 @@ bool gkc_sink_host_behind(gkc_ctx* c, uint64_t n_records)
         }
     }
     (void)hipGetLastError();                                        // (hipErrorNotReady of the queries)
+    // (against the LARGEST batch of the pass so far, not this one: the small batches at the end of a ramp would otherwise see the whole batch in hand of the
+    //  expansion threads as "1.5 batches behind" and travel raw — 16 instead of 6 bytes per record on the link at the very end of the step)
+    uint64_t ref = U->max_batch_records.load(); if (n_records > ref) { U->max_batch_records = n_records; ref = n_records; }
     const bool behind = gkc_tun().sink_adaptive == 2 ? (U->n_decisions++ & 1) != 0                       // (tests: packed and raw batches alternate in one pass)
-                                                     : pending * PK_BLOCK > std::max<uint64_t>(n_records + n_records / 2, (uint64_t)1 << 22);
+                                                     : pending * PK_BLOCK > std::max<uint64_t>(ref + ref / 2, (uint64_t)1 << 22);
     if (behind) { g_sink_why = "the host is behind with the expansion (landed, unexpanded records beyond 1.5 batches): this batch travels raw"; U->n_adaptive_raw++; }
     return behind;
 }
