@@ -1,6 +1,6 @@
 #!/bin/bash
 # (GPU box) Round-6 probes in ONE call:  bash tools/round6_probes.sh   -> gpurun_out/r06_*
-#   1. bench.py dry runs at 8 ranks on the one GPU (gloo-backed transport): 10^6 reads per rank, and 1.25e7 per rank (10^8 in all) with the sink-mode trial
+#   1. bench.py dry runs at 8 ranks on the one GPU (gloo-backed transport): 10^6 reads per rank, and 5e6 per rank (4e7 in all: 8 contexts share the one GPU's memory) with the sink-mode trial
 #   2. frequency-order minimizers: L2 (TCC) hit / miss / request counters of k_scan_tile in both modes
 #   3. the headline's lead-in: first Stage-B batch of a lane 1/4 (round 5), 1/8, 1/16 of the others
 set -u
